@@ -1,0 +1,326 @@
+/*
+ * rsgpu.h — C-ABI of librsgpu.so: the MI355X (gfx950) implementation of the
+ * Racing-SLAM per-frame hot path (descriptor matching -> triangulation ->
+ * local-window bundle adjustment).
+ *
+ * This header is the whole drop-in boundary.  The reference has no FFI layer
+ * (SURVEY.md §8b): its boundary is link-time, four translation units
+ *   src/MapMatcher.cpp, src/Triangulation.cpp, src/Optimization.cpp,
+ *   src/LocalWindow.cpp
+ * behind four headers.  A maintainer replaces those four .cpp files with the
+ * shims shown in INTEGRATION.md; every shim function flattens the reference's
+ * pointer graph (Frame / MapPoint / Map) to the SoA arrays below and calls one
+ * entry point of this header.  Each entry point cites the reference code it
+ * replaces.
+ *
+ * Conventions
+ *  - extern "C", plain pointers and sizes only; no exceptions cross the ABI.
+ *  - Every function returns an rs_status (0 = RS_OK).  rs_last_error() returns
+ *    a human-readable message for the last failure on that context.
+ *  - Pointers named d_* are DEVICE pointers (HBM of the context's GPU).
+ *    Pointers named h_* are HOST pointers.  Small fixed-size parameters
+ *    (poses, intrinsics, options) are host memory and are copied by value.
+ *  - All work is enqueued on the context's stream (rs_context_set_stream);
+ *    functions that return results in host memory synchronise that stream.
+ *  - Matrices are ROW-MAJOR unless stated (Eigen's default is column-major:
+ *    the shim transposes 16 floats).  A pose is the 4x4 world->camera
+ *    transform exactly as Frame::pose() (src/Frame.h:46).
+ *  - Descriptors are 32-byte rows (256-bit ORB, src/features/OrbFeatureExtractor.h:14-22),
+ *    row i at byte offset 32*i; device descriptor arrays must be 16-byte aligned.
+ *  - One context per GPU / per process rank; a context is not re-entrant
+ *    (the reference's callers are single threaded, SURVEY.md §8b "Threading").
+ */
+#ifndef RSGPU_H
+#define RSGPU_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RSGPU_ABI_VERSION 1
+#define RS_DESC_BYTES 32
+
+typedef enum rs_status {
+    RS_OK = 0,
+    RS_ERR_INVALID = 1,     /* bad argument (null pointer, negative size, unsorted CSR ...) */
+    RS_ERR_HIP = 2,         /* a HIP runtime call failed; see rs_last_error */
+    RS_ERR_NOMEM = 3,       /* workspace allocation failed */
+    RS_ERR_UNSUPPORTED = 4, /* valid request outside the implemented envelope */
+    RS_ERR_RCCL = 5,        /* RCCL missing or a collective failed */
+    RS_ERR_NO_DEVICE = 6    /* no gfx950 device visible: there is NO CPU fallback */
+} rs_status;
+
+typedef struct rs_context rs_context;
+
+/* ------------------------------------------------------------------ context */
+
+int rs_abi_version(void);
+
+/* Creates a context bound to HIP device `device_id`.  Fails with
+ * RS_ERR_NO_DEVICE when no GPU is visible: the product path never falls back
+ * to the CPU. */
+int rs_context_create(int device_id, rs_context** out_ctx);
+int rs_context_destroy(rs_context* ctx);
+/* `hip_stream` is a hipStream_t (NULL = the legacy default stream). */
+int rs_context_set_stream(rs_context* ctx, void* hip_stream);
+int rs_context_synchronize(rs_context* ctx);
+const char* rs_last_error(const rs_context* ctx);
+
+/* --------------------------------------------------- a4: match_descriptors */
+
+/* Brute-force 2-nearest-neighbour search under 256-bit Hamming distance.
+ * Replaces cv::BFMatcher(NORM_HAMMING).knnMatch(query, train, knn, 2) at
+ * src/MapMatcher.cpp:147-148.
+ *
+ * d_query [batch][nq][32] u8, d_train [batch][nt][32] u8.
+ * Outputs, each [batch][nq] int32:
+ *   d_idx0/d_dist0 = nearest train row and its distance,
+ *   d_idx1/d_dist1 = second nearest (idx1 = -1, dist1 = -1 when nt == 1).
+ * Ties: the lower train index is the nearer neighbour (OpenCV batchDistance
+ * inserts with strict compares).  Bit-exact integer results.
+ * nq == 0 or nt == 0 is valid: nothing is written. */
+int rs_hamming_knn2(rs_context* ctx,
+                    const uint8_t* d_query, int nq,
+                    const uint8_t* d_train, int nt, int batch,
+                    int32_t* d_idx0, int32_t* d_dist0,
+                    int32_t* d_idx1, int32_t* d_dist1);
+
+/* knnMatch + the two filters of MapMatcher::match_descriptors
+ * (src/MapMatcher.cpp:150-161): keep query q iff
+ *   dist0 <= max_distance                       (:152, note '>' rejects)
+ *   and (nt < 2 or 4*dist0 <= 3*dist1)          (:156, MATCH_RATIO 0.75 :18)
+ * Accepted matches are emitted in ascending query order (the order knn is
+ * iterated in), compacted per batch item:
+ *   d_match_query [batch][nq], d_match_train [batch][nq], d_match_count [batch].
+ * Entries past d_match_count[b] are unspecified.
+ * Any of d_idx0..d_dist1 may be NULL when the raw kNN result is not wanted. */
+int rs_match_descriptors(rs_context* ctx,
+                         const uint8_t* d_query, int nq,
+                         const uint8_t* d_train, int nt, int batch,
+                         int max_distance,
+                         int32_t* d_match_query, int32_t* d_match_train,
+                         int32_t* d_match_count,
+                         int32_t* d_idx0, int32_t* d_dist0,
+                         int32_t* d_idx1, int32_t* d_dist1);
+
+/* ------------------------------------------- a2/a3: reprojection-gated match */
+
+/* KD-tree over a frame's keypoints, flattened.  Mirrors KDTree2D
+ * (src/KDTree.cpp:8-43): median split on x at even depth, y at odd depth,
+ * mid = (start+end)/2.  Node i of the arrays is a tree node; root is node
+ * `root`.  rs_kdtree_build (host) fills the three arrays (each [n]).
+ * Equal-coordinate ties are resolved by (coordinate, keypoint index): the
+ * reference leaves that to std::nth_element (unspecified). */
+int rs_kdtree_build(const float* h_keypoints /*[n][2]*/, int n,
+                    int32_t* h_node_kp /*[n] keypoint index of node*/,
+                    int32_t* h_node_left /*[n] child node or -1*/,
+                    int32_t* h_node_right /*[n]*/,
+                    int32_t* h_root /*[1]*/);
+
+typedef struct rs_frame_view {
+    float pose[16];          /* world->camera, row-major (Frame::pose, src/Frame.h:46) */
+    float fx, fy, cx, cy;    /* Camera intrinsics (src/Camera.cpp:5-13) */
+    int width, height;       /* Camera::is_in_image bounds (src/Camera.cpp:34-37) */
+    int n_keypoints;
+    const float* d_keypoints;      /* [n][2] pixel coordinates */
+    const uint8_t* d_descriptors;  /* [n][32] */
+    const uint8_t* d_kp_matched;   /* [n] Frame::is_matched(index) (src/Frame.cpp:143-146) */
+    const int32_t* d_kd_node_kp;   /* [n] from rs_kdtree_build */
+    const int32_t* d_kd_left;      /* [n] */
+    const int32_t* d_kd_right;     /* [n] */
+    int kd_root;
+} rs_frame_view;
+
+typedef struct rs_map_view {
+    int n_points;                  /* candidate points, in MAP ORDER (src/Map.h:66) */
+    const float* d_positions;      /* [P][3] MapPoint::position */
+    const uint8_t* d_eligible;     /* [P] 1 = run the point.  The shim clears it for
+                                      points the frame already matches (src/MapMatcher.cpp:53)
+                                      and points not seen by required_observer (:169);
+                                      match_for_fuse skips nulls the same way (:121-123). */
+    const int32_t* d_obs_ptr;      /* [P+1] CSR: observations of point p are
+                                      d_obs_ptr[p] .. d_obs_ptr[p+1]-1, in the order
+                                      MapPoint::observations() is iterated */
+    const int32_t* d_obs_kf;       /* [M] observing keyframe (index into d_kf_centers) */
+    const int32_t* d_obs_desc;     /* [M] row of that observation's descriptor in d_desc_pool */
+    const float* d_kf_centers;     /* [KF][3] Frame::camera_center (src/Frame.cpp:39-42) */
+    const uint8_t* d_desc_pool;    /* [rows][32] descriptors of all keyframes */
+} rs_map_view;
+
+/* MapMatcher::match / match_for_fuse (src/MapMatcher.cpp:45-98,117-127,165-175).
+ * For every eligible point: project, in-image, viewing-angle (>= 0.5) and
+ * distance-range gates in f32, KD radius search r = 20 px in the reference's
+ * traversal order, min Hamming over (candidate keypoint x observation) with a
+ * strict '<' starting from max_distance, then per-keypoint strict-'<' argmin
+ * over points in map order.
+ *   replace = 0: match_map / match_key_frame (already-matched keypoints skipped)
+ *   replace = 1: match_for_fuse
+ * Outputs:
+ *   d_point_kp   [P] best keypoint for the point or -1;  d_point_dist [P] (max_distance if none)
+ *   d_prop_point [N] winning point (map order index) per keypoint or -1; d_prop_dist [N]
+ *   d_match_kp / d_match_point [N] + d_match_count[1]: accepted_matches()
+ *   (src/MapMatcher.cpp:34-43), ascending keypoint index.
+ * Integer outputs are bit-exact against the oracle; the f32 gates follow the
+ * operation order documented in oracle/reproj_match.c. */
+int rs_reproj_match(rs_context* ctx, const rs_frame_view* frame,
+                    const rs_map_view* map, int replace, int max_distance,
+                    int32_t* d_point_kp, int32_t* d_point_dist,
+                    int32_t* d_prop_point, int32_t* d_prop_dist,
+                    int32_t* d_match_kp, int32_t* d_match_point,
+                    int32_t* d_match_count);
+
+/* ------------------------------------------------------ a5-a7: triangulation */
+
+/* triangulation::triangulate_points (src/Triangulation.cpp:37-106), batched.
+ * Correspondence i uses pose table entries d_pose_idx1[i] / d_pose_idx2[i]
+ * (NULL = entry 0 / entry 1: the two-frame overload :28-35; per-item indices
+ * give Mapper::triangulate_tracks' pattern, src/Mapper.cpp:246-259, in one
+ * launch).  P = K*[R|t] in f32 (src/Camera.cpp:47-57), DLT rows
+ * x*P[2]-P[0], y*P[2]-P[1] per view, f64 one-sided Jacobi SVD, right singular
+ * vector of the smallest singular value rounded to f32, then the f32 gates:
+ * cheirality (:78), parallax cosine > min_parallax_cosine rejects (:83-88),
+ * reprojection error > max_reprojection_error rejects (:95-100).
+ *   d_xyz  [n][3] dehomogenised point of EVERY correspondence (kept or not)
+ *   d_keep [n]    1 = passed all gates
+ *   d_out_index [n], d_out_xyz [n][3], d_out_count[1]: the compacted
+ *   TriangulatedPoint list in input order (match_index = input index).
+ * n == 0 is valid (empty guard :46-48). */
+int rs_triangulate(rs_context* ctx,
+                   const float* d_uv1 /*[n][2]*/, const float* d_uv2 /*[n][2]*/, int n,
+                   const float* d_poses /*[n_poses][16] row-major*/, int n_poses,
+                   const int32_t* d_pose_idx1, const int32_t* d_pose_idx2,
+                   const float h_intrinsics[4] /*fx,fy,cx,cy*/,
+                   float min_parallax_cosine, float max_reprojection_error,
+                   float* d_xyz, uint8_t* d_keep,
+                   int32_t* d_out_index, float* d_out_xyz, int32_t* d_out_count);
+
+/* ----------------------------------------------------- a9-a13: optimisation */
+
+typedef enum rs_ba_termination {
+    RS_BA_NO_CONVERGENCE = 0,     /* max_num_iterations reached */
+    RS_BA_CONVERGENCE_FUNCTION = 1,
+    RS_BA_CONVERGENCE_PARAMETER = 2,
+    RS_BA_CONVERGENCE_GRADIENT = 3,
+    RS_BA_CONVERGENCE_RADIUS = 4,
+    RS_BA_FAILURE = 5             /* too many consecutive invalid steps / non-finite cost */
+} rs_ba_termination;
+
+/* Ceres 2.x trust-region defaults restated; solve() in the
+ * reference only sets the iteration cap (src/Optimization.cpp:127-134). */
+typedef struct rs_ba_options {
+    int max_num_iterations;             /* BA_ITERATIONS / POSE_ITERATIONS = 10 (:118-119) */
+    double huber_delta;                 /* sqrt(5.991) (:219,:311) */
+    double initial_trust_region_radius; /* 1e4 */
+    double max_trust_region_radius;     /* 1e16 */
+    double min_trust_region_radius;     /* 1e-32 */
+    double min_relative_decrease;       /* 1e-3 */
+    double min_lm_diagonal;             /* 1e-6 */
+    double max_lm_diagonal;             /* 1e32 */
+    double function_tolerance;          /* 1e-6 */
+    double gradient_tolerance;          /* 1e-10 */
+    double parameter_tolerance;         /* 1e-8 */
+    int max_num_consecutive_invalid_steps; /* 5 */
+    int jacobi_scaling;                 /* 1 */
+} rs_ba_options;
+
+void rs_ba_default_options(rs_ba_options* opt);
+
+typedef struct rs_ba_summary {
+    int termination;        /* rs_ba_termination */
+    int iterations;         /* LM iterations run (successful + unsuccessful) */
+    int successful_steps;
+    int usable;             /* the reference's accept rule (src/Optimization.cpp:136-141):
+                               termination != FAILURE && isfinite(final) && final <= initial */
+    double initial_cost;    /* 1/2 sum rho(|r|^2) at the input */
+    double final_cost;
+    double final_radius;
+} rs_ba_summary;
+
+/* optimization::bundle_adjust's solve (src/Optimization.cpp:269-374): Huber-robust
+ * reprojection residuals (:21-72), Levenberg-Marquardt with point-block Schur
+ * elimination, all in f64.
+ *   d_cameras [C][6] f64 in/out: angle-axis(R_cw) then camera centre (pack_pose :144-149)
+ *   h_cam_free [C] u8: FrameConfig::optimize; fixed cameras keep their residuals (:304-315)
+ *   d_points  [P][3] f64 in/out: the FREE points (>= 2 observations and seen by a
+ *             free frame, :287-302); points that are not free are not passed
+ *   observations sorted by point (CSR): d_obs_ptr [P+1], d_obs_cam [M], d_obs_uv [M][2] f32
+ * d_cameras / d_points are overwritten only when summary.usable is 1, exactly
+ * like the reference writes back only on an accepted solve (:360-372).
+ * With an RCCL communicator attached (rs_comm_init_rank) the points/observations
+ * are this rank's landmark shard, cameras are replicated, and the reduced
+ * camera system and the cost are all-reduced every LM step. */
+int rs_bundle_adjust(rs_context* ctx,
+                     int n_cameras, int n_points, int n_obs,
+                     double* d_cameras, const uint8_t* h_cam_free,
+                     double* d_points,
+                     const int32_t* d_obs_ptr, const int32_t* d_obs_cam,
+                     const float* d_obs_uv,
+                     const float h_intrinsics[4],
+                     const rs_ba_options* options /*NULL = defaults*/,
+                     rs_ba_summary* h_summary);
+
+/* optimization::refine_pose (src/Optimization.cpp:194-267), vision-only:
+ * the same residual with the points held constant, 6 unknowns.
+ *   h_camera [6] f64 in/out;  d_points [n][3] f64;  d_uv [n][2] f32.
+ * n == 0 returns RS_OK with summary.usable = 0 ("nothing to constrain", :227-229). */
+int rs_refine_pose(rs_context* ctx, double h_camera[6],
+                   const double* d_points, const float* d_uv, int n,
+                   const float h_intrinsics[4],
+                   const rs_ba_options* options, rs_ba_summary* h_summary);
+
+/* pack_pose / unpack_pose (src/Optimization.cpp:144-159, a10).  Host only:
+ * R -> angle-axis in f32 through a quaternion (ceres::RotationMatrixToAngleAxis<float>),
+ * centre = -R^T t (src/Frame.cpp:39-42), widened to f64; and back. */
+void rs_pack_pose(const float h_pose[16], double h_camera[6]);
+void rs_unpack_pose(const double h_camera[6], float h_pose[16]);
+
+/* ------------------------------------------------------- a8: local window */
+
+/* optimization::build_local_window (src/LocalWindow.cpp:10-52).  Host only.
+ * Keyframes are 0..n_key_frames-1 in Mapper order; new_frame is the index of
+ * the new frame in that list, or -1 when it is not (yet) a keyframe.
+ * The covisibility input is CSR: frame f (0..n_key_frames; entry n_key_frames
+ * is the new frame when new_frame == -1) matches points
+ * h_frame_pt[h_frame_ptr[f] .. h_frame_ptr[f+1]-1]; point p is observed by
+ * keyframes h_pt_obs[h_pt_ptr[p] .. h_pt_ptr[p+1]-1].
+ * Output (capacity n_key_frames+1): h_out_frame[i] (n_key_frames = the new
+ * non-keyframe), h_out_optimize[i]; *h_out_count entries. */
+int rs_build_local_window(int n_key_frames, int new_frame, int window_size, int fix_oldest,
+                          const int32_t* h_frame_ptr, const int32_t* h_frame_pt,
+                          const int32_t* h_pt_ptr, const int32_t* h_pt_obs,
+                          int32_t* h_out_frame, uint8_t* h_out_optimize, int32_t* h_out_count);
+
+/* ------------------------------------------------------------- multi-GPU */
+
+#define RS_COMM_ID_BYTES 128
+/* One process per GPU.  Rank 0 calls rs_comm_get_unique_id, the host program
+ * distributes the bytes (bench.py: torch.distributed broadcast), every rank
+ * calls rs_comm_init_rank.  Only rs_bundle_adjust communicates (sum all-reduce
+ * of the reduced camera system + cost over RCCL/xGMI); matching and
+ * triangulation shard with no collective. */
+int rs_comm_get_unique_id(uint8_t h_id[RS_COMM_ID_BYTES]);
+int rs_comm_init_rank(rs_context* ctx, const uint8_t h_id[RS_COMM_ID_BYTES], int n_ranks, int rank);
+int rs_comm_destroy(rs_context* ctx);
+
+/* ------------------------------------------------------------- profiling */
+
+/* Per-kernel HIP-event timing on the context's stream (the hipEvent analogue
+ * of the reference's time_it(), src/Helpers.h:8-25).  Between begin and end
+ * every kernel the library launches is bracketed by events; end synchronises
+ * and returns the totals.  Kernel names are stable identifiers (K1..K9). */
+#define RS_PROF_MAX 32
+typedef struct rs_prof_entry {
+    char name[32];
+    int launches;
+    double total_ms;
+} rs_prof_entry;
+int rs_prof_begin(rs_context* ctx);
+int rs_prof_end(rs_context* ctx, rs_prof_entry* h_entries /*[RS_PROF_MAX]*/, int* h_count);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RSGPU_H */

@@ -1,0 +1,302 @@
+"""ctypes bindings of oracle/liboracle.so — the CPU restatement of the hot path.
+
+TEST INFRASTRUCTURE ONLY (see oracle/rs_oracle.h): imported by tests/,
+__graft_entry__.smoke() and bench.py's cpu_baseline leg, never by the product
+package.  PARITY UNPINNED: the reference ships no fixtures for this path.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+i32p = C.POINTER(C.c_int32)
+u8p = C.POINTER(C.c_uint8)
+f32p = C.POINTER(C.c_float)
+f64p = C.POINTER(C.c_double)
+
+
+def build(force=False):
+    so = os.path.join(_HERE, "liboracle.so")
+    srcs = [os.path.join(_HERE, f) for f in os.listdir(_HERE) if f.endswith((".c", ".h"))]
+    if force or not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs):
+        subprocess.check_call(["make", "-C", _HERE, "-B", "liboracle.so"], stdout=subprocess.DEVNULL)
+    return so
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        so = os.path.join(_HERE, "liboracle.so")
+        if not os.path.exists(so):
+            build()
+        _LIB = C.CDLL(so)
+    return _LIB
+
+
+def _p(a, t):
+    return None if a is None else a.ctypes.data_as(t)
+
+
+class FrameView(C.Structure):
+    _fields_ = [("pose", C.c_float * 16), ("fx", C.c_float), ("fy", C.c_float), ("cx", C.c_float),
+                ("cy", C.c_float), ("width", C.c_int), ("height", C.c_int), ("n_keypoints", C.c_int),
+                ("keypoints", C.c_void_p), ("descriptors", C.c_void_p), ("kp_matched", C.c_void_p),
+                ("kd_node_kp", C.c_void_p), ("kd_left", C.c_void_p), ("kd_right", C.c_void_p),
+                ("kd_root", C.c_int)]
+
+
+class MapView(C.Structure):
+    _fields_ = [("n_points", C.c_int), ("positions", C.c_void_p), ("eligible", C.c_void_p),
+                ("obs_ptr", C.c_void_p), ("obs_kf", C.c_void_p), ("obs_desc", C.c_void_p),
+                ("kf_centers", C.c_void_p), ("desc_pool", C.c_void_p)]
+
+
+class BaOptions(C.Structure):
+    _fields_ = [("max_num_iterations", C.c_int), ("huber_delta", C.c_double),
+                ("initial_trust_region_radius", C.c_double), ("max_trust_region_radius", C.c_double),
+                ("min_trust_region_radius", C.c_double), ("min_relative_decrease", C.c_double),
+                ("min_lm_diagonal", C.c_double), ("max_lm_diagonal", C.c_double),
+                ("function_tolerance", C.c_double), ("gradient_tolerance", C.c_double),
+                ("parameter_tolerance", C.c_double), ("max_num_consecutive_invalid_steps", C.c_int),
+                ("jacobi_scaling", C.c_int)]
+
+
+class BaSummary(C.Structure):
+    _fields_ = [("termination", C.c_int), ("iterations", C.c_int), ("successful_steps", C.c_int),
+                ("usable", C.c_int), ("initial_cost", C.c_double), ("final_cost", C.c_double),
+                ("final_radius", C.c_double)]
+
+    def as_dict(self):
+        return {k: getattr(self, k) for k, _ in self._fields_}
+
+
+def default_options():
+    o = BaOptions()
+    lib().orc_ba_default_options(C.byref(o))
+    return o
+
+
+# ---------------------------------------------------------------- matching
+def hamming_knn2(query, train):
+    q = np.ascontiguousarray(query, np.uint8)
+    t = np.ascontiguousarray(train, np.uint8)
+    nq, nt = len(q), len(t)
+    out = [np.full(nq, -7, np.int32) for _ in range(4)]
+    rc = lib().orc_hamming_knn2(_p(q, u8p), nq, _p(t, u8p), nt, *[_p(o, i32p) for o in out])
+    assert rc == 0
+    return out
+
+
+def match_descriptors(query, train, max_distance=64):
+    q = np.ascontiguousarray(query, np.uint8)
+    t = np.ascontiguousarray(train, np.uint8)
+    nq, nt = len(q), len(t)
+    mq = np.zeros(max(nq, 1), np.int32)
+    mt = np.zeros(max(nq, 1), np.int32)
+    cnt = np.zeros(1, np.int32)
+    rc = lib().orc_match_descriptors(_p(q, u8p), nq, _p(t, u8p), nt, int(max_distance),
+                                     _p(mq, i32p), _p(mt, i32p), _p(cnt, i32p))
+    assert rc == 0
+    n = int(cnt[0])
+    return mq[:n].copy(), mt[:n].copy()
+
+
+def kdtree_build(keypoints):
+    kp = np.ascontiguousarray(keypoints, np.float32)
+    n = len(kp)
+    node_kp = np.zeros(max(n, 1), np.int32)
+    left = np.zeros(max(n, 1), np.int32)
+    right = np.zeros(max(n, 1), np.int32)
+    root = np.zeros(1, np.int32)
+    rc = lib().orc_kdtree_build(_p(kp, f32p), n, _p(node_kp, i32p), _p(left, i32p), _p(right, i32p),
+                                _p(root, i32p))
+    assert rc == 0
+    return node_kp[:n], left[:n], right[:n], int(root[0])
+
+
+def kdtree_radius(keypoints, tree, x, y, radius):
+    kp = np.ascontiguousarray(keypoints, np.float32)
+    node_kp, left, right, root = tree
+    out = np.zeros(max(len(kp), 1), np.int32)
+    L = lib()
+    L.orc_kdtree_radius.argtypes = [f32p, i32p, i32p, i32p, C.c_int, C.c_float, C.c_float, C.c_float, i32p, C.c_int]
+    n = L.orc_kdtree_radius(_p(kp, f32p), _p(node_kp, i32p), _p(left, i32p), _p(right, i32p), root,
+                            float(x), float(y), float(radius), _p(out, i32p), len(out))
+    return out[:n].copy()
+
+
+def reproj_match(frame, mp, replace=0, max_distance=64):
+    """frame/mp are dicts of numpy arrays (see synth.make_match_scene)."""
+    fv = FrameView()
+    keep = []
+
+    def ptr(a, dt):
+        a = np.ascontiguousarray(a, dt)
+        keep.append(a)
+        return a.ctypes.data
+
+    fv.pose[:] = list(np.asarray(frame["pose"], np.float32).reshape(16))
+    fv.fx, fv.fy, fv.cx, fv.cy = [float(v) for v in frame["K"]]
+    fv.width, fv.height = int(frame["width"]), int(frame["height"])
+    N = len(frame["keypoints"])
+    fv.n_keypoints = N
+    fv.keypoints = ptr(frame["keypoints"], np.float32)
+    fv.descriptors = ptr(frame["descriptors"], np.uint8)
+    fv.kp_matched = ptr(frame["kp_matched"], np.uint8)
+    fv.kd_node_kp = ptr(frame["kd_node_kp"], np.int32)
+    fv.kd_left = ptr(frame["kd_left"], np.int32)
+    fv.kd_right = ptr(frame["kd_right"], np.int32)
+    fv.kd_root = int(frame["kd_root"])
+    mv = MapView()
+    P = len(mp["positions"])
+    mv.n_points = P
+    mv.positions = ptr(mp["positions"], np.float32)
+    mv.eligible = ptr(mp["eligible"], np.uint8)
+    mv.obs_ptr = ptr(mp["obs_ptr"], np.int32)
+    mv.obs_kf = ptr(mp["obs_kf"], np.int32)
+    mv.obs_desc = ptr(mp["obs_desc"], np.int32)
+    mv.kf_centers = ptr(mp["kf_centers"], np.float32)
+    mv.desc_pool = ptr(mp["desc_pool"], np.uint8)
+    point_kp = np.zeros(max(P, 1), np.int32)
+    point_dist = np.zeros(max(P, 1), np.int32)
+    prop_point = np.zeros(max(N, 1), np.int32)
+    prop_dist = np.zeros(max(N, 1), np.int32)
+    mkp = np.zeros(max(N, 1), np.int32)
+    mpt = np.zeros(max(N, 1), np.int32)
+    cnt = np.zeros(1, np.int32)
+    rc = lib().orc_reproj_match(C.byref(fv), C.byref(mv), int(replace), int(max_distance),
+                                _p(point_kp, i32p), _p(point_dist, i32p), _p(prop_point, i32p),
+                                _p(prop_dist, i32p), _p(mkp, i32p), _p(mpt, i32p), _p(cnt, i32p))
+    assert rc == 0
+    n = int(cnt[0])
+    return dict(point_kp=point_kp[:P], point_dist=point_dist[:P], prop_point=prop_point[:N],
+                prop_dist=prop_dist[:N], match_kp=mkp[:n].copy(), match_point=mpt[:n].copy())
+
+
+# ----------------------------------------------------------- triangulation
+def triangulate(uv1, uv2, poses, K, idx1=None, idx2=None, min_parallax_cosine=0.9999, max_reproj=2.0):
+    uv1 = np.ascontiguousarray(uv1, np.float32)
+    uv2 = np.ascontiguousarray(uv2, np.float32)
+    poses = np.ascontiguousarray(poses, np.float32).reshape(-1, 16)
+    Kc = (C.c_float * 4)(*[float(v) for v in K])
+    n = len(uv1)
+    xyz = np.zeros((max(n, 1), 3), np.float32)
+    keep = np.zeros(max(n, 1), np.uint8)
+    oi = np.zeros(max(n, 1), np.int32)
+    ox = np.zeros((max(n, 1), 3), np.float32)
+    cnt = np.zeros(1, np.int32)
+    i1 = None if idx1 is None else np.ascontiguousarray(idx1, np.int32)
+    i2 = None if idx2 is None else np.ascontiguousarray(idx2, np.int32)
+    L = lib()
+    L.orc_triangulate.argtypes = [f32p, f32p, C.c_int, f32p, C.c_int, i32p, i32p, C.c_float * 4,
+                                  C.c_float, C.c_float, f32p, u8p, i32p, f32p, i32p]
+    rc = L.orc_triangulate(_p(uv1, f32p), _p(uv2, f32p), n, _p(poses, f32p), len(poses),
+                           _p(i1, i32p), _p(i2, i32p), Kc, float(min_parallax_cosine), float(max_reproj),
+                           _p(xyz, f32p), _p(keep, u8p), _p(oi, i32p), _p(ox, f32p), _p(cnt, i32p))
+    assert rc == 0
+    m = int(cnt[0])
+    return dict(xyz=xyz[:n], keep=keep[:n], out_index=oi[:m].copy(), out_xyz=ox[:m].copy())
+
+
+def null_vector4(A):
+    A = np.ascontiguousarray(A, np.float64).reshape(16)
+    v = np.zeros(4)
+    s = np.zeros(4)
+    lib().orc_null_vector4(_p(A, f64p), _p(v, f64p), _p(s, f64p))
+    return v, s
+
+
+def pack_pose(pose):
+    p = np.ascontiguousarray(pose, np.float32).reshape(16)
+    cam = np.zeros(6)
+    lib().orc_pack_pose(_p(p, f32p), _p(cam, f64p))
+    return cam
+
+
+def unpack_pose(cam):
+    c = np.ascontiguousarray(cam, np.float64)
+    p = np.zeros(16, np.float32)
+    lib().orc_unpack_pose(_p(c, f64p), _p(p, f32p))
+    return p.reshape(4, 4)
+
+
+# --------------------------------------------------------------------- BA
+def reprojection(cam, pt, uv, K):
+    cam = np.ascontiguousarray(cam, np.float64)
+    pt = np.ascontiguousarray(pt, np.float64)
+    uv = np.ascontiguousarray(uv, np.float32)
+    Kc = np.ascontiguousarray(K, np.float32)
+    r = np.zeros(2)
+    jc = np.zeros(12)
+    jp = np.zeros(6)
+    lib().orc_reprojection(_p(cam, f64p), _p(pt, f64p), _p(uv, f32p), _p(Kc, f32p), _p(r, f64p),
+                           _p(jc, f64p), _p(jp, f64p))
+    return r, jc.reshape(2, 6), jp.reshape(2, 3)
+
+
+def bundle_adjust(cams, cam_free, points, obs_ptr, obs_cam, obs_uv, K, options=None):
+    cams = np.array(cams, np.float64, order="C")
+    points = np.array(points, np.float64, order="C")
+    cam_free = np.ascontiguousarray(cam_free, np.uint8)
+    obs_ptr = np.ascontiguousarray(obs_ptr, np.int32)
+    obs_cam = np.ascontiguousarray(obs_cam, np.int32)
+    obs_uv = np.ascontiguousarray(obs_uv, np.float32)
+    Kc = np.ascontiguousarray(K, np.float32)
+    s = BaSummary()
+    rc = lib().orc_bundle_adjust(len(cams), len(points), len(obs_cam), _p(cams, f64p), _p(cam_free, u8p),
+                                 _p(points, f64p), _p(obs_ptr, i32p), _p(obs_cam, i32p), _p(obs_uv, f32p),
+                                 _p(Kc, f32p), None if options is None else C.byref(options), C.byref(s))
+    assert rc == 0
+    return cams, points, s.as_dict()
+
+
+def ba_linearize(cams, points, obs_ptr, obs_cam, obs_uv, K, huber_delta=5.991 ** 0.5):
+    cams = np.ascontiguousarray(cams, np.float64)
+    points = np.ascontiguousarray(points, np.float64)
+    obs_ptr = np.ascontiguousarray(obs_ptr, np.int32)
+    obs_cam = np.ascontiguousarray(obs_cam, np.int32)
+    obs_uv = np.ascontiguousarray(obs_uv, np.float32)
+    Kc = np.ascontiguousarray(K, np.float32)
+    Cn, Pn = len(cams), len(points)
+    U = np.zeros((Cn, 6, 6)); gc = np.zeros((Cn, 6)); V = np.zeros((Pn, 3, 3)); gp = np.zeros((Pn, 3))
+    cost = np.zeros(1)
+    L = lib()
+    L.orc_ba_linearize.argtypes = [C.c_int, C.c_int, f64p, f64p, i32p, i32p, f32p, f32p, C.c_double,
+                                   f64p, f64p, f64p, f64p, f64p]
+    rc = L.orc_ba_linearize(Cn, Pn, _p(cams, f64p), _p(points, f64p), _p(obs_ptr, i32p), _p(obs_cam, i32p),
+                            _p(obs_uv, f32p), _p(Kc, f32p), float(huber_delta), _p(U, f64p), _p(gc, f64p),
+                            _p(V, f64p), _p(gp, f64p), _p(cost, f64p))
+    assert rc == 0
+    return U, gc, V, gp, float(cost[0])
+
+
+def refine_pose(cam, points, uv, K, options=None):
+    cam = np.array(cam, np.float64, order="C")
+    points = np.ascontiguousarray(points, np.float64)
+    uv = np.ascontiguousarray(uv, np.float32)
+    Kc = np.ascontiguousarray(K, np.float32)
+    s = BaSummary()
+    rc = lib().orc_refine_pose(_p(cam, f64p), _p(points, f64p), _p(uv, f32p), len(points), _p(Kc, f32p),
+                               None if options is None else C.byref(options), C.byref(s))
+    assert rc == 0
+    return cam, s.as_dict()
+
+
+def build_local_window(n_kf, new_frame, window, fix_oldest, frame_ptr, frame_pt, pt_ptr, pt_obs):
+    frame_ptr = np.ascontiguousarray(frame_ptr, np.int32)
+    frame_pt = np.ascontiguousarray(frame_pt, np.int32)
+    pt_ptr = np.ascontiguousarray(pt_ptr, np.int32)
+    pt_obs = np.ascontiguousarray(pt_obs, np.int32)
+    of = np.zeros(n_kf + 1, np.int32)
+    oo = np.zeros(n_kf + 1, np.uint8)
+    cnt = np.zeros(1, np.int32)
+    rc = lib().orc_build_local_window(n_kf, new_frame, window, int(fix_oldest), _p(frame_ptr, i32p),
+                                      _p(frame_pt, i32p), _p(pt_ptr, i32p), _p(pt_obs, i32p), _p(of, i32p),
+                                      _p(oo, u8p), _p(cnt, i32p))
+    assert rc == 0
+    n = int(cnt[0])
+    return of[:n].copy(), oo[:n].copy()

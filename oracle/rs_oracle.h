@@ -1,0 +1,150 @@
+/*
+ * rs_oracle.h — CPU restatement (plain C) of the Racing-SLAM hot path.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Nothing under oracle/ is part of the product:
+ * only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may
+ * load liboracle.so, and only as the checker / the reported CPU baseline.
+ *
+ * PARITY UNPINNED: the reference (GregVS/Racing-SLAM) ships no tests, golden
+ * vectors or fixtures for this path and cannot be built
+ * here (OpenCV, Eigen and Ceres are absent from the image).  Each function
+ * restates the reference file:line it cites plus the published algorithm of
+ * the third-party call underneath (OpenCV 4.x BFMatcher / triangulatePoints,
+ * Ceres 2.x trust-region LM + Schur; pinned only by vcpkg baseline
+ * 4b6c50d962cc20aaa3ef457f8ba683b586263cfb).  The restatement is validated in
+ * tests/ against independent numpy/scipy formulations.
+ *
+ * All pointers are host pointers.  Layouts are identical to include/rsgpu.h so
+ * one set of arrays drives both the oracle and the GPU library.
+ */
+#ifndef RS_ORACLE_H
+#define RS_ORACLE_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* -- hamming.c ---------------------------------------------------------- */
+int orc_hamming_knn2(const uint8_t* query, int nq, const uint8_t* train, int nt,
+                     int32_t* idx0, int32_t* dist0, int32_t* idx1, int32_t* dist1);
+int orc_match_descriptors(const uint8_t* query, int nq, const uint8_t* train, int nt,
+                          int max_distance, int32_t* match_query, int32_t* match_train,
+                          int32_t* match_count);
+
+/* -- kdtree.c ----------------------------------------------------------- */
+int orc_kdtree_build(const float* keypoints, int n, int32_t* node_kp, int32_t* node_left,
+                     int32_t* node_right, int32_t* root);
+/* radius search in the reference's traversal order; returns count (<= cap) */
+int orc_kdtree_radius(const float* keypoints, const int32_t* node_kp, const int32_t* node_left,
+                      const int32_t* node_right, int root, float x, float y, float radius,
+                      int32_t* out, int cap);
+
+/* -- reproj_match.c ----------------------------------------------------- */
+typedef struct orc_frame_view {
+    float pose[16];
+    float fx, fy, cx, cy;
+    int width, height;
+    int n_keypoints;
+    const float* keypoints;
+    const uint8_t* descriptors;
+    const uint8_t* kp_matched;
+    const int32_t* kd_node_kp;
+    const int32_t* kd_left;
+    const int32_t* kd_right;
+    int kd_root;
+} orc_frame_view;
+
+typedef struct orc_map_view {
+    int n_points;
+    const float* positions;
+    const uint8_t* eligible;
+    const int32_t* obs_ptr;
+    const int32_t* obs_kf;
+    const int32_t* obs_desc;
+    const float* kf_centers;
+    const uint8_t* desc_pool;
+} orc_map_view;
+
+int orc_reproj_match(const orc_frame_view* frame, const orc_map_view* map, int replace,
+                     int max_distance, int32_t* point_kp, int32_t* point_dist,
+                     int32_t* prop_point, int32_t* prop_dist, int32_t* match_kp,
+                     int32_t* match_point, int32_t* match_count);
+
+/* -- triangulate.c ------------------------------------------------------ */
+int orc_triangulate(const float* uv1, const float* uv2, int n, const float* poses, int n_poses,
+                    const int32_t* pose_idx1, const int32_t* pose_idx2,
+                    const float intrinsics[4], float min_parallax_cosine,
+                    float max_reprojection_error, float* xyz, uint8_t* keep,
+                    int32_t* out_index, float* out_xyz, int32_t* out_count);
+/* 4x4 f64 one-sided Jacobi SVD null vector (exposed for tests): v = right
+ * singular vector of the smallest singular value of row-major A. */
+void orc_null_vector4(const double A[16], double v[4], double sigma[4]);
+
+/* -- rotation.c --------------------------------------------------------- */
+void orc_pack_pose(const float pose[16], double camera[6]);
+void orc_unpack_pose(const double camera[6], float pose[16]);
+void orc_angle_axis_rotate_point(const double aa[3], const double pt[3], double out[3]);
+
+/* -- ba.c --------------------------------------------------------------- */
+typedef struct orc_ba_options {
+    int max_num_iterations;
+    double huber_delta;
+    double initial_trust_region_radius;
+    double max_trust_region_radius;
+    double min_trust_region_radius;
+    double min_relative_decrease;
+    double min_lm_diagonal;
+    double max_lm_diagonal;
+    double function_tolerance;
+    double gradient_tolerance;
+    double parameter_tolerance;
+    int max_num_consecutive_invalid_steps;
+    int jacobi_scaling;
+} orc_ba_options;
+
+typedef struct orc_ba_summary {
+    int termination;
+    int iterations;
+    int successful_steps;
+    int usable;
+    double initial_cost;
+    double final_cost;
+    double final_radius;
+} orc_ba_summary;
+
+void orc_ba_default_options(orc_ba_options* opt);
+
+/* residual + autodiff-equivalent Jacobians of one observation (forward-mode
+ * jets through the reference functor).  jc [2][6], jp [2][3], row-major. */
+void orc_reprojection(const double cam[6], const double pt[3], const float uv[2],
+                      const float intrinsics[4], double r[2], double jc[12], double jp[6]);
+
+int orc_bundle_adjust(int n_cameras, int n_points, int n_obs, double* cameras,
+                      const uint8_t* cam_free, double* points, const int32_t* obs_ptr,
+                      const int32_t* obs_cam, const float* obs_uv, const float intrinsics[4],
+                      const orc_ba_options* options, orc_ba_summary* summary);
+
+/* One linearisation at the given state (no update), for tests and for the
+ * multi-GPU sharding tests: fills the UNDAMPED normal equations
+ *   U [C][6][6], gc [C][6], V [P][3][3], gp [P][3] and the robust cost. */
+int orc_ba_linearize(int n_cameras, int n_points, const double* cameras, const double* points,
+                     const int32_t* obs_ptr, const int32_t* obs_cam, const float* obs_uv,
+                     const float intrinsics[4], double huber_delta, double* U, double* gc,
+                     double* V, double* gp, double* cost);
+
+int orc_refine_pose(double camera[6], const double* points, const float* uv, int n,
+                    const float intrinsics[4], const orc_ba_options* options,
+                    orc_ba_summary* summary);
+
+/* -- local_window.c ----------------------------------------------------- */
+int orc_build_local_window(int n_key_frames, int new_frame, int window_size, int fix_oldest,
+                           const int32_t* frame_ptr, const int32_t* frame_pt,
+                           const int32_t* pt_ptr, const int32_t* pt_obs, int32_t* out_frame,
+                           uint8_t* out_optimize, int32_t* out_count);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

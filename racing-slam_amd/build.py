@@ -1,0 +1,71 @@
+"""Builds librsgpu.so (hand-written HIP for gfx950 + the C-ABI) in-tree with hipcc.
+
+    python -m build  (from this directory)  or  build.build()
+
+The shared object is git-ignored but travels to the GPU box with the snapshot.
+"""
+import os
+import shutil
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+OUT = os.path.join(HERE, "librsgpu.so")
+ARCH = "gfx950"
+
+# (source, extra flags).  The f32-gate kernels are compiled without FMA
+# contraction so that they execute the oracle's IEEE operations one for one.
+SOURCES = [
+    ("context.hip", []),
+    ("hamming.hip", []),
+    ("triangulate.hip", ["-ffp-contract=off"]),
+    ("reproj_match.hip", ["-ffp-contract=off"]),
+    ("ba.hip", ["-munsafe-fp-atomics"]),
+    ("host.cpp", ["-ffp-contract=off"]),
+]
+COMMON = ["-O3", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function", f"--offload-arch={ARCH}"]
+
+
+def hipcc():
+    for c in (shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
+        if c and os.path.exists(c):
+            return c
+    raise RuntimeError("hipcc not found: librsgpu cannot be built (there is no CPU fallback)")
+
+
+def _stale(target, deps):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build(force=False, verbose=False):
+    cc = hipcc()
+    objdir = os.path.join(HERE, "build")
+    os.makedirs(objdir, exist_ok=True)
+    headers = [os.path.join(CSRC, "common.h"), os.path.join(HERE, "..", "include", "rsgpu.h"), __file__]
+    objs = []
+    rebuilt = False
+    for src, extra in SOURCES:
+        path = os.path.join(CSRC, src)
+        obj = os.path.join(objdir, src + ".o")
+        objs.append(obj)
+        if force or _stale(obj, [path] + headers):
+            lang = ["-x", "hip"] if src.endswith(".hip") else []
+            cmd = [cc] + COMMON + extra + lang + ["-c", path, "-o", obj]
+            if verbose:
+                print(" ".join(cmd), flush=True)
+            subprocess.check_call(cmd)
+            rebuilt = True
+    if rebuilt or not os.path.exists(OUT):
+        cmd = [cc, "-shared", "-fPIC", f"--offload-arch={ARCH}", "-o", OUT] + objs + ["-ldl"]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.check_call(cmd)
+    return OUT
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, verbose=True))

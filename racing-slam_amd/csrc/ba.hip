@@ -1,0 +1,1014 @@
+// ba.hip — K5..K9: local-window bundle adjustment (Levenberg-Marquardt with
+// point-block Schur elimination) and pose-only refinement, all in f64, with
+// the whole LM schedule resident on the device (no host round trip until the
+// summary is read).
+//
+// Replaces optimization::bundle_adjust / refine_pose's ceres::Solve
+// (reference src/Optimization.cpp:21-72,127-142,194-267,269-374).  The Ceres
+// trust-region schedule restated here is documented in oracle/ba.c and
+// SURVEY.md §8 a11; this file works in UNSCALED parameters, which is
+// algebraically identical to Ceres' Jacobi-scaled solve:
+//     (H + Lambda) delta = -g,   Lambda_i = clamp(s_i^2 H_ii, 1e-6, 1e32) / (radius s_i^2),
+//     s_i = 1 / (1 + sqrt(H_ii at the first linearisation)),
+//     model_cost_change = 1/2 (delta' Lambda delta - delta' g).
+//
+// Kernel chain per LM iteration (all launches unconditional; each kernel
+// returns at once when state.done is set):
+//   K5 ba_linearize_schur  one lane per landmark: analytic Jacobians (left
+//                          Jacobian of SO(3), Jacobians never stored), Huber
+//                          weights, V/gp, U/gc (LDS-reduced), damped V^-1,
+//                          Schur products into S and the reduced rhs
+//   [RCCL all-reduce of the accumulators when landmark-sharded]
+//   K7 ba_reduced_solve    one workgroup: S = U + Lambda_c - sum Y W', dense
+//                          Cholesky in LDS, delta_c, candidate cameras
+//   K8 ba_backsub_cost     one lane per landmark: delta_p, candidate points,
+//                          model-cost terms, robust cost at the candidate
+//   [RCCL all-reduce of 4 scalars]
+//   K9 ba_decide           accept / reject, radius update, termination tests
+#include <math.h>
+
+#include "common.h"
+
+#define BA_PREP 24            // doubles per camera: R[9] Jl[9] c[3] small pad pad
+#define BA_THREADS 64
+#define BA_MAX_LDS_N 128      // largest reduced system kept in LDS by K7
+
+struct BaState {
+    double radius, decrease_factor, x_cost, initial_cost;
+    double cam_scal[4];       // K7: mcc_c, step_sq_c, x_sq_c, unused
+    int iter, successful, invalid_steps, done;
+    int termination, cur, have_scale, solver_failed;
+    int fresh, usable, pad0, pad1;
+};
+
+struct BaDims {
+    int C, Cf, P, M, n;       // n = 6*Cf
+    float fx, fy, cx, cy;
+    double huber_a;
+};
+
+struct BaBufs {
+    const int32_t* obs_ptr;   // [P+1]
+    const int32_t* obs_cam;   // [M]
+    const float2* obs_uv;     // [M]
+    double* Xc;      // [2][C][6]
+    double* Xp;      // [2][P][3]
+    double* prep;    // [2][C][BA_PREP]
+    int32_t* slot;   // [C]  reduced-system slot of a free camera or -1
+    double* sc;      // [n]
+    double* sp;      // [P][3]
+    double* Vinv;    // [P][6]  (xx xy xz yy yz zz)
+    double* gp;      // [P][3]
+    double* lamp;    // [P][3]
+    // accumulators, contiguous for one all-reduce: S[n*n] rhs[n] U[Cf*36] gc[n] scal[2]
+    double* acc;
+    size_t acc_count;
+    double* S; double* rhs; double* U; double* gc; double* scal;   // scal: cost_x, fail_count
+    double* gmax;    // [1] bits of a non-negative double (max all-reduce)
+    double* pt_scal; // [4] K8: cand_cost, mcc_p, step_sq_p, x_sq_p
+    double* dc;      // [n]
+    BaState* st;
+};
+
+struct BaOpt {
+    int max_iter, max_invalid, jacobi;
+    double r0, rmax, rmin, min_rel, dmin, dmax, ftol, gtol, ptol;
+};
+
+// ----------------------------------------------------------------- device math
+__device__ __forceinline__ void cam_prepare(const double* cam, double* out)
+{
+    const double ax = cam[0], ay = cam[1], az = cam[2];
+    const double th2 = ax * ax + ay * ay + az * az;
+    double A, B, Cc, small;
+    if (th2 > 2.220446049250313e-16) {
+        const double th = sqrt(th2);
+        const double sh = sin(0.5 * th);
+        A = sin(th) / th;
+        B = 2.0 * sh * sh / th2;
+        Cc = (th - sin(th)) / (th2 * th);
+        small = 0.0;
+    } else {   // ceres::AngleAxisRotatePoint's first-order branch: R = I + [w]x, d/dw = -[q]x
+        A = 1.0; B = 0.0; Cc = 0.0; small = 1.0;
+    }
+    const double W[9] = {0, -az, ay, az, 0, -ax, -ay, ax, 0};
+    const double W2[9] = {-(ay * ay + az * az), ax * ay, ax * az, ax * ay, -(ax * ax + az * az), ay * az,
+                          ax * az, ay * az, -(ax * ax + ay * ay)};
+#pragma unroll
+    for (int i = 0; i < 9; i++) {
+        const double id = (i == 0 || i == 4 || i == 8) ? 1.0 : 0.0;
+        out[i] = id + A * W[i] + B * W2[i];          // R
+        out[9 + i] = id + B * W[i] + Cc * W2[i];     // left Jacobian of SO(3)
+    }
+    out[18] = cam[3]; out[19] = cam[4]; out[20] = cam[5];
+    out[21] = small; out[22] = 0.0; out[23] = 0.0;
+}
+
+struct ObsLin {
+    double r0, r1, w, rho;
+    double jc[12];   // 2x6  [d/d aa | d/d centre]
+    double jp[6];    // 2x3
+};
+
+template <bool JAC>
+__device__ __forceinline__ void obs_eval(const double* __restrict__ cp, const double X[3], float2 uv,
+                                         const BaDims& d, ObsLin& o)
+{
+    const double q0 = X[0] - cp[18], q1 = X[1] - cp[19], q2 = X[2] - cp[20];
+    const double p0 = cp[0] * q0 + cp[1] * q1 + cp[2] * q2;
+    const double p1 = cp[3] * q0 + cp[4] * q1 + cp[5] * q2;
+    const double p2 = cp[6] * q0 + cp[7] * q1 + cp[8] * q2;
+    const double fx = (double)d.fx, fy = (double)d.fy;
+    o.r0 = fx * p0 / p2 + (double)d.cx - (double)uv.x;     // src/Optimization.cpp:48-49
+    o.r1 = fy * p1 / p2 + (double)d.cy - (double)uv.y;
+    const double s = o.r0 * o.r0 + o.r1 * o.r1;
+    const double b2 = d.huber_a * d.huber_a;
+    if (s > b2) {   // ceres::HuberLoss
+        const double r = sqrt(s);
+        o.rho = 2.0 * d.huber_a * r - b2;
+        o.w = d.huber_a / r;
+    } else {
+        o.rho = s;
+        o.w = 1.0;
+    }
+    if (JAC) {
+        const double iz = 1.0 / p2;
+        const double a = fx * iz, b = fy * iz;
+        const double ax = -a * p0 * iz, bx = -b * p1 * iz;
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+            o.jp[k] = a * cp[k] + ax * cp[6 + k];
+            o.jp[3 + k] = b * cp[3 + k] + bx * cp[6 + k];
+            o.jc[3 + k] = -o.jp[k];
+            o.jc[9 + k] = -o.jp[3 + k];
+        }
+        const bool small = cp[21] != 0.0;
+        const double v0 = small ? q0 : p0, v1 = small ? q1 : p1, v2 = small ? q2 : p2;
+#pragma unroll
+        for (int k = 0; k < 3; k++) {   // d p / d aa_k = Jl[:,k] x v
+            const double m0 = cp[9 + k], m1 = cp[12 + k], m2 = cp[15 + k];
+            const double c0 = m1 * v2 - m2 * v1, c1 = m2 * v0 - m0 * v2, c2 = m0 * v1 - m1 * v0;
+            o.jc[k] = a * c0 + ax * c2;
+            o.jc[6 + k] = b * c1 + bx * c2;
+        }
+    }
+}
+
+__device__ __forceinline__ double wave_sum(double v)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    return v;
+}
+
+// symmetric 3x3 inverse through Cholesky (InvertPSDMatrix<3>); false if not PD
+__device__ __forceinline__ bool inv3_psd(const double V[6], double I[6])
+{
+    const double l00s = V[0];
+    if (!(l00s > 0.0)) return false;
+    const double l00 = sqrt(l00s);
+    const double l10 = V[1] / l00, l20 = V[2] / l00;
+    const double l11s = V[3] - l10 * l10;
+    if (!(l11s > 0.0)) return false;
+    const double l11 = sqrt(l11s);
+    const double l21 = (V[4] - l20 * l10) / l11;
+    const double l22s = V[5] - l20 * l20 - l21 * l21;
+    if (!(l22s > 0.0)) return false;
+    const double l22 = sqrt(l22s);
+    const double i00 = 1.0 / l00, i11 = 1.0 / l11, i22 = 1.0 / l22;
+    const double i10 = -l10 * i00 * i11;
+    const double i21 = -l21 * i11 * i22;
+    const double i20 = -(l20 * i00 + l21 * i10) * i22;
+    I[0] = i00 * i00 + i10 * i10 + i20 * i20;
+    I[1] = i10 * i11 + i20 * i21;
+    I[2] = i20 * i22;
+    I[3] = i11 * i11 + i21 * i21;
+    I[4] = i21 * i22;
+    I[5] = i22 * i22;
+    return isfinite(I[0]) && isfinite(I[3]) && isfinite(I[5]);
+}
+
+__device__ __forceinline__ void atomic_max_nonneg(double* addr, double v)
+{
+    atomicMax((unsigned long long*)addr, (unsigned long long)__double_as_longlong(v));
+}
+
+__device__ __forceinline__ double clampd(double v, double lo, double hi) { return fmin(fmax(v, lo), hi); }
+
+// ---------------------------------------------------------------------- K0
+__global__ void ba_init(BaDims d, BaBufs b, BaOpt opt, const double* __restrict__ cams_in,
+                        const double* __restrict__ pts_in)
+{
+    const int tid = blockIdx.x * blockDim.x + threadIdx.x, nth = gridDim.x * blockDim.x;
+    for (int i = tid; i < d.C * 6; i += nth) { b.Xc[i] = cams_in[i]; b.Xc[d.C * 6 + i] = cams_in[i]; }
+    for (int i = tid; i < d.P * 3; i += nth) b.Xp[i] = pts_in[i];
+    for (int c = tid; c < d.C; c += nth) cam_prepare(cams_in + 6 * c, b.prep + (size_t)c * BA_PREP);
+    for (size_t i = tid; i < b.acc_count; i += nth) b.acc[i] = 0.0;
+    if (tid < 4) b.pt_scal[tid] = 0.0;
+    if (tid == 0) {
+        *b.gmax = 0.0;
+        BaState s;
+        s.radius = opt.r0; s.decrease_factor = 2.0; s.x_cost = 0.0; s.initial_cost = 0.0;
+        s.cam_scal[0] = s.cam_scal[1] = s.cam_scal[2] = s.cam_scal[3] = 0.0;
+        s.iter = 0; s.successful = 0; s.invalid_steps = 0; s.done = 0;
+        s.termination = 0; s.cur = 0; s.have_scale = 0; s.solver_failed = 0;
+        s.fresh = 1; s.usable = 0; s.pad0 = 0; s.pad1 = 0;
+        *b.st = s;
+    }
+}
+
+// ---------------------------------------------------------------------- K5
+__global__ __launch_bounds__(BA_THREADS) void ba_linearize_schur(BaDims d, BaBufs b, BaOpt opt)
+{
+    extern __shared__ __attribute__((aligned(16))) double lds[];   // [Cf][42]: U(36) gc(6)
+    const BaState st = *b.st;
+    if (st.done) return;
+    const int nlds = d.Cf * 42;
+    for (int i = threadIdx.x; i < nlds; i += blockDim.x) lds[i] = 0.0;
+    __syncthreads();
+
+    const double* prep = b.prep + (size_t)st.cur * d.C * BA_PREP;
+    const double* Xp = b.Xp + (size_t)st.cur * d.P * 3;
+    double cost = 0.0, gmax = 0.0, fail = 0.0;
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p < d.P) {
+        const double X[3] = {Xp[3 * (size_t)p], Xp[3 * (size_t)p + 1], Xp[3 * (size_t)p + 2]};
+        const int o0 = b.obs_ptr[p], o1 = b.obs_ptr[p + 1];
+        double V[6] = {0, 0, 0, 0, 0, 0}, g[3] = {0, 0, 0};
+        ObsLin o;
+        for (int oi = o0; oi < o1; oi++) {
+            const int c = b.obs_cam[oi];
+            obs_eval<true>(prep + (size_t)c * BA_PREP, X, b.obs_uv[oi], d, o);
+            cost += 0.5 * o.rho;
+            const double w = o.w;
+            V[0] += w * (o.jp[0] * o.jp[0] + o.jp[3] * o.jp[3]);
+            V[1] += w * (o.jp[0] * o.jp[1] + o.jp[3] * o.jp[4]);
+            V[2] += w * (o.jp[0] * o.jp[2] + o.jp[3] * o.jp[5]);
+            V[3] += w * (o.jp[1] * o.jp[1] + o.jp[4] * o.jp[4]);
+            V[4] += w * (o.jp[1] * o.jp[2] + o.jp[4] * o.jp[5]);
+            V[5] += w * (o.jp[2] * o.jp[2] + o.jp[5] * o.jp[5]);
+#pragma unroll
+            for (int k = 0; k < 3; k++) g[k] += w * (o.jp[k] * o.r0 + o.jp[3 + k] * o.r1);
+            const int s = b.slot[c];
+            if (s >= 0) {
+                double* u = lds + s * 42;
+#pragma unroll
+                for (int a = 0; a < 6; a++) {
+#pragma unroll
+                    for (int e = a; e < 6; e++) atomicAdd(&u[a * 6 + e], w * (o.jc[a] * o.jc[e] + o.jc[6 + a] * o.jc[6 + e]));
+                    atomicAdd(&u[36 + a], w * (o.jc[a] * o.r0 + o.jc[6 + a] * o.r1));
+                }
+            }
+        }
+        gmax = fmax(fabs(g[0]), fmax(fabs(g[1]), fabs(g[2])));
+        // Jacobi scaling (first linearisation) and LM damping of the point block
+        double sp[3], lam[3];
+        const double Vd[3] = {V[0], V[3], V[5]};
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+            if (!st.have_scale) {
+                sp[k] = opt.jacobi ? 1.0 / (1.0 + sqrt(Vd[k])) : 1.0;
+                b.sp[3 * (size_t)p + k] = sp[k];
+            } else {
+                sp[k] = b.sp[3 * (size_t)p + k];
+            }
+            const double s2 = sp[k] * sp[k];
+            lam[k] = clampd(s2 * Vd[k], opt.dmin, opt.dmax) / (st.radius * s2);
+            b.lamp[3 * (size_t)p + k] = lam[k];
+            b.gp[3 * (size_t)p + k] = g[k];
+        }
+        double Vdm[6] = {V[0] + lam[0], V[1], V[2], V[3] + lam[1], V[4], V[5] + lam[2]}, I[6];
+        const bool ok = inv3_psd(Vdm, I);
+        if (!ok) { fail = 1.0; I[0] = I[1] = I[2] = I[3] = I[4] = I[5] = 0.0; }
+#pragma unroll
+        for (int k = 0; k < 6; k++) b.Vinv[6 * (size_t)p + k] = I[k];
+        // Schur products: S[si,sj] -= Y_i W_j^T, rhs[si] -= Y_i g,  Y_i = W_i V^-1, W_i = w Jc_i^T Jp_i
+        if (ok) {
+            for (int oi = o0; oi < o1; oi++) {
+                const int ci = b.obs_cam[oi];
+                const int si = b.slot[ci];
+                if (si < 0) continue;
+                obs_eval<true>(prep + (size_t)ci * BA_PREP, X, b.obs_uv[oi], d, o);
+                double Y[18];
+#pragma unroll
+                for (int a = 0; a < 6; a++) {
+                    const double w0 = o.w * (o.jc[a] * o.jp[0] + o.jc[6 + a] * o.jp[3]);
+                    const double w1 = o.w * (o.jc[a] * o.jp[1] + o.jc[6 + a] * o.jp[4]);
+                    const double w2 = o.w * (o.jc[a] * o.jp[2] + o.jc[6 + a] * o.jp[5]);
+                    Y[a * 3 + 0] = w0 * I[0] + w1 * I[1] + w2 * I[2];
+                    Y[a * 3 + 1] = w0 * I[1] + w1 * I[3] + w2 * I[4];
+                    Y[a * 3 + 2] = w0 * I[2] + w1 * I[4] + w2 * I[5];
+                    atomicAdd(&b.rhs[6 * si + a], -(Y[a * 3] * g[0] + Y[a * 3 + 1] * g[1] + Y[a * 3 + 2] * g[2]));
+                }
+                ObsLin oj;
+                for (int ojx = o0; ojx < o1; ojx++) {
+                    const int cj = b.obs_cam[ojx];
+                    const int sj = b.slot[cj];
+                    if (sj < 0) continue;
+                    obs_eval<true>(prep + (size_t)cj * BA_PREP, X, b.obs_uv[ojx], d, oj);
+                    double* Sblk = b.S + (size_t)(6 * si) * d.n + 6 * sj;
+#pragma unroll
+                    for (int e = 0; e < 6; e++) {
+                        const double w0 = oj.w * (oj.jc[e] * oj.jp[0] + oj.jc[6 + e] * oj.jp[3]);
+                        const double w1 = oj.w * (oj.jc[e] * oj.jp[1] + oj.jc[6 + e] * oj.jp[4]);
+                        const double w2 = oj.w * (oj.jc[e] * oj.jp[2] + oj.jc[6 + e] * oj.jp[5]);
+#pragma unroll
+                        for (int a = 0; a < 6; a++)
+                            atomicAdd(&Sblk[(size_t)a * d.n + e], -(Y[a * 3] * w0 + Y[a * 3 + 1] * w1 + Y[a * 3 + 2] * w2));
+                    }
+                }
+            }
+        }
+    }
+    // block reductions
+    cost = wave_sum(cost);
+    fail = wave_sum(fail);
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) gmax = fmax(gmax, __shfl_down(gmax, off, 64));
+    if ((threadIdx.x & 63) == 0) {
+        atomicAdd(&b.scal[0], cost);
+        if (fail > 0.0) atomicAdd(&b.scal[1], fail);
+        atomic_max_nonneg(b.gmax, gmax);
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < nlds; i += blockDim.x) {
+        const int s = i / 42, k = i % 42;
+        const double v = lds[i];
+        if (v != 0.0) {
+            if (k < 36) atomicAdd(&b.U[s * 36 + k], v);
+            else atomicAdd(&b.gc[6 * s + (k - 36)], v);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------- K7
+// Single workgroup.  S lives in LDS when n <= BA_MAX_LDS_N, otherwise in place
+// in the global accumulator.
+__global__ __launch_bounds__(256) void ba_reduced_solve(BaDims d, BaBufs b, BaOpt opt, int use_lds)
+{
+    extern __shared__ __attribute__((aligned(16))) double sm[];
+    const int n = d.n, tid = threadIdx.x, nt = blockDim.x;
+    __shared__ BaState st;
+    __shared__ int s_fail;
+    __shared__ double red[8];
+    if (tid == 0) { st = *b.st; s_fail = 0; }
+    __syncthreads();
+    if (st.done) return;
+    double* S = use_lds ? sm : b.S;
+    double* y = use_lds ? sm + (size_t)n * n : b.dc;    // rhs / solution vector
+    double* lam = use_lds ? y + n : b.rhs;               // camera damping (rhs buffer is free once y is formed)
+
+    // (1) fresh linearisation: cost at x, Jacobi scaling of the camera blocks, gradient test
+    if (st.fresh) {
+        if (tid == 0) {
+            st.x_cost = b.scal[0];
+            if (st.iter == 0) st.initial_cost = st.x_cost;
+        }
+        if (!st.have_scale)
+            for (int i = tid; i < n; i += nt) {
+                const double h = b.U[(i / 6) * 36 + (i % 6) * 7];
+                b.sc[i] = opt.jacobi ? 1.0 / (1.0 + sqrt(h)) : 1.0;
+            }
+        double gm = 0.0;
+        for (int i = tid; i < n; i += nt) gm = fmax(gm, fabs(b.gc[i]));
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) gm = fmax(gm, __shfl_down(gm, off, 64));
+        if ((tid & 63) == 0) red[tid >> 6] = gm;
+        __syncthreads();
+        if (tid == 0) {
+            double g = __longlong_as_double((long long)*(unsigned long long*)b.gmax);
+            for (int w = 0; w < (nt + 63) / 64; w++) g = fmax(g, red[w]);
+            if (!isfinite(st.x_cost)) { st.done = 1; st.termination = RS_BA_FAILURE; }
+            else if (g <= opt.gtol) { st.done = 1; st.termination = RS_BA_CONVERGENCE_GRADIENT; }
+        }
+        __syncthreads();
+        if (st.done) { if (tid == 0) *b.st = st; return; }
+    }
+    __syncthreads();
+
+    // (2) assemble S = U + Lambda_c + (-sum Y W^T), y = gc + (-sum Y g)
+    const double radius = st.radius;
+    for (int i = tid; i < n; i += nt) {
+        const double h = b.U[(i / 6) * 36 + (i % 6) * 7];
+        const double s2 = b.sc[i] * b.sc[i];
+        const double l = clampd(s2 * h, opt.dmin, opt.dmax) / (radius * s2);
+        const double yy = b.gc[i] + b.rhs[i];   // lam may alias rhs (global path): same thread, same index
+        lam[i] = l;
+        y[i] = yy;
+    }
+    __syncthreads();
+    for (int idx = tid; idx < n * n; idx += nt) {
+        const int i = idx / n, j = idx % n;
+        double v = b.S[idx];
+        if (i / 6 == j / 6) {
+            const int a = i % 6, e = j % 6;
+            v += (a <= e) ? b.U[(i / 6) * 36 + a * 6 + e] : b.U[(i / 6) * 36 + e * 6 + a];
+            if (i == j) v += lam[i];
+        }
+        S[idx] = v;
+    }
+    __syncthreads();
+
+    // (3) dense Cholesky S = L L^T (left-looking, column j by thread-per-row)
+    for (int j = 0; j < n; j++) {
+        for (int i = j + tid; i < n; i += nt) {
+            double acc = S[(size_t)i * n + j];
+            for (int k = 0; k < j; k++) acc -= S[(size_t)i * n + k] * S[(size_t)j * n + k];
+            S[(size_t)i * n + j] = acc;   // unscaled column
+        }
+        __syncthreads();
+        const double dj = S[(size_t)j * n + j];
+        if (!(dj > 0.0) || !isfinite(dj)) { if (tid == 0) s_fail = 1; }
+        const double inv = 1.0 / sqrt(dj);
+        __syncthreads();
+        for (int i = j + tid; i < n; i += nt) S[(size_t)i * n + j] = (i == j) ? sqrt(dj) : S[(size_t)i * n + j] * inv;
+        __syncthreads();
+    }
+    if (b.scal[1] > 0.0 && tid == 0) s_fail = 1;
+    __syncthreads();
+    if (s_fail) {
+        if (tid == 0) { st.solver_failed = 1; *b.st = st; }
+        return;
+    }
+    // (4) forward / backward substitution, column oriented
+    for (int j = 0; j < n; j++) {
+        if (tid == 0) y[j] = y[j] / S[(size_t)j * n + j];
+        __syncthreads();
+        const double yj = y[j];
+        for (int i = j + 1 + tid; i < n; i += nt) y[i] -= S[(size_t)i * n + j] * yj;
+        __syncthreads();
+    }
+    for (int j = n - 1; j >= 0; j--) {
+        if (tid == 0) y[j] = y[j] / S[(size_t)j * n + j];
+        __syncthreads();
+        const double yj = y[j];
+        for (int i = tid; i < j; i += nt) y[i] -= S[(size_t)j * n + i] * yj;
+        __syncthreads();
+    }
+    // (5) delta_c = -y, candidate cameras, camera part of the scalars
+    double mcc = 0.0, ssq = 0.0, xsq = 0.0;
+    bool bad = false;
+    const double* Xc = b.Xc + (size_t)st.cur * d.C * 6;
+    double* Xn = b.Xc + (size_t)(st.cur ^ 1) * d.C * 6;
+    for (int c = tid; c < d.C; c += nt) {
+        const int s = b.slot[c];
+        bool active = false;
+        if (s >= 0)
+            for (int k = 0; k < 6; k++) active = active || b.U[s * 36 + k * 7] > 0.0;
+        for (int k = 0; k < 6; k++) {
+            const double x = Xc[6 * c + k];
+            double dlt = 0.0;
+            if (s >= 0) {
+                dlt = -y[6 * s + k];
+                if (!isfinite(dlt)) bad = true;
+                mcc += 0.5 * (dlt * dlt * lam[6 * s + k] - dlt * b.gc[6 * s + k]);
+                const double xn = x + dlt;
+                if (active) { ssq += (x - xn) * (x - xn); xsq += x * x; }
+                Xn[6 * c + k] = xn;
+            } else {
+                Xn[6 * c + k] = x;
+            }
+        }
+        cam_prepare(Xn + 6 * c, b.prep + ((size_t)(st.cur ^ 1) * d.C + c) * BA_PREP);
+    }
+    __syncthreads();   // all reads of y done before dc (may alias y) is rewritten
+    for (int i = tid; i < n; i += nt) { const double v = -y[i]; b.dc[i] = v; }   // dc may alias y: same index
+    mcc = wave_sum(mcc); ssq = wave_sum(ssq); xsq = wave_sum(xsq);
+    if (__any(bad) && (tid & 63) == 0) s_fail = 1;
+    __syncthreads();
+    __shared__ double red3[4][3];
+    if ((tid & 63) == 0) { red3[tid >> 6][0] = mcc; red3[tid >> 6][1] = ssq; red3[tid >> 6][2] = xsq; }
+    __syncthreads();
+    if (tid == 0) {
+        double a0 = 0, a1 = 0, a2 = 0;
+        for (int w = 0; w < (nt + 63) / 64; w++) { a0 += red3[w][0]; a1 += red3[w][1]; a2 += red3[w][2]; }
+        st.cam_scal[0] = a0; st.cam_scal[1] = a1; st.cam_scal[2] = a2;
+        st.solver_failed = s_fail;
+        *b.st = st;
+    }
+}
+
+// ---------------------------------------------------------------------- K8
+__global__ __launch_bounds__(BA_THREADS) void ba_backsub_cost(BaDims d, BaBufs b)
+{
+    const BaState st = *b.st;
+    if (st.done || st.solver_failed) return;
+    const double* prep = b.prep + (size_t)st.cur * d.C * BA_PREP;
+    const double* prepn = b.prep + (size_t)(st.cur ^ 1) * d.C * BA_PREP;
+    const double* Xp = b.Xp + (size_t)st.cur * d.P * 3;
+    double* Xn = b.Xp + (size_t)(st.cur ^ 1) * d.P * 3;
+    double cost = 0.0, mcc = 0.0, ssq = 0.0, xsq = 0.0;
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p < d.P) {
+        const double X[3] = {Xp[3 * (size_t)p], Xp[3 * (size_t)p + 1], Xp[3 * (size_t)p + 2]};
+        const int o0 = b.obs_ptr[p], o1 = b.obs_ptr[p + 1];
+        double t[3] = {b.gp[3 * (size_t)p], b.gp[3 * (size_t)p + 1], b.gp[3 * (size_t)p + 2]};
+        const double g[3] = {t[0], t[1], t[2]};
+        ObsLin o;
+        for (int oi = o0; oi < o1; oi++) {
+            const int c = b.obs_cam[oi];
+            const int s = b.slot[c];
+            if (s < 0) continue;
+            obs_eval<true>(prep + (size_t)c * BA_PREP, X, b.obs_uv[oi], d, o);
+            double m0 = 0.0, m1 = 0.0;
+#pragma unroll
+            for (int a = 0; a < 6; a++) { const double dc = b.dc[6 * s + a]; m0 += o.jc[a] * dc; m1 += o.jc[6 + a] * dc; }
+#pragma unroll
+            for (int k = 0; k < 3; k++) t[k] += o.w * (o.jp[k] * m0 + o.jp[3 + k] * m1);   // W_i^T delta_c
+        }
+        const double* I = b.Vinv + 6 * (size_t)p;
+        const double dp[3] = {-(I[0] * t[0] + I[1] * t[1] + I[2] * t[2]), -(I[1] * t[0] + I[3] * t[1] + I[4] * t[2]),
+                              -(I[2] * t[0] + I[4] * t[1] + I[5] * t[2])};
+        double Xc[3];
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+            Xc[k] = X[k] + dp[k];
+            Xn[3 * (size_t)p + k] = Xc[k];
+            mcc += 0.5 * (dp[k] * dp[k] * b.lamp[3 * (size_t)p + k] - dp[k] * g[k]);
+            ssq += (X[k] - Xc[k]) * (X[k] - Xc[k]);
+            xsq += X[k] * X[k];
+        }
+        for (int oi = o0; oi < o1; oi++) {
+            obs_eval<false>(prepn + (size_t)b.obs_cam[oi] * BA_PREP, Xc, b.obs_uv[oi], d, o);
+            cost += 0.5 * o.rho;
+        }
+    }
+    cost = wave_sum(cost); mcc = wave_sum(mcc); ssq = wave_sum(ssq); xsq = wave_sum(xsq);
+    if ((threadIdx.x & 63) == 0) {
+        atomicAdd(&b.pt_scal[0], cost);
+        atomicAdd(&b.pt_scal[1], mcc);
+        atomicAdd(&b.pt_scal[2], ssq);
+        atomicAdd(&b.pt_scal[3], xsq);
+    }
+}
+
+// ---------------------------------------------------------------------- K9
+__global__ __launch_bounds__(256) void ba_decide(BaDims d, BaBufs b, BaOpt opt)
+{
+    __shared__ int was_done;
+    if (threadIdx.x == 0) {
+        BaState st = *b.st;
+        was_done = st.done;
+        if (!st.done) {
+            st.iter++;
+            const double cand = b.pt_scal[0];
+            const double mcc = b.pt_scal[1] + st.cam_scal[0];
+            const double step_norm = sqrt(b.pt_scal[2] + st.cam_scal[1]);
+            const double x_norm = sqrt(b.pt_scal[3] + st.cam_scal[2]);
+            st.fresh = 0;
+            if (st.solver_failed || !(mcc > 0.0)) {
+                // TrustRegionMinimizer::HandleInvalidStep
+                if (++st.invalid_steps >= opt.max_invalid) { st.done = 1; st.termination = RS_BA_FAILURE; }
+                else { st.radius /= st.decrease_factor; st.decrease_factor *= 2.0; }
+            } else {
+                st.invalid_steps = 0;
+                if (step_norm <= opt.ptol * (x_norm + opt.ptol)) { st.done = 1; st.termination = RS_BA_CONVERGENCE_PARAMETER; }
+                else if (fabs(st.x_cost - cand) <= opt.ftol * st.x_cost) { st.done = 1; st.termination = RS_BA_CONVERGENCE_FUNCTION; }
+                else {
+                    const double rel = (st.x_cost - cand) / mcc;
+                    if (rel > opt.min_rel && isfinite(cand)) {
+                        st.cur ^= 1;
+                        st.successful++;
+                        const double t = 2.0 * rel - 1.0;
+                        st.radius = st.radius / fmax(1.0 / 3.0, 1.0 - t * t * t);
+                        st.radius = fmin(opt.rmax, st.radius);
+                        st.decrease_factor = 2.0;
+                        st.fresh = 1;
+                        st.x_cost = cand;   // replaced by K5's evaluation at the new point
+                    } else {
+                        st.radius /= st.decrease_factor;
+                        st.decrease_factor *= 2.0;
+                        if (st.radius < opt.rmin) { st.done = 1; st.termination = RS_BA_CONVERGENCE_RADIUS; }
+                    }
+                }
+            }
+            st.solver_failed = 0;
+            st.have_scale = 1;
+            if (!st.done && st.iter >= opt.max_iter) { st.done = 1; st.termination = RS_BA_NO_CONVERGENCE; }
+            *b.st = st;
+        }
+    }
+    __syncthreads();
+    if (was_done) return;
+    // reset the accumulators for the next linearisation
+    const int tid = blockIdx.x * blockDim.x + threadIdx.x, nth = gridDim.x * blockDim.x;
+    for (size_t i = tid; i < b.acc_count; i += nth) b.acc[i] = 0.0;
+    if (tid < 4) b.pt_scal[tid] = 0.0;
+    if (tid == 0) *b.gmax = 0.0;
+}
+
+// -------------------------------------------------------------------- finalize
+__global__ void ba_finalize(BaDims d, BaBufs b, double* __restrict__ cams_out, const uint8_t* __restrict__ cam_free,
+                            double* __restrict__ pts_out)
+{
+    __shared__ int usable, cur;
+    if (threadIdx.x == 0) {
+        BaState st = *b.st;
+        // after a successful step the cost at the new point is K5's value if it ran, else the candidate cost
+        const bool ok = st.termination != RS_BA_FAILURE && isfinite(st.x_cost) && st.x_cost <= st.initial_cost;
+        usable = ok ? 1 : 0;
+        cur = st.cur;
+        if (blockIdx.x == 0) { st.usable = usable; *b.st = st; }
+    }
+    __syncthreads();
+    if (!usable) return;
+    const int tid = blockIdx.x * blockDim.x + threadIdx.x, nth = gridDim.x * blockDim.x;
+    const double* Xc = b.Xc + (size_t)cur * d.C * 6;
+    const double* Xp = b.Xp + (size_t)cur * d.P * 3;
+    for (int i = tid; i < d.C * 6; i += nth)
+        if (cam_free[i / 6]) cams_out[i] = Xc[i];
+    for (int i = tid; i < d.P * 3; i += nth) pts_out[i] = Xp[i];
+}
+
+// ------------------------------------------------------------------ host side
+extern "C" void rs_ba_default_options(rs_ba_options* o)
+{
+    if (!o) return;
+    o->max_num_iterations = 10;
+    o->huber_delta = sqrt(5.991);
+    o->initial_trust_region_radius = 1e4;
+    o->max_trust_region_radius = 1e16;
+    o->min_trust_region_radius = 1e-32;
+    o->min_relative_decrease = 1e-3;
+    o->min_lm_diagonal = 1e-6;
+    o->max_lm_diagonal = 1e32;
+    o->function_tolerance = 1e-6;
+    o->gradient_tolerance = 1e-10;
+    o->parameter_tolerance = 1e-8;
+    o->max_num_consecutive_invalid_steps = 5;
+    o->jacobi_scaling = 1;
+}
+
+void rs_ba_cache_free(rs_context* ctx) { (void)ctx; }
+
+static size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+extern "C" int rs_bundle_adjust(rs_context* ctx, int n_cameras, int n_points, int n_obs, double* d_cameras,
+                                const uint8_t* h_cam_free, double* d_points, const int32_t* d_obs_ptr,
+                                const int32_t* d_obs_cam, const float* d_obs_uv, const float h_intrinsics[4],
+                                const rs_ba_options* options, rs_ba_summary* h_summary)
+{
+    if (!ctx || !h_summary) return RS_ERR_INVALID;
+    memset(h_summary, 0, sizeof *h_summary);
+    if (n_cameras < 0 || n_points < 0 || n_obs < 0) return rs_fail(ctx, RS_ERR_INVALID, "negative size");
+    if (n_cameras == 0 || n_points == 0 || n_obs == 0) {   // nothing to optimise
+        if (ctx->n_ranks > 1) return rs_fail(ctx, RS_ERR_UNSUPPORTED, "empty shard in a multi-rank solve");
+        h_summary->usable = 0;
+        h_summary->termination = RS_BA_FAILURE;
+        return RS_OK;
+    }
+    if (!d_cameras || !h_cam_free || !d_points || !d_obs_ptr || !d_obs_cam || !d_obs_uv || !h_intrinsics)
+        return rs_fail(ctx, RS_ERR_INVALID, "null pointer");
+    rs_ba_options def;
+    if (!options) { rs_ba_default_options(&def); options = &def; }
+    RS_HIP(ctx, hipSetDevice(ctx->device));
+
+    BaDims d;
+    d.C = n_cameras; d.P = n_points; d.M = n_obs;
+    std::vector<int32_t> slot(n_cameras);
+    d.Cf = 0;
+    for (int c = 0; c < n_cameras; c++) slot[c] = h_cam_free[c] ? d.Cf++ : -1;
+    d.n = 6 * d.Cf;
+    d.fx = h_intrinsics[0]; d.fy = h_intrinsics[1]; d.cx = h_intrinsics[2]; d.cy = h_intrinsics[3];
+    d.huber_a = options->huber_delta;
+    BaOpt opt;
+    opt.max_iter = options->max_num_iterations; opt.max_invalid = options->max_num_consecutive_invalid_steps;
+    opt.jacobi = options->jacobi_scaling; opt.r0 = options->initial_trust_region_radius;
+    opt.rmax = options->max_trust_region_radius; opt.rmin = options->min_trust_region_radius;
+    opt.min_rel = options->min_relative_decrease; opt.dmin = options->min_lm_diagonal;
+    opt.dmax = options->max_lm_diagonal; opt.ftol = options->function_tolerance;
+    opt.gtol = options->gradient_tolerance; opt.ptol = options->parameter_tolerance;
+    if (opt.max_iter < 0 || opt.max_iter > 1000) return rs_fail(ctx, RS_ERR_INVALID, "max_num_iterations out of range");
+    if (d.Cf * 42 * sizeof(double) > 60 * 1024) return rs_fail(ctx, RS_ERR_UNSUPPORTED, "more than 182 free cameras");
+
+    // workspace carve (all offsets multiples of 256 B)
+    const size_t n = (size_t)d.n, C = (size_t)d.C, P = (size_t)d.P;
+    size_t off = 0;
+    auto carve = [&](size_t bytes) { size_t o = off; off += align_up(bytes, 256); return o; };
+    const size_t o_Xc = carve(sizeof(double) * 2 * C * 6), o_Xp = carve(sizeof(double) * 2 * P * 3);
+    const size_t o_prep = carve(sizeof(double) * 2 * C * BA_PREP), o_slot = carve(sizeof(int32_t) * C);
+    const size_t o_sc = carve(sizeof(double) * (n + 1)), o_sp = carve(sizeof(double) * P * 3);
+    const size_t o_Vinv = carve(sizeof(double) * P * 6), o_gp = carve(sizeof(double) * P * 3);
+    const size_t o_lamp = carve(sizeof(double) * P * 3);
+    const size_t acc_count = n * n + n + (size_t)d.Cf * 36 + n + 2;
+    const size_t o_acc = carve(sizeof(double) * acc_count);
+    const size_t o_gmax = carve(sizeof(double)), o_pts = carve(sizeof(double) * 4), o_dc = carve(sizeof(double) * (n + 1));
+    const size_t o_st = carve(sizeof(BaState));
+    const size_t o_free = carve(C);
+    void* wsv = nullptr;
+    int rc = rs_workspace(ctx, off, &wsv);
+    if (rc) return rc;
+    char* ws = (char*)wsv;
+    BaBufs b;
+    b.obs_ptr = d_obs_ptr; b.obs_cam = d_obs_cam; b.obs_uv = (const float2*)d_obs_uv;
+    b.Xc = (double*)(ws + o_Xc); b.Xp = (double*)(ws + o_Xp); b.prep = (double*)(ws + o_prep);
+    b.slot = (int32_t*)(ws + o_slot); b.sc = (double*)(ws + o_sc); b.sp = (double*)(ws + o_sp);
+    b.Vinv = (double*)(ws + o_Vinv); b.gp = (double*)(ws + o_gp); b.lamp = (double*)(ws + o_lamp);
+    b.acc = (double*)(ws + o_acc); b.acc_count = acc_count;
+    b.S = b.acc; b.rhs = b.S + n * n; b.U = b.rhs + n; b.gc = b.U + (size_t)d.Cf * 36; b.scal = b.gc + n;
+    b.gmax = (double*)(ws + o_gmax); b.pt_scal = (double*)(ws + o_pts); b.dc = (double*)(ws + o_dc);
+    b.st = (BaState*)(ws + o_st);
+
+    void* pin = nullptr;
+    rc = rs_pinned(ctx, sizeof(int32_t) * C + sizeof(BaState) + C, &pin);
+    if (rc) return rc;
+    BaState* h_st = (BaState*)pin;
+    int32_t* h_slot = (int32_t*)((char*)pin + sizeof(BaState));
+    uint8_t* h_free = (uint8_t*)(h_slot + C);
+    memcpy(h_slot, slot.data(), sizeof(int32_t) * C);
+    memcpy(h_free, h_cam_free, C);
+    RS_HIP(ctx, hipMemcpyAsync(b.slot, h_slot, sizeof(int32_t) * C, hipMemcpyHostToDevice, ctx->stream));
+    uint8_t* d_cam_free = (uint8_t*)(ws + o_free);
+    RS_HIP(ctx, hipMemcpyAsync(d_cam_free, h_free, C, hipMemcpyHostToDevice, ctx->stream));
+
+    const int use_lds = d.n <= BA_MAX_LDS_N ? 1 : 0;
+    const size_t k7_lds = use_lds ? sizeof(double) * (n * n + 2 * n + 8) : 0;
+    if (k7_lds > 48 * 1024)
+        RS_HIP(ctx, hipFuncSetAttribute((const void*)ba_reduced_solve, hipFuncAttributeMaxDynamicSharedMemorySize, (int)k7_lds));
+    const size_t k5_lds = sizeof(double) * (size_t)d.Cf * 42;
+    if (k5_lds > 48 * 1024)
+        RS_HIP(ctx, hipFuncSetAttribute((const void*)ba_linearize_schur, hipFuncAttributeMaxDynamicSharedMemorySize, (int)k5_lds));
+
+    const int pblocks = (d.P + BA_THREADS - 1) / BA_THREADS;
+    hipStream_t s = ctx->stream;
+    {
+        rs_prof_scope ps(ctx, "K0_ba_init");
+        hipLaunchKernelGGL(ba_init, dim3(64), dim3(256), 0, s, d, b, opt, (const double*)d_cameras, (const double*)d_points);
+    }
+    for (int it = 0; it < opt.max_iter; it++) {
+        {
+            rs_prof_scope ps(ctx, "K5_ba_linearize_schur");
+            hipLaunchKernelGGL(ba_linearize_schur, dim3(pblocks), dim3(BA_THREADS), k5_lds, s, d, b, opt);
+        }
+        if (ctx->n_ranks > 1) {
+            rs_prof_scope ps(ctx, "C1_allreduce_system");
+            rc = rs_allreduce_f64(ctx, b.acc, b.acc_count, false);
+            if (rc) return rc;
+            rc = rs_allreduce_f64(ctx, b.gmax, 1, true);
+            if (rc) return rc;
+        }
+        {
+            rs_prof_scope ps(ctx, "K7_ba_reduced_solve");
+            hipLaunchKernelGGL(ba_reduced_solve, dim3(1), dim3(256), k7_lds, s, d, b, opt, use_lds);
+        }
+        {
+            rs_prof_scope ps(ctx, "K8_ba_backsub_cost");
+            hipLaunchKernelGGL(ba_backsub_cost, dim3(pblocks), dim3(BA_THREADS), 0, s, d, b);
+        }
+        if (ctx->n_ranks > 1) {
+            rs_prof_scope ps(ctx, "C2_allreduce_cost");
+            rc = rs_allreduce_f64(ctx, b.pt_scal, 4, false);
+            if (rc) return rc;
+        }
+        {
+            rs_prof_scope ps(ctx, "K9_ba_decide");
+            hipLaunchKernelGGL(ba_decide, dim3(1), dim3(256), 0, s, d, b, opt);
+        }
+    }
+    {
+        rs_prof_scope ps(ctx, "K10_ba_finalize");
+        hipLaunchKernelGGL(ba_finalize, dim3(1), dim3(1024), 0, s, d, b, d_cameras, (const uint8_t*)d_cam_free, d_points);
+    }
+    RS_HIP(ctx, hipMemcpyAsync(h_st, b.st, sizeof(BaState), hipMemcpyDeviceToHost, s));
+    RS_HIP(ctx, hipStreamSynchronize(s));
+    RS_HIP(ctx, hipGetLastError());
+    h_summary->termination = h_st->termination;
+    h_summary->iterations = h_st->iter;
+    h_summary->successful_steps = h_st->successful;
+    h_summary->usable = h_st->usable;
+    h_summary->initial_cost = h_st->initial_cost;
+    h_summary->final_cost = h_st->x_cost;
+    h_summary->final_radius = h_st->radius;
+    return RS_OK;
+}
+
+// ------------------------------------------------------------- refine_pose
+// optimization::refine_pose (src/Optimization.cpp:194-267), vision-only: one
+// camera block, points constant.  The whole LM loop runs inside ONE launch of
+// a single workgroup (6 unknowns; <= 2000 residual pairs): per iteration a
+// block reduction of the 6x6 normal equations, a register Cholesky on lane 0
+// and a second reduction for the candidate cost.
+#define RP_THREADS 256
+
+__device__ __forceinline__ void block_sum(double* vals, int count, double* scratch /*[4][32]*/)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int k = 0; k < count; k++) {
+        const double v = wave_sum(vals[k]);
+        if (lane == 0) scratch[wave * 32 + k] = v;
+    }
+    __syncthreads();
+    for (int k = 0; k < count; k++) {
+        double t = 0.0;
+        for (int w = 0; w < RP_THREADS / 64; w++) t += scratch[w * 32 + k];
+        vals[k] = t;
+    }
+    __syncthreads();
+}
+
+__global__ __launch_bounds__(RP_THREADS) void ba_refine_pose(BaDims d, BaOpt opt, const double* __restrict__ pts,
+                                                            const float2* __restrict__ uv, int n,
+                                                            double* __restrict__ cam_io, BaState* __restrict__ st_out)
+{
+    __shared__ double x[6], xn[6], prep[BA_PREP], prepn[BA_PREP], scratch[4 * 32];
+    __shared__ BaState st;
+    __shared__ double sc[6];
+    const int tid = threadIdx.x;
+    if (tid == 0) {
+        for (int k = 0; k < 6; k++) x[k] = cam_io[k];
+        cam_prepare(x, prep);
+        st.radius = opt.r0; st.decrease_factor = 2.0; st.x_cost = 0.0; st.initial_cost = 0.0;
+        st.iter = 0; st.successful = 0; st.invalid_steps = 0; st.done = 0; st.termination = 0; st.cur = 0;
+        st.have_scale = 0; st.solver_failed = 0; st.fresh = 1; st.usable = 0;
+    }
+    __syncthreads();
+    double acc[28];
+    while (true) {
+        // linearise at x (recomputed after a rejected step too: same values)
+        for (int k = 0; k < 28; k++) acc[k] = 0.0;
+        ObsLin o;
+        for (int i = tid; i < n; i += RP_THREADS) {
+            const double X[3] = {pts[3 * (size_t)i], pts[3 * (size_t)i + 1], pts[3 * (size_t)i + 2]};
+            obs_eval<true>(prep, X, uv[i], d, o);
+            int q = 0;
+#pragma unroll
+            for (int a = 0; a < 6; a++) {
+#pragma unroll
+                for (int e = a; e < 6; e++) acc[q++] += o.w * (o.jc[a] * o.jc[e] + o.jc[6 + a] * o.jc[6 + e]);
+            }
+#pragma unroll
+            for (int a = 0; a < 6; a++) acc[21 + a] += o.w * (o.jc[a] * o.r0 + o.jc[6 + a] * o.r1);
+            acc[27] += 0.5 * o.rho;
+        }
+        block_sum(acc, 28, scratch);
+        if (tid == 0) {
+            double H[6][6], g[6], lam[6], dlt[6];
+            int q = 0;
+            for (int a = 0; a < 6; a++)
+                for (int e = a; e < 6; e++) { H[a][e] = acc[q]; H[e][a] = acc[q]; q++; }
+            for (int a = 0; a < 6; a++) g[a] = acc[21 + a];
+            if (st.fresh) {
+                st.x_cost = acc[27];
+                if (st.iter == 0) st.initial_cost = st.x_cost;
+                if (!st.have_scale)
+                    for (int a = 0; a < 6; a++) sc[a] = opt.jacobi ? 1.0 / (1.0 + sqrt(H[a][a])) : 1.0;
+                double gm = 0.0;
+                for (int a = 0; a < 6; a++) gm = fmax(gm, fabs(g[a]));
+                if (!isfinite(st.x_cost)) { st.done = 1; st.termination = RS_BA_FAILURE; }
+                else if (gm <= opt.gtol) { st.done = 1; st.termination = RS_BA_CONVERGENCE_GRADIENT; }
+            }
+            if (!st.done && st.iter >= opt.max_iter) { st.done = 1; st.termination = RS_BA_NO_CONVERGENCE; }
+            if (!st.done) {
+                bool fail = false;
+                for (int a = 0; a < 6; a++) {
+                    const double s2 = sc[a] * sc[a];
+                    lam[a] = clampd(s2 * H[a][a], opt.dmin, opt.dmax) / (st.radius * s2);
+                    H[a][a] += lam[a];
+                }
+                // Cholesky 6x6
+                for (int j = 0; j < 6 && !fail; j++) {
+                    double dj = H[j][j];
+                    for (int k = 0; k < j; k++) dj -= H[j][k] * H[j][k];
+                    if (!(dj > 0.0) || !isfinite(dj)) { fail = true; break; }
+                    dj = sqrt(dj);
+                    H[j][j] = dj;
+                    for (int i = j + 1; i < 6; i++) {
+                        double s = H[i][j];
+                        for (int k = 0; k < j; k++) s -= H[i][k] * H[j][k];
+                        H[i][j] = s / dj;
+                    }
+                }
+                if (!fail) {
+                    for (int i = 0; i < 6; i++) {
+                        double s = g[i];
+                        for (int k = 0; k < i; k++) s -= H[i][k] * dlt[k];
+                        dlt[i] = s / H[i][i];
+                    }
+                    for (int i = 5; i >= 0; i--) {
+                        double s = dlt[i];
+                        for (int k = i + 1; k < 6; k++) s -= H[k][i] * dlt[k];
+                        dlt[i] = s / H[i][i];
+                    }
+                    double mcc = 0.0, ssq = 0.0, xsq = 0.0;
+                    for (int a = 0; a < 6; a++) {
+                        dlt[a] = -dlt[a];
+                        if (!isfinite(dlt[a])) fail = true;
+                        mcc += 0.5 * (dlt[a] * dlt[a] * lam[a] - dlt[a] * g[a]);
+                        xn[a] = x[a] + dlt[a];
+                        ssq += (x[a] - xn[a]) * (x[a] - xn[a]);
+                        xsq += x[a] * x[a];
+                    }
+                    st.cam_scal[0] = mcc; st.cam_scal[1] = ssq; st.cam_scal[2] = xsq;
+                    cam_prepare(xn, prepn);
+                }
+                st.solver_failed = fail ? 1 : 0;
+            }
+        }
+        __syncthreads();
+        if (st.done) break;
+        double cc[1] = {0.0};
+        if (!st.solver_failed) {
+            for (int i = tid; i < n; i += RP_THREADS) {
+                const double X[3] = {pts[3 * (size_t)i], pts[3 * (size_t)i + 1], pts[3 * (size_t)i + 2]};
+                obs_eval<false>(prepn, X, uv[i], d, o);
+                cc[0] += 0.5 * o.rho;
+            }
+        }
+        block_sum(cc, 1, scratch);
+        if (tid == 0) {
+            st.iter++;
+            const double cand = cc[0], mcc = st.cam_scal[0];
+            st.fresh = 0;
+            if (st.solver_failed || !(mcc > 0.0)) {
+                if (++st.invalid_steps >= opt.max_invalid) { st.done = 1; st.termination = RS_BA_FAILURE; }
+                else { st.radius /= st.decrease_factor; st.decrease_factor *= 2.0; }
+            } else {
+                st.invalid_steps = 0;
+                const double step_norm = sqrt(st.cam_scal[1]), x_norm = sqrt(st.cam_scal[2]);
+                if (step_norm <= opt.ptol * (x_norm + opt.ptol)) { st.done = 1; st.termination = RS_BA_CONVERGENCE_PARAMETER; }
+                else if (fabs(st.x_cost - cand) <= opt.ftol * st.x_cost) { st.done = 1; st.termination = RS_BA_CONVERGENCE_FUNCTION; }
+                else {
+                    const double rel = (st.x_cost - cand) / mcc;
+                    if (rel > opt.min_rel && isfinite(cand)) {
+                        for (int a = 0; a < 6; a++) x[a] = xn[a];
+                        for (int a = 0; a < BA_PREP; a++) prep[a] = prepn[a];
+                        st.successful++;
+                        const double t = 2.0 * rel - 1.0;
+                        st.radius = fmin(opt.rmax, st.radius / fmax(1.0 / 3.0, 1.0 - t * t * t));
+                        st.decrease_factor = 2.0;
+                        st.fresh = 1;
+                        st.x_cost = cand;
+                    } else {
+                        st.radius /= st.decrease_factor;
+                        st.decrease_factor *= 2.0;
+                        if (st.radius < opt.rmin) { st.done = 1; st.termination = RS_BA_CONVERGENCE_RADIUS; }
+                    }
+                }
+            }
+            st.solver_failed = 0;
+            st.have_scale = 1;
+        }
+        __syncthreads();
+        if (st.done) break;
+    }
+    if (tid == 0) {
+        st.usable = (st.termination != RS_BA_FAILURE && isfinite(st.x_cost) && st.x_cost <= st.initial_cost) ? 1 : 0;
+        if (st.usable)
+            for (int k = 0; k < 6; k++) cam_io[k] = x[k];
+        *st_out = st;
+    }
+}
+
+extern "C" int rs_refine_pose(rs_context* ctx, double h_camera[6], const double* d_points, const float* d_uv, int n,
+                              const float h_intrinsics[4], const rs_ba_options* options, rs_ba_summary* h_summary)
+{
+    if (!ctx || !h_summary || !h_camera) return RS_ERR_INVALID;
+    memset(h_summary, 0, sizeof *h_summary);
+    if (n < 0) return rs_fail(ctx, RS_ERR_INVALID, "negative n");
+    if (n == 0) return RS_OK;   // "nothing to constrain", src/Optimization.cpp:227-229
+    if (!d_points || !d_uv || !h_intrinsics) return rs_fail(ctx, RS_ERR_INVALID, "null pointer");
+    rs_ba_options def;
+    if (!options) { rs_ba_default_options(&def); options = &def; }
+    RS_HIP(ctx, hipSetDevice(ctx->device));
+    BaDims d;
+    d.C = 1; d.Cf = 1; d.P = n; d.M = n; d.n = 6;
+    d.fx = h_intrinsics[0]; d.fy = h_intrinsics[1]; d.cx = h_intrinsics[2]; d.cy = h_intrinsics[3];
+    d.huber_a = options->huber_delta;
+    BaOpt opt;
+    opt.max_iter = options->max_num_iterations; opt.max_invalid = options->max_num_consecutive_invalid_steps;
+    opt.jacobi = options->jacobi_scaling; opt.r0 = options->initial_trust_region_radius;
+    opt.rmax = options->max_trust_region_radius; opt.rmin = options->min_trust_region_radius;
+    opt.min_rel = options->min_relative_decrease; opt.dmin = options->min_lm_diagonal;
+    opt.dmax = options->max_lm_diagonal; opt.ftol = options->function_tolerance;
+    opt.gtol = options->gradient_tolerance; opt.ptol = options->parameter_tolerance;
+    void* wsv = nullptr;
+    int rc = rs_workspace(ctx, 1024, &wsv);
+    if (rc) return rc;
+    double* d_cam = (double*)wsv;
+    BaState* d_st = (BaState*)((char*)wsv + 256);
+    void* pin = nullptr;
+    rc = rs_pinned(ctx, 512, &pin);
+    if (rc) return rc;
+    double* h_cam = (double*)pin;
+    BaState* h_st = (BaState*)((char*)pin + 256);
+    memcpy(h_cam, h_camera, 6 * sizeof(double));
+    hipStream_t s = ctx->stream;
+    RS_HIP(ctx, hipMemcpyAsync(d_cam, h_cam, 6 * sizeof(double), hipMemcpyHostToDevice, s));
+    {
+        rs_prof_scope ps(ctx, "K11_refine_pose");
+        hipLaunchKernelGGL(ba_refine_pose, dim3(1), dim3(RP_THREADS), 0, s, d, opt, d_points, (const float2*)d_uv, n, d_cam, d_st);
+    }
+    RS_HIP(ctx, hipMemcpyAsync(h_cam, d_cam, 6 * sizeof(double), hipMemcpyDeviceToHost, s));
+    RS_HIP(ctx, hipMemcpyAsync(h_st, d_st, sizeof(BaState), hipMemcpyDeviceToHost, s));
+    RS_HIP(ctx, hipStreamSynchronize(s));
+    RS_HIP(ctx, hipGetLastError());
+    if (h_st->usable) memcpy(h_camera, h_cam, 6 * sizeof(double));
+    h_summary->termination = h_st->termination;
+    h_summary->iterations = h_st->iter;
+    h_summary->successful_steps = h_st->successful;
+    h_summary->usable = h_st->usable;
+    h_summary->initial_cost = h_st->initial_cost;
+    h_summary->final_cost = h_st->x_cost;
+    h_summary->final_radius = h_st->radius;
+    return RS_OK;
+}

@@ -1,0 +1,75 @@
+// common.h — internal declarations shared by the HIP translation units of librsgpu.so.
+// gfx950 (MI355X) only: 64-lane wavefronts, no portability layer.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <string>
+#include <vector>
+
+#include "../../include/rsgpu.h"
+
+#define RS_WAVE 64
+
+struct rs_prof_slot {
+    char name[32];
+    int launches;
+    std::vector<hipEvent_t> ev;   // pairs (start, stop)
+};
+
+struct rs_context {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    std::string err;
+    // grow-only device workspace (never freed inside an enqueue path)
+    void* ws = nullptr;
+    size_t ws_bytes = 0;
+    // pinned host scratch for small result read-back
+    void* pinned = nullptr;
+    size_t pinned_bytes = 0;
+    // profiling
+    bool prof_on = false;
+    std::vector<rs_prof_slot> prof;
+    // RCCL (loaded with dlopen; see comm.hip)
+    void* comm = nullptr;
+    int n_ranks = 1;
+    int rank = 0;
+    // cached BA graph / buffers live in ba.hip
+    void* ba_cache = nullptr;
+};
+
+int rs_fail(rs_context* ctx, int code, const char* fmt, ...);
+
+#define RS_HIP(ctx, call)                                                                  \
+    do {                                                                                   \
+        hipError_t e__ = (call);                                                           \
+        if (e__ != hipSuccess)                                                             \
+            return rs_fail((ctx), RS_ERR_HIP, "%s failed: %s (%s:%d)", #call,              \
+                           hipGetErrorString(e__), __FILE__, __LINE__);                    \
+    } while (0)
+
+// workspace: returns a device pointer with at least `bytes` bytes, 256-B aligned.
+int rs_workspace(rs_context* ctx, size_t bytes, void** out);
+int rs_pinned(rs_context* ctx, size_t bytes, void** out);
+
+// profiling brackets around a kernel launch
+void rs_prof_start(rs_context* ctx, const char* name);
+void rs_prof_stop(rs_context* ctx, const char* name);
+
+struct rs_prof_scope {
+    rs_context* c;
+    const char* n;
+    rs_prof_scope(rs_context* ctx, const char* name) : c(ctx), n(name) { if (c->prof_on) rs_prof_start(c, n); }
+    ~rs_prof_scope() { if (c->prof_on) rs_prof_stop(c, n); }
+};
+
+// comm.hip: sum / max all-reduce of f64 on the context stream (no-op when n_ranks == 1)
+int rs_allreduce_f64(rs_context* ctx, double* d_buf, size_t count, bool is_max);
+
+// ordered stream compaction used by matching and triangulation (compact.hip):
+// out_idx[0..count) = ascending i with flag[i] != 0, for `batch` independent
+// segments of length n each (segment b at offset b*n).
+void rs_launch_compact(rs_context* ctx, const uint8_t* d_flag, int n, int batch, int32_t* d_out_idx,
+                       int32_t* d_out_count);

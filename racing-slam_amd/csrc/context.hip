@@ -1,0 +1,259 @@
+// context.hip — context lifetime, workspace, HIP-event profiling and the RCCL
+// communicator of librsgpu.so.
+#include <dlfcn.h>
+#include <stdarg.h>
+
+#include "common.h"
+
+int rs_fail(rs_context* ctx, int code, const char* fmt, ...)
+{
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    if (ctx) ctx->err = buf;
+    else fprintf(stderr, "rsgpu: %s\n", buf);
+    return code;
+}
+
+extern "C" int rs_abi_version(void) { return RSGPU_ABI_VERSION; }
+
+extern "C" int rs_context_create(int device_id, rs_context** out)
+{
+    if (!out) return RS_ERR_INVALID;
+    *out = nullptr;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) {
+        fprintf(stderr, "rsgpu: no HIP device visible; librsgpu has no CPU fallback\n");
+        return RS_ERR_NO_DEVICE;
+    }
+    if (device_id < 0 || device_id >= n) return RS_ERR_INVALID;
+    if (hipSetDevice(device_id) != hipSuccess) return RS_ERR_HIP;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device_id) != hipSuccess) return RS_ERR_HIP;
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+        fprintf(stderr, "rsgpu: device %d is %s; this library is built for gfx950 only\n", device_id,
+                prop.gcnArchName);
+        return RS_ERR_NO_DEVICE;
+    }
+    rs_context* c = new rs_context();
+    c->device = device_id;
+    *out = c;
+    return RS_OK;
+}
+
+void rs_ba_cache_free(rs_context* ctx);
+
+extern "C" int rs_context_destroy(rs_context* ctx)
+{
+    if (!ctx) return RS_OK;
+    (void)hipSetDevice(ctx->device);
+    rs_comm_destroy(ctx);
+    rs_ba_cache_free(ctx);
+    if (ctx->ws) (void)hipFree(ctx->ws);
+    if (ctx->pinned) (void)hipHostFree(ctx->pinned);
+    for (auto& s : ctx->prof)
+        for (auto e : s.ev) (void)hipEventDestroy(e);
+    delete ctx;
+    return RS_OK;
+}
+
+extern "C" int rs_context_set_stream(rs_context* ctx, void* s)
+{
+    if (!ctx) return RS_ERR_INVALID;
+    ctx->stream = (hipStream_t)s;
+    return RS_OK;
+}
+
+extern "C" int rs_context_synchronize(rs_context* ctx)
+{
+    if (!ctx) return RS_ERR_INVALID;
+    RS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return RS_OK;
+}
+
+extern "C" const char* rs_last_error(const rs_context* ctx) { return ctx ? ctx->err.c_str() : "null context"; }
+
+int rs_workspace(rs_context* ctx, size_t bytes, void** out)
+{
+    if (bytes > ctx->ws_bytes) {
+        // growing is a synchronising event (first call / larger problem only)
+        RS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        if (ctx->ws) RS_HIP(ctx, hipFree(ctx->ws));
+        ctx->ws = nullptr;
+        ctx->ws_bytes = 0;
+        size_t want = (bytes + (1u << 20)) & ~((size_t)(1u << 20) - 1);
+        if (hipMalloc(&ctx->ws, want) != hipSuccess) return rs_fail(ctx, RS_ERR_NOMEM, "workspace of %zu bytes", want);
+        ctx->ws_bytes = want;
+    }
+    *out = ctx->ws;
+    return RS_OK;
+}
+
+int rs_pinned(rs_context* ctx, size_t bytes, void** out)
+{
+    if (bytes > ctx->pinned_bytes) {
+        if (ctx->pinned) RS_HIP(ctx, hipHostFree(ctx->pinned));
+        ctx->pinned = nullptr;
+        size_t want = bytes < 4096 ? 4096 : bytes;
+        if (hipHostMalloc(&ctx->pinned, want, hipHostMallocDefault) != hipSuccess)
+            return rs_fail(ctx, RS_ERR_NOMEM, "pinned buffer of %zu bytes", want);
+        ctx->pinned_bytes = want;
+    }
+    *out = ctx->pinned;
+    return RS_OK;
+}
+
+// ------------------------------------------------------------------ profiling
+static rs_prof_slot* prof_slot(rs_context* ctx, const char* name)
+{
+    for (auto& s : ctx->prof)
+        if (strcmp(s.name, name) == 0) return &s;
+    if (ctx->prof.size() >= RS_PROF_MAX) return nullptr;
+    rs_prof_slot s;
+    memset(s.name, 0, sizeof s.name);
+    strncpy(s.name, name, sizeof s.name - 1);
+    s.launches = 0;
+    ctx->prof.push_back(s);
+    return &ctx->prof.back();
+}
+
+void rs_prof_start(rs_context* ctx, const char* name)
+{
+    rs_prof_slot* s = prof_slot(ctx, name);
+    if (!s) return;
+    hipEvent_t a, b;
+    if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) return;
+    s->ev.push_back(a);
+    s->ev.push_back(b);
+    (void)hipEventRecord(a, ctx->stream);
+}
+
+void rs_prof_stop(rs_context* ctx, const char* name)
+{
+    rs_prof_slot* s = prof_slot(ctx, name);
+    if (!s || s->ev.size() < 2) return;
+    (void)hipEventRecord(s->ev.back(), ctx->stream);
+    s->launches++;
+}
+
+extern "C" int rs_prof_begin(rs_context* ctx)
+{
+    if (!ctx) return RS_ERR_INVALID;
+    for (auto& s : ctx->prof)
+        for (auto e : s.ev) (void)hipEventDestroy(e);
+    ctx->prof.clear();
+    ctx->prof_on = true;
+    return RS_OK;
+}
+
+extern "C" int rs_prof_end(rs_context* ctx, rs_prof_entry* entries, int* count)
+{
+    if (!ctx || !entries || !count) return RS_ERR_INVALID;
+    ctx->prof_on = false;
+    RS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    int n = 0;
+    for (auto& s : ctx->prof) {
+        rs_prof_entry& e = entries[n++];
+        memcpy(e.name, s.name, sizeof e.name);
+        e.launches = s.launches;
+        e.total_ms = 0.0;
+        for (size_t i = 0; i + 1 < s.ev.size(); i += 2) {
+            float ms = 0.f;
+            if (hipEventElapsedTime(&ms, s.ev[i], s.ev[i + 1]) == hipSuccess) e.total_ms += ms;
+        }
+        for (auto ev : s.ev) (void)hipEventDestroy(ev);
+        s.ev.clear();
+    }
+    ctx->prof.clear();
+    *count = n;
+    return RS_OK;
+}
+
+// ----------------------------------------------------------------------- RCCL
+// RCCL is bound at run time: a torch process has already loaded librccl.so.1
+// (soname match => the same library instance), a plain C++ host gets ROCm's.
+typedef struct { char internal[128]; } rs_nccl_uid;
+typedef int (*fn_get_uid)(rs_nccl_uid*);
+typedef int (*fn_init_rank)(void**, int, rs_nccl_uid, int);
+typedef int (*fn_destroy)(void*);
+typedef int (*fn_allreduce)(const void*, void*, size_t, int, int, void*, hipStream_t);
+typedef const char* (*fn_errstr)(int);
+
+static struct {
+    void* h = nullptr;
+    fn_get_uid get_uid = nullptr;
+    fn_init_rank init_rank = nullptr;
+    fn_destroy destroy = nullptr;
+    fn_allreduce allreduce = nullptr;
+    fn_errstr errstr = nullptr;
+} g_rccl;
+
+static int rccl_load(rs_context* ctx)
+{
+    if (g_rccl.h) return RS_OK;
+    const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+    for (const char* n : names) {
+        g_rccl.h = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
+        if (g_rccl.h) break;
+    }
+    if (!g_rccl.h) return rs_fail(ctx, RS_ERR_RCCL, "cannot dlopen librccl: %s", dlerror());
+    g_rccl.get_uid = (fn_get_uid)dlsym(g_rccl.h, "ncclGetUniqueId");
+    g_rccl.init_rank = (fn_init_rank)dlsym(g_rccl.h, "ncclCommInitRank");
+    g_rccl.destroy = (fn_destroy)dlsym(g_rccl.h, "ncclCommDestroy");
+    g_rccl.allreduce = (fn_allreduce)dlsym(g_rccl.h, "ncclAllReduce");
+    g_rccl.errstr = (fn_errstr)dlsym(g_rccl.h, "ncclGetErrorString");
+    if (!g_rccl.get_uid || !g_rccl.init_rank || !g_rccl.destroy || !g_rccl.allreduce)
+        return rs_fail(ctx, RS_ERR_RCCL, "librccl lacks the expected symbols");
+    return RS_OK;
+}
+
+extern "C" int rs_comm_get_unique_id(uint8_t id[RS_COMM_ID_BYTES])
+{
+    int rc = rccl_load(nullptr);
+    if (rc) return rc;
+    rs_nccl_uid u;
+    memset(&u, 0, sizeof u);
+    int e = g_rccl.get_uid(&u);
+    if (e != 0) return rs_fail(nullptr, RS_ERR_RCCL, "ncclGetUniqueId: %d", e);
+    memcpy(id, &u, RS_COMM_ID_BYTES);
+    return RS_OK;
+}
+
+extern "C" int rs_comm_init_rank(rs_context* ctx, const uint8_t id[RS_COMM_ID_BYTES], int n_ranks, int rank)
+{
+    if (!ctx || !id || n_ranks < 1 || rank < 0 || rank >= n_ranks) return RS_ERR_INVALID;
+    int rc = rccl_load(ctx);
+    if (rc) return rc;
+    if (ctx->comm) rs_comm_destroy(ctx);
+    RS_HIP(ctx, hipSetDevice(ctx->device));
+    rs_nccl_uid u;
+    memcpy(&u, id, RS_COMM_ID_BYTES);
+    void* comm = nullptr;
+    int e = g_rccl.init_rank(&comm, n_ranks, u, rank);
+    if (e != 0) return rs_fail(ctx, RS_ERR_RCCL, "ncclCommInitRank: %s", g_rccl.errstr ? g_rccl.errstr(e) : "?");
+    ctx->comm = comm;
+    ctx->n_ranks = n_ranks;
+    ctx->rank = rank;
+    return RS_OK;
+}
+
+extern "C" int rs_comm_destroy(rs_context* ctx)
+{
+    if (!ctx) return RS_ERR_INVALID;
+    if (ctx->comm && g_rccl.destroy) g_rccl.destroy(ctx->comm);
+    ctx->comm = nullptr;
+    ctx->n_ranks = 1;
+    ctx->rank = 0;
+    return RS_OK;
+}
+
+int rs_allreduce_f64(rs_context* ctx, double* d_buf, size_t count, bool is_max)
+{
+    if (ctx->n_ranks <= 1 || !ctx->comm) return RS_OK;
+    // ncclFloat64 = 8, ncclSum = 0, ncclMax = 2
+    int e = g_rccl.allreduce(d_buf, d_buf, count, 8, is_max ? 2 : 0, ctx->comm, ctx->stream);
+    if (e != 0) return rs_fail(ctx, RS_ERR_RCCL, "ncclAllReduce: %s", g_rccl.errstr ? g_rccl.errstr(e) : "?");
+    return RS_OK;
+}

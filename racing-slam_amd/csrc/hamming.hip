@@ -1,0 +1,187 @@
+// hamming.hip — K1: brute-force 2-NN under 256-bit Hamming distance, and the
+// match_descriptors filters + ordered compaction.
+//
+// Replaces cv::BFMatcher(NORM_HAMMING).knnMatch(k=2) + the Lowe / max-distance
+// filters of MapMatcher::match_descriptors (reference src/MapMatcher.cpp:129-163).
+//
+// Mapping to gfx950: one lane owns one query descriptor (8 VGPRs); train rows
+// are wave-uniform, so they stream through the SCALAR cache (s_load_dwordx8)
+// and the inner loop is pure VALU: 8 v_xor + 8 v_bcnt_u32_b32 (accumulating
+// form) + key pack + a 2-deep sorted insert.  The pair space is cut into
+// (query block of 64) x (train split) so that ~2k waves cover the 1024 SIMDs;
+// the 4 waves of a workgroup take 4 consecutive train sub-ranges and merge
+// through LDS.  The packed key (dist << 20 | train index) orders candidates by
+// distance first and index second, which is exactly OpenCV's tie rule.
+#include "common.h"
+
+#define K1_WAVES 4
+#define K1_KEY_NONE 0xFFFFFFFFu
+#define K1_IDX_BITS 20
+#define K1_IDX_MASK ((1u << K1_IDX_BITS) - 1u)
+
+__device__ __forceinline__ void top2_insert(uint32_t& k0, uint32_t& k1, uint32_t key)
+{
+    k1 = min(k1, max(k0, key));
+    k0 = min(k0, key);
+}
+
+__global__ __launch_bounds__(64 * K1_WAVES) void k1_hamming_knn2(
+    const uint4* __restrict__ query, int nq, const uint4* __restrict__ train, int nt,
+    int rows_per_wave, int nsplit, uint2* __restrict__ part)
+{
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int b = blockIdx.z;
+    const int qi = blockIdx.x * 64 + lane;
+    const uint4* q = query + (size_t)b * nq * 2;
+    const uint4* t = train + (size_t)b * nt * 2;
+
+    uint4 qa = make_uint4(0, 0, 0, 0), qb = make_uint4(0, 0, 0, 0);
+    if (qi < nq) { qa = q[2 * qi]; qb = q[2 * qi + 1]; }
+
+    const int t0 = (blockIdx.y * K1_WAVES + wave) * rows_per_wave;
+    const int t1 = min(t0 + rows_per_wave, nt);
+    uint32_t k0 = K1_KEY_NONE, k1 = K1_KEY_NONE;
+#pragma unroll 4
+    for (int j = t0; j < t1; ++j) {
+        const uint4 ta = t[2 * j], tb = t[2 * j + 1];   // wave-uniform address -> scalar loads
+        uint32_t d = __builtin_popcount(qa.x ^ ta.x);
+        d += __builtin_popcount(qa.y ^ ta.y);
+        d += __builtin_popcount(qa.z ^ ta.z);
+        d += __builtin_popcount(qa.w ^ ta.w);
+        d += __builtin_popcount(qb.x ^ tb.x);
+        d += __builtin_popcount(qb.y ^ tb.y);
+        d += __builtin_popcount(qb.z ^ tb.z);
+        d += __builtin_popcount(qb.w ^ tb.w);
+        top2_insert(k0, k1, (d << K1_IDX_BITS) | (uint32_t)j);
+    }
+
+    __shared__ uint32_t sk[K1_WAVES][2][64];
+    sk[wave][0][lane] = k0;
+    sk[wave][1][lane] = k1;
+    __syncthreads();
+    if (wave == 0) {
+#pragma unroll
+        for (int w = 1; w < K1_WAVES; ++w) {
+            top2_insert(k0, k1, sk[w][0][lane]);
+            top2_insert(k0, k1, sk[w][1][lane]);
+        }
+        if (qi < nq) part[((size_t)b * nsplit + blockIdx.y) * nq + qi] = make_uint2(k0, k1);
+    }
+}
+
+// One workgroup per batch item: merge the split partials, decode, apply the
+// filters of src/MapMatcher.cpp:150-161 and emit the accepted matches in
+// ascending query order.
+__global__ __launch_bounds__(1024) void k1_merge_filter(
+    const uint2* __restrict__ part, int nq, int nt, int nsplit, int max_distance, int do_filter,
+    int32_t* __restrict__ idx0, int32_t* __restrict__ dist0, int32_t* __restrict__ idx1,
+    int32_t* __restrict__ dist1, int32_t* __restrict__ match_query, int32_t* __restrict__ match_train,
+    int32_t* __restrict__ match_count)
+{
+    const int b = blockIdx.x;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    __shared__ int wave_count[16];
+    __shared__ int running;
+    if (threadIdx.x == 0) running = 0;
+    __syncthreads();
+    for (int base = 0; base < nq; base += 1024) {
+        const int qi = base + threadIdx.x;
+        uint32_t k0 = K1_KEY_NONE, k1 = K1_KEY_NONE;
+        if (qi < nq) {
+            for (int s = 0; s < nsplit; ++s) {
+                const uint2 p = part[((size_t)b * nsplit + s) * nq + qi];
+                top2_insert(k0, k1, p.x);
+                top2_insert(k0, k1, p.y);
+            }
+        }
+        const int i0 = (int)(k0 & K1_IDX_MASK), d0 = (int)(k0 >> K1_IDX_BITS);
+        const bool has1 = k1 != K1_KEY_NONE;
+        const int i1 = has1 ? (int)(k1 & K1_IDX_MASK) : -1, d1 = has1 ? (int)(k1 >> K1_IDX_BITS) : -1;
+        if (qi < nq) {
+            const size_t o = (size_t)b * nq + qi;
+            if (idx0) idx0[o] = i0;
+            if (dist0) dist0[o] = d0;
+            if (idx1) idx1[o] = i1;
+            if (dist1) dist1[o] = d1;
+        }
+        if (!do_filter) continue;
+        bool ok = qi < nq && d0 <= max_distance;              // :152
+        if (ok && nt >= 2 && 4 * d0 > 3 * d1) ok = false;     // :156, 0.75 = 3/4 exactly
+        const unsigned long long m = __ballot(ok);
+        if (lane == 0) wave_count[wave] = __popcll(m);
+        __syncthreads();
+        int off = running;
+        for (int w = 0; w < wave; ++w) off += wave_count[w];
+        off += __popcll(m & ((1ull << lane) - 1ull));
+        if (ok) {
+            match_query[(size_t)b * nq + off] = qi;
+            match_train[(size_t)b * nq + off] = i0;
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            int tot = 0;
+            for (int w = 0; w < 16; ++w) tot += wave_count[w];
+            running += tot;
+        }
+        __syncthreads();
+    }
+    if (do_filter && threadIdx.x == 0) match_count[b] = running;
+}
+
+static int knn2_launch(rs_context* ctx, const uint8_t* d_query, int nq, const uint8_t* d_train, int nt,
+                       int batch, int max_distance, int do_filter, int32_t* mq, int32_t* mt, int32_t* mc,
+                       int32_t* i0, int32_t* d0, int32_t* i1, int32_t* d1)
+{
+    if (!ctx) return RS_ERR_INVALID;
+    if (nq < 0 || nt < 0 || batch < 0) return rs_fail(ctx, RS_ERR_INVALID, "negative size");
+    if (nt >= (1 << K1_IDX_BITS)) return rs_fail(ctx, RS_ERR_UNSUPPORTED, "nt must be < 2^20");
+    if (batch == 0) return RS_OK;
+    if (nq == 0 || nt == 0) {   // empty guard, src/MapMatcher.cpp:139-141
+        if (do_filter && mc) RS_HIP(ctx, hipMemsetAsync(mc, 0, sizeof(int32_t) * (size_t)batch, ctx->stream));
+        return RS_OK;
+    }
+    if (!d_query || !d_train) return rs_fail(ctx, RS_ERR_INVALID, "null descriptor pointer");
+    if (((uintptr_t)d_query | (uintptr_t)d_train) & 15) return rs_fail(ctx, RS_ERR_INVALID, "descriptors must be 16-byte aligned");
+    if (do_filter && (!mq || !mt || !mc)) return rs_fail(ctx, RS_ERR_INVALID, "null match output");
+    RS_HIP(ctx, hipSetDevice(ctx->device));
+
+    const int nqb = (nq + 63) / 64;
+    // aim at ~2048 waves in flight (2 per SIMD), at least 8 train rows per wave
+    int nsplit = (2048 + K1_WAVES * nqb * batch - 1) / (K1_WAVES * nqb * batch);
+    const int max_split = (nt + 8 * K1_WAVES - 1) / (8 * K1_WAVES);
+    if (nsplit > max_split) nsplit = max_split;
+    if (nsplit < 1) nsplit = 1;
+    const int rows_per_wave = (nt + nsplit * K1_WAVES - 1) / (nsplit * K1_WAVES);
+    void* ws = nullptr;
+    int rc = rs_workspace(ctx, sizeof(uint2) * (size_t)batch * nsplit * nq, &ws);
+    if (rc) return rc;
+    {
+        rs_prof_scope ps(ctx, "K1_hamming_knn2");
+        hipLaunchKernelGGL(k1_hamming_knn2, dim3(nqb, nsplit, batch), dim3(64 * K1_WAVES), 0, ctx->stream,
+                           (const uint4*)d_query, nq, (const uint4*)d_train, nt, rows_per_wave, nsplit, (uint2*)ws);
+    }
+    {
+        rs_prof_scope ps(ctx, "K1b_merge_filter");
+        hipLaunchKernelGGL(k1_merge_filter, dim3(batch), dim3(1024), 0, ctx->stream, (const uint2*)ws, nq, nt,
+                           nsplit, max_distance, do_filter, i0, d0, i1, d1, mq, mt, mc);
+    }
+    RS_HIP(ctx, hipGetLastError());
+    return RS_OK;
+}
+
+extern "C" int rs_hamming_knn2(rs_context* ctx, const uint8_t* d_query, int nq, const uint8_t* d_train, int nt,
+                               int batch, int32_t* d_idx0, int32_t* d_dist0, int32_t* d_idx1, int32_t* d_dist1)
+{
+    return knn2_launch(ctx, d_query, nq, d_train, nt, batch, 0, 0, nullptr, nullptr, nullptr, d_idx0, d_dist0,
+                       d_idx1, d_dist1);
+}
+
+extern "C" int rs_match_descriptors(rs_context* ctx, const uint8_t* d_query, int nq, const uint8_t* d_train,
+                                    int nt, int batch, int max_distance, int32_t* d_match_query,
+                                    int32_t* d_match_train, int32_t* d_match_count, int32_t* d_idx0,
+                                    int32_t* d_dist0, int32_t* d_idx1, int32_t* d_dist1)
+{
+    return knn2_launch(ctx, d_query, nq, d_train, nt, batch, max_distance, 1, d_match_query, d_match_train,
+                       d_match_count, d_idx0, d_dist0, d_idx1, d_dist1);
+}

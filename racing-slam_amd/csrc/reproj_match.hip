@@ -1,0 +1,258 @@
+// reproj_match.hip — K2/K3: reprojection-gated map-point <-> keypoint matching.
+//
+// Replaces MapMatcher::match / match_map / match_key_frame / match_for_fuse
+// (reference src/MapMatcher.cpp:45-98,107-127,165-175) together with the
+// per-point helpers it calls: Camera::project / is_in_image (src/Camera.cpp:25-37),
+// MapPoint::avg_viewing_normal / observed_distance_range (src/MapPoint.cpp:24-45)
+// and KDTree2D::radius_search (src/KDTree.cpp:45-82).
+//
+// K2: one lane per map point.  Projection and the three f32 gates, then the
+// KD-tree radius search walked with an explicit stack kept in LDS, visiting
+// nodes in exactly the reference's recursion order (node, near child, far
+// child) so that "first candidate wins ties" is preserved.  Every accepted
+// candidate is compared against all observations of the point with 8 xor +
+// 8 v_bcnt.  The winner per point goes into a packed 64-bit atomicMin on the
+// keypoint's slot (dist << 32 | map order), which reproduces the reference's
+// sequential strict-'<' proposal table: min distance, earliest point on ties.
+// K3: one workgroup decodes the table and emits accepted_matches() in
+// ascending keypoint order.
+// Built with -ffp-contract=off so the f32 gates execute the oracle's operations.
+#include "common.h"
+
+#define K2_THREADS 256
+#define K2_STACK 40
+
+struct K2Frame {
+    float T[16];
+    float fx, fy, cx, cy;
+    int width, height, n_keypoints, kd_root;
+    const float2* kp;
+    const uint4* desc;
+    const uint8_t* kp_matched;
+    const int32_t* kd_node_kp;
+    const int32_t* kd_left;
+    const int32_t* kd_right;
+};
+
+struct K2Map {
+    int n_points;
+    const float* pos;
+    const uint8_t* eligible;
+    const int32_t* obs_ptr;
+    const int32_t* obs_kf;
+    const int32_t* obs_desc;
+    const float* kf_centers;
+    const uint4* pool;
+};
+
+__device__ __forceinline__ float dot3f(const float* a, const float* b) { return (a[0] * b[0] + a[1] * b[1]) + a[2] * b[2]; }
+
+__device__ __forceinline__ void normalize3f(float* v)
+{
+    const float n = dot3f(v, v);
+    if (n > 0.0f) {
+        const float s = sqrtf(n);
+        v[0] = v[0] / s; v[1] = v[1] / s; v[2] = v[2] / s;
+    }
+}
+
+__device__ __forceinline__ int hamming256(const uint4 a0, const uint4 a1, const uint4 b0, const uint4 b1)
+{
+    int d = __builtin_popcount(a0.x ^ b0.x);
+    d += __builtin_popcount(a0.y ^ b0.y);
+    d += __builtin_popcount(a0.z ^ b0.z);
+    d += __builtin_popcount(a0.w ^ b0.w);
+    d += __builtin_popcount(a1.x ^ b1.x);
+    d += __builtin_popcount(a1.y ^ b1.y);
+    d += __builtin_popcount(a1.z ^ b1.z);
+    d += __builtin_popcount(a1.w ^ b1.w);
+    return d;
+}
+
+__global__ __launch_bounds__(K2_THREADS) void k2_reproj_match(K2Frame f, K2Map m, int replace, int max_distance,
+                                                             int32_t* __restrict__ point_kp,
+                                                             int32_t* __restrict__ point_dist,
+                                                             unsigned long long* __restrict__ prop)
+{
+    __shared__ int stack[K2_STACK][K2_THREADS];
+    const int p = blockIdx.x * K2_THREADS + threadIdx.x;
+    if (p >= m.n_points) return;
+    int out_kp = -1, out_d = max_distance;
+    do {
+        if (!m.eligible[p]) break;
+        const float X[3] = {m.pos[3 * (size_t)p], m.pos[3 * (size_t)p + 1], m.pos[3 * (size_t)p + 2]};
+        const float* T = f.T;
+        // Camera::project (src/Camera.cpp:25-32): K * pose.block<3,4> first, then * homogeneous
+        float uvw[3];
+        {
+            float KP[12];
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                KP[0 * 4 + j] = (f.fx * T[0 * 4 + j] + 0.0f * T[1 * 4 + j]) + f.cx * T[2 * 4 + j];
+                KP[1 * 4 + j] = (0.0f * T[0 * 4 + j] + f.fy * T[1 * 4 + j]) + f.cy * T[2 * 4 + j];
+                KP[2 * 4 + j] = (0.0f * T[0 * 4 + j] + 0.0f * T[1 * 4 + j]) + 1.0f * T[2 * 4 + j];
+            }
+#pragma unroll
+            for (int i = 0; i < 3; i++)
+                uvw[i] = (KP[4 * i] * X[0] + KP[4 * i + 1] * X[1]) + (KP[4 * i + 2] * X[2] + KP[4 * i + 3] * 1.0f);
+        }
+        float u, v;
+        if (uvw[2] < 0.0f) { u = -1.0f; v = -1.0f; }
+        else { u = uvw[0] / uvw[2]; v = uvw[1] / uvw[2]; }
+        if (!(u >= 0.0f && u < (float)f.width && v >= 0.0f && v < (float)f.height)) break;   // :58
+
+        // Frame::camera_center = -R^T t (src/Frame.cpp:39-42)
+        float center[3];
+#pragma unroll
+        for (int i = 0; i < 3; i++) {
+            const float a[3] = {-T[0 * 4 + i], -T[1 * 4 + i], -T[2 * 4 + i]};
+            const float t[3] = {T[3], T[7], T[11]};
+            center[i] = dot3f(a, t);
+        }
+        const float ray[3] = {X[0] - center[0], X[1] - center[1], X[2] - center[2]};
+        const int o0 = m.obs_ptr[p], o1 = m.obs_ptr[p + 1];
+        float normal[3] = {0.0f, 0.0f, 0.0f};
+        float nearest = 3.402823466e+38f, furthest = 0.0f;
+        for (int o = o0; o < o1; o++) {                                  // src/MapPoint.cpp:24-45
+            const float* C = m.kf_centers + 3 * (size_t)m.obs_kf[o];
+            float d[3] = {X[0] - C[0], X[1] - C[1], X[2] - C[2]};
+            const float dist = sqrtf(dot3f(d, d));
+            nearest = dist < nearest ? dist : nearest;
+            furthest = furthest < dist ? dist : furthest;
+            normalize3f(d);
+            normalize3f(d);
+            normal[0] += d[0]; normal[1] += d[1]; normal[2] += d[2];
+        }
+        normalize3f(normal);
+        float rn[3] = {ray[0], ray[1], ray[2]};
+        normalize3f(rn);
+        if (dot3f(normal, rn) < 0.5f) break;                             // :62-66
+        const float distance = sqrtf(dot3f(ray, ray));
+        if (distance < nearest / 2.0f || distance > furthest * 1.25f) break;   // :69-73
+
+        // KDTree2D::radius_search, r = 20 px (src/MapMatcher.cpp:75, src/KDTree.cpp:45-82)
+        const float r2 = 20.0f * 20.0f;
+        int best_kp = 0, best_d = max_distance;
+        int sp = 0;
+        if (f.kd_root >= 0) stack[sp++][threadIdx.x] = f.kd_root;      // entry = node | depth parity << 30
+        while (sp > 0) {
+            const int e = stack[--sp][threadIdx.x];
+            const int node = e & 0x3FFFFFFF, odd = (e >> 30) & 1;
+            const int kp = f.kd_node_kp[node];
+            const float2 q = f.kp[kp];
+            const float dx = q.x - u, dy = q.y - v;
+            const float d2 = dx * dx + dy * dy;
+            if (d2 <= r2 && (replace || !f.kp_matched[kp])) {            // :65, :81
+                const uint4 a0 = f.desc[2 * (size_t)kp], a1 = f.desc[2 * (size_t)kp + 1];
+                for (int o = o0; o < o1; o++) {
+                    const size_t row = (size_t)m.obs_desc[o];
+                    const int hd = hamming256(a0, a1, m.pool[2 * row], m.pool[2 * row + 1]);
+                    if (hd < best_d) { best_d = hd; best_kp = kp; }       // :88-91
+                }
+            }
+            const float delta = odd ? dy : dx;
+            const int l = f.kd_left[node], r = f.kd_right[node];
+            const int near_child = (delta > 0) ? l : r;
+            const int far_child = (delta > 0) ? r : l;
+            const int child_tag = (odd ^ 1) << 30;
+            if (delta * delta <= r2 && far_child >= 0 && sp < K2_STACK) stack[sp++][threadIdx.x] = far_child | child_tag;
+            if (near_child >= 0 && sp < K2_STACK) stack[sp++][threadIdx.x] = near_child | child_tag;
+        }
+        if (best_d < max_distance) {
+            out_kp = best_kp;
+            out_d = best_d;
+            // :95-97 sequential strict-'<' over map order == atomicMin of (dist, map order)
+            atomicMin(&prop[best_kp], ((unsigned long long)(unsigned)best_d << 32) | (unsigned)p);
+        }
+    } while (0);
+    point_kp[p] = out_kp;
+    point_dist[p] = out_d;
+}
+
+__global__ __launch_bounds__(1024) void k3_accept(const unsigned long long* __restrict__ prop, int n,
+                                                  int max_distance, int32_t* __restrict__ prop_point,
+                                                  int32_t* __restrict__ prop_dist, int32_t* __restrict__ match_kp,
+                                                  int32_t* __restrict__ match_point, int32_t* __restrict__ match_count)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    __shared__ int wave_count[16];
+    __shared__ int running;
+    if (threadIdx.x == 0) running = 0;
+    __syncthreads();
+    for (int base = 0; base < n; base += 1024) {
+        const int i = base + threadIdx.x;
+        bool ok = false;
+        int pt = -1, dist = max_distance;
+        if (i < n) {
+            const unsigned long long v = prop[i];
+            if (v != ~0ull) { ok = true; pt = (int)(unsigned)(v & 0xFFFFFFFFull); dist = (int)(v >> 32); }
+            prop_point[i] = pt;
+            prop_dist[i] = dist;
+        }
+        const unsigned long long mk = __ballot(ok);
+        if (lane == 0) wave_count[wave] = __popcll(mk);
+        __syncthreads();
+        int off = running;
+        for (int w = 0; w < wave; ++w) off += wave_count[w];
+        off += __popcll(mk & ((1ull << lane) - 1ull));
+        if (ok) { match_kp[off] = i; match_point[off] = pt; }            // accepted_matches :34-43
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            int tot = 0;
+            for (int w = 0; w < 16; ++w) tot += wave_count[w];
+            running += tot;
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *match_count = running;
+}
+
+extern "C" int rs_reproj_match(rs_context* ctx, const rs_frame_view* fr, const rs_map_view* mp, int replace,
+                               int max_distance, int32_t* d_point_kp, int32_t* d_point_dist,
+                               int32_t* d_prop_point, int32_t* d_prop_dist, int32_t* d_match_kp,
+                               int32_t* d_match_point, int32_t* d_match_count)
+{
+    if (!ctx || !fr || !mp) return RS_ERR_INVALID;
+    const int N = fr->n_keypoints, P = mp->n_points;
+    if (N < 0 || P < 0) return rs_fail(ctx, RS_ERR_INVALID, "negative size");
+    if (!d_match_count) return rs_fail(ctx, RS_ERR_INVALID, "null match_count");
+    if (N >= (1 << 30)) return rs_fail(ctx, RS_ERR_UNSUPPORTED, "too many keypoints");
+    RS_HIP(ctx, hipSetDevice(ctx->device));
+    if (N == 0) {
+        RS_HIP(ctx, hipMemsetAsync(d_match_count, 0, sizeof(int32_t), ctx->stream));
+        if (P > 0 && d_point_kp) RS_HIP(ctx, hipMemsetAsync(d_point_kp, 0xFF, sizeof(int32_t) * (size_t)P, ctx->stream));
+        return RS_OK;
+    }
+    if (!d_prop_point || !d_prop_dist || !d_match_kp || !d_match_point)
+        return rs_fail(ctx, RS_ERR_INVALID, "null output");
+    if (P > 0 && (!d_point_kp || !d_point_dist || !mp->d_positions || !mp->d_eligible || !mp->d_obs_ptr))
+        return rs_fail(ctx, RS_ERR_INVALID, "null map pointer");
+    void* ws = nullptr;
+    int rc = rs_workspace(ctx, sizeof(unsigned long long) * (size_t)N, &ws);
+    if (rc) return rc;
+    unsigned long long* prop = (unsigned long long*)ws;
+    RS_HIP(ctx, hipMemsetAsync(prop, 0xFF, sizeof(unsigned long long) * (size_t)N, ctx->stream));
+    if (P > 0) {
+        K2Frame f;
+        memcpy(f.T, fr->pose, sizeof f.T);
+        f.fx = fr->fx; f.fy = fr->fy; f.cx = fr->cx; f.cy = fr->cy;
+        f.width = fr->width; f.height = fr->height; f.n_keypoints = N; f.kd_root = fr->kd_root;
+        f.kp = (const float2*)fr->d_keypoints; f.desc = (const uint4*)fr->d_descriptors;
+        f.kp_matched = fr->d_kp_matched; f.kd_node_kp = fr->d_kd_node_kp; f.kd_left = fr->d_kd_left;
+        f.kd_right = fr->d_kd_right;
+        K2Map m;
+        m.n_points = P; m.pos = mp->d_positions; m.eligible = mp->d_eligible; m.obs_ptr = mp->d_obs_ptr;
+        m.obs_kf = mp->d_obs_kf; m.obs_desc = mp->d_obs_desc; m.kf_centers = mp->d_kf_centers;
+        m.pool = (const uint4*)mp->d_desc_pool;
+        rs_prof_scope ps(ctx, "K2_reproj_match");
+        hipLaunchKernelGGL(k2_reproj_match, dim3((P + K2_THREADS - 1) / K2_THREADS), dim3(K2_THREADS), 0,
+                           ctx->stream, f, m, replace, max_distance, d_point_kp, d_point_dist, prop);
+    }
+    {
+        rs_prof_scope ps(ctx, "K3_accept");
+        hipLaunchKernelGGL(k3_accept, dim3(1), dim3(1024), 0, ctx->stream, prop, N, max_distance, d_prop_point,
+                           d_prop_dist, d_match_kp, d_match_point, d_match_count);
+    }
+    RS_HIP(ctx, hipGetLastError());
+    return RS_OK;
+}

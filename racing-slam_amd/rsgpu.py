@@ -1,0 +1,303 @@
+"""ctypes binding of librsgpu.so (include/rsgpu.h) for the Python harness.
+
+PyTorch is plumbing only here: device memory (torch tensors) and the stream.
+Every call goes through the C-ABI; a missing library or a missing GPU raises —
+there is no CPU fallback in the product path.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "librsgpu.so")
+
+EXPORTS = [
+    "rs_abi_version", "rs_context_create", "rs_context_destroy", "rs_context_set_stream",
+    "rs_context_synchronize", "rs_last_error", "rs_hamming_knn2", "rs_match_descriptors",
+    "rs_kdtree_build", "rs_reproj_match", "rs_triangulate", "rs_ba_default_options",
+    "rs_bundle_adjust", "rs_refine_pose", "rs_pack_pose", "rs_unpack_pose", "rs_build_local_window",
+    "rs_comm_get_unique_id", "rs_comm_init_rank", "rs_comm_destroy", "rs_prof_begin", "rs_prof_end",
+]
+
+_lib = None
+
+
+class RsError(RuntimeError):
+    pass
+
+
+def load():
+    """Loads librsgpu.so.  torch is imported first so that the HIP runtime the
+    library binds to (soname libamdhip64.so.7) is the one torch already mapped."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RsError(f"{LIB_PATH} is missing: build it with __graft_entry__.build() "
+                          "(hipcc, gfx950); there is no CPU fallback")
+        import torch  # noqa: F401
+        _lib = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
+        _lib.rs_last_error.restype = C.c_char_p
+        _lib.rs_last_error.argtypes = [C.c_void_p]
+    return _lib
+
+
+class FrameView(C.Structure):
+    _fields_ = [("pose", C.c_float * 16), ("fx", C.c_float), ("fy", C.c_float), ("cx", C.c_float),
+                ("cy", C.c_float), ("width", C.c_int), ("height", C.c_int), ("n_keypoints", C.c_int),
+                ("d_keypoints", C.c_void_p), ("d_descriptors", C.c_void_p), ("d_kp_matched", C.c_void_p),
+                ("d_kd_node_kp", C.c_void_p), ("d_kd_left", C.c_void_p), ("d_kd_right", C.c_void_p),
+                ("kd_root", C.c_int)]
+
+
+class MapView(C.Structure):
+    _fields_ = [("n_points", C.c_int), ("d_positions", C.c_void_p), ("d_eligible", C.c_void_p),
+                ("d_obs_ptr", C.c_void_p), ("d_obs_kf", C.c_void_p), ("d_obs_desc", C.c_void_p),
+                ("d_kf_centers", C.c_void_p), ("d_desc_pool", C.c_void_p)]
+
+
+class BaOptions(C.Structure):
+    _fields_ = [("max_num_iterations", C.c_int), ("huber_delta", C.c_double),
+                ("initial_trust_region_radius", C.c_double), ("max_trust_region_radius", C.c_double),
+                ("min_trust_region_radius", C.c_double), ("min_relative_decrease", C.c_double),
+                ("min_lm_diagonal", C.c_double), ("max_lm_diagonal", C.c_double),
+                ("function_tolerance", C.c_double), ("gradient_tolerance", C.c_double),
+                ("parameter_tolerance", C.c_double), ("max_num_consecutive_invalid_steps", C.c_int),
+                ("jacobi_scaling", C.c_int)]
+
+
+class BaSummary(C.Structure):
+    _fields_ = [("termination", C.c_int), ("iterations", C.c_int), ("successful_steps", C.c_int),
+                ("usable", C.c_int), ("initial_cost", C.c_double), ("final_cost", C.c_double),
+                ("final_radius", C.c_double)]
+
+    def as_dict(self):
+        return {k: getattr(self, k) for k, _ in self._fields_}
+
+
+class ProfEntry(C.Structure):
+    _fields_ = [("name", C.c_char * 32), ("launches", C.c_int), ("total_ms", C.c_double)]
+
+
+def default_options():
+    o = BaOptions()
+    load().rs_ba_default_options(C.byref(o))
+    return o
+
+
+def _dp(t):
+    """device pointer of a torch tensor (or None)"""
+    if t is None:
+        return None
+    assert t.is_cuda and t.is_contiguous(), "device tensors must be contiguous CUDA/HIP tensors"
+    return C.c_void_p(t.data_ptr())
+
+
+# ---- host-only helpers (no GPU needed) ---------------------------------------
+def pack_pose(pose):
+    p = np.ascontiguousarray(pose, np.float32).reshape(16)
+    cam = np.zeros(6)
+    load().rs_pack_pose(p.ctypes.data_as(C.c_void_p), cam.ctypes.data_as(C.c_void_p))
+    return cam
+
+
+def unpack_pose(cam):
+    c = np.ascontiguousarray(cam, np.float64)
+    p = np.zeros(16, np.float32)
+    load().rs_unpack_pose(c.ctypes.data_as(C.c_void_p), p.ctypes.data_as(C.c_void_p))
+    return p.reshape(4, 4)
+
+
+def kdtree_build(keypoints):
+    kp = np.ascontiguousarray(keypoints, np.float32)
+    n = len(kp)
+    node_kp = np.zeros(max(n, 1), np.int32)
+    left = np.zeros(max(n, 1), np.int32)
+    right = np.zeros(max(n, 1), np.int32)
+    root = np.zeros(1, np.int32)
+    rc = load().rs_kdtree_build(kp.ctypes.data_as(C.c_void_p), n, node_kp.ctypes.data_as(C.c_void_p),
+                                left.ctypes.data_as(C.c_void_p), right.ctypes.data_as(C.c_void_p),
+                                root.ctypes.data_as(C.c_void_p))
+    if rc:
+        raise RsError(f"rs_kdtree_build -> {rc}")
+    return node_kp[:n], left[:n], right[:n], int(root[0])
+
+
+def build_local_window(n_kf, new_frame, window, fix_oldest, frame_ptr, frame_pt, pt_ptr, pt_obs):
+    a = [np.ascontiguousarray(x, np.int32) for x in (frame_ptr, frame_pt, pt_ptr, pt_obs)]
+    of = np.zeros(n_kf + 1, np.int32)
+    oo = np.zeros(n_kf + 1, np.uint8)
+    cnt = np.zeros(1, np.int32)
+    rc = load().rs_build_local_window(n_kf, new_frame, window, int(fix_oldest),
+                                      *[x.ctypes.data_as(C.c_void_p) for x in a],
+                                      of.ctypes.data_as(C.c_void_p), oo.ctypes.data_as(C.c_void_p),
+                                      cnt.ctypes.data_as(C.c_void_p))
+    if rc:
+        raise RsError(f"rs_build_local_window -> {rc}")
+    n = int(cnt[0])
+    return of[:n].copy(), oo[:n].copy()
+
+
+# ---- GPU context -------------------------------------------------------------
+class Context:
+    def __init__(self, device=0):
+        import torch
+        self.lib = load()
+        self.torch = torch
+        if not torch.cuda.is_available():
+            raise RsError("no GPU visible: librsgpu has no CPU fallback")
+        self.device = torch.device("cuda", device)
+        self.h = C.c_void_p()
+        rc = self.lib.rs_context_create(int(device), C.byref(self.h))
+        if rc:
+            raise RsError(f"rs_context_create -> {rc}")
+        self.use_stream(torch.cuda.current_stream(self.device))
+
+    def use_stream(self, stream):
+        self._check(self.lib.rs_context_set_stream(self.h, C.c_void_p(stream.cuda_stream)), "set_stream")
+
+    def close(self):
+        if self.h:
+            self.lib.rs_context_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def _check(self, rc, what):
+        if rc:
+            msg = self.lib.rs_last_error(self.h)
+            raise RsError(f"{what} -> status {rc}: {msg.decode() if msg else ''}")
+
+    def dev(self, a, dtype=None):
+        t = self.torch.from_numpy(np.ascontiguousarray(a if dtype is None else np.asarray(a, dtype)))
+        return t.to(self.device)
+
+    def empty(self, shape, dtype):
+        return self.torch.empty(shape, dtype=dtype, device=self.device)
+
+    # -- a4
+    def hamming_knn2(self, d_query, d_train, nq, nt, batch=1):
+        t = self.torch
+        outs = [self.empty((batch, max(nq, 1)), t.int32) for _ in range(4)]
+        self._check(self.lib.rs_hamming_knn2(self.h, _dp(d_query), nq, _dp(d_train), nt, batch,
+                                             *[_dp(o) for o in outs]), "rs_hamming_knn2")
+        return outs
+
+    def match_descriptors(self, d_query, d_train, nq, nt, batch=1, max_distance=64, raw=False, out=None):
+        t = self.torch
+        if out is None:
+            out = dict(mq=self.empty((batch, max(nq, 1)), t.int32), mt=self.empty((batch, max(nq, 1)), t.int32),
+                       cnt=self.empty((batch,), t.int32))
+            if raw:
+                out["raw"] = [self.empty((batch, max(nq, 1)), t.int32) for _ in range(4)]
+        rawp = [_dp(o) for o in out["raw"]] if "raw" in out else [None] * 4
+        self._check(self.lib.rs_match_descriptors(self.h, _dp(d_query), nq, _dp(d_train), nt, batch,
+                                                  int(max_distance), _dp(out["mq"]), _dp(out["mt"]),
+                                                  _dp(out["cnt"]), *rawp), "rs_match_descriptors")
+        return out
+
+    # -- a2/a3
+    def make_frame_view(self, frame):
+        """frame: dict of numpy arrays (synth.make_match_scene); returns (FrameView, keepalive)."""
+        fv = FrameView()
+        keep = {}
+        fv.pose[:] = list(np.asarray(frame["pose"], np.float32).reshape(16))
+        fv.fx, fv.fy, fv.cx, fv.cy = [float(v) for v in frame["K"]]
+        fv.width, fv.height = int(frame["width"]), int(frame["height"])
+        fv.n_keypoints = len(frame["keypoints"])
+        for name, key, dt in (("d_keypoints", "keypoints", np.float32), ("d_descriptors", "descriptors", np.uint8),
+                              ("d_kp_matched", "kp_matched", np.uint8), ("d_kd_node_kp", "kd_node_kp", np.int32),
+                              ("d_kd_left", "kd_left", np.int32), ("d_kd_right", "kd_right", np.int32)):
+            keep[name] = self.dev(frame[key], dt)
+            setattr(fv, name, keep[name].data_ptr())
+        fv.kd_root = int(frame["kd_root"])
+        return fv, keep
+
+    def make_map_view(self, mp):
+        mv = MapView()
+        keep = {}
+        mv.n_points = len(mp["positions"])
+        for name, key, dt in (("d_positions", "positions", np.float32), ("d_eligible", "eligible", np.uint8),
+                              ("d_obs_ptr", "obs_ptr", np.int32), ("d_obs_kf", "obs_kf", np.int32),
+                              ("d_obs_desc", "obs_desc", np.int32), ("d_kf_centers", "kf_centers", np.float32),
+                              ("d_desc_pool", "desc_pool", np.uint8)):
+            keep[name] = self.dev(mp[key], dt)
+            setattr(mv, name, keep[name].data_ptr())
+        return mv, keep
+
+    def reproj_match(self, fv, mv, replace=0, max_distance=64, out=None):
+        t = self.torch
+        N, P = fv.n_keypoints, mv.n_points
+        if out is None:
+            out = dict(point_kp=self.empty((max(P, 1),), t.int32), point_dist=self.empty((max(P, 1),), t.int32),
+                       prop_point=self.empty((max(N, 1),), t.int32), prop_dist=self.empty((max(N, 1),), t.int32),
+                       match_kp=self.empty((max(N, 1),), t.int32), match_point=self.empty((max(N, 1),), t.int32),
+                       count=self.empty((1,), t.int32))
+        self._check(self.lib.rs_reproj_match(self.h, C.byref(fv), C.byref(mv), int(replace), int(max_distance),
+                                             _dp(out["point_kp"]), _dp(out["point_dist"]), _dp(out["prop_point"]),
+                                             _dp(out["prop_dist"]), _dp(out["match_kp"]), _dp(out["match_point"]),
+                                             _dp(out["count"])), "rs_reproj_match")
+        return out
+
+    # -- a5-a7
+    def triangulate(self, d_uv1, d_uv2, n, d_poses, n_poses, K, d_idx1=None, d_idx2=None,
+                    min_parallax_cosine=0.9999, max_reproj=2.0, out=None):
+        t = self.torch
+        if out is None:
+            out = dict(xyz=self.empty((max(n, 1), 3), t.float32), keep=self.empty((max(n, 1),), t.uint8),
+                       out_index=self.empty((max(n, 1),), t.int32), out_xyz=self.empty((max(n, 1), 3), t.float32),
+                       count=self.empty((1,), t.int32))
+        Kc = (C.c_float * 4)(*[float(v) for v in K])
+        self._check(self.lib.rs_triangulate(self.h, _dp(d_uv1), _dp(d_uv2), int(n), _dp(d_poses), int(n_poses),
+                                            _dp(d_idx1), _dp(d_idx2), Kc, C.c_float(min_parallax_cosine),
+                                            C.c_float(max_reproj), _dp(out["xyz"]), _dp(out["keep"]),
+                                            _dp(out["out_index"]), _dp(out["out_xyz"]), _dp(out["count"])),
+                    "rs_triangulate")
+        return out
+
+    # -- a9-a13
+    def bundle_adjust(self, d_cams, cam_free, d_points, d_obs_ptr, d_obs_cam, d_obs_uv, K, options=None):
+        cam_free = np.ascontiguousarray(cam_free, np.uint8)
+        Kc = (C.c_float * 4)(*[float(v) for v in K])
+        s = BaSummary()
+        self._check(self.lib.rs_bundle_adjust(self.h, int(d_cams.shape[0]), int(d_points.shape[0]),
+                                              int(d_obs_cam.shape[0]), _dp(d_cams),
+                                              cam_free.ctypes.data_as(C.c_void_p), _dp(d_points), _dp(d_obs_ptr),
+                                              _dp(d_obs_cam), _dp(d_obs_uv), Kc,
+                                              None if options is None else C.byref(options), C.byref(s)),
+                    "rs_bundle_adjust")
+        return s.as_dict()
+
+    def refine_pose(self, cam, d_points, d_uv, K, options=None):
+        cam = np.array(cam, np.float64, order="C")
+        Kc = (C.c_float * 4)(*[float(v) for v in K])
+        s = BaSummary()
+        self._check(self.lib.rs_refine_pose(self.h, cam.ctypes.data_as(C.c_void_p), _dp(d_points), _dp(d_uv),
+                                            int(d_points.shape[0]), Kc,
+                                            None if options is None else C.byref(options), C.byref(s)),
+                    "rs_refine_pose")
+        return cam, s.as_dict()
+
+    # -- multi-GPU
+    @staticmethod
+    def comm_unique_id():
+        buf = (C.c_uint8 * 128)()
+        rc = load().rs_comm_get_unique_id(buf)
+        if rc:
+            raise RsError(f"rs_comm_get_unique_id -> {rc}")
+        return bytes(buf)
+
+    def comm_init(self, uid, n_ranks, rank):
+        buf = (C.c_uint8 * 128).from_buffer_copy(uid)
+        self._check(self.lib.rs_comm_init_rank(self.h, buf, int(n_ranks), int(rank)), "rs_comm_init_rank")
+
+    # -- profiling
+    def prof_begin(self):
+        self._check(self.lib.rs_prof_begin(self.h), "rs_prof_begin")
+
+    def prof_end(self):
+        ent = (ProfEntry * 32)()
+        n = C.c_int(0)
+        self._check(self.lib.rs_prof_end(self.h, ent, C.byref(n)), "rs_prof_end")
+        return {ent[i].name.decode(): (ent[i].launches, ent[i].total_ms) for i in range(n.value)}
+
+    def synchronize(self):
+        self._check(self.lib.rs_context_synchronize(self.h), "rs_context_synchronize")

@@ -1,0 +1,249 @@
+"""Synthetic inputs for the hot path, shaped as SURVEY.md §8(d) / BASELINE.json configs.
+
+All inputs are generated on the host with numpy's PCG64 (seed 0x5EED0000 +
+config id) and handed unchanged to the GPU library, the oracle and the CPU
+baseline, so every leg sees bit-identical arrays.  There is no dataset: the
+reference's inputs are video frames; here keypoints are projections of random
+landmarks and descriptors are random 256-bit strings with 5 % bit flips per
+observation (true-match Hamming ~13, impostor ~128).
+"""
+import numpy as np
+
+SEED_BASE = 0x5EED0000
+
+
+def rng_for(config_id, stream=0):
+    return np.random.default_rng([SEED_BASE + int(config_id), int(stream)])
+
+
+def yaw_matrix(deg):
+    a = np.deg2rad(deg)
+    c, s = np.cos(a), np.sin(a)
+    return np.array([[c, 0, s], [0, 1, 0], [-s, 0, c]])
+
+
+def make_pose(R_wc, centre):
+    """world->camera 4x4 (f32) from camera-to-world rotation and centre."""
+    T = np.eye(4)
+    T[:3, :3] = R_wc.T
+    T[:3, 3] = -R_wc.T @ centre
+    return T.astype(np.float32)
+
+
+def rodrigues(aa):
+    th = np.linalg.norm(aa)
+    if th < 1e-12:
+        return np.eye(3)
+    k = aa / th
+    Kx = np.array([[0, -k[2], k[1]], [k[2], 0, -k[0]], [-k[1], k[0], 0]])
+    return np.eye(3) + np.sin(th) * Kx + (1 - np.cos(th)) * Kx @ Kx
+
+
+def log_so3(R):
+    c = np.clip((np.trace(R) - 1) / 2, -1, 1)
+    th = np.arccos(c)
+    if th < 1e-12:
+        return np.zeros(3)
+    w = np.array([R[2, 1] - R[1, 2], R[0, 2] - R[2, 0], R[1, 0] - R[0, 1]]) / (2 * np.sin(th))
+    return w * th
+
+
+def random_descriptors(rng, n):
+    return rng.integers(0, 256, size=(n, 32), dtype=np.uint8)
+
+
+def flip_bits(rng, desc, p=0.05):
+    bits = np.unpackbits(desc, axis=1)
+    flips = rng.random(bits.shape) < p
+    return np.packbits(bits ^ flips.astype(np.uint8), axis=1)
+
+
+def project(T, K, X):
+    Xc = X @ T[:3, :3].T.astype(np.float64) + T[:3, 3].astype(np.float64)
+    u = K[0] * Xc[:, 0] / Xc[:, 2] + K[2]
+    v = K[1] * Xc[:, 1] / Xc[:, 2] + K[3]
+    return np.stack([u, v], 1), Xc[:, 2]
+
+
+def pair_config(config_id):
+    if config_id == 1:
+        return dict(width=640, height=480, K=np.array([500, 500, 320, 240], np.float32), n=500, unmatched=0.0)
+    return dict(width=1920, height=1080, K=np.array([1000, 1000, 960, 540], np.float32), n=2000, unmatched=0.10)
+
+
+def make_pair(config_id=2, seed_stream=0, n=None):
+    """Two-frame scene of cfg 1 / cfg 2: returns a dict with
+    desc1/kp1 (train, the keyframe), desc2/kp2 (query, the new frame), poses [2][16], K."""
+    cfg = pair_config(config_id)
+    rng = rng_for(config_id, seed_stream)
+    N = cfg["n"] if n is None else int(n)
+    K, W, H = cfg["K"].astype(np.float64), cfg["width"], cfg["height"]
+    T1 = make_pose(np.eye(3), np.zeros(3))
+    T2 = make_pose(yaw_matrix(2.0), np.array([0.2, 0.0, 0.05]))
+    n_shared = int(round(N * (1.0 - cfg["unmatched"])))
+    # landmarks uniform in frame 1's frustum, depth U[4,20]
+    z = rng.uniform(4, 20, n_shared)
+    u = rng.uniform(0, W, n_shared)
+    v = rng.uniform(0, H, n_shared)
+    X = np.stack([(u - K[2]) / K[0] * z, (v - K[3]) / K[1] * z, z], 1)
+    base = random_descriptors(rng, n_shared)
+    kp1, _ = project(T1, K, X)
+    kp2, _ = project(T2, K, X)
+    kp1 = kp1 + rng.normal(0, 0.5, kp1.shape)
+    kp2 = kp2 + rng.normal(0, 0.5, kp2.shape)
+    d1 = flip_bits(rng, base)
+    d2 = flip_bits(rng, base)
+    n_extra = N - n_shared
+    if n_extra > 0:
+        for kp, d in ((kp1, d1), (kp2, d2)):
+            pass
+        e1 = np.stack([rng.uniform(0, W, n_extra), rng.uniform(0, H, n_extra)], 1)
+        e2 = np.stack([rng.uniform(0, W, n_extra), rng.uniform(0, H, n_extra)], 1)
+        kp1 = np.concatenate([kp1, e1]); kp2 = np.concatenate([kp2, e2])
+        d1 = np.concatenate([d1, random_descriptors(rng, n_extra)])
+        d2 = np.concatenate([d2, random_descriptors(rng, n_extra)])
+    # independent shuffles so that index i in frame 1 is not index i in frame 2
+    p1 = rng.permutation(N)
+    p2 = rng.permutation(N)
+    return dict(desc1=np.ascontiguousarray(d1[p1]), kp1=kp1[p1].astype(np.float32),
+                desc2=np.ascontiguousarray(d2[p2]), kp2=kp2[p2].astype(np.float32),
+                poses=np.stack([T1.reshape(16), T2.reshape(16)]).astype(np.float32),
+                K=cfg["K"], width=W, height=H,
+                truth12=(np.argsort(p1), np.argsort(p2), n_shared))
+
+
+def make_ba_window(n_kf=20, n_points=10000, config_id=3, seed_stream=0, n_fixed=2,
+                   run_min=2, run_max=10, pixel_noise=0.5, outlier_frac=0.02,
+                   rot_noise_deg=0.5, trans_noise=0.01, depth_noise=0.01):
+    """cfg 3 / cfg 5 window: keyframes on a gently curving forward track, each landmark
+    seen by a run of consecutive keyframes.  Returns the flat BA problem
+    (cams [C][6] = angle-axis(R_cw) + centre, points [P][3], CSR observations) plus
+    the ground truth and the keyframe poses."""
+    rng = rng_for(config_id, seed_stream)
+    K = np.array([1000, 1000, 960, 540], np.float32)
+    Kd = K.astype(np.float64)
+    W, H = 1920, 1080
+    R = np.eye(3)
+    c = np.zeros(3)
+    Rs, cs = [], []
+    for i in range(n_kf):
+        Rs.append(R.copy()); cs.append(c.copy())
+        R = R @ yaw_matrix(1.5)
+        c = c + R @ np.array([0, 0, 0.5])
+    poses_true = np.stack([make_pose(Rs[i], cs[i]) for i in range(n_kf)])
+    run_max = min(run_max, n_kf)
+    run_len = rng.integers(run_min, run_max + 1, n_points)
+    start = (rng.random(n_points) * (n_kf - run_len + 1)).astype(np.int64)
+    mid = start + run_len // 2
+    z = rng.uniform(4, 20, n_points)
+    u = rng.uniform(0.1 * W, 0.9 * W, n_points)
+    v = rng.uniform(0.1 * H, 0.9 * H, n_points)
+    Xc = np.stack([(u - Kd[2]) / Kd[0] * z, (v - Kd[3]) / Kd[1] * z, z], 1)
+    Rm = np.stack([Rs[m] for m in mid]); cm = np.stack([cs[m] for m in mid])
+    X = np.einsum("nij,nj->ni", Rm, Xc) + cm
+    obs_ptr = np.zeros(n_points + 1, np.int32)
+    obs_ptr[1:] = np.cumsum(run_len)
+    M = int(obs_ptr[-1])
+    obs_cam = np.concatenate([np.arange(s, s + l) for s, l in zip(start, run_len)]).astype(np.int32)
+    obs_pt = np.repeat(np.arange(n_points), run_len)
+    uv = np.zeros((M, 2))
+    for k in range(n_kf):
+        sel = obs_cam == k
+        if sel.any():
+            uv[sel], _ = project(poses_true[k], Kd, X[obs_pt[sel]])
+    uv += rng.normal(0, pixel_noise, uv.shape)
+    out = rng.random(M) < outlier_frac
+    uv[out] += rng.uniform(-30, 30, (int(out.sum()), 2))
+    # perturbed initial state
+    cams = np.zeros((n_kf, 6))
+    cams_true = np.zeros((n_kf, 6))
+    for i in range(n_kf):
+        Rcw = Rs[i].T
+        cams_true[i, :3] = log_so3(Rcw); cams_true[i, 3:] = cs[i]
+        if i < n_fixed:
+            cams[i] = cams_true[i]
+        else:
+            dR = rodrigues(rng.normal(0, np.deg2rad(rot_noise_deg) / np.sqrt(3), 3))
+            cams[i, :3] = log_so3(dR @ Rcw)
+            cams[i, 3:] = cs[i] + rng.normal(0, trans_noise * 0.5, 3)
+    cams = cams.astype(np.float32).astype(np.float64)   # pack_pose output is f32-valued
+    cams_true = cams_true.astype(np.float32).astype(np.float64)
+    depth_scale = 1.0 + rng.normal(0, depth_noise, n_points)
+    pts = cm + (X - cm) * depth_scale[:, None]
+    pts = pts.astype(np.float32).astype(np.float64)     # MapPoint::position is f32
+    cam_free = np.ones(n_kf, np.uint8)
+    cam_free[:n_fixed] = 0
+    return dict(cams=cams, cam_free=cam_free, points=pts, obs_ptr=obs_ptr, obs_cam=obs_cam,
+                obs_uv=uv.astype(np.float32), K=K, cams_true=cams_true, points_true=X,
+                poses_true=poses_true, width=W, height=H, run_start=start.astype(np.int32),
+                run_len=run_len.astype(np.int32))
+
+
+def shard_ba_by_landmark(prob, n_shards, shard):
+    """Landmark shard `shard` of `n_shards` (contiguous blocks of landmarks;
+    cameras replicated) — SURVEY.md §8(e)."""
+    P = len(prob["points"])
+    lo = (P * shard) // n_shards
+    hi = (P * (shard + 1)) // n_shards
+    o0, o1 = int(prob["obs_ptr"][lo]), int(prob["obs_ptr"][hi])
+    out = dict(prob)
+    out["points"] = prob["points"][lo:hi].copy()
+    out["obs_ptr"] = (prob["obs_ptr"][lo:hi + 1] - o0).astype(np.int32)
+    out["obs_cam"] = prob["obs_cam"][o0:o1].copy()
+    out["obs_uv"] = prob["obs_uv"][o0:o1].copy()
+    out["point_range"] = (lo, hi)
+    return out
+
+
+def make_match_scene(window=None, n_keypoints=2000, config_id=3, seed_stream=7, matched_frac=0.3,
+                     kdtree_build=None):
+    """Reprojection-gated matching scene (a2): the newest frame of a BA window
+    against the window's landmarks.  Every landmark observation gets a
+    descriptor row in the pool; the frame sees a subset of the landmarks plus
+    clutter keypoints; `matched_frac` of its keypoints are already matched."""
+    if window is None:
+        window = make_ba_window(config_id=config_id)
+    rng = rng_for(config_id, seed_stream)
+    K = window["K"].astype(np.float64)
+    W, H = window["width"], window["height"]
+    P = len(window["points"])
+    n_kf = len(window["cams"])
+    X = window["points_true"]
+    # the frame: one step beyond the last keyframe
+    T_last = window["poses_true"][-1].astype(np.float64)
+    R_wc = T_last[:3, :3].T @ yaw_matrix(1.5)
+    centre = -T_last[:3, :3].T @ T_last[:3, 3] + R_wc @ np.array([0, 0, 0.5])
+    pose = make_pose(R_wc, centre)
+    uv, zc = project(pose, K, X)
+    vis = (zc > 0.5) & (uv[:, 0] >= 0) & (uv[:, 0] < W) & (uv[:, 1] >= 0) & (uv[:, 1] < H)
+    vis_idx = np.flatnonzero(vis)
+    n_seen = min(len(vis_idx), int(n_keypoints * 0.8))
+    seen = rng.choice(vis_idx, n_seen, replace=False) if n_seen > 0 else np.zeros(0, np.int64)
+    base = random_descriptors(rng, P)
+    kp = uv[seen] + rng.normal(0, 1.5, (n_seen, 2))
+    desc = flip_bits(rng, base[seen])
+    n_extra = n_keypoints - n_seen
+    kp = np.concatenate([kp, np.stack([rng.uniform(0, W, n_extra), rng.uniform(0, H, n_extra)], 1)])
+    desc = np.concatenate([desc, random_descriptors(rng, n_extra)])
+    perm = rng.permutation(n_keypoints)
+    kp = kp[perm].astype(np.float32)
+    desc = np.ascontiguousarray(desc[perm])
+    kp_matched = (rng.random(n_keypoints) < matched_frac).astype(np.uint8)
+    # observation descriptors: one pool row per observation
+    M = len(window["obs_cam"])
+    obs_pt = np.repeat(np.arange(P), np.diff(window["obs_ptr"]))
+    desc_pool = flip_bits(rng, base[obs_pt])
+    obs_desc = rng.permutation(M).astype(np.int32)        # rows are not in observation order
+    pool = np.zeros_like(desc_pool)
+    pool[obs_desc] = desc_pool
+    kf_centers = window["cams_true"][:, 3:].astype(np.float32)
+    eligible = (rng.random(P) < 0.9).astype(np.uint8)
+    frame = dict(pose=pose.reshape(16), K=window["K"], width=W, height=H, keypoints=kp,
+                 descriptors=desc, kp_matched=kp_matched)
+    if kdtree_build is not None:
+        node_kp, left, right, root = kdtree_build(kp)
+        frame.update(kd_node_kp=node_kp, kd_left=left, kd_right=right, kd_root=root)
+    mp = dict(positions=window["points"].astype(np.float32), eligible=eligible,
+              obs_ptr=window["obs_ptr"], obs_kf=window["obs_cam"], obs_desc=obs_desc,
+              kf_centers=kf_centers, desc_pool=pool)
+    return frame, mp

@@ -1,0 +1,281 @@
+"""GPU parity tests: the HIP path (through the C-ABI) against the CPU oracle on
+identical seeded inputs.  Integer / index results are compared bit for bit;
+floating point results within the tolerance written next to each assert.
+PARITY UNPINNED against the reference itself (it ships no fixtures): the oracle
+is the restatement documented in oracle/*.c.
+"""
+import numpy as np
+import pytest
+
+from conftest import to_np
+
+pytestmark = pytest.mark.gpu
+
+
+def _knn_case(ctx, oracle, q, t):
+    nq, nt = len(q), len(t)
+    dq, dt = ctx.dev(q), ctx.dev(t)
+    got = [to_np(x)[0, :nq] for x in ctx.hamming_knn2(dq, dt, nq, nt)]
+    ref = oracle.hamming_knn2(q, t)
+    for g, r, name in zip(got, ref, ("idx0", "dist0", "idx1", "dist1")):
+        assert np.array_equal(g, r), name
+    m = ctx.match_descriptors(dq, dt, nq, nt)
+    cnt = int(to_np(m["cnt"])[0])
+    rq, rt = oracle.match_descriptors(q, t)
+    assert cnt == len(rq)
+    assert np.array_equal(to_np(m["mq"])[0, :cnt], rq)
+    assert np.array_equal(to_np(m["mt"])[0, :cnt], rt)
+    return cnt
+
+
+@pytest.mark.parametrize("config_id", [1, 2])
+def test_match_descriptors_configs(ctx, oracle, synth, config_id):
+    pr = synth.make_pair(config_id)
+    cnt = _knn_case(ctx, oracle, pr["desc2"], pr["desc1"])
+    assert cnt > 0.5 * len(pr["desc2"]) * 0.8
+
+
+@pytest.mark.parametrize("nq,nt", [(1, 1), (7, 1), (1, 2), (65, 33), (130, 77), (64, 4096), (1000, 3)])
+def test_knn2_ragged_sizes(ctx, oracle, nq, nt):
+    rng = np.random.default_rng(nq * 1000 + nt)
+    q = rng.integers(0, 256, (nq, 32), dtype=np.uint8)
+    t = rng.integers(0, 256, (nt, 32), dtype=np.uint8)
+    _knn_case(ctx, oracle, q, t)
+
+
+def test_knn2_ties_and_thresholds(ctx, oracle):
+    """equal distances (lower train index must win), d0 == 64 (accepted), 4*d0 == 3*d1 (accepted)."""
+    rng = np.random.default_rng(5)
+    q = rng.integers(0, 256, (200, 32), dtype=np.uint8)
+    t = np.zeros((300, 32), np.uint8)
+    for i in range(300):
+        src = q[i % 200].copy()
+        bits = np.unpackbits(src)
+        flip = rng.choice(256, size=[0, 3, 48, 64, 64, 65, 85][i % 7], replace=False)
+        bits[flip] ^= 1
+        t[i] = np.packbits(bits)
+    t[100:110] = t[0]           # exact duplicates: ties at every rank
+    q[150:160] = q[0]
+    _knn_case(ctx, oracle, q, t)
+
+
+def test_match_descriptors_batched(ctx, oracle, synth):
+    prs = [synth.make_pair(1, seed_stream=s) for s in range(3)]
+    q = np.stack([p["desc2"] for p in prs])
+    t = np.stack([p["desc1"] for p in prs])
+    nq, nt = q.shape[1], t.shape[1]
+    m = ctx.match_descriptors(ctx.dev(q), ctx.dev(t), nq, nt, batch=3, raw=True)
+    for b in range(3):
+        rq, rt = oracle.match_descriptors(q[b], t[b])
+        cnt = int(to_np(m["cnt"])[b])
+        assert cnt == len(rq)
+        assert np.array_equal(to_np(m["mq"])[b, :cnt], rq)
+        assert np.array_equal(to_np(m["mt"])[b, :cnt], rt)
+        ref = oracle.hamming_knn2(q[b], t[b])
+        for g, r in zip(m["raw"], ref):
+            assert np.array_equal(to_np(g)[b], r)
+
+
+def test_match_descriptors_empty(ctx):
+    import torch
+    q = torch.zeros((4, 32), dtype=torch.uint8, device=ctx.device)
+    m = ctx.match_descriptors(q, q, 4, 0)
+    assert int(to_np(m["cnt"])[0]) == 0
+    m = ctx.match_descriptors(q, q, 0, 4)
+    assert int(to_np(m["cnt"])[0]) == 0
+
+
+# ------------------------------------------------------------ triangulation
+def _tri_case(ctx, oracle, uv1, uv2, poses, K, idx1=None, idx2=None, cos=0.9999, err=2.0):
+    n = len(uv1)
+    d = ctx.triangulate(ctx.dev(uv1, np.float32), ctx.dev(uv2, np.float32), n, ctx.dev(poses, np.float32),
+                        len(poses), K, None if idx1 is None else ctx.dev(idx1, np.int32),
+                        None if idx2 is None else ctx.dev(idx2, np.int32), cos, err)
+    ref = oracle.triangulate(uv1, uv2, poses, K, idx1, idx2, cos, err)
+    xyz = to_np(d["xyz"])[:n]
+    keep = to_np(d["keep"])[:n]
+    # f32 tolerance: 1e-5 relative (the f64 SVD + f32 rounding is the same arithmetic on both
+    # sides; with -ffp-contract=off the results are expected to be bit-identical)
+    assert np.allclose(xyz, ref["xyz"], rtol=1e-5, atol=1e-6)
+    exact = np.array_equal(xyz.view(np.uint32), ref["xyz"].view(np.uint32))
+    assert np.array_equal(keep, ref["keep"]), "gate decisions differ"
+    cnt = int(to_np(d["count"])[0])
+    assert cnt == len(ref["out_index"])
+    assert np.array_equal(to_np(d["out_index"])[:cnt], ref["out_index"])
+    assert np.allclose(to_np(d["out_xyz"])[:cnt], ref["out_xyz"], rtol=1e-5, atol=1e-6)
+    return exact, cnt
+
+
+@pytest.mark.parametrize("config_id", [1, 2])
+def test_triangulate_pair(ctx, oracle, synth, config_id):
+    pr = synth.make_pair(config_id)
+    mq, mt = oracle.match_descriptors(pr["desc2"], pr["desc1"])
+    uv1, uv2 = pr["kp1"][mt], pr["kp2"][mq]
+    exact, cnt = _tri_case(ctx, oracle, uv1, uv2, pr["poses"], pr["K"])
+    assert cnt > 0
+    assert exact, "positions are expected bit-exact with contraction off"
+    # Mapper's gates (src/Mapper.cpp:37-38)
+    _tri_case(ctx, oracle, uv1, uv2, pr["poses"], pr["K"], cos=1.0, err=4.0)
+
+
+def test_triangulate_tracks_per_item_poses(ctx, oracle, synth):
+    w = synth.make_ba_window(n_kf=8, n_points=300, run_max=6)
+    rng = np.random.default_rng(3)
+    poses = w["poses_true"].reshape(-1, 16)
+    first = w["obs_ptr"][:-1]
+    last = w["obs_ptr"][1:] - 1
+    idx1 = w["obs_cam"][first]
+    idx2 = w["obs_cam"][last]
+    uv1, uv2 = w["obs_uv"][first], w["obs_uv"][last]
+    exact, cnt = _tri_case(ctx, oracle, uv1, uv2, poses, w["K"], idx1, idx2, cos=1.0, err=4.0)
+    assert cnt > 100
+    del rng
+
+
+def test_triangulate_empty_and_degenerate(ctx, oracle, synth):
+    pr = synth.make_pair(1)
+    d = ctx.triangulate(ctx.dev(pr["kp1"]), ctx.dev(pr["kp2"]), 0, ctx.dev(pr["poses"]), 2, pr["K"])
+    assert int(to_np(d["count"])[0]) == 0
+    # identical poses: zero baseline -> everything rejected by parallax, nothing crashes
+    poses = np.stack([pr["poses"][0], pr["poses"][0]])
+    _tri_case(ctx, oracle, pr["kp1"][:64], pr["kp1"][:64] + 0.25, poses, pr["K"])
+
+
+# ------------------------------------------------------- reprojection match
+def _reproj_case(ctx, oracle, rs, frame, mp, replace):
+    fv, k1 = ctx.make_frame_view(frame)
+    mv, k2 = ctx.make_map_view(mp)
+    out = ctx.reproj_match(fv, mv, replace=replace)
+    ref = oracle.reproj_match(frame, mp, replace=replace)
+    P, N = len(mp["positions"]), len(frame["keypoints"])
+    assert np.array_equal(to_np(out["point_kp"])[:P], ref["point_kp"])
+    assert np.array_equal(to_np(out["point_dist"])[:P], ref["point_dist"])
+    assert np.array_equal(to_np(out["prop_point"])[:N], ref["prop_point"])
+    assert np.array_equal(to_np(out["prop_dist"])[:N], ref["prop_dist"])
+    cnt = int(to_np(out["count"])[0])
+    assert cnt == len(ref["match_kp"])
+    assert np.array_equal(to_np(out["match_kp"])[:cnt], ref["match_kp"])
+    assert np.array_equal(to_np(out["match_point"])[:cnt], ref["match_point"])
+    return cnt
+
+
+@pytest.mark.parametrize("replace", [0, 1])
+def test_reproj_match_window(ctx, oracle, rs, synth, replace):
+    w = synth.make_ba_window(n_kf=10, n_points=3000)
+    frame, mp = synth.make_match_scene(w, n_keypoints=1500, kdtree_build=rs.kdtree_build)
+    cnt = _reproj_case(ctx, oracle, rs, frame, mp, replace)
+    assert cnt > 100
+
+
+def test_reproj_match_dense_candidates_and_ties(ctx, oracle, rs, synth):
+    """many keypoints inside every search disc + duplicated descriptors: exercises the
+    KD traversal-order and map-order tie rules."""
+    w = synth.make_ba_window(n_kf=6, n_points=400, run_max=5)
+    frame, mp = synth.make_match_scene(w, n_keypoints=600, kdtree_build=rs.kdtree_build, matched_frac=0.1)
+    rng = np.random.default_rng(9)
+    kp = frame["keypoints"]
+    kp[:] = kp[rng.integers(0, 40, len(kp))] + rng.integers(-6, 7, kp.shape).astype(np.float32)
+    frame["descriptors"][:] = frame["descriptors"][rng.integers(0, 25, len(kp))]
+    mp["desc_pool"][:] = frame["descriptors"][rng.integers(0, 25, len(mp["desc_pool"]))]
+    bits = rng.integers(0, 256, mp["desc_pool"].shape, dtype=np.uint8) & rng.integers(0, 256, mp["desc_pool"].shape, dtype=np.uint8) & 0x11
+    mp["desc_pool"] ^= bits
+    node_kp, left, right, root = rs.kdtree_build(kp)
+    frame.update(kd_node_kp=node_kp, kd_left=left, kd_right=right, kd_root=root)
+    # project the map onto those clusters so that discs are crowded
+    for replace in (0, 1):
+        _reproj_case(ctx, oracle, rs, frame, mp, replace)
+
+
+# ----------------------------------------------------------------------- BA
+def _ba_case(ctx, oracle, w, options=None, o_options=None):
+    ref_c, ref_p, ref_s = oracle.bundle_adjust(w["cams"], w["cam_free"], w["points"], w["obs_ptr"], w["obs_cam"],
+                                               w["obs_uv"], w["K"], o_options)
+    dc, dp = ctx.dev(w["cams"]), ctx.dev(w["points"])
+    s = ctx.bundle_adjust(dc, w["cam_free"], dp, ctx.dev(w["obs_ptr"]), ctx.dev(w["obs_cam"]),
+                          ctx.dev(w["obs_uv"]), w["K"], options)
+    return to_np(dc), to_np(dp), s, ref_c, ref_p, ref_s
+
+
+def test_bundle_adjust_small(ctx, oracle, synth):
+    w = synth.make_ba_window(n_kf=6, n_points=200, run_max=5)
+    c, p, s, rc, rp, rs_ = _ba_case(ctx, oracle, w)
+    assert s["usable"] == rs_["usable"] == 1
+    assert s["iterations"] == rs_["iterations"]
+    assert s["successful_steps"] == rs_["successful_steps"]
+    assert s["termination"] == rs_["termination"]
+    # f64 LM trajectories: identical schedule, different summation order / analytic vs jet
+    # Jacobians -> agreement far below the f32 boundary (1e-7): tolerance 1e-8 relative
+    assert np.isclose(s["initial_cost"], rs_["initial_cost"], rtol=1e-12)
+    assert np.isclose(s["final_cost"], rs_["final_cost"], rtol=1e-8)
+    assert np.allclose(c, rc, rtol=1e-7, atol=1e-9)
+    assert np.allclose(p, rp, rtol=1e-7, atol=1e-8)
+    # fixed cameras untouched
+    assert np.array_equal(c[:2], w["cams"][:2])
+
+
+def test_bundle_adjust_cfg3_window(ctx, oracle, synth):
+    """BASELINE.json configs[2]: 20 KF x 10k landmarks x ~60k observations, 10 LM iterations."""
+    w = synth.make_ba_window()
+    c, p, s, rc, rp, rs_ = _ba_case(ctx, oracle, w)
+    assert s["usable"] == 1 and rs_["usable"] == 1
+    assert (s["iterations"], s["successful_steps"]) == (rs_["iterations"], rs_["successful_steps"])
+    assert np.isclose(s["final_cost"], rs_["final_cost"], rtol=1e-7)
+    assert np.allclose(c, rc, rtol=1e-6, atol=1e-8)
+    assert np.allclose(p, rp, rtol=1e-6, atol=1e-7)
+    assert s["final_cost"] < 0.2 * s["initial_cost"]
+
+
+def test_bundle_adjust_rejected_keeps_input(ctx, synth):
+    """solve()'s accept rule (src/Optimization.cpp:136-141): an unusable result leaves inputs untouched."""
+    w = synth.make_ba_window(n_kf=5, n_points=80, run_max=4)
+    w["points"][:] = np.nan    # non-finite cost -> FAILURE
+    dc, dp = ctx.dev(w["cams"]), ctx.dev(w["points"])
+    s = ctx.bundle_adjust(dc, w["cam_free"], dp, ctx.dev(w["obs_ptr"]), ctx.dev(w["obs_cam"]),
+                          ctx.dev(w["obs_uv"]), w["K"])
+    assert s["usable"] == 0
+    assert np.array_equal(to_np(dc), w["cams"])
+
+
+def test_bundle_adjust_two_frame_init(ctx, oracle, synth):
+    """Initialization's call pattern (src/Initialization.cpp:249): 2 frames, the first fixed."""
+    w = synth.make_ba_window(n_kf=2, n_points=150, run_min=2, run_max=2, n_fixed=1)
+    c, p, s, rc, rp, rs_ = _ba_case(ctx, oracle, w)
+    assert s["usable"] == rs_["usable"]
+    assert np.allclose(c, rc, rtol=1e-6, atol=1e-8)
+    assert np.allclose(p, rp, rtol=1e-6, atol=1e-7)
+
+
+def test_bundle_adjust_options_iterations(ctx, oracle, rs, synth):
+    w = synth.make_ba_window(n_kf=6, n_points=200, run_max=5, config_id=5)
+    o = rs.default_options(); o.max_num_iterations = 3
+    oo = oracle.default_options(); oo.max_num_iterations = 3
+    c, p, s, rc, rp, rs_ = _ba_case(ctx, oracle, w, o, oo)
+    assert s["iterations"] == rs_["iterations"] == 3
+    assert np.allclose(c, rc, rtol=1e-7, atol=1e-9)
+
+
+def test_refine_pose(ctx, oracle, synth):
+    w = synth.make_ba_window(n_kf=4, n_points=600, run_min=4, run_max=4)
+    sel = np.flatnonzero(w["obs_cam"] == 3)
+    pts = w["points_true"][np.repeat(np.arange(len(w["points"])), np.diff(w["obs_ptr"]))[sel]]
+    uv = w["obs_uv"][sel]
+    cam0 = w["cams"][3].copy()
+    ref_cam, ref_s = oracle.refine_pose(cam0, pts, uv, w["K"])
+    cam, s = ctx.refine_pose(cam0, ctx.dev(pts), ctx.dev(uv), w["K"])
+    assert s["usable"] == ref_s["usable"] == 1
+    assert (s["iterations"], s["successful_steps"], s["termination"]) == \
+        (ref_s["iterations"], ref_s["successful_steps"], ref_s["termination"])
+    assert np.isclose(s["final_cost"], ref_s["final_cost"], rtol=1e-8)
+    assert np.allclose(cam, ref_cam, rtol=1e-7, atol=1e-9)
+    # empty input: "nothing to constrain"
+    cam2, s2 = ctx.refine_pose(cam0, ctx.dev(pts[:0]), ctx.dev(uv[:0]), w["K"])
+    assert s2["usable"] == 0 and np.array_equal(cam2, cam0)
+
+
+def test_profiling_names(ctx, synth):
+    pr = synth.make_pair(1)
+    ctx.prof_begin()
+    ctx.match_descriptors(ctx.dev(pr["desc2"]), ctx.dev(pr["desc1"]), 500, 500)
+    prof = ctx.prof_end()
+    assert "K1_hamming_knn2" in prof and prof["K1_hamming_knn2"][0] == 1
+    assert prof["K1_hamming_knn2"][1] > 0
