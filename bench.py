@@ -1,0 +1,221 @@
+#!/usr/bin/env python3
+"""bench.py — match + triangulate + local-BA passes/sec (BASELINE.json's metric).
+
+One STEP = one pass of the hot path over one batch of synthetic input, inputs
+resident in HBM before the timed region:
+  (1) brute-force 2-NN Hamming + Lowe/threshold match, 2000 x 2000 ORB rows   (cfg 2, a4)
+  (2) reprojection-gated match of the new frame against the window's landmarks (a2)
+  (3) two-view DLT triangulation + gates of the accepted pairs                 (cfg 2, a6)
+  (4) 10-iteration local bundle adjustment, 20 KF x 10k landmarks x ~60k obs   (cfg 3, a12)
+N > 1 (one process per GPU, launched by torch.distributed.run): every rank runs
+(1)-(3) on its own frame pair and owns a 10k-landmark shard of a 20-KF window
+with N x 10k landmarks; the BA all-reduces the reduced camera system over
+RCCL/xGMI each LM step.  value = N passes / step time (weak scaling).
+
+Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline`
+(dominant kernel, HIP-event timed) and `cpu_baseline` (the oracle, rank 0, N=1).
+"""
+import argparse
+import importlib
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for _p in (ROOT, os.path.join(ROOT, "oracle")):
+    if _p not in sys.path:
+        sys.path.insert(0, _p)
+
+import numpy as np  # noqa: E402
+
+FP64_PEAK_TFLOPS = 78.6   # MI355X fp64 vector == fp64 MFMA peak (public spec)
+HBM_PEAK_GBS = 8000.0     # /opt/skills/guides/MI355X_MICROARCH.md
+
+
+def algorithmic_work(w, n_free):
+    """Per-LM-iteration algorithmic work of the BA, unpadded and sparse."""
+    k = np.diff(w["obs_ptr"]).astype(np.float64)
+    M, P, C = float(k.sum()), float(len(k)), float(len(w["cams"]))
+    n = 6.0 * n_free
+    lin_flops = 500.0 * M
+    schur_flops = float(np.sum(50 + 108 * k + 216 * k * (k + 1) / 2 + 72 * k))
+    solve_flops = n ** 3 / 3
+    lin_bytes = 16 * M + 2 * 24 * P + 2 * 48 * C + 8 * n * n
+    cost_bytes = 16 * M + 24 * P + 48 * C
+    return dict(M=M, P=P, C=C, lin_flops=lin_flops, schur_flops=schur_flops, solve_flops=solve_flops,
+                lin_bytes=lin_bytes, cost_bytes=cost_bytes)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-passes", type=int, default=12)
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    pkg = importlib.import_module("racing-slam_amd")
+    rs, synth = pkg.rsgpu, pkg.synth
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run (one process per GPU)")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the product path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    ctx = rs.Context(local_rank)
+    if world > 1:
+        uid = torch.zeros(128, dtype=torch.uint8, device=ctx.device)
+        if rank == 0:
+            uid.copy_(torch.frombuffer(bytearray(rs.Context.comm_unique_id()), dtype=torch.uint8))
+        dist.broadcast(uid, 0)
+        ctx.comm_init(bytes(uid.cpu().numpy().tobytes()), world, rank)
+
+    # ---------------------------------------------------------------- inputs
+    pair = synth.make_pair(2, seed_stream=rank)                         # cfg 2, this rank's frame pair
+    window_all = synth.make_ba_window(n_kf=20, n_points=10000 * world)  # cfg 3 (x N landmarks)
+    window = synth.shard_ba_by_landmark(window_all, world, rank) if world > 1 else window_all
+    shard_for_match = dict(window_all)
+    if world > 1:
+        lo, hi = window["point_range"]
+        o0, o1 = int(window_all["obs_ptr"][lo]), int(window_all["obs_ptr"][hi])
+        shard_for_match.update(points=window_all["points"][lo:hi], points_true=window_all["points_true"][lo:hi],
+                               obs_ptr=window["obs_ptr"], obs_cam=window["obs_cam"], obs_uv=window["obs_uv"])
+        del o0, o1
+    frame, mp = synth.make_match_scene(shard_for_match, n_keypoints=2000, kdtree_build=rs.kdtree_build)
+
+    nq, nt = len(pair["desc2"]), len(pair["desc1"])
+    d_q, d_t = ctx.dev(pair["desc2"]), ctx.dev(pair["desc1"])
+    d_kp1, d_kp2 = ctx.dev(pair["kp1"]), ctx.dev(pair["kp2"])
+    d_poses = ctx.dev(pair["poses"])
+    fv, keep_f = ctx.make_frame_view(frame)
+    mv, keep_m = ctx.make_map_view(mp)
+    cams0, pts0 = ctx.dev(window["cams"]), ctx.dev(window["points"])
+    d_cams, d_pts = cams0.clone(), pts0.clone()
+    d_optr, d_ocam, d_ouv = ctx.dev(window["obs_ptr"]), ctx.dev(window["obs_cam"]), ctx.dev(window["obs_uv"])
+    m_out = ctx.match_descriptors(d_q, d_t, nq, nt)
+    r_out = ctx.reproj_match(fv, mv)
+    t_out = ctx.triangulate_matches(d_kp1, d_kp2, m_out["mt"], m_out["mq"], m_out["cnt"], nq, d_poses, pair["K"])
+
+    last = {}
+
+    def one_pass():
+        ctx.match_descriptors(d_q, d_t, nq, nt, out=m_out)
+        ctx.reproj_match(fv, mv, out=r_out)
+        ctx.triangulate_matches(d_kp1, d_kp2, m_out["mt"], m_out["mq"], m_out["cnt"], nq, d_poses, pair["K"], out=t_out)
+        d_cams.copy_(cams0)
+        d_pts.copy_(pts0)
+        last["ba"] = ctx.bundle_adjust(d_cams, window["cam_free"], d_pts, d_optr, d_ocam, d_ouv, window["K"])
+
+    for _ in range(args.warmup):
+        one_pass()
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        one_pass()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=ctx.device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    ms_per_step = 1e3 * elapsed / max(args.steps, 1)
+    value = world * args.steps / elapsed
+
+    # ------------------------------------------- per-kernel HIP-event timing
+    ctx.prof_begin()
+    for _ in range(args.steps):
+        one_pass()
+    prof = ctx.prof_end()
+    per_kernel = {k: dict(launches=v[0], avg_us=1e3 * v[1] / max(v[0], 1), total_ms=v[1]) for k, v in prof.items()}
+    dom = max(per_kernel, key=lambda k: per_kernel[k]["total_ms"]) if per_kernel else None
+    n_free = int(np.sum(window["cam_free"]))
+    work = algorithmic_work(window, n_free)
+    roofline = None
+    if dom is not None:
+        avg_s = per_kernel[dom]["avg_us"] * 1e-6
+        if dom.startswith("K5"):
+            flops = work["lin_flops"] + work["schur_flops"]
+            roofline = dict(kernel=dom, bound="mfma", achieved=flops / avg_s / 1e12, peak=FP64_PEAK_TFLOPS,
+                            unit="TFLOP/s", traffic=None, algorithmic_flops_per_launch=flops)
+        elif dom.startswith("K7"):
+            flops = work["solve_flops"]
+            roofline = dict(kernel=dom, bound="mfma", achieved=flops / avg_s / 1e12, peak=FP64_PEAK_TFLOPS,
+                            unit="TFLOP/s", traffic=None, algorithmic_flops_per_launch=flops)
+        elif dom.startswith("K8"):
+            nbytes = work["cost_bytes"] + 16 * work["M"] + 2 * 24 * work["P"]
+            roofline = dict(kernel=dom, bound="hbm", achieved=nbytes / avg_s / 1e9, peak=HBM_PEAK_GBS,
+                            unit="GB/s", traffic=None, algorithmic_bytes_per_launch=nbytes)
+        elif dom.startswith("K1_"):
+            nbytes = 32.0 * (nq + nt) + 12.0 * nq
+            roofline = dict(kernel=dom, bound="hbm", achieved=nbytes / avg_s / 1e9, peak=HBM_PEAK_GBS,
+                            unit="GB/s", traffic=None, algorithmic_bytes_per_launch=nbytes)
+        else:
+            nbytes = work["lin_bytes"]
+            roofline = dict(kernel=dom, bound="hbm", achieved=nbytes / avg_s / 1e9, peak=HBM_PEAK_GBS,
+                            unit="GB/s", traffic=None, algorithmic_bytes_per_launch=nbytes)
+        roofline["frac"] = roofline["achieved"] / roofline["peak"]
+        roofline["avg_launch_us"] = per_kernel[dom]["avg_us"]
+        roofline["timing"] = "hip events per launch on the library stream, %d instrumented passes" % args.steps
+
+    # ------------------------------------------------- CPU baseline (rank 0)
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        import pyoracle as O
+        O.build()
+        passes = max(1, args.cpu_passes)
+        t0 = time.perf_counter()
+        for _ in range(passes):
+            mq, mt = O.match_descriptors(pair["desc2"], pair["desc1"])
+            O.reproj_match(frame, mp)
+            O.triangulate(pair["kp1"][mt], pair["kp2"][mq], pair["poses"], pair["K"])
+            O.bundle_adjust(window["cams"], window["cam_free"], window["points"], window["obs_ptr"],
+                            window["obs_cam"], window["obs_uv"], window["K"])
+        dt = time.perf_counter() - t0
+        cpu = dict(value=passes / dt, unit="passes/s", cores=1, kind="port",
+                   sample="%d full passes of the same workload (oracle/liboracle.so, gcc -O2, 1 thread; "
+                          "faithful restatement, not the reference binary)" % passes)
+
+    if rank == 0:
+        out = {
+            "metric": "match+triangulate+local-BA passes/sec @ 2k kpts/frame, 20-KF x 10k-pt window",
+            "value": value, "unit": "passes/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "u8 Hamming (match), f64 (DLT SVD, BA), f32 (gates)", "data": "synthetic",
+            "config": {"workload": "cfg2 pair (2000x2000 brute-force match + 2000-slot DLT triangulation) + "
+                                   "reprojection-gated match (2000 kp x 10k landmarks) + cfg3 local BA "
+                                   "(20 KF, 10k landmarks, ~60k obs, 10 LM iterations) per GPU",
+                       "passes_per_step": world,
+                       "ba_landmarks_total": int(len(window_all["points"])),
+                       "ba_obs_per_gpu": int(len(window["obs_cam"])),
+                       "parallelism": "landmark-sharded BA, RCCL all-reduce of the reduced camera system" if world > 1 else "single GPU"},
+            "roofline": roofline,
+            "cpu_baseline": cpu,
+            "per_kernel_us": {k: round(v["avg_us"], 2) for k, v in sorted(per_kernel.items())},
+            "per_kernel_launches_per_pass": {k: v["launches"] / max(args.steps, 1) for k, v in sorted(per_kernel.items())},
+            "ba_summary": last.get("ba"),
+            "speedup_vs_cpu_baseline": (value / cpu["value"]) if cpu else None,
+        }
+        print(json.dumps(out))
+    ctx.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -197,6 +197,23 @@ int rs_triangulate(rs_context* ctx,
                    float* d_xyz, uint8_t* d_keep,
                    int32_t* d_out_index, float* d_out_xyz, int32_t* d_out_count);
 
+/* triangulate_points(frame1, frame2, matches, camera) (src/Triangulation.cpp:28-35) with
+ * get_matching_points (:11-26) fused and the match list left on the device:
+ * correspondence i = (d_kp1[d_match_train[i]], d_kp2[d_match_query[i]]) for
+ * i < min(*d_n_matches, max_matches); poses = {pose of frame1, pose of frame2}.
+ * Feeds rs_match_descriptors' output straight into the triangulation with no
+ * host round trip.  Outputs as rs_triangulate, indexed by match position;
+ * entries at i >= *d_n_matches are not written. */
+int rs_triangulate_matches(rs_context* ctx,
+                           const float* d_kp1 /*[n1][2] frame1 = train side*/,
+                           const float* d_kp2 /*[n2][2] frame2 = query side*/,
+                           const int32_t* d_match_train, const int32_t* d_match_query,
+                           const int32_t* d_n_matches /*[1] device*/, int max_matches,
+                           const float* d_poses /*[2][16]*/, const float h_intrinsics[4],
+                           float min_parallax_cosine, float max_reprojection_error,
+                           float* d_xyz, uint8_t* d_keep,
+                           int32_t* d_out_index, float* d_out_xyz, int32_t* d_out_count);
+
 /* ----------------------------------------------------- a9-a13: optimisation */
 
 typedef enum rs_ba_termination {

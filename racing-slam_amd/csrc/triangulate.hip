@@ -103,9 +103,11 @@ __device__ __forceinline__ void projection_rows(const TriParams& k, const float*
 __global__ __launch_bounds__(64) void k4_triangulate(
     const float2* __restrict__ uv1, const float2* __restrict__ uv2, int n,
     const float* __restrict__ poses, const int32_t* __restrict__ idx1, const int32_t* __restrict__ idx2,
+    const int32_t* __restrict__ gather1, const int32_t* __restrict__ gather2, const int32_t* __restrict__ d_n,
     TriParams prm, float* __restrict__ xyz, uint8_t* __restrict__ keep)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (d_n) n = min(n, *d_n);          // match count produced on the device (K1b)
     if (i >= n) return;
     float T1[16], T2[16];
     {
@@ -118,7 +120,8 @@ __global__ __launch_bounds__(64) void k4_triangulate(
             T2[4 * r] = vb.x; T2[4 * r + 1] = vb.y; T2[4 * r + 2] = vb.z; T2[4 * r + 3] = vb.w;
         }
     }
-    const float2 p1 = uv1[i], p2 = uv2[i];
+    // get_matching_points (src/Triangulation.cpp:11-26) fused: optional gather through the match list
+    const float2 p1 = uv1[gather1 ? gather1[i] : i], p2 = uv2[gather2 ? gather2[i] : i];
     double At[4][4], Vt[4][4], W[4];
     {
         float P1[12], P2[12];
@@ -211,9 +214,11 @@ __global__ __launch_bounds__(64) void k4_triangulate(
 
 // Single workgroup: ordered compaction of the kept correspondences (:102).
 __global__ __launch_bounds__(1024) void k4_compact(const uint8_t* __restrict__ keep, const float* __restrict__ xyz,
-                                                   int n, int32_t* __restrict__ out_index,
+                                                   int n, const int32_t* __restrict__ d_n,
+                                                   int32_t* __restrict__ out_index,
                                                    float* __restrict__ out_xyz, int32_t* __restrict__ out_count)
 {
+    if (d_n) n = min(n, *d_n);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     __shared__ int wave_count[16];
     __shared__ int running;
@@ -245,11 +250,11 @@ __global__ __launch_bounds__(1024) void k4_compact(const uint8_t* __restrict__ k
     if (threadIdx.x == 0) *out_count = running;
 }
 
-extern "C" int rs_triangulate(rs_context* ctx, const float* d_uv1, const float* d_uv2, int n,
-                              const float* d_poses, int n_poses, const int32_t* d_pose_idx1,
-                              const int32_t* d_pose_idx2, const float h_intrinsics[4],
-                              float min_parallax_cosine, float max_reprojection_error, float* d_xyz,
-                              uint8_t* d_keep, int32_t* d_out_index, float* d_out_xyz, int32_t* d_out_count)
+static int tri_launch(rs_context* ctx, const float* d_uv1, const float* d_uv2, int n, const float* d_poses,
+                      int n_poses, const int32_t* d_pose_idx1, const int32_t* d_pose_idx2,
+                      const int32_t* g1, const int32_t* g2, const int32_t* d_n, const float h_intrinsics[4],
+                      float min_parallax_cosine, float max_reprojection_error, float* d_xyz, uint8_t* d_keep,
+                      int32_t* d_out_index, float* d_out_xyz, int32_t* d_out_count)
 {
     if (!ctx) return RS_ERR_INVALID;
     if (n < 0) return rs_fail(ctx, RS_ERR_INVALID, "negative n");
@@ -268,13 +273,38 @@ extern "C" int rs_triangulate(rs_context* ctx, const float* d_uv1, const float* 
     {
         rs_prof_scope ps(ctx, "K4_triangulate_dlt");
         hipLaunchKernelGGL(k4_triangulate, dim3((n + 63) / 64), dim3(64), 0, ctx->stream, (const float2*)d_uv1,
-                           (const float2*)d_uv2, n, d_poses, d_pose_idx1, d_pose_idx2, prm, d_xyz, d_keep);
+                           (const float2*)d_uv2, n, d_poses, d_pose_idx1, d_pose_idx2, g1, g2, d_n, prm, d_xyz, d_keep);
     }
     {
         rs_prof_scope ps(ctx, "K4b_compact");
-        hipLaunchKernelGGL(k4_compact, dim3(1), dim3(1024), 0, ctx->stream, d_keep, d_xyz, n, d_out_index,
+        hipLaunchKernelGGL(k4_compact, dim3(1), dim3(1024), 0, ctx->stream, d_keep, d_xyz, n, d_n, d_out_index,
                            d_out_xyz, d_out_count);
     }
     RS_HIP(ctx, hipGetLastError());
     return RS_OK;
+}
+
+extern "C" int rs_triangulate(rs_context* ctx, const float* d_uv1, const float* d_uv2, int n,
+                              const float* d_poses, int n_poses, const int32_t* d_pose_idx1,
+                              const int32_t* d_pose_idx2, const float h_intrinsics[4],
+                              float min_parallax_cosine, float max_reprojection_error, float* d_xyz,
+                              uint8_t* d_keep, int32_t* d_out_index, float* d_out_xyz, int32_t* d_out_count)
+{
+    return tri_launch(ctx, d_uv1, d_uv2, n, d_poses, n_poses, d_pose_idx1, d_pose_idx2, nullptr, nullptr, nullptr,
+                      h_intrinsics, min_parallax_cosine, max_reprojection_error, d_xyz, d_keep, d_out_index,
+                      d_out_xyz, d_out_count);
+}
+
+extern "C" int rs_triangulate_matches(rs_context* ctx, const float* d_kp1, const float* d_kp2,
+                                      const int32_t* d_match_train, const int32_t* d_match_query,
+                                      const int32_t* d_n_matches, int max_matches, const float* d_poses,
+                                      const float h_intrinsics[4], float min_parallax_cosine,
+                                      float max_reprojection_error, float* d_xyz, uint8_t* d_keep,
+                                      int32_t* d_out_index, float* d_out_xyz, int32_t* d_out_count)
+{
+    if (ctx && max_matches > 0 && (!d_match_train || !d_match_query || !d_n_matches))
+        return rs_fail(ctx, RS_ERR_INVALID, "null match list");
+    return tri_launch(ctx, d_kp1, d_kp2, max_matches, d_poses, 2, nullptr, nullptr, d_match_train, d_match_query,
+                      d_n_matches, h_intrinsics, min_parallax_cosine, max_reprojection_error, d_xyz, d_keep,
+                      d_out_index, d_out_xyz, d_out_count);
 }

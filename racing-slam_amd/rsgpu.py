@@ -15,7 +15,7 @@ LIB_PATH = os.path.join(_HERE, "librsgpu.so")
 EXPORTS = [
     "rs_abi_version", "rs_context_create", "rs_context_destroy", "rs_context_set_stream",
     "rs_context_synchronize", "rs_last_error", "rs_hamming_knn2", "rs_match_descriptors",
-    "rs_kdtree_build", "rs_reproj_match", "rs_triangulate", "rs_ba_default_options",
+    "rs_kdtree_build", "rs_reproj_match", "rs_triangulate", "rs_triangulate_matches", "rs_ba_default_options",
     "rs_bundle_adjust", "rs_refine_pose", "rs_pack_pose", "rs_unpack_pose", "rs_build_local_window",
     "rs_comm_get_unique_id", "rs_comm_init_rank", "rs_comm_destroy", "rs_prof_begin", "rs_prof_end",
 ]
@@ -251,6 +251,22 @@ class Context:
                                             C.c_float(max_reproj), _dp(out["xyz"]), _dp(out["keep"]),
                                             _dp(out["out_index"]), _dp(out["out_xyz"]), _dp(out["count"])),
                     "rs_triangulate")
+        return out
+
+    def triangulate_matches(self, d_kp1, d_kp2, d_mt, d_mq, d_cnt, max_matches, d_poses, K,
+                            min_parallax_cosine=0.9999, max_reproj=2.0, out=None):
+        t = self.torch
+        n = max_matches
+        if out is None:
+            out = dict(xyz=self.empty((max(n, 1), 3), t.float32), keep=self.empty((max(n, 1),), t.uint8),
+                       out_index=self.empty((max(n, 1),), t.int32), out_xyz=self.empty((max(n, 1), 3), t.float32),
+                       count=self.empty((1,), t.int32))
+        Kc = (C.c_float * 4)(*[float(v) for v in K])
+        self._check(self.lib.rs_triangulate_matches(self.h, _dp(d_kp1), _dp(d_kp2), _dp(d_mt), _dp(d_mq), _dp(d_cnt),
+                                                    int(n), _dp(d_poses), Kc, C.c_float(min_parallax_cosine),
+                                                    C.c_float(max_reproj), _dp(out["xyz"]), _dp(out["keep"]),
+                                                    _dp(out["out_index"]), _dp(out["out_xyz"]), _dp(out["count"])),
+                    "rs_triangulate_matches")
         return out
 
     # -- a9-a13

@@ -118,6 +118,22 @@ def test_triangulate_pair(ctx, oracle, synth, config_id):
     _tri_case(ctx, oracle, uv1, uv2, pr["poses"], pr["K"], cos=1.0, err=4.0)
 
 
+def test_triangulate_matches_device_list(ctx, oracle, synth):
+    """rs_triangulate_matches: get_matching_points fused, match list + count stay on the device."""
+    pr = synth.make_pair(1)
+    nq = len(pr["desc2"])
+    m = ctx.match_descriptors(ctx.dev(pr["desc2"]), ctx.dev(pr["desc1"]), nq, len(pr["desc1"]))
+    d = ctx.triangulate_matches(ctx.dev(pr["kp1"]), ctx.dev(pr["kp2"]), m["mt"], m["mq"], m["cnt"], nq,
+                                ctx.dev(pr["poses"]), pr["K"])
+    mq, mt = oracle.match_descriptors(pr["desc2"], pr["desc1"])
+    ref = oracle.triangulate(pr["kp1"][mt], pr["kp2"][mq], pr["poses"], pr["K"])
+    n = len(mq)
+    assert np.array_equal(to_np(d["keep"])[:n], ref["keep"])
+    assert np.array_equal(to_np(d["xyz"])[:n].view(np.uint32), ref["xyz"].view(np.uint32))
+    cnt = int(to_np(d["count"])[0])
+    assert cnt == len(ref["out_index"]) and np.array_equal(to_np(d["out_index"])[:cnt], ref["out_index"])
+
+
 def test_triangulate_tracks_per_item_poses(ctx, oracle, synth):
     w = synth.make_ba_window(n_kf=8, n_points=300, run_max=6)
     rng = np.random.default_rng(3)
