@@ -25,175 +25,7 @@
 //                          model-cost terms, robust cost at the candidate
 //   [RCCL all-reduce of 4 scalars]
 //   K9 ba_decide           accept / reject, radius update, termination tests
-#include <math.h>
-
-#include "common.h"
-
-#define BA_PREP 24            // doubles per camera: R[9] Jl[9] c[3] small pad pad
-#define BA_THREADS 64
-#define BA_MAX_LDS_N 128      // largest reduced system kept in LDS by K7
-
-struct BaState {
-    double radius, decrease_factor, x_cost, initial_cost;
-    double cam_scal[4];       // K7: mcc_c, step_sq_c, x_sq_c, unused
-    int iter, successful, invalid_steps, done;
-    int termination, cur, have_scale, solver_failed;
-    int fresh, usable, pad0, pad1;
-};
-
-struct BaDims {
-    int C, Cf, P, M, n;       // n = 6*Cf
-    float fx, fy, cx, cy;
-    double huber_a;
-};
-
-struct BaBufs {
-    const int32_t* obs_ptr;   // [P+1]
-    const int32_t* obs_cam;   // [M]
-    const float2* obs_uv;     // [M]
-    double* Xc;      // [2][C][6]
-    double* Xp;      // [2][P][3]
-    double* prep;    // [2][C][BA_PREP]
-    int32_t* slot;   // [C]  reduced-system slot of a free camera or -1
-    double* sc;      // [n]
-    double* sp;      // [P][3]
-    double* Vinv;    // [P][6]  (xx xy xz yy yz zz)
-    double* gp;      // [P][3]
-    double* lamp;    // [P][3]
-    // accumulators, contiguous for one all-reduce: S[n*n] rhs[n] U[Cf*36] gc[n] scal[2]
-    double* acc;
-    size_t acc_count;
-    double* S; double* rhs; double* U; double* gc; double* scal;   // scal: cost_x, fail_count
-    double* gmax;    // [1] bits of a non-negative double (max all-reduce)
-    double* pt_scal; // [4] K8: cand_cost, mcc_p, step_sq_p, x_sq_p
-    double* dc;      // [n]
-    BaState* st;
-};
-
-struct BaOpt {
-    int max_iter, max_invalid, jacobi;
-    double r0, rmax, rmin, min_rel, dmin, dmax, ftol, gtol, ptol;
-};
-
-// ----------------------------------------------------------------- device math
-__device__ __forceinline__ void cam_prepare(const double* cam, double* out)
-{
-    const double ax = cam[0], ay = cam[1], az = cam[2];
-    const double th2 = ax * ax + ay * ay + az * az;
-    double A, B, Cc, small;
-    if (th2 > 2.220446049250313e-16) {
-        const double th = sqrt(th2);
-        const double sh = sin(0.5 * th);
-        A = sin(th) / th;
-        B = 2.0 * sh * sh / th2;
-        Cc = (th - sin(th)) / (th2 * th);
-        small = 0.0;
-    } else {   // ceres::AngleAxisRotatePoint's first-order branch: R = I + [w]x, d/dw = -[q]x
-        A = 1.0; B = 0.0; Cc = 0.0; small = 1.0;
-    }
-    const double W[9] = {0, -az, ay, az, 0, -ax, -ay, ax, 0};
-    const double W2[9] = {-(ay * ay + az * az), ax * ay, ax * az, ax * ay, -(ax * ax + az * az), ay * az,
-                          ax * az, ay * az, -(ax * ax + ay * ay)};
-#pragma unroll
-    for (int i = 0; i < 9; i++) {
-        const double id = (i == 0 || i == 4 || i == 8) ? 1.0 : 0.0;
-        out[i] = id + A * W[i] + B * W2[i];          // R
-        out[9 + i] = id + B * W[i] + Cc * W2[i];     // left Jacobian of SO(3)
-    }
-    out[18] = cam[3]; out[19] = cam[4]; out[20] = cam[5];
-    out[21] = small; out[22] = 0.0; out[23] = 0.0;
-}
-
-struct ObsLin {
-    double r0, r1, w, rho;
-    double jc[12];   // 2x6  [d/d aa | d/d centre]
-    double jp[6];    // 2x3
-};
-
-template <bool JAC>
-__device__ __forceinline__ void obs_eval(const double* __restrict__ cp, const double X[3], float2 uv,
-                                         const BaDims& d, ObsLin& o)
-{
-    const double q0 = X[0] - cp[18], q1 = X[1] - cp[19], q2 = X[2] - cp[20];
-    const double p0 = cp[0] * q0 + cp[1] * q1 + cp[2] * q2;
-    const double p1 = cp[3] * q0 + cp[4] * q1 + cp[5] * q2;
-    const double p2 = cp[6] * q0 + cp[7] * q1 + cp[8] * q2;
-    const double fx = (double)d.fx, fy = (double)d.fy;
-    o.r0 = fx * p0 / p2 + (double)d.cx - (double)uv.x;     // src/Optimization.cpp:48-49
-    o.r1 = fy * p1 / p2 + (double)d.cy - (double)uv.y;
-    const double s = o.r0 * o.r0 + o.r1 * o.r1;
-    const double b2 = d.huber_a * d.huber_a;
-    if (s > b2) {   // ceres::HuberLoss
-        const double r = sqrt(s);
-        o.rho = 2.0 * d.huber_a * r - b2;
-        o.w = d.huber_a / r;
-    } else {
-        o.rho = s;
-        o.w = 1.0;
-    }
-    if (JAC) {
-        const double iz = 1.0 / p2;
-        const double a = fx * iz, b = fy * iz;
-        const double ax = -a * p0 * iz, bx = -b * p1 * iz;
-#pragma unroll
-        for (int k = 0; k < 3; k++) {
-            o.jp[k] = a * cp[k] + ax * cp[6 + k];
-            o.jp[3 + k] = b * cp[3 + k] + bx * cp[6 + k];
-            o.jc[3 + k] = -o.jp[k];
-            o.jc[9 + k] = -o.jp[3 + k];
-        }
-        const bool small = cp[21] != 0.0;
-        const double v0 = small ? q0 : p0, v1 = small ? q1 : p1, v2 = small ? q2 : p2;
-#pragma unroll
-        for (int k = 0; k < 3; k++) {   // d p / d aa_k = Jl[:,k] x v
-            const double m0 = cp[9 + k], m1 = cp[12 + k], m2 = cp[15 + k];
-            const double c0 = m1 * v2 - m2 * v1, c1 = m2 * v0 - m0 * v2, c2 = m0 * v1 - m1 * v0;
-            o.jc[k] = a * c0 + ax * c2;
-            o.jc[6 + k] = b * c1 + bx * c2;
-        }
-    }
-}
-
-__device__ __forceinline__ double wave_sum(double v)
-{
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
-    return v;
-}
-
-// symmetric 3x3 inverse through Cholesky (InvertPSDMatrix<3>); false if not PD
-__device__ __forceinline__ bool inv3_psd(const double V[6], double I[6])
-{
-    const double l00s = V[0];
-    if (!(l00s > 0.0)) return false;
-    const double l00 = sqrt(l00s);
-    const double l10 = V[1] / l00, l20 = V[2] / l00;
-    const double l11s = V[3] - l10 * l10;
-    if (!(l11s > 0.0)) return false;
-    const double l11 = sqrt(l11s);
-    const double l21 = (V[4] - l20 * l10) / l11;
-    const double l22s = V[5] - l20 * l20 - l21 * l21;
-    if (!(l22s > 0.0)) return false;
-    const double l22 = sqrt(l22s);
-    const double i00 = 1.0 / l00, i11 = 1.0 / l11, i22 = 1.0 / l22;
-    const double i10 = -l10 * i00 * i11;
-    const double i21 = -l21 * i11 * i22;
-    const double i20 = -(l20 * i00 + l21 * i10) * i22;
-    I[0] = i00 * i00 + i10 * i10 + i20 * i20;
-    I[1] = i10 * i11 + i20 * i21;
-    I[2] = i20 * i22;
-    I[3] = i11 * i11 + i21 * i21;
-    I[4] = i21 * i22;
-    I[5] = i22 * i22;
-    return isfinite(I[0]) && isfinite(I[3]) && isfinite(I[5]);
-}
-
-__device__ __forceinline__ void atomic_max_nonneg(double* addr, double v)
-{
-    atomicMax((unsigned long long*)addr, (unsigned long long)__double_as_longlong(v));
-}
-
-__device__ __forceinline__ double clampd(double v, double lo, double hi) { return fmin(fmax(v, lo), hi); }
+#include "ba_common.h"
 
 // ---------------------------------------------------------------------- K0
 __global__ void ba_init(BaDims d, BaBufs b, BaOpt opt, const double* __restrict__ cams_in,
@@ -399,7 +231,7 @@ __global__ __launch_bounds__(256) void ba_reduced_solve(BaDims d, BaBufs b, BaOp
     __syncthreads();
     for (int idx = tid; idx < n * n; idx += nt) {
         const int i = idx / n, j = idx % n;
-        double v = b.S[idx];
+        double v = (i <= j) ? b.S[idx] : b.S[(size_t)j * n + i];   // S is accumulated in its upper triangle
         if (i / 6 == j / 6) {
             const int a = i % 6, e = j % 6;
             v += (a <= e) ? b.U[(i / 6) * 36 + a * 6 + e] : b.U[(i / 6) * 36 + e * 6 + a];
@@ -695,6 +527,8 @@ extern "C" int rs_bundle_adjust(rs_context* ctx, int n_cameras, int n_points, in
     const size_t o_gmax = carve(sizeof(double)), o_pts = carve(sizeof(double) * 4), o_dc = carve(sizeof(double) * (n + 1));
     const size_t o_st = carve(sizeof(BaState));
     const size_t o_free = carve(C);
+    const bool use_mfma = d.Cf >= 1 && d.Cf <= 128;
+    const size_t o_grp = carve(use_mfma ? ba_group_bytes(d.P, d.Cf) : 16);
     void* wsv = nullptr;
     int rc = rs_workspace(ctx, off, &wsv);
     if (rc) return rc;
@@ -721,13 +555,15 @@ extern "C" int rs_bundle_adjust(rs_context* ctx, int n_cameras, int n_points, in
     uint8_t* d_cam_free = (uint8_t*)(ws + o_free);
     RS_HIP(ctx, hipMemcpyAsync(d_cam_free, h_free, C, hipMemcpyHostToDevice, ctx->stream));
 
-    const int use_lds = d.n <= BA_MAX_LDS_N ? 1 : 0;
-    const size_t k7_lds = use_lds ? sizeof(double) * (n * n + 2 * n + 8) : 0;
-    if (k7_lds > 48 * 1024)
-        RS_HIP(ctx, hipFuncSetAttribute((const void*)ba_reduced_solve, hipFuncAttributeMaxDynamicSharedMemorySize, (int)k7_lds));
+    const bool solve_lds = d.n >= 6 && d.n <= BA_MAX_LDS_N;
+    if (solve_lds && ba_prepare_reduced_solve_lds(d.n) != 0) return rs_fail(ctx, RS_ERR_HIP, "LDS attribute (K7)");
     const size_t k5_lds = sizeof(double) * (size_t)d.Cf * 42;
-    if (k5_lds > 48 * 1024)
+    if (!use_mfma && k5_lds > 48 * 1024)
         RS_HIP(ctx, hipFuncSetAttribute((const void*)ba_linearize_schur, hipFuncAttributeMaxDynamicSharedMemorySize, (int)k5_lds));
+    if (use_mfma && ba_prepare_schur(d.Cf) != 0) return rs_fail(ctx, RS_ERR_HIP, "LDS attribute (K5)");
+    BaGroup grp;
+    memset(&grp, 0, sizeof grp);
+    if (use_mfma) ba_group_carve(ws + o_grp, d.P, d.Cf, &grp);
 
     const int pblocks = (d.P + BA_THREADS - 1) / BA_THREADS;
     hipStream_t s = ctx->stream;
@@ -735,8 +571,15 @@ extern "C" int rs_bundle_adjust(rs_context* ctx, int n_cameras, int n_points, in
         rs_prof_scope ps(ctx, "K0_ba_init");
         hipLaunchKernelGGL(ba_init, dim3(64), dim3(256), 0, s, d, b, opt, (const double*)d_cameras, (const double*)d_points);
     }
+    if (use_mfma) {
+        rc = ba_launch_grouping(ctx, d, b, grp);
+        if (rc) return rc;
+    }
     for (int it = 0; it < opt.max_iter; it++) {
-        {
+        if (use_mfma) {
+            rs_prof_scope ps(ctx, "K5_ba_schur_mfma");
+            ba_launch_schur(s, d, b, opt, grp);
+        } else {
             rs_prof_scope ps(ctx, "K5_ba_linearize_schur");
             hipLaunchKernelGGL(ba_linearize_schur, dim3(pblocks), dim3(BA_THREADS), k5_lds, s, d, b, opt);
         }
@@ -747,9 +590,12 @@ extern "C" int rs_bundle_adjust(rs_context* ctx, int n_cameras, int n_points, in
             rc = rs_allreduce_f64(ctx, b.gmax, 1, true);
             if (rc) return rc;
         }
-        {
+        if (solve_lds) {
             rs_prof_scope ps(ctx, "K7_ba_reduced_solve");
-            hipLaunchKernelGGL(ba_reduced_solve, dim3(1), dim3(256), k7_lds, s, d, b, opt, use_lds);
+            ba_launch_reduced_solve_lds(s, d, b, opt);
+        } else {
+            rs_prof_scope ps(ctx, "K7_ba_reduced_solve_global");
+            hipLaunchKernelGGL(ba_reduced_solve, dim3(1), dim3(256), 0, s, d, b, opt, 0);
         }
         {
             rs_prof_scope ps(ctx, "K8_ba_backsub_cost");

@@ -1,0 +1,197 @@
+// ba_common.h — structures and device math shared by the bundle-adjustment
+// translation units (ba.hip, ba_solve.hip, ba_schur.hip).
+#pragma once
+#include <math.h>
+
+#include "common.h"
+
+#define BA_PREP 24            // doubles per camera: R[9] Jl[9] c[3] small pad pad
+#define BA_THREADS 64
+#define BA_MAX_LDS_N 126      // largest reduced system kept in LDS by K7
+
+struct BaState {
+    double radius, decrease_factor, x_cost, initial_cost;
+    double cam_scal[4];       // K7: mcc_c, step_sq_c, x_sq_c, unused
+    int iter, successful, invalid_steps, done;
+    int termination, cur, have_scale, solver_failed;
+    int fresh, usable, pad0, pad1;
+};
+
+struct BaDims {
+    int C, Cf, P, M, n;       // n = 6*Cf
+    float fx, fy, cx, cy;
+    double huber_a;
+};
+
+struct BaBufs {
+    const int32_t* obs_ptr;   // [P+1]
+    const int32_t* obs_cam;   // [M]
+    const float2* obs_uv;     // [M]
+    double* Xc;      // [2][C][6]
+    double* Xp;      // [2][P][3]
+    double* prep;    // [2][C][BA_PREP]
+    int32_t* slot;   // [C]  reduced-system slot of a free camera or -1
+    double* sc;      // [n]
+    double* sp;      // [P][3]
+    double* Vinv;    // [P][6]  (xx xy xz yy yz zz)
+    double* gp;      // [P][3]
+    double* lamp;    // [P][3]
+    // accumulators, contiguous for one all-reduce: S[n*n] rhs[n] U[Cf*36] gc[n] scal[2]
+    double* acc;
+    size_t acc_count;
+    double* S; double* rhs; double* U; double* gc; double* scal;   // scal: cost_x, fail_count
+    double* gmax;    // [1] bits of a non-negative double (max all-reduce)
+    double* pt_scal; // [4] K8: cand_cost, mcc_p, step_sq_p, x_sq_p
+    double* dc;      // [n]
+    BaState* st;
+};
+
+struct BaOpt {
+    int max_iter, max_invalid, jacobi;
+    double r0, rmax, rmin, min_rel, dmin, dmax, ftol, gtol, ptol;
+};
+
+// ----------------------------------------------------------------- device math
+__device__ __forceinline__ void cam_prepare(const double* cam, double* out)
+{
+    const double ax = cam[0], ay = cam[1], az = cam[2];
+    const double th2 = ax * ax + ay * ay + az * az;
+    double A, B, Cc, small;
+    if (th2 > 2.220446049250313e-16) {
+        const double th = sqrt(th2);
+        const double sh = sin(0.5 * th);
+        A = sin(th) / th;
+        B = 2.0 * sh * sh / th2;
+        Cc = (th - sin(th)) / (th2 * th);
+        small = 0.0;
+    } else {   // ceres::AngleAxisRotatePoint's first-order branch: R = I + [w]x, d/dw = -[q]x
+        A = 1.0; B = 0.0; Cc = 0.0; small = 1.0;
+    }
+    const double W[9] = {0, -az, ay, az, 0, -ax, -ay, ax, 0};
+    const double W2[9] = {-(ay * ay + az * az), ax * ay, ax * az, ax * ay, -(ax * ax + az * az), ay * az,
+                          ax * az, ay * az, -(ax * ax + ay * ay)};
+#pragma unroll
+    for (int i = 0; i < 9; i++) {
+        const double id = (i == 0 || i == 4 || i == 8) ? 1.0 : 0.0;
+        out[i] = id + A * W[i] + B * W2[i];          // R
+        out[9 + i] = id + B * W[i] + Cc * W2[i];     // left Jacobian of SO(3)
+    }
+    out[18] = cam[3]; out[19] = cam[4]; out[20] = cam[5];
+    out[21] = small; out[22] = 0.0; out[23] = 0.0;
+}
+
+struct ObsLin {
+    double r0, r1, w, rho;
+    double jc[12];   // 2x6  [d/d aa | d/d centre]
+    double jp[6];    // 2x3
+};
+
+template <bool JAC>
+__device__ __forceinline__ void obs_eval(const double* __restrict__ cp, const double X[3], float2 uv,
+                                         const BaDims& d, ObsLin& o)
+{
+    const double q0 = X[0] - cp[18], q1 = X[1] - cp[19], q2 = X[2] - cp[20];
+    const double p0 = cp[0] * q0 + cp[1] * q1 + cp[2] * q2;
+    const double p1 = cp[3] * q0 + cp[4] * q1 + cp[5] * q2;
+    const double p2 = cp[6] * q0 + cp[7] * q1 + cp[8] * q2;
+    const double fx = (double)d.fx, fy = (double)d.fy;
+    o.r0 = fx * p0 / p2 + (double)d.cx - (double)uv.x;     // src/Optimization.cpp:48-49
+    o.r1 = fy * p1 / p2 + (double)d.cy - (double)uv.y;
+    const double s = o.r0 * o.r0 + o.r1 * o.r1;
+    const double b2 = d.huber_a * d.huber_a;
+    if (s > b2) {   // ceres::HuberLoss
+        const double r = sqrt(s);
+        o.rho = 2.0 * d.huber_a * r - b2;
+        o.w = d.huber_a / r;
+    } else {
+        o.rho = s;
+        o.w = 1.0;
+    }
+    if (JAC) {
+        const double iz = 1.0 / p2;
+        const double a = fx * iz, b = fy * iz;
+        const double ax = -a * p0 * iz, bx = -b * p1 * iz;
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+            o.jp[k] = a * cp[k] + ax * cp[6 + k];
+            o.jp[3 + k] = b * cp[3 + k] + bx * cp[6 + k];
+            o.jc[3 + k] = -o.jp[k];
+            o.jc[9 + k] = -o.jp[3 + k];
+        }
+        const bool small = cp[21] != 0.0;
+        const double v0 = small ? q0 : p0, v1 = small ? q1 : p1, v2 = small ? q2 : p2;
+#pragma unroll
+        for (int k = 0; k < 3; k++) {   // d p / d aa_k = Jl[:,k] x v
+            const double m0 = cp[9 + k], m1 = cp[12 + k], m2 = cp[15 + k];
+            const double c0 = m1 * v2 - m2 * v1, c1 = m2 * v0 - m0 * v2, c2 = m0 * v1 - m1 * v0;
+            o.jc[k] = a * c0 + ax * c2;
+            o.jc[6 + k] = b * c1 + bx * c2;
+        }
+    }
+}
+
+__device__ __forceinline__ double wave_sum(double v)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    return v;
+}
+
+// symmetric 3x3 inverse through Cholesky (InvertPSDMatrix<3>); false if not PD
+__device__ __forceinline__ bool inv3_psd(const double V[6], double I[6])
+{
+    const double l00s = V[0];
+    if (!(l00s > 0.0)) return false;
+    const double l00 = sqrt(l00s);
+    const double l10 = V[1] / l00, l20 = V[2] / l00;
+    const double l11s = V[3] - l10 * l10;
+    if (!(l11s > 0.0)) return false;
+    const double l11 = sqrt(l11s);
+    const double l21 = (V[4] - l20 * l10) / l11;
+    const double l22s = V[5] - l20 * l20 - l21 * l21;
+    if (!(l22s > 0.0)) return false;
+    const double l22 = sqrt(l22s);
+    const double i00 = 1.0 / l00, i11 = 1.0 / l11, i22 = 1.0 / l22;
+    const double i10 = -l10 * i00 * i11;
+    const double i21 = -l21 * i11 * i22;
+    const double i20 = -(l20 * i00 + l21 * i10) * i22;
+    I[0] = i00 * i00 + i10 * i10 + i20 * i20;
+    I[1] = i10 * i11 + i20 * i21;
+    I[2] = i20 * i22;
+    I[3] = i11 * i11 + i21 * i21;
+    I[4] = i21 * i22;
+    I[5] = i22 * i22;
+    return isfinite(I[0]) && isfinite(I[3]) && isfinite(I[5]);
+}
+
+__device__ __forceinline__ void atomic_max_nonneg(double* addr, double v)
+{
+    atomicMax((unsigned long long*)addr, (unsigned long long)__double_as_longlong(v));
+}
+
+__device__ __forceinline__ double clampd(double v, double lo, double hi) { return fmin(fmax(v, lo), hi); }
+
+
+// ---- landmark grouping for the MFMA Schur kernel (ba_schur.hip)
+struct BaGroup {
+    int32_t* sorted;        // [P] landmark order
+    int32_t* bucket;        // [P]
+    uint64_t* mask;         // [P][2] free-slot bitmask of the landmark
+    int32_t* hist;          // [Cf*Cf + 2] histogram / offsets
+    int32_t* cursor;        // [Cf*Cf + 2]
+    uint64_t* item_mask;    // [n_items][2]
+    int n_items;
+    int n_buckets;
+};
+
+
+size_t ba_group_bytes(int P, int Cf);
+void ba_group_carve(char* base, int P, int Cf, BaGroup* g);
+int ba_launch_grouping(rs_context* ctx, const BaDims& d, const BaBufs& b, const BaGroup& g);
+size_t ba_schur_lds_bytes(int Cf);
+int ba_prepare_schur(int Cf);
+void ba_launch_schur(hipStream_t s, const BaDims& d, const BaBufs& b, const BaOpt& opt, const BaGroup& g);
+// ---- LDS-resident reduced solve (ba_solve.hip), n = 6*Cf <= BA_MAX_LDS_N
+size_t ba_reduced_solve_lds_bytes(int n);
+int ba_prepare_reduced_solve_lds(int n);
+void ba_launch_reduced_solve_lds(hipStream_t s, const BaDims& d, const BaBufs& b, const BaOpt& opt);

@@ -1,0 +1,458 @@
+// ba_schur.hip — K5: linearisation + point-block Schur complement on the f64
+// matrix cores (v_mfma_f64_16x16x4_f64), and the one-off landmark grouping
+// that makes it possible.
+//
+// Replaces, per LM iteration, the residual/Jacobian evaluation
+// (ReprojectionError, reference src/Optimization.cpp:21-72), the Huber
+// corrector and Ceres' SchurEliminator inside ceres::Solve (:360).
+//
+// Idea.  S = U + Lambda - sum_p W_p V_p^-1 W_p^T is a sum of rank-3 updates.
+// With V_p = L_p L_p^T and Y_p = W_p L_p^-T (6k x 3 for a landmark seen by k free
+// cameras) the sum is a SYRK:  S -= Y Y^T  with Y = [Y_1 Y_2 ...].  Landmarks are
+// sorted once per solve by (first, last) free-camera slot, so 16 consecutive
+// landmarks ("an item") touch a small union of cameras (<= 10 for a local
+// window).  One WAVE owns one item: it writes the 16 Y_p into a COMPACT row
+// space (6 rows per camera of the union, + 1 row carrying L_p^-1 g_p) in LDS,
+// then runs a dense 64 x 48 (x 64) SYRK on the matrix cores — K = 48 columns,
+// no padding along K — and scatter-adds the small dense result into the global
+// S / rhs once per item.  The extra row makes the reduced right-hand side
+// sum_p W_p V_p^-1 g_p fall out of the same MFMAs.  Jacobians live only in
+// registers; nothing per-observation is written to HBM.
+//
+// Item classes: union <= 10 cameras -> 4x4 tiles (NT = 4, 16 landmarks per
+// SYRK); <= 21 cameras -> 8x8 tiles (NT = 8, two half-items of 8 landmarks to
+// stay inside the same 30 KB LDS tile); larger unions fall back to per-landmark
+// f64 atomics (correct for any covisibility, slow).
+#include "ba_common.h"
+
+#define IT_L 16                 // landmarks per item
+#define SCH_WAVES 4             // waves (items) per workgroup
+#define YT_STRIDE4 81           // doubles per K-column, NT = 4 (64 rows + 17: odd*... see DESIGN.md)
+#define YT_STRIDE8 145          // NT = 8
+#define YT_DOUBLES (48 * YT_STRIDE4)   // 3888 doubles = 31104 B per wave (NT=8 half: 24*145 = 3480)
+
+typedef __attribute__((ext_vector_type(4))) double d4;
+
+// ------------------------------------------------------------ setup kernels
+__global__ void ba_group_count(BaDims d, BaBufs b, BaGroup g)
+{
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= d.P) return;
+    uint64_t m0 = 0, m1 = 0;
+    int first = 1 << 30, last = -1;
+    for (int o = b.obs_ptr[p]; o < b.obs_ptr[p + 1]; o++) {
+        const int s = b.slot[b.obs_cam[o]];
+        if (s < 0) continue;
+        if (s < 64) m0 |= 1ull << s; else m1 |= 1ull << (s - 64);
+        first = min(first, s);
+        last = max(last, s);
+    }
+    g.mask[2 * (size_t)p] = m0;
+    g.mask[2 * (size_t)p + 1] = m1;
+    const int bk = last < 0 ? d.Cf * d.Cf : first * d.Cf + last;
+    g.bucket[p] = bk;
+    atomicAdd(&g.hist[bk], 1);
+}
+
+__global__ __launch_bounds__(1024) void ba_group_scan(BaGroup g)
+{
+    // exclusive scan of hist[0..n_buckets) into cursor (single workgroup)
+    __shared__ int wsum[16];
+    __shared__ int carry;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (threadIdx.x == 0) carry = 0;
+    __syncthreads();
+    for (int base = 0; base < g.n_buckets; base += 1024) {
+        const int i = base + threadIdx.x;
+        const int v = i < g.n_buckets ? g.hist[i] : 0;
+        int x = v;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const int t = __shfl_up(x, off, 64);
+            if (lane >= off) x += t;
+        }
+        if (lane == 63) wsum[wave] = x;
+        __syncthreads();
+        int pre = carry;
+        for (int w = 0; w < wave; w++) pre += wsum[w];
+        if (i < g.n_buckets) g.cursor[i] = pre + x - v;
+        __syncthreads();
+        if (threadIdx.x == 1023) carry = pre + x;
+        __syncthreads();
+    }
+}
+
+__global__ void ba_group_scatter(BaDims d, BaGroup g)
+{
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= d.P) return;
+    const int pos = atomicAdd(&g.cursor[g.bucket[p]], 1);
+    g.sorted[pos] = p;
+}
+
+__global__ void ba_group_items(BaDims d, BaGroup g)
+{
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= g.n_items) return;
+    uint64_t m0 = 0, m1 = 0;
+    for (int l = 0; l < IT_L; l++) {
+        const int q = t * IT_L + l;
+        if (q >= d.P) break;
+        const int p = g.sorted[q];
+        m0 |= g.mask[2 * (size_t)p];
+        m1 |= g.mask[2 * (size_t)p + 1];
+    }
+    g.item_mask[2 * (size_t)t] = m0;
+    g.item_mask[2 * (size_t)t + 1] = m1;
+}
+
+// ------------------------------------------------------------------ helpers
+__device__ __forceinline__ int rank_in_mask(uint64_t m0, uint64_t m1, int s)
+{
+    if (s < 64) return __popcll(m0 & ((1ull << s) - 1ull));
+    return __popcll(m0) + __popcll(m1 & ((1ull << (s - 64)) - 1ull));
+}
+
+__device__ __forceinline__ int nth_set_bit(uint64_t m0, uint64_t m1, int r)
+{
+    // index of the r-th (0-based) set bit of the 128-bit mask
+    uint64_t m = m0;
+    int base = 0;
+    const int c0 = __popcll(m0);
+    if (r >= c0) { r -= c0; m = m1; base = 64; }
+    for (int i = 0; i < r; i++) m &= m - 1;
+    return base + __builtin_ctzll(m);
+}
+
+// cholesky of the damped point block; Li = L^-1 (lower, row-major 6 entries: 00 10 11 20 21 22)
+__device__ __forceinline__ bool chol3_inv(const double V[6], double Li[6], double I[6])
+{
+    const double l00s = V[0];
+    if (!(l00s > 0.0)) return false;
+    const double l00 = sqrt(l00s);
+    const double l10 = V[1] / l00, l20 = V[2] / l00;
+    const double l11s = V[3] - l10 * l10;
+    if (!(l11s > 0.0)) return false;
+    const double l11 = sqrt(l11s);
+    const double l21 = (V[4] - l20 * l10) / l11;
+    const double l22s = V[5] - l20 * l20 - l21 * l21;
+    if (!(l22s > 0.0)) return false;
+    const double l22 = sqrt(l22s);
+    const double i00 = 1.0 / l00, i11 = 1.0 / l11, i22 = 1.0 / l22;
+    const double i10 = -l10 * i00 * i11;
+    const double i21 = -l21 * i11 * i22;
+    const double i20 = -(l20 * i00 + l21 * i10) * i22;
+    Li[0] = i00; Li[1] = i10; Li[2] = i11; Li[3] = i20; Li[4] = i21; Li[5] = i22;
+    I[0] = i00 * i00 + i10 * i10 + i20 * i20;
+    I[1] = i10 * i11 + i20 * i21;
+    I[2] = i20 * i22;
+    I[3] = i11 * i11 + i21 * i21;
+    I[4] = i21 * i22;
+    I[5] = i22 * i22;
+    return isfinite(I[0]) && isfinite(I[3]) && isfinite(I[5]);
+}
+
+// SYRK of the compact item on the matrix cores + scatter into S / rhs.
+//   yt     : LDS tile, column-major [col][STRIDE], rows [0, 6*ns] used (row 6*ns = rhs row)
+//   ncols  : 3 * landmarks in this batch (multiple of 4 up to padding: columns beyond are zero)
+template <int NT, int STRIDE>
+__device__ __forceinline__ void syrk_scatter(const double* yt, int nchunks, int ns, const int* gslot, int n,
+                                             double* __restrict__ S, double* __restrict__ rhs)
+{
+    const int lane = threadIdx.x & 63;
+    const int lr = lane & 15, lk = lane >> 4;
+    d4 acc[NT][NT];
+#pragma unroll
+    for (int r = 0; r < NT; r++)
+#pragma unroll
+        for (int c = 0; c < NT; c++) acc[r][c] = (d4){0.0, 0.0, 0.0, 0.0};
+    const int nrow = 6 * ns;                 // rhs row index
+    const int nt_used = (nrow + 16) / 16;    // tile rows that carry data (incl. the rhs row)
+    for (int kc = 0; kc < nchunks; kc++) {
+        double a[NT];
+        const double* col = yt + (size_t)(kc * 4 + lk) * STRIDE + lr;
+#pragma unroll
+        for (int r = 0; r < NT; r++) a[r] = (r < nt_used) ? col[16 * r] : 0.0;
+#pragma unroll
+        for (int r = 0; r < NT; r++)
+#pragma unroll
+            for (int c = r; c < NT; c++)
+                if (c < nt_used) acc[r][c] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[r], a[c], acc[r][c], 0, 0, 0);
+    }
+    // C/D layout of v_mfma_f64_16x16x4_f64: col = lane & 15, row = (lane >> 4) + 4 * reg
+#pragma unroll
+    for (int r = 0; r < NT; r++)
+#pragma unroll
+        for (int c = r; c < NT; c++) {
+            if (c >= nt_used) continue;
+#pragma unroll
+            for (int reg = 0; reg < 4; reg++) {
+                const int R = 16 * r + lk + 4 * reg, Cc = 16 * c + lr;
+                const double v = acc[r][c][reg];
+                if (R >= nrow || Cc > nrow || R > Cc) continue;
+                const int gr = 6 * gslot[R / 6] + R % 6;
+                if (Cc == nrow) atomicAdd(&rhs[gr], -v);
+                else atomicAdd(&S[(size_t)gr * n + 6 * gslot[Cc / 6] + Cc % 6], -v);
+            }
+        }
+}
+
+// ---------------------------------------------------------------------- K5
+__global__ __launch_bounds__(64 * SCH_WAVES) void ba_schur_mfma(BaDims d, BaBufs b, BaOpt opt, BaGroup g)
+{
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    const BaState st = *b.st;
+    if (st.done) return;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    double* yt = lds + (size_t)wave * YT_DOUBLES;
+    double* ulds = lds + (size_t)SCH_WAVES * YT_DOUBLES;        // [Cf][42]
+    int* gslot = (int*)(ulds + (size_t)d.Cf * 42) + wave * 24;  // [24] compact row block -> camera slot
+    const int nlds = d.Cf * 42;
+    for (int i = threadIdx.x; i < nlds; i += blockDim.x) ulds[i] = 0.0;
+    __syncthreads();
+
+    const double* prep = b.prep + (size_t)st.cur * d.C * BA_PREP;
+    const double* Xp = b.Xp + (size_t)st.cur * d.P * 3;
+    const int item = blockIdx.x * SCH_WAVES + wave;
+    double cost = 0.0, gmax = 0.0, fail = 0.0;
+    if (item < g.n_items) {
+        const int l = lane & 15, sub = lane >> 4;
+        const int q = item * IT_L + l;
+        const int p = q < d.P ? g.sorted[q] : -1;
+        const uint64_t um0 = g.item_mask[2 * (size_t)item], um1 = g.item_mask[2 * (size_t)item + 1];
+        const int ns = __popcll(um0) + __popcll(um1);
+        if (lane < 24) gslot[lane] = lane < ns ? nth_set_bit(um0, um1, lane) : 0;
+
+        double X[3] = {0, 0, 0};
+        int o0 = 0, nobs = 0;
+        if (p >= 0) {
+            X[0] = Xp[3 * (size_t)p]; X[1] = Xp[3 * (size_t)p + 1]; X[2] = Xp[3 * (size_t)p + 2];
+            o0 = b.obs_ptr[p];
+            nobs = b.obs_ptr[p + 1] - o0;
+        }
+        // ---- pass 1: V, g, cost, U/gc
+        double V[6] = {0, 0, 0, 0, 0, 0}, gv[3] = {0, 0, 0};
+        ObsLin o;
+        for (int j = sub; j < nobs; j += 4) {
+            int jj = j + l; while (jj >= nobs) jj -= nobs;     // staggered start: lanes of one round hit different cameras
+            const int oi = o0 + jj;
+            const int c = b.obs_cam[oi];
+            obs_eval<true>(prep + (size_t)c * BA_PREP, X, b.obs_uv[oi], d, o);
+            cost += 0.5 * o.rho;
+            const double w = o.w;
+            V[0] += w * (o.jp[0] * o.jp[0] + o.jp[3] * o.jp[3]);
+            V[1] += w * (o.jp[0] * o.jp[1] + o.jp[3] * o.jp[4]);
+            V[2] += w * (o.jp[0] * o.jp[2] + o.jp[3] * o.jp[5]);
+            V[3] += w * (o.jp[1] * o.jp[1] + o.jp[4] * o.jp[4]);
+            V[4] += w * (o.jp[1] * o.jp[2] + o.jp[4] * o.jp[5]);
+            V[5] += w * (o.jp[2] * o.jp[2] + o.jp[5] * o.jp[5]);
+#pragma unroll
+            for (int k = 0; k < 3; k++) gv[k] += w * (o.jp[k] * o.r0 + o.jp[3 + k] * o.r1);
+            const int s = b.slot[c];
+            if (s >= 0) {
+                double* u = ulds + s * 42;
+#pragma unroll
+                for (int a = 0; a < 6; a++) {
+#pragma unroll
+                    for (int e = a; e < 6; e++) atomicAdd(&u[a * 6 + e], w * (o.jc[a] * o.jc[e] + o.jc[6 + a] * o.jc[6 + e]));
+                    atomicAdd(&u[36 + a], w * (o.jc[a] * o.r0 + o.jc[6 + a] * o.r1));
+                }
+            }
+        }
+        // the 4 sub-lanes of a landmark (lanes l, l+16, l+32, l+48) combine their partial sums
+#pragma unroll
+        for (int k = 0; k < 6; k++) { V[k] += __shfl_xor(V[k], 16, 64); V[k] += __shfl_xor(V[k], 32, 64); }
+#pragma unroll
+        for (int k = 0; k < 3; k++) { gv[k] += __shfl_xor(gv[k], 16, 64); gv[k] += __shfl_xor(gv[k], 32, 64); }
+
+        double Li[6] = {0, 0, 0, 0, 0, 0}, I[6] = {0, 0, 0, 0, 0, 0};
+        bool ok = false;
+        if (p >= 0) {
+            if (sub == 0) gmax = fmax(fabs(gv[0]), fmax(fabs(gv[1]), fabs(gv[2])));
+            double sp[3], lam[3];
+            const double Vd[3] = {V[0], V[3], V[5]};
+#pragma unroll
+            for (int k = 0; k < 3; k++) {
+                if (!st.have_scale) sp[k] = opt.jacobi ? 1.0 / (1.0 + sqrt(Vd[k])) : 1.0;
+                else sp[k] = b.sp[3 * (size_t)p + k];
+                const double s2 = sp[k] * sp[k];
+                lam[k] = clampd(s2 * Vd[k], opt.dmin, opt.dmax) / (st.radius * s2);
+            }
+            const double Vdm[6] = {V[0] + lam[0], V[1], V[2], V[3] + lam[1], V[4], V[5] + lam[2]};
+            ok = chol3_inv(Vdm, Li, I);
+            if (!ok) {
+#pragma unroll
+                for (int k = 0; k < 6; k++) { I[k] = 0.0; Li[k] = 0.0; }
+                if (sub == 0) fail = 1.0;
+            }
+            if (sub == 0) {
+#pragma unroll
+                for (int k = 0; k < 3; k++) {
+                    if (!st.have_scale) b.sp[3 * (size_t)p + k] = sp[k];
+                    b.lamp[3 * (size_t)p + k] = lam[k];
+                    b.gp[3 * (size_t)p + k] = gv[k];
+                }
+#pragma unroll
+                for (int k = 0; k < 6; k++) b.Vinv[6 * (size_t)p + k] = I[k];
+            }
+        }
+        // t = L^-1 g : the rhs row
+        const double t0 = Li[0] * gv[0], t1 = Li[1] * gv[0] + Li[2] * gv[1], t2 = Li[3] * gv[0] + Li[4] * gv[1] + Li[5] * gv[2];
+
+        // ---- pass 2: Y into LDS (compact rows), SYRK on the matrix cores, scatter
+        if (ns > 0 && ns <= 21) {
+            const bool big = ns > 10;
+            const int nbatch = big ? 2 : 1, lb_n = big ? 8 : 16;
+            const int stride = big ? YT_STRIDE8 : YT_STRIDE4;
+            for (int bt = 0; bt < nbatch; bt++) {
+                const int ncol = 3 * lb_n;
+                for (int i = lane; i < ncol * stride; i += 64) yt[i] = 0.0;
+                __builtin_amdgcn_s_waitcnt(0xc07f);
+                __builtin_amdgcn_wave_barrier();
+                const int lb = l - bt * lb_n;
+                if (p >= 0 && ok && lb >= 0 && lb < lb_n) {
+                    for (int j = sub; j < nobs; j += 4) {
+                        const int oi = o0 + j;
+                        const int c = b.obs_cam[oi];
+                        const int s = b.slot[c];
+                        if (s < 0) continue;
+                        obs_eval<true>(prep + (size_t)c * BA_PREP, X, b.obs_uv[oi], d, o);
+                        const int pos = rank_in_mask(um0, um1, s);
+                        double* dst = yt + (size_t)(3 * lb) * stride + 6 * pos;
+#pragma unroll
+                        for (int a = 0; a < 6; a++) {
+                            const double w0 = o.w * (o.jc[a] * o.jp[0] + o.jc[6 + a] * o.jp[3]);
+                            const double w1 = o.w * (o.jc[a] * o.jp[1] + o.jc[6 + a] * o.jp[4]);
+                            const double w2 = o.w * (o.jc[a] * o.jp[2] + o.jc[6 + a] * o.jp[5]);
+                            // Y = W L^-T :  Y[a][dd] = sum_e W[a][e] Linv[dd][e]
+                            dst[a] = w0 * Li[0];
+                            dst[stride + a] = w0 * Li[1] + w1 * Li[2];
+                            dst[2 * stride + a] = w0 * Li[3] + w1 * Li[4] + w2 * Li[5];
+                        }
+                    }
+                    if (sub == 0) {
+                        double* dst = yt + (size_t)(3 * lb) * stride + 6 * ns;
+                        dst[0] = t0; dst[stride] = t1; dst[2 * stride] = t2;
+                    }
+                }
+                __builtin_amdgcn_s_waitcnt(0xc07f);
+                __builtin_amdgcn_wave_barrier();
+                if (big) syrk_scatter<8, YT_STRIDE8>(yt, ncol / 4, ns, gslot, d.n, b.S, b.rhs);
+                else syrk_scatter<4, YT_STRIDE4>(yt, ncol / 4, ns, gslot, d.n, b.S, b.rhs);
+                __builtin_amdgcn_s_waitcnt(0xc07f);
+                __builtin_amdgcn_wave_barrier();
+            }
+        } else if (ns > 21) {
+            // generic fallback: per-landmark f64 atomics (any covisibility pattern)
+            if (p >= 0 && ok && sub == 0) {
+                for (int oi = o0; oi < o0 + nobs; oi++) {
+                    const int si = b.slot[b.obs_cam[oi]];
+                    if (si < 0) continue;
+                    obs_eval<true>(prep + (size_t)b.obs_cam[oi] * BA_PREP, X, b.obs_uv[oi], d, o);
+                    double Y[18];
+#pragma unroll
+                    for (int a = 0; a < 6; a++) {
+                        const double w0 = o.w * (o.jc[a] * o.jp[0] + o.jc[6 + a] * o.jp[3]);
+                        const double w1 = o.w * (o.jc[a] * o.jp[1] + o.jc[6 + a] * o.jp[4]);
+                        const double w2 = o.w * (o.jc[a] * o.jp[2] + o.jc[6 + a] * o.jp[5]);
+                        Y[a * 3 + 0] = w0 * I[0] + w1 * I[1] + w2 * I[2];
+                        Y[a * 3 + 1] = w0 * I[1] + w1 * I[3] + w2 * I[4];
+                        Y[a * 3 + 2] = w0 * I[2] + w1 * I[4] + w2 * I[5];
+                        atomicAdd(&b.rhs[6 * si + a], -(Y[a * 3] * gv[0] + Y[a * 3 + 1] * gv[1] + Y[a * 3 + 2] * gv[2]));
+                    }
+                    ObsLin oj;
+                    for (int ojx = o0; ojx < o0 + nobs; ojx++) {
+                        const int sj = b.slot[b.obs_cam[ojx]];
+                        if (sj < si) continue;      // upper block triangle only
+                        obs_eval<true>(prep + (size_t)b.obs_cam[ojx] * BA_PREP, X, b.obs_uv[ojx], d, oj);
+                        double* Sblk = b.S + (size_t)(6 * si) * d.n + 6 * sj;
+#pragma unroll
+                        for (int e = 0; e < 6; e++) {
+                            const double w0 = oj.w * (oj.jc[e] * oj.jp[0] + oj.jc[6 + e] * oj.jp[3]);
+                            const double w1 = oj.w * (oj.jc[e] * oj.jp[1] + oj.jc[6 + e] * oj.jp[4]);
+                            const double w2 = oj.w * (oj.jc[e] * oj.jp[2] + oj.jc[6 + e] * oj.jp[5]);
+#pragma unroll
+                            for (int a = 0; a < 6; a++)
+                                if (sj > si || a <= e)
+                                    atomicAdd(&Sblk[(size_t)a * d.n + e], -(Y[a * 3] * w0 + Y[a * 3 + 1] * w1 + Y[a * 3 + 2] * w2));
+                        }
+                    }
+                }
+            }
+        }
+    }
+    cost = wave_sum(cost);
+    fail = wave_sum(fail);
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) gmax = fmax(gmax, __shfl_down(gmax, off, 64));
+    if (lane == 0) {
+        if (cost != 0.0) atomicAdd(&b.scal[0], cost);
+        if (fail > 0.0) atomicAdd(&b.scal[1], fail);
+        if (gmax > 0.0) atomic_max_nonneg(b.gmax, gmax);
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < nlds; i += blockDim.x) {
+        const int s = i / 42, k = i % 42;
+        const double v = ulds[i];
+        if (v != 0.0) {
+            if (k < 36) atomicAdd(&b.U[s * 36 + k], v);
+            else atomicAdd(&b.gc[6 * s + (k - 36)], v);
+        }
+    }
+}
+
+// ------------------------------------------------------------------ host glue
+size_t ba_group_bytes(int P, int Cf)
+{
+    const size_t nb = (size_t)Cf * Cf + 2;
+    const size_t ni = ((size_t)P + IT_L - 1) / IT_L;
+    return 256 * 8 + sizeof(int32_t) * (2 * (size_t)P + 2 * nb) + sizeof(uint64_t) * (2 * (size_t)P + 2 * ni);
+}
+
+static size_t al256(size_t v) { return (v + 255) & ~(size_t)255; }
+
+void ba_group_carve(char* base, int P, int Cf, BaGroup* g)
+{
+    const size_t nb = (size_t)Cf * Cf + 2;
+    const size_t ni = ((size_t)P + IT_L - 1) / IT_L;
+    size_t off = 0;
+    g->sorted = (int32_t*)(base + off); off += al256(sizeof(int32_t) * P);
+    g->bucket = (int32_t*)(base + off); off += al256(sizeof(int32_t) * P);
+    g->hist = (int32_t*)(base + off); off += al256(sizeof(int32_t) * nb);
+    g->cursor = (int32_t*)(base + off); off += al256(sizeof(int32_t) * nb);
+    g->mask = (uint64_t*)(base + off); off += al256(sizeof(uint64_t) * 2 * P);
+    g->item_mask = (uint64_t*)(base + off); off += al256(sizeof(uint64_t) * 2 * ni);
+    g->n_items = (int)ni;
+    g->n_buckets = (int)nb - 1;
+}
+
+int ba_launch_grouping(rs_context* ctx, const BaDims& d, const BaBufs& b, const BaGroup& g)
+{
+    hipStream_t s = ctx->stream;
+    RS_HIP(ctx, hipMemsetAsync(g.hist, 0, sizeof(int32_t) * ((size_t)g.n_buckets + 1), s));
+    rs_prof_scope ps(ctx, "K5s_group_landmarks");
+    const int pb = (d.P + 255) / 256;
+    hipLaunchKernelGGL(ba_group_count, dim3(pb), dim3(256), 0, s, d, b, g);
+    hipLaunchKernelGGL(ba_group_scan, dim3(1), dim3(1024), 0, s, g);
+    hipLaunchKernelGGL(ba_group_scatter, dim3(pb), dim3(256), 0, s, d, g);
+    hipLaunchKernelGGL(ba_group_items, dim3((g.n_items + 255) / 256), dim3(256), 0, s, d, g);
+    return RS_OK;
+}
+
+size_t ba_schur_lds_bytes(int Cf)
+{
+    return sizeof(double) * ((size_t)SCH_WAVES * YT_DOUBLES + (size_t)Cf * 42) + sizeof(int) * SCH_WAVES * 24;
+}
+
+int ba_prepare_schur(int Cf)
+{
+    return (int)hipFuncSetAttribute((const void*)ba_schur_mfma, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    (int)ba_schur_lds_bytes(Cf));
+}
+
+void ba_launch_schur(hipStream_t s, const BaDims& d, const BaBufs& b, const BaOpt& opt, const BaGroup& g)
+{
+    const int blocks = (g.n_items + SCH_WAVES - 1) / SCH_WAVES;
+    hipLaunchKernelGGL(ba_schur_mfma, dim3(blocks), dim3(64 * SCH_WAVES), ba_schur_lds_bytes(d.Cf), s, d, b, opt, g);
+}
