@@ -527,7 +527,7 @@ extern "C" int rs_bundle_adjust(rs_context* ctx, int n_cameras, int n_points, in
     const size_t o_gmax = carve(sizeof(double)), o_pts = carve(sizeof(double) * 4), o_dc = carve(sizeof(double) * (n + 1));
     const size_t o_st = carve(sizeof(BaState));
     const size_t o_free = carve(C);
-    const bool use_mfma = d.Cf >= 1 && d.Cf <= 128;
+    const bool use_mfma = d.Cf >= 1 && d.Cf <= 128 && ba_schur_lds_bytes(d.C, d.Cf) <= 160 * 1024;
     const size_t o_grp = carve(use_mfma ? ba_group_bytes(d.P, d.Cf) : 16);
     void* wsv = nullptr;
     int rc = rs_workspace(ctx, off, &wsv);
@@ -560,7 +560,7 @@ extern "C" int rs_bundle_adjust(rs_context* ctx, int n_cameras, int n_points, in
     const size_t k5_lds = sizeof(double) * (size_t)d.Cf * 42;
     if (!use_mfma && k5_lds > 48 * 1024)
         RS_HIP(ctx, hipFuncSetAttribute((const void*)ba_linearize_schur, hipFuncAttributeMaxDynamicSharedMemorySize, (int)k5_lds));
-    if (use_mfma && ba_prepare_schur(d.Cf) != 0) return rs_fail(ctx, RS_ERR_HIP, "LDS attribute (K5)");
+    if (use_mfma && ba_prepare_schur(d.C, d.Cf) != 0) return rs_fail(ctx, RS_ERR_HIP, "LDS attribute (K5)");
     BaGroup grp;
     memset(&grp, 0, sizeof grp);
     if (use_mfma) ba_group_carve(ws + o_grp, d.P, d.Cf, &grp);

@@ -188,8 +188,8 @@ struct BaGroup {
 size_t ba_group_bytes(int P, int Cf);
 void ba_group_carve(char* base, int P, int Cf, BaGroup* g);
 int ba_launch_grouping(rs_context* ctx, const BaDims& d, const BaBufs& b, const BaGroup& g);
-size_t ba_schur_lds_bytes(int Cf);
-int ba_prepare_schur(int Cf);
+size_t ba_schur_lds_bytes(int C, int Cf);
+int ba_prepare_schur(int C, int Cf);
 void ba_launch_schur(hipStream_t s, const BaDims& d, const BaBufs& b, const BaOpt& opt, const BaGroup& g);
 // ---- LDS-resident reduced solve (ba_solve.hip), n = 6*Cf <= BA_MAX_LDS_N
 size_t ba_reduced_solve_lds_bytes(int n);

@@ -25,11 +25,14 @@
 // f64 atomics (correct for any covisibility, slow).
 #include "ba_common.h"
 
-#define IT_L 16                 // landmarks per item
-#define SCH_WAVES 4             // waves (items) per workgroup
-#define YT_STRIDE4 81           // doubles per K-column, NT = 4 (64 rows + 17: odd*... see DESIGN.md)
-#define YT_STRIDE8 145          // NT = 8
-#define YT_DOUBLES (48 * YT_STRIDE4)   // 3888 doubles = 31104 B per wave (NT=8 half: 24*145 = 3480)
+#define IT_L 64                 // landmarks per item (= per workgroup; 16 per wave)
+#define SCH_WAVES 4             // waves per workgroup
+#define YT_STRIDE4 81           // doubles per K-column, NT = 4: 64 rows + 17 (17 mod 32 keeps the two
+                                // half-wave column groups of a ds_read_b64 on disjoint banks; 3*81*2 = 6 mod 32
+                                // spreads the 16 producer lanes over 16 bank pairs)
+#define YT_STRIDE8 145          // NT = 8: 128 rows + 17
+#define YT_DOUBLES (192 * YT_STRIDE4)  // 15552 doubles = 124416 B per workgroup (NT=8: 96 cols * 145 = 13920)
+#define SCH_MAXC_LDS 64         // cameras staged in LDS when the window has at most this many
 
 typedef __attribute__((ext_vector_type(4))) double d4;
 
@@ -152,52 +155,64 @@ __device__ __forceinline__ bool chol3_inv(const double V[6], double Li[6], doubl
     return isfinite(I[0]) && isfinite(I[3]) && isfinite(I[5]);
 }
 
-// SYRK of the compact item on the matrix cores + scatter into S / rhs.
-//   yt     : LDS tile, column-major [col][STRIDE], rows [0, 6*ns] used (row 6*ns = rhs row)
-//   ncols  : 3 * landmarks in this batch (multiple of 4 up to padding: columns beyond are zero)
-template <int NT, int STRIDE>
+// Upper-triangle tile list shared by the 4 waves of a workgroup: tile id t -> (r, c), r <= c.
+__device__ __forceinline__ void tile_rc(int t, int NT, int& r, int& c)
+{
+    // row-major enumeration of the upper triangle of an NT x NT tile grid
+    r = 0;
+    int rem = t, len = NT;
+    while (rem >= len) { rem -= len; len--; r++; }
+    c = r + rem;
+}
+
+// SYRK of the compact item on the matrix cores + scatter into S / rhs.  Each wave owns the
+// tiles  wave, wave + 4, ...  of the upper triangle and runs over ALL K-chunks of the tile.
+//   yt : LDS tile, column-major [col][STRIDE]; rows [0, 6*ns] used (row 6*ns = rhs row)
+template <int NT, int TPW, int STRIDE>
 __device__ __forceinline__ void syrk_scatter(const double* yt, int nchunks, int ns, const int* gslot, int n,
-                                             double* __restrict__ S, double* __restrict__ rhs)
+                                             int wave, double* __restrict__ S, double* __restrict__ rhs)
 {
     const int lane = threadIdx.x & 63;
     const int lr = lane & 15, lk = lane >> 4;
-    d4 acc[NT][NT];
-#pragma unroll
-    for (int r = 0; r < NT; r++)
-#pragma unroll
-        for (int c = 0; c < NT; c++) acc[r][c] = (d4){0.0, 0.0, 0.0, 0.0};
     const int nrow = 6 * ns;                 // rhs row index
     const int nt_used = (nrow + 16) / 16;    // tile rows that carry data (incl. the rhs row)
+    d4 acc[TPW];
+    int tr[TPW], tc[TPW];
+#pragma unroll
+    for (int t = 0; t < TPW; t++) {
+        acc[t] = (d4){0.0, 0.0, 0.0, 0.0};
+        int r = 0, c = NT;
+        if (wave + SCH_WAVES * t < NT * (NT + 1) / 2) tile_rc(wave + SCH_WAVES * t, NT, r, c);
+        tr[t] = r; tc[t] = c;               // c >= nt_used marks an unused slot
+    }
     for (int kc = 0; kc < nchunks; kc++) {
-        double a[NT];
         const double* col = yt + (size_t)(kc * 4 + lk) * STRIDE + lr;
 #pragma unroll
-        for (int r = 0; r < NT; r++) a[r] = (r < nt_used) ? col[16 * r] : 0.0;
-#pragma unroll
-        for (int r = 0; r < NT; r++)
-#pragma unroll
-            for (int c = r; c < NT; c++)
-                if (c < nt_used) acc[r][c] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[r], a[c], acc[r][c], 0, 0, 0);
+        for (int t = 0; t < TPW; t++) {
+            if (tc[t] < nt_used) {
+                const double a = col[16 * tr[t]], bb = col[16 * tc[t]];
+                acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, bb, acc[t], 0, 0, 0);
+            }
+        }
     }
     // C/D layout of v_mfma_f64_16x16x4_f64: col = lane & 15, row = (lane >> 4) + 4 * reg
 #pragma unroll
-    for (int r = 0; r < NT; r++)
+    for (int t = 0; t < TPW; t++) {
+        if (tc[t] >= nt_used) continue;
 #pragma unroll
-        for (int c = r; c < NT; c++) {
-            if (c >= nt_used) continue;
-#pragma unroll
-            for (int reg = 0; reg < 4; reg++) {
-                const int R = 16 * r + lk + 4 * reg, Cc = 16 * c + lr;
-                const double v = acc[r][c][reg];
-                if (R >= nrow || Cc > nrow || R > Cc) continue;
-                const int gr = 6 * gslot[R / 6] + R % 6;
-                if (Cc == nrow) atomicAdd(&rhs[gr], -v);
-                else atomicAdd(&S[(size_t)gr * n + 6 * gslot[Cc / 6] + Cc % 6], -v);
-            }
+        for (int reg = 0; reg < 4; reg++) {
+            const int R = 16 * tr[t] + lk + 4 * reg, Cc = 16 * tc[t] + lr;
+            const double v = acc[t][reg];
+            if (R >= nrow || Cc > nrow || R > Cc) continue;
+            const int gr = 6 * gslot[R / 6] + R % 6;
+            if (Cc == nrow) atomicAdd(&rhs[gr], -v);
+            else atomicAdd(&S[(size_t)gr * n + 6 * gslot[Cc / 6] + Cc % 6], -v);
         }
+    }
 }
 
 // ---------------------------------------------------------------------- K5
+// One workgroup = one item of IT_L = 64 sorted landmarks (16 per wave).
 __global__ __launch_bounds__(64 * SCH_WAVES) void ba_schur_mfma(BaDims d, BaBufs b, BaOpt opt, BaGroup g)
 {
     extern __shared__ __attribute__((aligned(16))) double lds[];
@@ -205,178 +220,180 @@ __global__ __launch_bounds__(64 * SCH_WAVES) void ba_schur_mfma(BaDims d, BaBufs
     if (st.done) return;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    double* yt = lds + (size_t)wave * YT_DOUBLES;
-    double* ulds = lds + (size_t)SCH_WAVES * YT_DOUBLES;        // [Cf][42]
-    int* gslot = (int*)(ulds + (size_t)d.Cf * 42) + wave * 24;  // [24] compact row block -> camera slot
+    double* yt = lds;                                            // WG tile
+    double* ulds = lds + YT_DOUBLES;                             // [Cf][42]
+    double* cprep = ulds + (size_t)d.Cf * 42;                    // [C][BA_PREP] camera block staged in LDS (C <= 64)
+    const bool lds_prep = d.C <= SCH_MAXC_LDS;
+    int* gslot = (int*)(cprep + (lds_prep ? (size_t)d.C * BA_PREP : 0));   // [24]
     const int nlds = d.Cf * 42;
     for (int i = threadIdx.x; i < nlds; i += blockDim.x) ulds[i] = 0.0;
+    const double* gprep = b.prep + (size_t)st.cur * d.C * BA_PREP;
+    if (lds_prep)
+        for (int i = threadIdx.x; i < d.C * BA_PREP; i += blockDim.x) cprep[i] = gprep[i];
+    const double* prep = lds_prep ? cprep : gprep;
+
+    const int item = blockIdx.x;
+    const uint64_t um0 = g.item_mask[2 * (size_t)item], um1 = g.item_mask[2 * (size_t)item + 1];
+    const int ns = __popcll(um0) + __popcll(um1);
+    if (threadIdx.x < 24) gslot[threadIdx.x] = (int)threadIdx.x < ns ? nth_set_bit(um0, um1, threadIdx.x) : 0;
     __syncthreads();
 
-    const double* prep = b.prep + (size_t)st.cur * d.C * BA_PREP;
     const double* Xp = b.Xp + (size_t)st.cur * d.P * 3;
-    const int item = blockIdx.x * SCH_WAVES + wave;
     double cost = 0.0, gmax = 0.0, fail = 0.0;
-    if (item < g.n_items) {
-        const int l = lane & 15, sub = lane >> 4;
-        const int q = item * IT_L + l;
-        const int p = q < d.P ? g.sorted[q] : -1;
-        const uint64_t um0 = g.item_mask[2 * (size_t)item], um1 = g.item_mask[2 * (size_t)item + 1];
-        const int ns = __popcll(um0) + __popcll(um1);
-        if (lane < 24) gslot[lane] = lane < ns ? nth_set_bit(um0, um1, lane) : 0;
+    const int l = lane & 15, sub = lane >> 4;
+    const int wl = 16 * wave + l;                    // landmark slot inside the item
+    const int q = item * IT_L + wl;
+    const int p = q < d.P ? g.sorted[q] : -1;
 
-        double X[3] = {0, 0, 0};
-        int o0 = 0, nobs = 0;
-        if (p >= 0) {
-            X[0] = Xp[3 * (size_t)p]; X[1] = Xp[3 * (size_t)p + 1]; X[2] = Xp[3 * (size_t)p + 2];
-            o0 = b.obs_ptr[p];
-            nobs = b.obs_ptr[p + 1] - o0;
-        }
-        // ---- pass 1: V, g, cost, U/gc
-        double V[6] = {0, 0, 0, 0, 0, 0}, gv[3] = {0, 0, 0};
-        ObsLin o;
-        for (int j = sub; j < nobs; j += 4) {
-            int jj = j + l; while (jj >= nobs) jj -= nobs;     // staggered start: lanes of one round hit different cameras
-            const int oi = o0 + jj;
-            const int c = b.obs_cam[oi];
-            obs_eval<true>(prep + (size_t)c * BA_PREP, X, b.obs_uv[oi], d, o);
-            cost += 0.5 * o.rho;
-            const double w = o.w;
-            V[0] += w * (o.jp[0] * o.jp[0] + o.jp[3] * o.jp[3]);
-            V[1] += w * (o.jp[0] * o.jp[1] + o.jp[3] * o.jp[4]);
-            V[2] += w * (o.jp[0] * o.jp[2] + o.jp[3] * o.jp[5]);
-            V[3] += w * (o.jp[1] * o.jp[1] + o.jp[4] * o.jp[4]);
-            V[4] += w * (o.jp[1] * o.jp[2] + o.jp[4] * o.jp[5]);
-            V[5] += w * (o.jp[2] * o.jp[2] + o.jp[5] * o.jp[5]);
+    double X[3] = {0, 0, 0};
+    int o0 = 0, nobs = 0;
+    if (p >= 0) {
+        X[0] = Xp[3 * (size_t)p]; X[1] = Xp[3 * (size_t)p + 1]; X[2] = Xp[3 * (size_t)p + 2];
+        o0 = b.obs_ptr[p];
+        nobs = b.obs_ptr[p + 1] - o0;
+    }
+    // ---- pass 1: V, g, cost, U/gc
+    double V[6] = {0, 0, 0, 0, 0, 0}, gv[3] = {0, 0, 0};
+    ObsLin o;
+    for (int j = sub; j < nobs; j += 4) {
+        int jj = j + l; while (jj >= nobs) jj -= nobs;     // staggered: lanes of one round hit different cameras
+        const int oi = o0 + jj;
+        const int c = b.obs_cam[oi];
+        obs_eval<true>(prep + (size_t)c * BA_PREP, X, b.obs_uv[oi], d, o);
+        cost += 0.5 * o.rho;
+        const double w = o.w;
+        V[0] += w * (o.jp[0] * o.jp[0] + o.jp[3] * o.jp[3]);
+        V[1] += w * (o.jp[0] * o.jp[1] + o.jp[3] * o.jp[4]);
+        V[2] += w * (o.jp[0] * o.jp[2] + o.jp[3] * o.jp[5]);
+        V[3] += w * (o.jp[1] * o.jp[1] + o.jp[4] * o.jp[4]);
+        V[4] += w * (o.jp[1] * o.jp[2] + o.jp[4] * o.jp[5]);
+        V[5] += w * (o.jp[2] * o.jp[2] + o.jp[5] * o.jp[5]);
 #pragma unroll
-            for (int k = 0; k < 3; k++) gv[k] += w * (o.jp[k] * o.r0 + o.jp[3 + k] * o.r1);
-            const int s = b.slot[c];
-            if (s >= 0) {
-                double* u = ulds + s * 42;
+        for (int k = 0; k < 3; k++) gv[k] += w * (o.jp[k] * o.r0 + o.jp[3 + k] * o.r1);
+        const int s = b.slot[c];
+        if (s >= 0) {
+            double* u = ulds + s * 42;
 #pragma unroll
-                for (int a = 0; a < 6; a++) {
+            for (int a = 0; a < 6; a++) {
 #pragma unroll
-                    for (int e = a; e < 6; e++) atomicAdd(&u[a * 6 + e], w * (o.jc[a] * o.jc[e] + o.jc[6 + a] * o.jc[6 + e]));
-                    atomicAdd(&u[36 + a], w * (o.jc[a] * o.r0 + o.jc[6 + a] * o.r1));
-                }
+                for (int e = a; e < 6; e++) atomicAdd(&u[a * 6 + e], w * (o.jc[a] * o.jc[e] + o.jc[6 + a] * o.jc[6 + e]));
+                atomicAdd(&u[36 + a], w * (o.jc[a] * o.r0 + o.jc[6 + a] * o.r1));
             }
         }
-        // the 4 sub-lanes of a landmark (lanes l, l+16, l+32, l+48) combine their partial sums
+    }
+    // the 4 sub-lanes of a landmark (lanes l, l+16, l+32, l+48) combine their partial sums
 #pragma unroll
-        for (int k = 0; k < 6; k++) { V[k] += __shfl_xor(V[k], 16, 64); V[k] += __shfl_xor(V[k], 32, 64); }
+    for (int k = 0; k < 6; k++) { V[k] += __shfl_xor(V[k], 16, 64); V[k] += __shfl_xor(V[k], 32, 64); }
 #pragma unroll
-        for (int k = 0; k < 3; k++) { gv[k] += __shfl_xor(gv[k], 16, 64); gv[k] += __shfl_xor(gv[k], 32, 64); }
+    for (int k = 0; k < 3; k++) { gv[k] += __shfl_xor(gv[k], 16, 64); gv[k] += __shfl_xor(gv[k], 32, 64); }
 
-        double Li[6] = {0, 0, 0, 0, 0, 0}, I[6] = {0, 0, 0, 0, 0, 0};
-        bool ok = false;
-        if (p >= 0) {
-            if (sub == 0) gmax = fmax(fabs(gv[0]), fmax(fabs(gv[1]), fabs(gv[2])));
-            double sp[3], lam[3];
-            const double Vd[3] = {V[0], V[3], V[5]};
+    double Li[6] = {0, 0, 0, 0, 0, 0}, I[6] = {0, 0, 0, 0, 0, 0};
+    bool ok = false;
+    if (p >= 0) {
+        if (sub == 0) gmax = fmax(fabs(gv[0]), fmax(fabs(gv[1]), fabs(gv[2])));
+        double sp[3], lam[3];
+        const double Vd[3] = {V[0], V[3], V[5]};
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+            if (!st.have_scale) sp[k] = opt.jacobi ? 1.0 / (1.0 + sqrt(Vd[k])) : 1.0;
+            else sp[k] = b.sp[3 * (size_t)p + k];
+            const double s2 = sp[k] * sp[k];
+            lam[k] = clampd(s2 * Vd[k], opt.dmin, opt.dmax) / (st.radius * s2);
+        }
+        const double Vdm[6] = {V[0] + lam[0], V[1], V[2], V[3] + lam[1], V[4], V[5] + lam[2]};
+        ok = chol3_inv(Vdm, Li, I);
+        if (!ok) {
+#pragma unroll
+            for (int k = 0; k < 6; k++) { I[k] = 0.0; Li[k] = 0.0; }
+            if (sub == 0) fail = 1.0;
+        }
+        if (sub == 0) {
 #pragma unroll
             for (int k = 0; k < 3; k++) {
-                if (!st.have_scale) sp[k] = opt.jacobi ? 1.0 / (1.0 + sqrt(Vd[k])) : 1.0;
-                else sp[k] = b.sp[3 * (size_t)p + k];
-                const double s2 = sp[k] * sp[k];
-                lam[k] = clampd(s2 * Vd[k], opt.dmin, opt.dmax) / (st.radius * s2);
+                if (!st.have_scale) b.sp[3 * (size_t)p + k] = sp[k];
+                b.lamp[3 * (size_t)p + k] = lam[k];
+                b.gp[3 * (size_t)p + k] = gv[k];
             }
-            const double Vdm[6] = {V[0] + lam[0], V[1], V[2], V[3] + lam[1], V[4], V[5] + lam[2]};
-            ok = chol3_inv(Vdm, Li, I);
-            if (!ok) {
 #pragma unroll
-                for (int k = 0; k < 6; k++) { I[k] = 0.0; Li[k] = 0.0; }
-                if (sub == 0) fail = 1.0;
-            }
-            if (sub == 0) {
-#pragma unroll
-                for (int k = 0; k < 3; k++) {
-                    if (!st.have_scale) b.sp[3 * (size_t)p + k] = sp[k];
-                    b.lamp[3 * (size_t)p + k] = lam[k];
-                    b.gp[3 * (size_t)p + k] = gv[k];
-                }
-#pragma unroll
-                for (int k = 0; k < 6; k++) b.Vinv[6 * (size_t)p + k] = I[k];
-            }
+            for (int k = 0; k < 6; k++) b.Vinv[6 * (size_t)p + k] = I[k];
         }
-        // t = L^-1 g : the rhs row
-        const double t0 = Li[0] * gv[0], t1 = Li[1] * gv[0] + Li[2] * gv[1], t2 = Li[3] * gv[0] + Li[4] * gv[1] + Li[5] * gv[2];
+    }
+    // t = L^-1 g : the rhs row
+    const double t0 = Li[0] * gv[0], t1 = Li[1] * gv[0] + Li[2] * gv[1], t2 = Li[3] * gv[0] + Li[4] * gv[1] + Li[5] * gv[2];
 
-        // ---- pass 2: Y into LDS (compact rows), SYRK on the matrix cores, scatter
-        if (ns > 0 && ns <= 21) {
-            const bool big = ns > 10;
-            const int nbatch = big ? 2 : 1, lb_n = big ? 8 : 16;
-            const int stride = big ? YT_STRIDE8 : YT_STRIDE4;
-            for (int bt = 0; bt < nbatch; bt++) {
-                const int ncol = 3 * lb_n;
-                for (int i = lane; i < ncol * stride; i += 64) yt[i] = 0.0;
-                __builtin_amdgcn_s_waitcnt(0xc07f);
-                __builtin_amdgcn_wave_barrier();
-                const int lb = l - bt * lb_n;
-                if (p >= 0 && ok && lb >= 0 && lb < lb_n) {
-                    for (int j = sub; j < nobs; j += 4) {
-                        const int oi = o0 + j;
-                        const int c = b.obs_cam[oi];
-                        const int s = b.slot[c];
-                        if (s < 0) continue;
-                        obs_eval<true>(prep + (size_t)c * BA_PREP, X, b.obs_uv[oi], d, o);
-                        const int pos = rank_in_mask(um0, um1, s);
-                        double* dst = yt + (size_t)(3 * lb) * stride + 6 * pos;
-#pragma unroll
-                        for (int a = 0; a < 6; a++) {
-                            const double w0 = o.w * (o.jc[a] * o.jp[0] + o.jc[6 + a] * o.jp[3]);
-                            const double w1 = o.w * (o.jc[a] * o.jp[1] + o.jc[6 + a] * o.jp[4]);
-                            const double w2 = o.w * (o.jc[a] * o.jp[2] + o.jc[6 + a] * o.jp[5]);
-                            // Y = W L^-T :  Y[a][dd] = sum_e W[a][e] Linv[dd][e]
-                            dst[a] = w0 * Li[0];
-                            dst[stride + a] = w0 * Li[1] + w1 * Li[2];
-                            dst[2 * stride + a] = w0 * Li[3] + w1 * Li[4] + w2 * Li[5];
-                        }
-                    }
-                    if (sub == 0) {
-                        double* dst = yt + (size_t)(3 * lb) * stride + 6 * ns;
-                        dst[0] = t0; dst[stride] = t1; dst[2 * stride] = t2;
-                    }
-                }
-                __builtin_amdgcn_s_waitcnt(0xc07f);
-                __builtin_amdgcn_wave_barrier();
-                if (big) syrk_scatter<8, YT_STRIDE8>(yt, ncol / 4, ns, gslot, d.n, b.S, b.rhs);
-                else syrk_scatter<4, YT_STRIDE4>(yt, ncol / 4, ns, gslot, d.n, b.S, b.rhs);
-                __builtin_amdgcn_s_waitcnt(0xc07f);
-                __builtin_amdgcn_wave_barrier();
-            }
-        } else if (ns > 21) {
-            // generic fallback: per-landmark f64 atomics (any covisibility pattern)
-            if (p >= 0 && ok && sub == 0) {
-                for (int oi = o0; oi < o0 + nobs; oi++) {
-                    const int si = b.slot[b.obs_cam[oi]];
-                    if (si < 0) continue;
-                    obs_eval<true>(prep + (size_t)b.obs_cam[oi] * BA_PREP, X, b.obs_uv[oi], d, o);
-                    double Y[18];
+    // ---- pass 2: Y into the LDS tile (compact rows), SYRK on the matrix cores, scatter
+    if (ns > 0 && ns <= 21) {
+        const bool big = ns > 10;
+        const int nbatch = big ? 2 : 1, lb_n = big ? 32 : 64;
+        const int stride = big ? YT_STRIDE8 : YT_STRIDE4;
+        for (int bt = 0; bt < nbatch; bt++) {
+            const int ncol = 3 * lb_n;
+            __syncthreads();                                   // previous batch fully consumed
+            for (int i = threadIdx.x; i < ncol * stride; i += blockDim.x) yt[i] = 0.0;
+            __syncthreads();
+            const int lb = wl - bt * lb_n;
+            if (p >= 0 && ok && lb >= 0 && lb < lb_n) {
+                for (int j = sub; j < nobs; j += 4) {
+                    const int oi = o0 + j;
+                    const int c = b.obs_cam[oi];
+                    const int s = b.slot[c];
+                    if (s < 0) continue;
+                    obs_eval<true>(prep + (size_t)c * BA_PREP, X, b.obs_uv[oi], d, o);
+                    const int pos = rank_in_mask(um0, um1, s);
+                    double* dst = yt + (size_t)(3 * lb) * stride + 6 * pos;
 #pragma unroll
                     for (int a = 0; a < 6; a++) {
                         const double w0 = o.w * (o.jc[a] * o.jp[0] + o.jc[6 + a] * o.jp[3]);
                         const double w1 = o.w * (o.jc[a] * o.jp[1] + o.jc[6 + a] * o.jp[4]);
                         const double w2 = o.w * (o.jc[a] * o.jp[2] + o.jc[6 + a] * o.jp[5]);
-                        Y[a * 3 + 0] = w0 * I[0] + w1 * I[1] + w2 * I[2];
-                        Y[a * 3 + 1] = w0 * I[1] + w1 * I[3] + w2 * I[4];
-                        Y[a * 3 + 2] = w0 * I[2] + w1 * I[4] + w2 * I[5];
-                        atomicAdd(&b.rhs[6 * si + a], -(Y[a * 3] * gv[0] + Y[a * 3 + 1] * gv[1] + Y[a * 3 + 2] * gv[2]));
+                        // Y = W L^-T :  Y[a][dd] = sum_e W[a][e] Linv[dd][e]
+                        dst[a] = w0 * Li[0];
+                        dst[stride + a] = w0 * Li[1] + w1 * Li[2];
+                        dst[2 * stride + a] = w0 * Li[3] + w1 * Li[4] + w2 * Li[5];
                     }
-                    ObsLin oj;
-                    for (int ojx = o0; ojx < o0 + nobs; ojx++) {
-                        const int sj = b.slot[b.obs_cam[ojx]];
-                        if (sj < si) continue;      // upper block triangle only
-                        obs_eval<true>(prep + (size_t)b.obs_cam[ojx] * BA_PREP, X, b.obs_uv[ojx], d, oj);
-                        double* Sblk = b.S + (size_t)(6 * si) * d.n + 6 * sj;
+                }
+                if (sub == 0) {
+                    double* dst = yt + (size_t)(3 * lb) * stride + 6 * ns;
+                    dst[0] = t0; dst[stride] = t1; dst[2 * stride] = t2;
+                }
+            }
+            __syncthreads();
+            if (big) syrk_scatter<8, 9, YT_STRIDE8>(yt, ncol / 4, ns, gslot, d.n, wave, b.S, b.rhs);
+            else syrk_scatter<4, 3, YT_STRIDE4>(yt, ncol / 4, ns, gslot, d.n, wave, b.S, b.rhs);
+        }
+    } else if (ns > 21) {
+        // generic fallback: per-landmark f64 atomics (any covisibility pattern)
+        if (p >= 0 && ok && sub == 0) {
+            for (int oi = o0; oi < o0 + nobs; oi++) {
+                const int si = b.slot[b.obs_cam[oi]];
+                if (si < 0) continue;
+                obs_eval<true>(prep + (size_t)b.obs_cam[oi] * BA_PREP, X, b.obs_uv[oi], d, o);
+                double Y[18];
 #pragma unroll
-                        for (int e = 0; e < 6; e++) {
-                            const double w0 = oj.w * (oj.jc[e] * oj.jp[0] + oj.jc[6 + e] * oj.jp[3]);
-                            const double w1 = oj.w * (oj.jc[e] * oj.jp[1] + oj.jc[6 + e] * oj.jp[4]);
-                            const double w2 = oj.w * (oj.jc[e] * oj.jp[2] + oj.jc[6 + e] * oj.jp[5]);
+                for (int a = 0; a < 6; a++) {
+                    const double w0 = o.w * (o.jc[a] * o.jp[0] + o.jc[6 + a] * o.jp[3]);
+                    const double w1 = o.w * (o.jc[a] * o.jp[1] + o.jc[6 + a] * o.jp[4]);
+                    const double w2 = o.w * (o.jc[a] * o.jp[2] + o.jc[6 + a] * o.jp[5]);
+                    Y[a * 3 + 0] = w0 * I[0] + w1 * I[1] + w2 * I[2];
+                    Y[a * 3 + 1] = w0 * I[1] + w1 * I[3] + w2 * I[4];
+                    Y[a * 3 + 2] = w0 * I[2] + w1 * I[4] + w2 * I[5];
+                    atomicAdd(&b.rhs[6 * si + a], -(Y[a * 3] * gv[0] + Y[a * 3 + 1] * gv[1] + Y[a * 3 + 2] * gv[2]));
+                }
+                ObsLin oj;
+                for (int ojx = o0; ojx < o0 + nobs; ojx++) {
+                    const int sj = b.slot[b.obs_cam[ojx]];
+                    if (sj < si) continue;      // upper block triangle only
+                    obs_eval<true>(prep + (size_t)b.obs_cam[ojx] * BA_PREP, X, b.obs_uv[ojx], d, oj);
+                    double* Sblk = b.S + (size_t)(6 * si) * d.n + 6 * sj;
 #pragma unroll
-                            for (int a = 0; a < 6; a++)
-                                if (sj > si || a <= e)
-                                    atomicAdd(&Sblk[(size_t)a * d.n + e], -(Y[a * 3] * w0 + Y[a * 3 + 1] * w1 + Y[a * 3 + 2] * w2));
-                        }
+                    for (int e = 0; e < 6; e++) {
+                        const double w0 = oj.w * (oj.jc[e] * oj.jp[0] + oj.jc[6 + e] * oj.jp[3]);
+                        const double w1 = oj.w * (oj.jc[e] * oj.jp[1] + oj.jc[6 + e] * oj.jp[4]);
+                        const double w2 = oj.w * (oj.jc[e] * oj.jp[2] + oj.jc[6 + e] * oj.jp[5]);
+#pragma unroll
+                        for (int a = 0; a < 6; a++)
+                            if (sj > si || a <= e)
+                                atomicAdd(&Sblk[(size_t)a * d.n + e], -(Y[a * 3] * w0 + Y[a * 3 + 1] * w1 + Y[a * 3 + 2] * w2));
                     }
                 }
             }
@@ -440,19 +457,19 @@ int ba_launch_grouping(rs_context* ctx, const BaDims& d, const BaBufs& b, const 
     return RS_OK;
 }
 
-size_t ba_schur_lds_bytes(int Cf)
+size_t ba_schur_lds_bytes(int C, int Cf)
 {
-    return sizeof(double) * ((size_t)SCH_WAVES * YT_DOUBLES + (size_t)Cf * 42) + sizeof(int) * SCH_WAVES * 24;
+    const size_t prep = C <= SCH_MAXC_LDS ? (size_t)C * BA_PREP : 0;
+    return sizeof(double) * ((size_t)YT_DOUBLES + (size_t)Cf * 42 + prep) + sizeof(int) * 32;
 }
 
-int ba_prepare_schur(int Cf)
+int ba_prepare_schur(int C, int Cf)
 {
     return (int)hipFuncSetAttribute((const void*)ba_schur_mfma, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    (int)ba_schur_lds_bytes(Cf));
+                                    (int)ba_schur_lds_bytes(C, Cf));
 }
 
 void ba_launch_schur(hipStream_t s, const BaDims& d, const BaBufs& b, const BaOpt& opt, const BaGroup& g)
 {
-    const int blocks = (g.n_items + SCH_WAVES - 1) / SCH_WAVES;
-    hipLaunchKernelGGL(ba_schur_mfma, dim3(blocks), dim3(64 * SCH_WAVES), ba_schur_lds_bytes(d.Cf), s, d, b, opt, g);
+    hipLaunchKernelGGL(ba_schur_mfma, dim3(g.n_items), dim3(64 * SCH_WAVES), ba_schur_lds_bytes(d.C, d.Cf), s, d, b, opt, g);
 }

@@ -31,6 +31,16 @@ __device__ __forceinline__ double readlane_f64(double v, int lane)
     return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
 }
 
+// 1/sqrt(x) from v_rsq_f64 + two Newton steps (quadratic convergence from ~2^-27)
+__device__ __forceinline__ double fast_rsqrt(double x)
+{
+    double y = __builtin_amdgcn_rsq(x);
+    const double h = 0.5 * x;
+    y = y * (1.5 - h * y * y);
+    y = y * (1.5 - h * y * y);
+    return y;
+}
+
 __global__ __launch_bounds__(K7_THREADS) void ba_reduced_solve_lds(BaDims d, BaBufs b, BaOpt opt)
 {
     extern __shared__ __attribute__((aligned(16))) double sm[];
@@ -40,6 +50,7 @@ __global__ __launch_bounds__(K7_THREADS) void ba_reduced_solve_lds(BaDims d, BaB
     double* lam = A + (size_t)(n + 1) * LD;        // [n] camera damping
     double* invd = lam + n;                        // [n] 1 / L_ii
     double* xs = invd + n;                         // [n] solution
+    double* Minv = xs + n;                         // [n/6][6][6] inverses of the diagonal blocks of L
     __shared__ BaState st;
     __shared__ int s_fail;
     __shared__ double red[4];
@@ -112,7 +123,7 @@ __global__ __launch_bounds__(K7_THREADS) void ba_reduced_solve_lds(BaDims d, BaB
             for (int c = 0; c < 6; c++) {
                 const double piv = readlane_f64(D[c], c);
                 if (!(piv > 0.0) || !isfinite(piv)) bad = true;
-                const double rs = 1.0 / sqrt(piv);
+                const double rs = fast_rsqrt(piv);
                 const double lac = D[c] * rs;          // lanes a >= c: L[a][c]; lane c: sqrt(piv)
                 D[c] = lac;
                 if (tid == c) invd[c0 + c] = rs;
@@ -130,6 +141,19 @@ __global__ __launch_bounds__(K7_THREADS) void ba_reduced_solve_lds(BaDims d, BaB
             if (bad && tid == 0) s_fail = 1;
         }
         __syncthreads();
+        // (b') lanes 250..255 (never own a panel row for n <= 126): column e of L_JJ^-1
+        if (tid >= 250) {
+            const int e = tid - 250;
+            double m[6];
+#pragma unroll
+            for (int a = 0; a < 6; a++) {
+                double sacc = (a == e) ? 1.0 : 0.0;
+#pragma unroll
+                for (int k = 0; k < a; k++) sacc -= A[(size_t)(c0 + a) * LD + c0 + k] * ((k >= e) ? m[k] : 0.0);
+                m[a] = (a >= e) ? sacc * invd[c0 + a] : 0.0;
+                Minv[J * 36 + a * 6 + e] = m[a];
+            }
+        }
         // (b) panel rows i > c0+5 (incl. the rhs row n): row_i <- row_i * L_JJ^-T
         {
             double Lb[21], iv[6];
@@ -197,17 +221,11 @@ __global__ __launch_bounds__(K7_THREADS) void ba_reduced_solve_lds(BaDims d, BaB
     double* y = A + (size_t)n * LD;
     for (int J = NB - 1; J >= 0; J--) {
         const int c0 = 6 * J;
-        if (tid == 0) {
-            double x[6];
+        if (tid < 6) {      // x_J = L_JJ^-T y_J as a mat-vec with the stored inverse block
+            double sacc = 0.0;
 #pragma unroll
-            for (int c = 5; c >= 0; c--) {
-                double s = y[c0 + c];
-#pragma unroll
-                for (int e = c + 1; e < 6; e++) s -= A[(size_t)(c0 + e) * LD + c0 + c] * x[e];
-                x[c] = s * invd[c0 + c];
-            }
-#pragma unroll
-            for (int c = 0; c < 6; c++) xs[c0 + c] = x[c];
+            for (int e = 0; e < 6; e++) sacc += Minv[J * 36 + e * 6 + tid] * y[c0 + e];
+            xs[c0 + tid] = sacc;
         }
         __syncthreads();
         for (int i = tid; i < c0; i += nt) {
@@ -260,7 +278,7 @@ __global__ __launch_bounds__(K7_THREADS) void ba_reduced_solve_lds(BaDims d, BaB
 size_t ba_reduced_solve_lds_bytes(int n)
 {
     const int LD = n + 1 + ((n & 1) ? 1 : 0);
-    return sizeof(double) * ((size_t)(n + 1) * LD + 3 * (size_t)n + 8);
+    return sizeof(double) * ((size_t)(n + 1) * LD + 3 * (size_t)n + 6 * (size_t)n + 8);
 }
 
 void ba_launch_reduced_solve_lds(hipStream_t s, const BaDims& d, const BaBufs& b, const BaOpt& opt)
