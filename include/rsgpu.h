@@ -336,6 +336,10 @@ typedef struct rs_prof_entry {
 } rs_prof_entry;
 int rs_prof_begin(rs_context* ctx);
 int rs_prof_end(rs_context* ctx, rs_prof_entry* h_entries /*[RS_PROF_MAX]*/, int* h_count);
+/* Diagnostic: shader-cycle totals per in-kernel phase of the last rs_bundle_adjust
+ * call (thread 0 of workgroup 0 stamps s_memtime at phase boundaries; slots 0-6
+ * K7, 8-14 K5).  n <= 64. */
+int rs_prof_counters(rs_context* ctx, uint64_t* h_out, int n);
 
 #ifdef __cplusplus
 }

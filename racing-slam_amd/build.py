@@ -24,9 +24,11 @@ SOURCES = [
     ("ba.hip", ["-munsafe-fp-atomics"]),
     ("ba_solve.hip", ["-munsafe-fp-atomics"]),
     ("ba_schur.hip", ["-munsafe-fp-atomics"]),
+    ("ba_update.hip", ["-munsafe-fp-atomics"]),
     ("host.cpp", ["-ffp-contract=off"]),
 ]
-COMMON = ["-O3", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function", f"--offload-arch={ARCH}"]
+STAMPS = ["-DRS_STAMPS=1"] if os.environ.get("RS_STAMPS") else []
+COMMON = STAMPS + ["-O3", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function", f"--offload-arch={ARCH}"]
 
 
 def hipcc():

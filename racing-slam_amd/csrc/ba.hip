@@ -36,9 +36,8 @@ __global__ void ba_init(BaDims d, BaBufs b, BaOpt opt, const double* __restrict_
     for (int i = tid; i < d.P * 3; i += nth) b.Xp[i] = pts_in[i];
     for (int c = tid; c < d.C; c += nth) cam_prepare(cams_in + 6 * c, b.prep + (size_t)c * BA_PREP);
     for (size_t i = tid; i < b.acc_count; i += nth) b.acc[i] = 0.0;
-    if (tid < 4) b.pt_scal[tid] = 0.0;
+    for (int i = tid; i < BA_NSLOT * BA_SLOT_STRIDE; i += nth) { b.pt_scal[i] = 0.0; b.gmax[i] = 0.0; }
     if (tid == 0) {
-        *b.gmax = 0.0;
         BaState s;
         s.radius = opt.r0; s.decrease_factor = 2.0; s.x_cost = 0.0; s.initial_cost = 0.0;
         s.cam_scal[0] = s.cam_scal[1] = s.cam_scal[2] = s.cam_scal[3] = 0.0;
@@ -61,6 +60,7 @@ __global__ __launch_bounds__(BA_THREADS) void ba_linearize_schur(BaDims d, BaBuf
 
     const double* prep = b.prep + (size_t)st.cur * d.C * BA_PREP;
     const double* Xp = b.Xp + (size_t)st.cur * d.P * 3;
+    const size_t rep_off = (size_t)(blockIdx.x & (BA_UREP - 1)) * b.cam_stride;
     double cost = 0.0, gmax = 0.0, fail = 0.0;
     const int p = blockIdx.x * blockDim.x + threadIdx.x;
     if (p < d.P) {
@@ -130,7 +130,7 @@ __global__ __launch_bounds__(BA_THREADS) void ba_linearize_schur(BaDims d, BaBuf
                     Y[a * 3 + 0] = w0 * I[0] + w1 * I[1] + w2 * I[2];
                     Y[a * 3 + 1] = w0 * I[1] + w1 * I[3] + w2 * I[4];
                     Y[a * 3 + 2] = w0 * I[2] + w1 * I[4] + w2 * I[5];
-                    atomicAdd(&b.rhs[6 * si + a], -(Y[a * 3] * g[0] + Y[a * 3 + 1] * g[1] + Y[a * 3 + 2] * g[2]));
+                    atomicAdd(&b.rhs[rep_off + 6 * si + a], -(Y[a * 3] * g[0] + Y[a * 3 + 1] * g[1] + Y[a * 3 + 2] * g[2]));
                 }
                 ObsLin oj;
                 for (int ojx = o0; ojx < o1; ojx++) {
@@ -158,17 +158,18 @@ __global__ __launch_bounds__(BA_THREADS) void ba_linearize_schur(BaDims d, BaBuf
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) gmax = fmax(gmax, __shfl_down(gmax, off, 64));
     if ((threadIdx.x & 63) == 0) {
-        atomicAdd(&b.scal[0], cost);
-        if (fail > 0.0) atomicAdd(&b.scal[1], fail);
-        atomic_max_nonneg(b.gmax, gmax);
+        const size_t slot = (size_t)(blockIdx.x & (BA_NSLOT - 1)) * BA_SLOT_STRIDE;
+        atomicAdd(&b.scal[slot], cost);
+        if (fail > 0.0) atomicAdd(&b.scal[slot + 1], fail);
+        atomic_max_nonneg(&b.gmax[slot], gmax);
     }
     __syncthreads();
     for (int i = threadIdx.x; i < nlds; i += blockDim.x) {
         const int s = i / 42, k = i % 42;
         const double v = lds[i];
         if (v != 0.0) {
-            if (k < 36) atomicAdd(&b.U[s * 36 + k], v);
-            else atomicAdd(&b.gc[6 * s + (k - 36)], v);
+            if (k < 36) atomicAdd(&b.U[rep_off + s * 36 + k], v);
+            else atomicAdd(&b.gc[rep_off + 6 * s + (k - 36)], v);
         }
     }
 }
@@ -186,15 +187,25 @@ __global__ __launch_bounds__(256) void ba_reduced_solve(BaDims d, BaBufs b, BaOp
     if (tid == 0) { st = *b.st; s_fail = 0; }
     __syncthreads();
     if (st.done) return;
+    // fold the BA_UREP replicas of the camera-side accumulators into replica 0
+    for (size_t i = tid; i < b.cam_stride; i += nt) {
+        double v = 0.0;
+        for (int r = 0; r < BA_UREP; r++) v += b.rhs[(size_t)r * b.cam_stride + i];
+        b.rhs[i] = v;
+    }
+    __syncthreads();
     double* S = use_lds ? sm : b.S;
     double* y = use_lds ? sm + (size_t)n * n : b.dc;    // rhs / solution vector
     double* lam = use_lds ? y + n : b.rhs;               // camera damping (rhs buffer is free once y is formed)
 
     // (1) fresh linearisation: cost at x, Jacobi scaling of the camera blocks, gradient test
     if (st.fresh) {
-        if (tid == 0) {
-            st.x_cost = b.scal[0];
-            if (st.iter == 0) st.initial_cost = st.x_cost;
+        if (tid < 64) {
+            const double c = slot_sum(b.scal, 0);
+            if (tid == 0) {
+                st.x_cost = c;
+                if (st.iter == 0) st.initial_cost = st.x_cost;
+            }
         }
         if (!st.have_scale)
             for (int i = tid; i < n; i += nt) {
@@ -207,8 +218,10 @@ __global__ __launch_bounds__(256) void ba_reduced_solve(BaDims d, BaBufs b, BaOp
         for (int off = 32; off > 0; off >>= 1) gm = fmax(gm, __shfl_down(gm, off, 64));
         if ((tid & 63) == 0) red[tid >> 6] = gm;
         __syncthreads();
+        double gslots = 0.0;
+        if (tid < 64) gslots = slot_max_bits(b.gmax);
         if (tid == 0) {
-            double g = __longlong_as_double((long long)*(unsigned long long*)b.gmax);
+            double g = gslots;
             for (int w = 0; w < (nt + 63) / 64; w++) g = fmax(g, red[w]);
             if (!isfinite(st.x_cost)) { st.done = 1; st.termination = RS_BA_FAILURE; }
             else if (g <= opt.gtol) { st.done = 1; st.termination = RS_BA_CONVERGENCE_GRADIENT; }
@@ -256,7 +269,7 @@ __global__ __launch_bounds__(256) void ba_reduced_solve(BaDims d, BaBufs b, BaOp
         for (int i = j + tid; i < n; i += nt) S[(size_t)i * n + j] = (i == j) ? sqrt(dj) : S[(size_t)i * n + j] * inv;
         __syncthreads();
     }
-    if (b.scal[1] > 0.0 && tid == 0) s_fail = 1;
+    if (tid < 64) { const double f = slot_sum(b.scal, 1); if (f > 0.0 && tid == 0) s_fail = 1; }
     __syncthreads();
     if (s_fail) {
         if (tid == 0) { st.solver_failed = 1; *b.st = st; }
@@ -367,10 +380,11 @@ __global__ __launch_bounds__(BA_THREADS) void ba_backsub_cost(BaDims d, BaBufs b
     }
     cost = wave_sum(cost); mcc = wave_sum(mcc); ssq = wave_sum(ssq); xsq = wave_sum(xsq);
     if ((threadIdx.x & 63) == 0) {
-        atomicAdd(&b.pt_scal[0], cost);
-        atomicAdd(&b.pt_scal[1], mcc);
-        atomicAdd(&b.pt_scal[2], ssq);
-        atomicAdd(&b.pt_scal[3], xsq);
+        const size_t slot = (size_t)(blockIdx.x & (BA_NSLOT - 1)) * BA_SLOT_STRIDE;
+        atomicAdd(&b.pt_scal[slot + 0], cost);
+        atomicAdd(&b.pt_scal[slot + 1], mcc);
+        atomicAdd(&b.pt_scal[slot + 2], ssq);
+        atomicAdd(&b.pt_scal[slot + 3], xsq);
     }
 }
 
@@ -378,15 +392,17 @@ __global__ __launch_bounds__(BA_THREADS) void ba_backsub_cost(BaDims d, BaBufs b
 __global__ __launch_bounds__(256) void ba_decide(BaDims d, BaBufs b, BaOpt opt)
 {
     __shared__ int was_done;
+    double ps0 = 0.0, ps1 = 0.0, ps2 = 0.0, ps3 = 0.0;
+    if (threadIdx.x < 64) { ps0 = slot_sum(b.pt_scal, 0); ps1 = slot_sum(b.pt_scal, 1); ps2 = slot_sum(b.pt_scal, 2); ps3 = slot_sum(b.pt_scal, 3); }
     if (threadIdx.x == 0) {
         BaState st = *b.st;
         was_done = st.done;
         if (!st.done) {
             st.iter++;
-            const double cand = b.pt_scal[0];
-            const double mcc = b.pt_scal[1] + st.cam_scal[0];
-            const double step_norm = sqrt(b.pt_scal[2] + st.cam_scal[1]);
-            const double x_norm = sqrt(b.pt_scal[3] + st.cam_scal[2]);
+            const double cand = ps0;
+            const double mcc = ps1 + st.cam_scal[0];
+            const double step_norm = sqrt(ps2 + st.cam_scal[1]);
+            const double x_norm = sqrt(ps3 + st.cam_scal[2]);
             st.fresh = 0;
             if (st.solver_failed || !(mcc > 0.0)) {
                 // TrustRegionMinimizer::HandleInvalidStep
@@ -425,8 +441,7 @@ __global__ __launch_bounds__(256) void ba_decide(BaDims d, BaBufs b, BaOpt opt)
     // reset the accumulators for the next linearisation
     const int tid = blockIdx.x * blockDim.x + threadIdx.x, nth = gridDim.x * blockDim.x;
     for (size_t i = tid; i < b.acc_count; i += nth) b.acc[i] = 0.0;
-    if (tid < 4) b.pt_scal[tid] = 0.0;
-    if (tid == 0) *b.gmax = 0.0;
+    for (int i = tid; i < BA_NSLOT * BA_SLOT_STRIDE; i += nth) { b.pt_scal[i] = 0.0; b.gmax[i] = 0.0; }
 }
 
 // -------------------------------------------------------------------- finalize
@@ -472,6 +487,15 @@ extern "C" void rs_ba_default_options(rs_ba_options* o)
 }
 
 void rs_ba_cache_free(rs_context* ctx) { (void)ctx; }
+
+extern "C" int rs_prof_counters(rs_context* ctx, uint64_t* h_out, int n)
+{
+    if (!ctx || !h_out || n < 0 || n > 64) return RS_ERR_INVALID;
+    if (!ctx->ba_cache) { for (int i = 0; i < n; i++) h_out[i] = 0; return RS_OK; }
+    RS_HIP(ctx, hipMemcpyAsync(h_out, ctx->ba_cache, sizeof(uint64_t) * (size_t)n, hipMemcpyDeviceToHost, ctx->stream));
+    RS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return RS_OK;
+}
 
 static size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
@@ -522,12 +546,15 @@ extern "C" int rs_bundle_adjust(rs_context* ctx, int n_cameras, int n_points, in
     const size_t o_sc = carve(sizeof(double) * (n + 1)), o_sp = carve(sizeof(double) * P * 3);
     const size_t o_Vinv = carve(sizeof(double) * P * 6), o_gp = carve(sizeof(double) * P * 3);
     const size_t o_lamp = carve(sizeof(double) * P * 3);
-    const size_t acc_count = n * n + n + (size_t)d.Cf * 36 + n + 2;
+    const size_t cam_stride = (size_t)d.Cf * 36 + 2 * n;
+    const size_t acc_count = n * n + (size_t)BA_UREP * cam_stride + (size_t)BA_NSLOT * BA_SLOT_STRIDE;
     const size_t o_acc = carve(sizeof(double) * acc_count);
-    const size_t o_gmax = carve(sizeof(double)), o_pts = carve(sizeof(double) * 4), o_dc = carve(sizeof(double) * (n + 1));
+    const size_t o_gmax = carve(sizeof(double) * BA_NSLOT * BA_SLOT_STRIDE), o_pts = carve(sizeof(double) * BA_NSLOT * BA_SLOT_STRIDE), o_dc = carve(sizeof(double) * (n + 1));
     const size_t o_st = carve(sizeof(BaState));
+    const size_t o_dbg = carve(sizeof(unsigned long long) * 64);
     const size_t o_free = carve(C);
     const bool use_mfma = d.Cf >= 1 && d.Cf <= 128 && ba_schur_lds_bytes(d.C, d.Cf) <= 160 * 1024;
+    const bool k8_lds = ba_backsub_lds_bytes(d.C, d.n) <= 64 * 1024;
     const size_t o_grp = carve(use_mfma ? ba_group_bytes(d.P, d.Cf) : 16);
     void* wsv = nullptr;
     int rc = rs_workspace(ctx, off, &wsv);
@@ -539,9 +566,13 @@ extern "C" int rs_bundle_adjust(rs_context* ctx, int n_cameras, int n_points, in
     b.slot = (int32_t*)(ws + o_slot); b.sc = (double*)(ws + o_sc); b.sp = (double*)(ws + o_sp);
     b.Vinv = (double*)(ws + o_Vinv); b.gp = (double*)(ws + o_gp); b.lamp = (double*)(ws + o_lamp);
     b.acc = (double*)(ws + o_acc); b.acc_count = acc_count;
-    b.S = b.acc; b.rhs = b.S + n * n; b.U = b.rhs + n; b.gc = b.U + (size_t)d.Cf * 36; b.scal = b.gc + n;
+    b.S = b.acc; b.rhs = b.S + n * n; b.U = b.rhs + n; b.gc = b.U + (size_t)d.Cf * 36;
+    b.cam_stride = cam_stride; b.scal = b.rhs + (size_t)BA_UREP * cam_stride;
     b.gmax = (double*)(ws + o_gmax); b.pt_scal = (double*)(ws + o_pts); b.dc = (double*)(ws + o_dc);
     b.st = (BaState*)(ws + o_st);
+    b.dbg = (unsigned long long*)(ws + o_dbg);
+    RS_HIP(ctx, hipMemsetAsync(b.dbg, 0, sizeof(unsigned long long) * 64, ctx->stream));
+    ctx->ba_cache = b.dbg;
 
     void* pin = nullptr;
     rc = rs_pinned(ctx, sizeof(int32_t) * C + sizeof(BaState) + C, &pin);
@@ -587,7 +618,7 @@ extern "C" int rs_bundle_adjust(rs_context* ctx, int n_cameras, int n_points, in
             rs_prof_scope ps(ctx, "C1_allreduce_system");
             rc = rs_allreduce_f64(ctx, b.acc, b.acc_count, false);
             if (rc) return rc;
-            rc = rs_allreduce_f64(ctx, b.gmax, 1, true);
+            rc = rs_allreduce_f64(ctx, b.gmax, BA_NSLOT * BA_SLOT_STRIDE, true);
             if (rc) return rc;
         }
         if (solve_lds) {
@@ -597,13 +628,16 @@ extern "C" int rs_bundle_adjust(rs_context* ctx, int n_cameras, int n_points, in
             rs_prof_scope ps(ctx, "K7_ba_reduced_solve_global");
             hipLaunchKernelGGL(ba_reduced_solve, dim3(1), dim3(256), 0, s, d, b, opt, 0);
         }
-        {
+        if (k8_lds) {
             rs_prof_scope ps(ctx, "K8_ba_backsub_cost");
+            ba_launch_backsub(s, d, b);
+        } else {
+            rs_prof_scope ps(ctx, "K8_ba_backsub_cost_global");
             hipLaunchKernelGGL(ba_backsub_cost, dim3(pblocks), dim3(BA_THREADS), 0, s, d, b);
         }
         if (ctx->n_ranks > 1) {
             rs_prof_scope ps(ctx, "C2_allreduce_cost");
-            rc = rs_allreduce_f64(ctx, b.pt_scal, 4, false);
+            rc = rs_allreduce_f64(ctx, b.pt_scal, BA_NSLOT * BA_SLOT_STRIDE, false);
             if (rc) return rc;
         }
         {

@@ -7,6 +7,11 @@
 
 #define BA_PREP 24            // doubles per camera: R[9] Jl[9] c[3] small pad pad
 #define BA_THREADS 64
+#define BA_NSLOT 64            // partial-sum slots (one 64-B line each) for the scalar reductions:
+                              // device-scope atomics on ONE line serialise at ~12 ns each
+#define BA_SLOT_STRIDE 8      // doubles per slot line
+#define BA_UREP 8             // replicas of the camera-side accumulators (U, gc, rhs): workgroup w adds
+                              // into replica w % 8, K7 folds them; cuts same-line atomic traffic 8x
 #define BA_MAX_LDS_N 126      // largest reduced system kept in LDS by K7
 
 struct BaState {
@@ -39,10 +44,13 @@ struct BaBufs {
     // accumulators, contiguous for one all-reduce: S[n*n] rhs[n] U[Cf*36] gc[n] scal[2]
     double* acc;
     size_t acc_count;
-    double* S; double* rhs; double* U; double* gc; double* scal;   // scal: cost_x, fail_count
-    double* gmax;    // [1] bits of a non-negative double (max all-reduce)
-    double* pt_scal; // [4] K8: cand_cost, mcc_p, step_sq_p, x_sq_p
+    double* S; double* rhs; double* U; double* gc;   // rhs/U/gc: replica 0; replica r at + r * cam_stride
+    size_t cam_stride;       // doubles per replica = Cf*36 + 2n
+    double* scal;    // [BA_NSLOT][8] per slot: cost_x, fail_count (summed by K7)
+    double* gmax;    // [BA_NSLOT][8] per slot: bits of a non-negative double (max; K7 folds)
+    double* pt_scal; // [BA_NSLOT][8] per slot, K8: cand_cost, mcc_p, step_sq_p, x_sq_p (summed by K9)
     double* dc;      // [n]
+    unsigned long long* dbg;   // [64] in-kernel phase cycle counters (diagnostic; rs_prof_counters)
     BaState* st;
 };
 
@@ -171,6 +179,53 @@ __device__ __forceinline__ void atomic_max_nonneg(double* addr, double v)
 
 __device__ __forceinline__ double clampd(double v, double lo, double hi) { return fmin(fmax(v, lo), hi); }
 
+// fold the BA_NSLOT partial slots (one wave, lane = slot); result valid in every lane
+__device__ __forceinline__ double slot_sum(const double* base, int field)
+{
+    double v = base[(size_t)(threadIdx.x & 63) * BA_SLOT_STRIDE + field];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+__device__ __forceinline__ double slot_max_bits(const double* base)
+{
+    double v = __longlong_as_double((long long)((const unsigned long long*)base)[(size_t)(threadIdx.x & 63) * BA_SLOT_STRIDE]);
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v = fmax(v, __shfl_xor(v, off, 64));
+    return v;
+}
+
+
+// phase stamps: thread 0 of block 0 accumulates s_memtime deltas per phase in REGISTERS
+// (static slot indices) and flushes them once at kernel end, so the stamps do not add
+// global-memory round trips to the phases they measure.
+#ifndef RS_STAMPS
+#define RS_STAMPS 0
+#endif
+#if RS_STAMPS
+#define BA_STAMP_DECL                                                                \
+    unsigned long long st_acc__[8] = {0, 0, 0, 0, 0, 0, 0, 0};                       \
+    unsigned long long t_prev__ = (threadIdx.x == 0 && blockIdx.x == gridDim.x / 2) ? clock64() : 0
+#define BA_STAMP(b, idx)                                                             \
+    do {                                                                             \
+        if (threadIdx.x == 0 && blockIdx.x == gridDim.x / 2) {                                   \
+            const unsigned long long t__ = clock64();                                \
+            st_acc__[(idx) & 7] += t__ - t_prev__;                                   \
+            t_prev__ = t__;                                                          \
+        }                                                                            \
+    } while (0)
+#define BA_STAMP_FLUSH(b, base)                                                      \
+    do {                                                                             \
+        if (threadIdx.x == 0 && blockIdx.x == gridDim.x / 2) {                                   \
+            _Pragma("unroll") for (int q__ = 0; q__ < 8; q__++)                      \
+                if (st_acc__[q__]) (b).dbg[(base) + q__] += st_acc__[q__];           \
+        }                                                                            \
+    } while (0)
+#else
+#define BA_STAMP_DECL do { } while (0)
+#define BA_STAMP(b, idx) do { } while (0)
+#define BA_STAMP_FLUSH(b, base) do { } while (0)
+#endif
 
 // ---- landmark grouping for the MFMA Schur kernel (ba_schur.hip)
 struct BaGroup {
@@ -195,3 +250,6 @@ void ba_launch_schur(hipStream_t s, const BaDims& d, const BaBufs& b, const BaOp
 size_t ba_reduced_solve_lds_bytes(int n);
 int ba_prepare_reduced_solve_lds(int n);
 void ba_launch_reduced_solve_lds(hipStream_t s, const BaDims& d, const BaBufs& b, const BaOpt& opt);
+// ---- back-substitution + candidate cost (ba_update.hip)
+size_t ba_backsub_lds_bytes(int C, int n);
+void ba_launch_backsub(hipStream_t s, const BaDims& d, const BaBufs& b);

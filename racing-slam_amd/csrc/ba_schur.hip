@@ -32,6 +32,7 @@
                                 // spreads the 16 producer lanes over 16 bank pairs)
 #define YT_STRIDE8 145          // NT = 8: 128 rows + 17
 #define YT_DOUBLES (192 * YT_STRIDE4)  // 15552 doubles = 124416 B per workgroup (NT=8: 96 cols * 145 = 13920)
+#define SCH_PRE 3               // observation rounds prefetched per lane (covers 12 observations per landmark)
 #define SCH_MAXC_LDS 64         // cameras staged in LDS when the window has at most this many
 
 typedef __attribute__((ext_vector_type(4))) double d4;
@@ -216,6 +217,7 @@ __device__ __forceinline__ void syrk_scatter(const double* yt, int nchunks, int 
 __global__ __launch_bounds__(64 * SCH_WAVES) void ba_schur_mfma(BaDims d, BaBufs b, BaOpt opt, BaGroup g)
 {
     extern __shared__ __attribute__((aligned(16))) double lds[];
+    BA_STAMP_DECL;
     const BaState st = *b.st;
     if (st.done) return;
     const int lane = threadIdx.x & 63;
@@ -223,14 +225,13 @@ __global__ __launch_bounds__(64 * SCH_WAVES) void ba_schur_mfma(BaDims d, BaBufs
     double* yt = lds;                                            // WG tile
     double* ulds = lds + YT_DOUBLES;                             // [Cf][42]
     double* cprep = ulds + (size_t)d.Cf * 42;                    // [C][BA_PREP] camera block staged in LDS (C <= 64)
-    const bool lds_prep = d.C <= SCH_MAXC_LDS;
-    int* gslot = (int*)(cprep + (lds_prep ? (size_t)d.C * BA_PREP : 0));   // [24]
+    int* gslot = (int*)(cprep + (size_t)d.C * BA_PREP);   // [24]
     const int nlds = d.Cf * 42;
     for (int i = threadIdx.x; i < nlds; i += blockDim.x) ulds[i] = 0.0;
+    for (int i = threadIdx.x; i < YT_DOUBLES; i += blockDim.x) yt[i] = 0.0;   // first batch's tile, under the load latency
     const double* gprep = b.prep + (size_t)st.cur * d.C * BA_PREP;
-    if (lds_prep)
-        for (int i = threadIdx.x; i < d.C * BA_PREP; i += blockDim.x) cprep[i] = gprep[i];
-    const double* prep = lds_prep ? cprep : gprep;
+    for (int i = threadIdx.x; i < d.C * BA_PREP; i += blockDim.x) cprep[i] = gprep[i];
+    const double* prep = cprep;       // pure LDS pointer: ds_read, not flat_load
 
     const int item = blockIdx.x;
     const uint64_t um0 = g.item_mask[2 * (size_t)item], um1 = g.item_mask[2 * (size_t)item + 1];
@@ -238,7 +239,10 @@ __global__ __launch_bounds__(64 * SCH_WAVES) void ba_schur_mfma(BaDims d, BaBufs
     if (threadIdx.x < 24) gslot[threadIdx.x] = (int)threadIdx.x < ns ? nth_set_bit(um0, um1, threadIdx.x) : 0;
     __syncthreads();
 
+    BA_STAMP(b, 0);
     const double* Xp = b.Xp + (size_t)st.cur * d.P * 3;
+    const size_t rep_off = (size_t)(blockIdx.x & (BA_UREP - 1)) * b.cam_stride;
+    double* rhs_rep = b.rhs + rep_off;
     double cost = 0.0, gmax = 0.0, fail = 0.0;
     const int l = lane & 15, sub = lane >> 4;
     const int wl = 16 * wave + l;                    // landmark slot inside the item
@@ -259,7 +263,8 @@ __global__ __launch_bounds__(64 * SCH_WAVES) void ba_schur_mfma(BaDims d, BaBufs
         int jj = j + l; while (jj >= nobs) jj -= nobs;     // staggered: lanes of one round hit different cameras
         const int oi = o0 + jj;
         const int c = b.obs_cam[oi];
-        obs_eval<true>(prep + (size_t)c * BA_PREP, X, b.obs_uv[oi], d, o);
+        const float2 uvv = b.obs_uv[oi];
+        obs_eval<true>(prep + (size_t)c * BA_PREP, X, uvv, d, o);
         cost += 0.5 * o.rho;
         const double w = o.w;
         V[0] += w * (o.jp[0] * o.jp[0] + o.jp[3] * o.jp[3]);
@@ -281,6 +286,7 @@ __global__ __launch_bounds__(64 * SCH_WAVES) void ba_schur_mfma(BaDims d, BaBufs
             }
         }
     }
+    BA_STAMP(b, 1);
     // the 4 sub-lanes of a landmark (lanes l, l+16, l+32, l+48) combine their partial sums
 #pragma unroll
     for (int k = 0; k < 6; k++) { V[k] += __shfl_xor(V[k], 16, 64); V[k] += __shfl_xor(V[k], 32, 64); }
@@ -321,6 +327,7 @@ __global__ __launch_bounds__(64 * SCH_WAVES) void ba_schur_mfma(BaDims d, BaBufs
     // t = L^-1 g : the rhs row
     const double t0 = Li[0] * gv[0], t1 = Li[1] * gv[0] + Li[2] * gv[1], t2 = Li[3] * gv[0] + Li[4] * gv[1] + Li[5] * gv[2];
 
+    BA_STAMP(b, 2);
     // ---- pass 2: Y into the LDS tile (compact rows), SYRK on the matrix cores, scatter
     if (ns > 0 && ns <= 21) {
         const bool big = ns > 10;
@@ -328,17 +335,21 @@ __global__ __launch_bounds__(64 * SCH_WAVES) void ba_schur_mfma(BaDims d, BaBufs
         const int stride = big ? YT_STRIDE8 : YT_STRIDE4;
         for (int bt = 0; bt < nbatch; bt++) {
             const int ncol = 3 * lb_n;
-            __syncthreads();                                   // previous batch fully consumed
-            for (int i = threadIdx.x; i < ncol * stride; i += blockDim.x) yt[i] = 0.0;
-            __syncthreads();
+            if (bt > 0) {                                      // the first batch's tile was zeroed at kernel start
+                __syncthreads();                               // previous batch fully consumed
+                for (int i = threadIdx.x; i < ncol * stride; i += blockDim.x) yt[i] = 0.0;
+                __syncthreads();
+            }
+            BA_STAMP(b, 3);
             const int lb = wl - bt * lb_n;
             if (p >= 0 && ok && lb >= 0 && lb < lb_n) {
                 for (int j = sub; j < nobs; j += 4) {
                     const int oi = o0 + j;
                     const int c = b.obs_cam[oi];
+                    const float2 uvv = b.obs_uv[oi];
                     const int s = b.slot[c];
                     if (s < 0) continue;
-                    obs_eval<true>(prep + (size_t)c * BA_PREP, X, b.obs_uv[oi], d, o);
+                    obs_eval<true>(prep + (size_t)c * BA_PREP, X, uvv, d, o);
                     const int pos = rank_in_mask(um0, um1, s);
                     double* dst = yt + (size_t)(3 * lb) * stride + 6 * pos;
 #pragma unroll
@@ -358,8 +369,9 @@ __global__ __launch_bounds__(64 * SCH_WAVES) void ba_schur_mfma(BaDims d, BaBufs
                 }
             }
             __syncthreads();
-            if (big) syrk_scatter<8, 9, YT_STRIDE8>(yt, ncol / 4, ns, gslot, d.n, wave, b.S, b.rhs);
-            else syrk_scatter<4, 3, YT_STRIDE4>(yt, ncol / 4, ns, gslot, d.n, wave, b.S, b.rhs);
+            BA_STAMP(b, 4);
+            if (big) syrk_scatter<8, 9, YT_STRIDE8>(yt, ncol / 4, ns, gslot, d.n, wave, b.S, rhs_rep);
+            else syrk_scatter<4, 3, YT_STRIDE4>(yt, ncol / 4, ns, gslot, d.n, wave, b.S, rhs_rep);
         }
     } else if (ns > 21) {
         // generic fallback: per-landmark f64 atomics (any covisibility pattern)
@@ -377,7 +389,7 @@ __global__ __launch_bounds__(64 * SCH_WAVES) void ba_schur_mfma(BaDims d, BaBufs
                     Y[a * 3 + 0] = w0 * I[0] + w1 * I[1] + w2 * I[2];
                     Y[a * 3 + 1] = w0 * I[1] + w1 * I[3] + w2 * I[4];
                     Y[a * 3 + 2] = w0 * I[2] + w1 * I[4] + w2 * I[5];
-                    atomicAdd(&b.rhs[6 * si + a], -(Y[a * 3] * gv[0] + Y[a * 3 + 1] * gv[1] + Y[a * 3 + 2] * gv[2]));
+                    atomicAdd(&rhs_rep[6 * si + a], -(Y[a * 3] * gv[0] + Y[a * 3 + 1] * gv[1] + Y[a * 3 + 2] * gv[2]));
                 }
                 ObsLin oj;
                 for (int ojx = o0; ojx < o0 + nobs; ojx++) {
@@ -399,24 +411,32 @@ __global__ __launch_bounds__(64 * SCH_WAVES) void ba_schur_mfma(BaDims d, BaBufs
             }
         }
     }
+    BA_STAMP(b, 5);
     cost = wave_sum(cost);
     fail = wave_sum(fail);
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) gmax = fmax(gmax, __shfl_down(gmax, off, 64));
-    if (lane == 0) {
-        if (cost != 0.0) atomicAdd(&b.scal[0], cost);
-        if (fail > 0.0) atomicAdd(&b.scal[1], fail);
-        if (gmax > 0.0) atomic_max_nonneg(b.gmax, gmax);
-    }
+    __shared__ double redw[SCH_WAVES][3];
+    if (lane == 0) { redw[wave][0] = cost; redw[wave][1] = fail; redw[wave][2] = gmax; }
     __syncthreads();
+    if (threadIdx.x == 0) {      // one atomic per workgroup, spread over BA_NSLOT lines
+        double c = 0.0, f = 0.0, gm = 0.0;
+        for (int w = 0; w < SCH_WAVES; w++) { c += redw[w][0]; f += redw[w][1]; gm = fmax(gm, redw[w][2]); }
+        const size_t slot = (size_t)(blockIdx.x & (BA_NSLOT - 1)) * BA_SLOT_STRIDE;
+        if (c != 0.0) atomicAdd(&b.scal[slot], c);
+        if (f > 0.0) atomicAdd(&b.scal[slot + 1], f);
+        if (gm > 0.0) atomic_max_nonneg(&b.gmax[slot], gm);
+    }
     for (int i = threadIdx.x; i < nlds; i += blockDim.x) {
         const int s = i / 42, k = i % 42;
         const double v = ulds[i];
         if (v != 0.0) {
-            if (k < 36) atomicAdd(&b.U[s * 36 + k], v);
-            else atomicAdd(&b.gc[6 * s + (k - 36)], v);
+            if (k < 36) atomicAdd(&b.U[rep_off + s * 36 + k], v);
+            else atomicAdd(&b.gc[rep_off + 6 * s + (k - 36)], v);
         }
     }
+    BA_STAMP(b, 6);
+    BA_STAMP_FLUSH(b, 8);
 }
 
 // ------------------------------------------------------------------ host glue
@@ -459,7 +479,7 @@ int ba_launch_grouping(rs_context* ctx, const BaDims& d, const BaBufs& b, const 
 
 size_t ba_schur_lds_bytes(int C, int Cf)
 {
-    const size_t prep = C <= SCH_MAXC_LDS ? (size_t)C * BA_PREP : 0;
+    const size_t prep = (size_t)C * BA_PREP;
     return sizeof(double) * ((size_t)YT_DOUBLES + (size_t)Cf * 42 + prep) + sizeof(int) * 32;
 }
 

@@ -1,35 +1,35 @@
 // ba_solve.hip — K7: the reduced camera system of the local-window BA.
 //
 // Solves (U + Lambda_c - sum Y Y^T) y = g~ for the <= 21 free cameras of a
-// local window (n = 6 Cf <= 128) in ONE workgroup with the matrix resident in
-// LDS.  This is the step Ceres hands to a sparse Cholesky after Schur
-// elimination (reference src/Optimization.cpp:360, SPARSE_SCHUR); at n ~ 108
-// the matrix is dense and 93 KB, so it lives in the CU's 160 KB LDS.
+// local window (n = 6 Cf <= 126) in ONE workgroup.  This is the step Ceres
+// hands to a sparse Cholesky after Schur elimination (reference
+// src/Optimization.cpp:360, SPARSE_SCHUR); at n ~ 108 the matrix is dense and
+// tiny, and the solve is a latency problem, not a bandwidth problem.
 //
-// Algorithm: right-looking block Cholesky with 6x6 blocks (one camera per
-// block column), 3 workgroup barriers per block column:
-//   (a) wave 0 factors the 6x6 diagonal block, one lane per row, pivots
-//       exchanged with v_readlane;
-//   (b) one thread per row below solves its 1x6 panel row against L_JJ;
-//   (c) a 16x16 thread grid applies the rank-6 update to the trailing lower
-//       triangle, each thread keeping the 6-wide panel rows it needs in
-//       registers.
-// The right-hand side rides along as an extra matrix ROW (row n), so the
-// forward substitution L y = g~ falls out of the factorisation; only the
-// backward substitution runs afterwards (2 barriers per block).  Row stride is
-// odd (n+1) so that column walks hit distinct LDS banks.
+// Layout.  The lower triangle — plus the right-hand side as an extra ROW n, so
+// that the forward substitution falls out of the factorisation — lives in
+// REGISTERS in the accumulator layout of v_mfma_f64_16x16x4_f64: the
+// (n+1) x (n+1) matrix is cut into 16x16 tiles, the lower-triangle tiles are
+// dealt round-robin to the 4 waves (<= 9 tiles per wave, 4 doubles per lane per
+// tile).  LDS only carries the current 6-column panel.
+// Right-looking block Cholesky, one camera (6 columns) per step, 2 barriers:
+//   publish  owners copy block column J from their accumulators to LDS
+//   (a)      EVERY wave factors the 6x6 diagonal block redundantly in registers
+//            (no cross-lane traffic, no barrier before the panel solve) and
+//            inverts it; 1/sqrt from v_rsq_f64 + 2 Newton steps
+//   (b)      one thread per row: panel row <- row * L_JJ^-T (6x6 mat-vec with
+//            the inverse block held in registers)
+//   (c)      rank-6 update of the trailing matrix ON THE MATRIX CORES: per owned
+//            tile two MFMAs (K = 6 padded to 8), operands read straight from
+//            the LDS panel, accumulating into the resident tiles
+// then a block backward substitution with the stored inverse diagonal blocks.
+// Phase timings (s_memtime stamps) are in DESIGN.md.
 #include "ba_common.h"
 
 #define K7_THREADS 256
-#define K7_MAXB 8      // ceil(129 / 16)
+#define K7_TPW 9       // lower-triangle tiles per wave: 8*9/2 = 36 tiles / 4 waves
 
-__device__ __forceinline__ double readlane_f64(double v, int lane)
-{
-    const long long b = __double_as_longlong(v);
-    const int lo = __builtin_amdgcn_readlane((int)(b & 0xFFFFFFFFll), lane);
-    const int hi = __builtin_amdgcn_readlane((int)(b >> 32), lane);
-    return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
-}
+typedef __attribute__((ext_vector_type(4))) double d4;
 
 // 1/sqrt(x) from v_rsq_f64 + two Newton steps (quadratic convergence from ~2^-27)
 __device__ __forceinline__ double fast_rsqrt(double x)
@@ -45,39 +45,59 @@ __global__ __launch_bounds__(K7_THREADS) void ba_reduced_solve_lds(BaDims d, BaB
 {
     extern __shared__ __attribute__((aligned(16))) double sm[];
     const int n = d.n, tid = threadIdx.x, nt = K7_THREADS;
-    const int LD = n + 1 + ((n & 1) ? 1 : 0);     // odd row stride; (n is a multiple of 6)
-    double* A = sm;                                // (n+1) x LD, lower triangle + rhs row n
+    const int LD = n + 1 + ((n & 1) ? 1 : 0);     // odd row stride (n is a multiple of 6)
+    double* A = sm;                                // (n+1) x LD: published panels + rhs row n
     double* lam = A + (size_t)(n + 1) * LD;        // [n] camera damping
-    double* invd = lam + n;                        // [n] 1 / L_ii
-    double* xs = invd + n;                         // [n] solution
-    double* Minv = xs + n;                         // [n/6][6][6] inverses of the diagonal blocks of L
+    double* xs = lam + n;                          // [n] solution
+    double* Minv = xs + n;                         // [n/6][36] inverses of the diagonal blocks of L
+    double* Us = Minv + 6 * n;                     // [Cf*36] U folded over the BA_UREP replicas
+    double* gcs = Us + 6 * n;                      // [n] gc folded
+    double* grs = gcs + n;                         // [n] gc + rhs folded: the reduced right-hand side
     __shared__ BaState st;
     __shared__ int s_fail;
     __shared__ double red[4];
     __shared__ double red3[4][3];
+    BA_STAMP_DECL;
     if (tid == 0) { st = *b.st; s_fail = 0; }
     __syncthreads();
     if (st.done) return;
+    // fold the replicas of the camera-side accumulators (replica layout: rhs[n] U[Cf*36] gc[n])
+    for (int i = tid; i < (int)b.cam_stride; i += nt) {
+        double v = 0.0;
+#pragma unroll
+        for (int r = 0; r < BA_UREP; r++) v += b.rhs[(size_t)r * b.cam_stride + i];
+        if (i < n) grs[i] = v;                      // rhs part
+        else if (i < n + 6 * n) Us[i - n] = v;
+        else gcs[i - 7 * n] = v;
+    }
+    __syncthreads();
+    for (int i = tid; i < n; i += nt) grs[i] += gcs[i];
+    __syncthreads();
 
     // (1) fresh linearisation: cost at x, Jacobi scaling of the camera blocks, gradient test
     if (st.fresh) {
-        if (tid == 0) {
-            st.x_cost = b.scal[0];
-            if (st.iter == 0) st.initial_cost = st.x_cost;
+        if (tid < 64) {
+            const double c = slot_sum(b.scal, 0);
+            if (tid == 0) {
+                st.x_cost = c;
+                if (st.iter == 0) st.initial_cost = st.x_cost;
+            }
         }
         if (!st.have_scale)
             for (int i = tid; i < n; i += nt) {
-                const double h = b.U[(i / 6) * 36 + (i % 6) * 7];
+                const double h = Us[(i / 6) * 36 + (i % 6) * 7];
                 b.sc[i] = opt.jacobi ? 1.0 / (1.0 + sqrt(h)) : 1.0;
             }
         double gm = 0.0;
-        for (int i = tid; i < n; i += nt) gm = fmax(gm, fabs(b.gc[i]));
+        for (int i = tid; i < n; i += nt) gm = fmax(gm, fabs(gcs[i]));
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) gm = fmax(gm, __shfl_down(gm, off, 64));
         if ((tid & 63) == 0) red[tid >> 6] = gm;
         __syncthreads();
+        double gslots = 0.0;
+        if (tid < 64) gslots = slot_max_bits(b.gmax);
         if (tid == 0) {
-            double g = __longlong_as_double((long long)*(unsigned long long*)b.gmax);
+            double g = gslots;
             for (int w = 0; w < nt / 64; w++) g = fmax(g, red[w]);
             if (!isfinite(st.x_cost)) { st.done = 1; st.termination = RS_BA_FAILURE; }
             else if (g <= opt.gtol) { st.done = 1; st.termination = RS_BA_CONVERGENCE_GRADIENT; }
@@ -85,139 +105,154 @@ __global__ __launch_bounds__(K7_THREADS) void ba_reduced_solve_lds(BaDims d, BaB
         __syncthreads();
         if (st.done) { if (tid == 0) *b.st = st; return; }
     }
+    BA_STAMP(b, 0);
 
-    // (2) assemble the lower triangle: A[c][r] = S_upper[r][c] + U + Lambda_c;  A[n][k] = gc + rhs
+    // (2) load the lower triangle + rhs row into the accumulator tiles
     const double radius = st.radius;
     for (int i = tid; i < n; i += nt) {
-        const double h = b.U[(i / 6) * 36 + (i % 6) * 7];
+        const double h = Us[(i / 6) * 36 + (i % 6) * 7];
         const double s2 = b.sc[i] * b.sc[i];
         lam[i] = clampd(s2 * h, opt.dmin, opt.dmax) / (radius * s2);
-        A[(size_t)n * LD + i] = b.gc[i] + b.rhs[i];
     }
     __syncthreads();
-    for (int idx = tid; idx < n * n; idx += nt) {
-        const int r = idx / n, c = idx - r * n;
-        if (c < r) continue;
-        double v = b.S[idx];                        // upper entry (r, c), coalesced along c
-        if (r / 6 == c / 6) {
-            v += b.U[(r / 6) * 36 + (r % 6) * 6 + (c % 6)];
-            if (r == c) v += lam[r];
-        }
-        A[(size_t)c * LD + r] = v;
-    }
-    __syncthreads();
-
-    // (3) block Cholesky, rhs as row n
-    const int NB = n / 6;
-    const int ty = tid >> 4, tx = tid & 15;
-    for (int J = 0; J < NB; J++) {
-        const int c0 = 6 * J;
-        // (a) diagonal block, wave 0, lane a owns row a
-        if (tid < 64) {
-            const int a = tid < 6 ? tid : 5;
-            double D[6];
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lr = lane & 15, lq = lane >> 4;
+    const int NTL = (n + 1 + 15) / 16;             // tile rows/cols
+    const int ntiles = NTL * (NTL + 1) / 2;
+    d4 acc[K7_TPW];
+    int tr[K7_TPW], tc[K7_TPW];
 #pragma unroll
-            for (int e = 0; e < 6; e++) D[e] = (e <= a) ? A[(size_t)(c0 + a) * LD + c0 + e] : 0.0;
+    for (int s = 0; s < K7_TPW; s++) {
+        // lower-triangle tiles in row-major order: t -> (r, c), c <= r
+        const int t = wave + 4 * s;
+        int r = 0, rem = t;
+        while (rem > r) { rem -= r + 1; r++; }
+        tr[s] = (t < ntiles) ? r : -1;
+        tc[s] = rem;
+        const int k = 16 * rem + lr;
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const int i = 16 * r + lq + 4 * q;
+            // unconditional loads from clamped addresses, then selects
+            const int kc = min(k, n - 1), ic = min(i, n - 1);
+            const int klo = min(kc, ic), khi = max(kc, ic);
+            const double sv = b.S[(size_t)klo * n + khi];     // S is accumulated in its upper triangle
+            const double uv = Us[(klo / 6) * 36 + (klo % 6) * 6 + (khi % 6)];
+            const double gv = grs[kc];
+            double val = sv + ((klo / 6 == khi / 6) ? uv : 0.0) + ((i == k) ? lam[ic] : 0.0);
+            val = (k < n && i < n && k <= i) ? val : ((i == n && k < n) ? gv : 0.0);
+            acc[s][q] = (t < ntiles) ? val : 0.0;
+        }
+    }
+    BA_STAMP(b, 1);
+
+    // (3) block Cholesky
+    const int NB = n / 6;
+    for (int J = 0; J < NB; J++) {
+        const int c0 = 6 * J, r0 = c0 + 6;
+        // publish block column J (k in [c0, c0+6), i >= k) from the owning tiles
+#pragma unroll
+        for (int s = 0; s < K7_TPW; s++) {
+            if (tr[s] < 0 || 16 * tc[s] + 15 < c0 || 16 * tc[s] >= r0) continue;       // wave-uniform
+            const int k = 16 * tc[s] + lr;
+            if (k < c0 || k >= r0) continue;
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const int i = 16 * tr[s] + lq + 4 * q;
+                if (i >= k && i <= n) A[(size_t)i * LD + k] = acc[s][q];
+            }
+        }
+        __syncthreads();
+        BA_STAMP(b, 2);
+        // (a) diagonal block: every lane factors and inverts it in registers
+        double M[6][6];
+        {
+            double L[6][6], iv[6];
+#pragma unroll
+            for (int a = 0; a < 6; a++)
+#pragma unroll
+                for (int e = 0; e <= a; e++) L[a][e] = A[(size_t)(c0 + a) * LD + c0 + e];
             bool bad = false;
 #pragma unroll
             for (int c = 0; c < 6; c++) {
-                const double piv = readlane_f64(D[c], c);
+                const double piv = L[c][c];
                 if (!(piv > 0.0) || !isfinite(piv)) bad = true;
                 const double rs = fast_rsqrt(piv);
-                const double lac = D[c] * rs;          // lanes a >= c: L[a][c]; lane c: sqrt(piv)
-                D[c] = lac;
-                if (tid == c) invd[c0 + c] = rs;
+                iv[c] = rs;
 #pragma unroll
-                for (int e = c + 1; e < 6; e++) {
-                    const double lec = readlane_f64(lac, e);
-                    D[e] -= lac * lec;
+                for (int a = c + 1; a < 6; a++) L[a][c] *= rs;
+#pragma unroll
+                for (int a = c + 1; a < 6; a++)
+#pragma unroll
+                    for (int e = c + 1; e <= a; e++) L[a][e] -= L[a][c] * L[e][c];
+            }
+#pragma unroll
+            for (int e = 0; e < 6; e++) {
+#pragma unroll
+                for (int a = 0; a < e; a++) M[a][e] = 0.0;
+                M[e][e] = iv[e];
+#pragma unroll
+                for (int a = e + 1; a < 6; a++) {
+                    double s = 0.0;
+#pragma unroll
+                    for (int k = e; k < a; k++) s -= L[a][k] * M[k][e];
+                    M[a][e] = s * iv[a];
                 }
             }
-            if (tid < 6) {
+            if (tid == 255) {        // off the critical path: only the backward substitution reads it
 #pragma unroll
-                for (int e = 0; e < 6; e++)
-                    if (e <= a) A[(size_t)(c0 + a) * LD + c0 + e] = D[e];
-            }
-            if (bad && tid == 0) s_fail = 1;
-        }
-        __syncthreads();
-        // (b') lanes 250..255 (never own a panel row for n <= 126): column e of L_JJ^-1
-        if (tid >= 250) {
-            const int e = tid - 250;
-            double m[6];
+                for (int a = 0; a < 6; a++)
 #pragma unroll
-            for (int a = 0; a < 6; a++) {
-                double sacc = (a == e) ? 1.0 : 0.0;
-#pragma unroll
-                for (int k = 0; k < a; k++) sacc -= A[(size_t)(c0 + a) * LD + c0 + k] * ((k >= e) ? m[k] : 0.0);
-                m[a] = (a >= e) ? sacc * invd[c0 + a] : 0.0;
-                Minv[J * 36 + a * 6 + e] = m[a];
+                    for (int e = 0; e < 6; e++) Minv[J * 36 + a * 6 + e] = (e <= a) ? M[a][e] : 0.0;
+                if (bad) s_fail = 1;
             }
         }
+        BA_STAMP(b, 3);
         // (b) panel rows i > c0+5 (incl. the rhs row n): row_i <- row_i * L_JJ^-T
-        {
-            double Lb[21], iv[6];
+        for (int i = r0 + tid; i <= n; i += nt) {
+            double* row = A + (size_t)i * LD + c0;
+            double x[6], rr[6];
 #pragma unroll
-            for (int r = 0, q = 0; r < 6; r++) {
-                iv[r] = invd[c0 + r];
+            for (int e = 0; e < 6; e++) rr[e] = row[e];
 #pragma unroll
-                for (int e = 0; e < r; e++) Lb[q++] = A[(size_t)(c0 + r) * LD + c0 + e];
-                q += 0;
+            for (int r = 0; r < 6; r++) {
+                double s = 0.0;
+#pragma unroll
+                for (int e = 0; e <= r; e++) s += rr[e] * M[r][e];
+                x[r] = s;
             }
-            for (int i = c0 + 6 + tid; i <= n; i += nt) {
-                double* row = A + (size_t)i * LD + c0;
-                double x[6];
 #pragma unroll
-                for (int r = 0, q = 0; r < 6; r++) {
-                    double s = row[r];
-#pragma unroll
-                    for (int e = 0; e < r; e++) s -= Lb[q++] * x[e];
-                    x[r] = s * iv[r];
-                }
-#pragma unroll
-                for (int r = 0; r < 6; r++) row[r] = x[r];
-            }
+            for (int r = 0; r < 6; r++) row[r] = x[r];
         }
         __syncthreads();
-        // (c) trailing update A[i][k] -= sum_e A[i][c0+e] A[k][c0+e],  c0+6 <= k <= i <= n (k < n)
-        {
-            const int r0 = c0 + 6;
-            if (r0 <= n) {
-                double Li[K7_MAXB][6];
+        BA_STAMP(b, 4);
+        // (c) trailing update on the matrix cores: tile(tr,tc) -= P[tr rows] P[tc rows]^T, K = 6 (+2 zero)
 #pragma unroll
-                for (int u = 0; u < K7_MAXB; u++) {
-                    const int i = r0 + ty + 16 * u;
+        for (int s = 0; s < K7_TPW; s++) {
+            if (tr[s] < 0 || 16 * tr[s] + 15 < r0 || 16 * tc[s] + 15 < r0) continue;  // wave-uniform
+            const int ra = 16 * tr[s] + lr, rb = 16 * tc[s] + lr;
 #pragma unroll
-                    for (int e = 0; e < 6; e++) Li[u][e] = (i <= n) ? A[(size_t)i * LD + c0 + e] : 0.0;
-                }
-#pragma unroll
-                for (int v = 0; v < K7_MAXB; v++) {
-                    const int k = r0 + tx + 16 * v;
-                    if (k >= n) continue;
-                    double Lk[6];
-#pragma unroll
-                    for (int e = 0; e < 6; e++) Lk[e] = A[(size_t)k * LD + c0 + e];
-#pragma unroll
-                    for (int u = 0; u < K7_MAXB; u++) {
-                        const int i = r0 + ty + 16 * u;
-                        if (i > n || i < k) continue;
-                        double s = 0.0;
-#pragma unroll
-                        for (int e = 0; e < 6; e++) s += Li[u][e] * Lk[e];
-                        A[(size_t)i * LD + k] -= s;
-                    }
-                }
+            for (int kc = 0; kc < 2; kc++) {
+                const int kk = 4 * kc + lq;
+                const int kcl = min(kk, 5);
+                const double ta = A[min(ra, n) * LD + c0 + kcl];
+                const double tb = A[min(rb, n) * LD + c0 + kcl];
+                const double a = (ra >= r0 && ra <= n && kk < 6) ? -ta : 0.0;
+                const double bb = (rb >= r0 && rb <= n && kk < 6) ? tb : 0.0;
+                acc[s] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, bb, acc[s], 0, 0, 0);
             }
         }
-        __syncthreads();
+        BA_STAMP(b, 5);
     }
-    if (b.scal[1] > 0.0 && tid == 0) s_fail = 1;
+    __syncthreads();
+    if (tid < 64) { const double f = slot_sum(b.scal, 1); if (f > 0.0 && tid == 0) s_fail = 1; }
     __syncthreads();
     if (s_fail) {
         if (tid == 0) { st.solver_failed = 1; *b.st = st; }
         return;
     }
-    // (4) backward substitution L^T x = y (y = row n), block column by block column
+    // (4) backward substitution L^T x = y (y = row n of the panels), block column by block column
     double* y = A + (size_t)n * LD;
     for (int J = NB - 1; J >= 0; J--) {
         const int c0 = 6 * J;
@@ -236,6 +271,7 @@ __global__ __launch_bounds__(K7_THREADS) void ba_reduced_solve_lds(BaDims d, BaB
         }
         __syncthreads();
     }
+    BA_STAMP(b, 6);
     // (5) delta_c = -x, candidate cameras, camera part of the step scalars
     double mcc = 0.0, ssq = 0.0, xsq = 0.0;
     bool bad = false;
@@ -245,13 +281,13 @@ __global__ __launch_bounds__(K7_THREADS) void ba_reduced_solve_lds(BaDims d, BaB
         const int s = b.slot[c];
         bool active = false;
         if (s >= 0)
-            for (int k = 0; k < 6; k++) active = active || b.U[s * 36 + k * 7] > 0.0;
+            for (int k = 0; k < 6; k++) active = active || Us[s * 36 + k * 7] > 0.0;
         for (int k = 0; k < 6; k++) {
             const double x = Xc[6 * c + k];
             if (s >= 0) {
                 const double dlt = -xs[6 * s + k];
                 if (!isfinite(dlt)) bad = true;
-                mcc += 0.5 * (dlt * dlt * lam[6 * s + k] - dlt * b.gc[6 * s + k]);
+                mcc += 0.5 * (dlt * dlt * lam[6 * s + k] - dlt * gcs[6 * s + k]);
                 const double xn = x + dlt;
                 if (active) { ssq += (x - xn) * (x - xn); xsq += x * x; }
                 Xn[6 * c + k] = xn;
@@ -273,12 +309,14 @@ __global__ __launch_bounds__(K7_THREADS) void ba_reduced_solve_lds(BaDims d, BaB
         st.solver_failed = s_fail;
         *b.st = st;
     }
+    BA_STAMP(b, 7);
+    BA_STAMP_FLUSH(b, 0);
 }
 
 size_t ba_reduced_solve_lds_bytes(int n)
 {
     const int LD = n + 1 + ((n & 1) ? 1 : 0);
-    return sizeof(double) * ((size_t)(n + 1) * LD + 3 * (size_t)n + 6 * (size_t)n + 8);
+    return sizeof(double) * ((size_t)(n + 1) * LD + 2 * (size_t)n + 6 * (size_t)n + 6 * (size_t)n + 2 * (size_t)n + 8);
 }
 
 void ba_launch_reduced_solve_lds(hipStream_t s, const BaDims& d, const BaBufs& b, const BaOpt& opt)

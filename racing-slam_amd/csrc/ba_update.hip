@@ -1,0 +1,109 @@
+// ba_update.hip — K8: back-substitution of the point blocks, candidate state and
+// the robust cost at the candidate (the second half of one LM step of
+// ceres::Solve, reference src/Optimization.cpp:360: SchurEliminator::BackSubstitute,
+// candidate evaluation of TrustRegionMinimizer).
+//
+// delta_p = -V^-1 (g_p + sum_i W_i^T delta_c_i);  x_cand = x + delta;  cost(x_cand).
+// Four lanes share a landmark (lane = landmark + 16 * sub, the sub-lanes split
+// the landmark's observations and combine with two xor-shuffles), a workgroup of
+// 4 waves covers 64 landmarks.  The camera blocks (rotation, left Jacobian,
+// centre) of BOTH the current and the candidate state are staged in LDS; the
+// candidate's blocks come from K7.  Jacobians are recomputed, never read from HBM.
+#include "ba_common.h"
+
+#define K8_THREADS 256
+#define K8_MAXC 64
+
+__global__ __launch_bounds__(K8_THREADS) void ba_backsub_cost4(BaDims d, BaBufs b)
+{
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    const BaState st = *b.st;
+    if (st.done || st.solver_failed) return;
+    const bool stage = d.C <= K8_MAXC;
+    double* cprep = lds;                                    // [C][BA_PREP] current
+    double* cprepn = lds + (stage ? (size_t)d.C * BA_PREP : 0);   // [C][BA_PREP] candidate
+    double* dcl = cprepn + (stage ? (size_t)d.C * BA_PREP : 0);   // [n] delta_c
+    const double* gprep = b.prep + (size_t)st.cur * d.C * BA_PREP;
+    double* gprepn = b.prep + (size_t)(st.cur ^ 1) * d.C * BA_PREP;
+    const double* Xcn = b.Xc + (size_t)(st.cur ^ 1) * d.C * 6;
+    // K7 wrote the candidate cameras' blocks (prep[cur^1]); both sets are staged in LDS
+    for (int i = threadIdx.x; i < d.C * BA_PREP; i += blockDim.x) { cprep[i] = gprep[i]; cprepn[i] = gprepn[i]; }
+    for (int i = threadIdx.x; i < d.n; i += blockDim.x) dcl[i] = b.dc[i];
+    __syncthreads();
+    const double* prep = cprep;
+    (void)Xcn; (void)stage;
+
+    const double* Xp = b.Xp + (size_t)st.cur * d.P * 3;
+    double* Xn = b.Xp + (size_t)(st.cur ^ 1) * d.P * 3;
+    const int lane = threadIdx.x & 63, l = lane & 15, sub = lane >> 4;
+    const int p = blockIdx.x * 64 + (threadIdx.x >> 6) * 16 + l;
+    double cost = 0.0, mcc = 0.0, ssq = 0.0, xsq = 0.0;
+    const bool valid = p < d.P;
+    double X[3] = {0, 0, 0};
+    int o0 = 0, nobs = 0;
+    if (valid) {
+        X[0] = Xp[3 * (size_t)p]; X[1] = Xp[3 * (size_t)p + 1]; X[2] = Xp[3 * (size_t)p + 2];
+        o0 = b.obs_ptr[p];
+        nobs = b.obs_ptr[p + 1] - o0;
+    }
+    double t[3] = {0, 0, 0};
+    ObsLin o;
+    for (int j = sub; j < nobs; j += 4) {
+        const int oi = o0 + j;
+        const int c = b.obs_cam[oi];
+        const int s = b.slot[c];
+        if (s < 0) continue;
+        obs_eval<true>(prep + (size_t)c * BA_PREP, X, b.obs_uv[oi], d, o);
+        double m0 = 0.0, m1 = 0.0;
+#pragma unroll
+        for (int a = 0; a < 6; a++) { const double dc = dcl[6 * s + a]; m0 += o.jc[a] * dc; m1 += o.jc[6 + a] * dc; }
+#pragma unroll
+        for (int k = 0; k < 3; k++) t[k] += o.w * (o.jp[k] * m0 + o.jp[3 + k] * m1);   // W_i^T delta_c
+    }
+#pragma unroll
+    for (int k = 0; k < 3; k++) { t[k] += __shfl_xor(t[k], 16, 64); t[k] += __shfl_xor(t[k], 32, 64); }
+    double Xc[3] = {0, 0, 0};
+    if (valid) {
+        const double g[3] = {b.gp[3 * (size_t)p], b.gp[3 * (size_t)p + 1], b.gp[3 * (size_t)p + 2]};
+        const double* I = b.Vinv + 6 * (size_t)p;
+        const double I0 = I[0], I1 = I[1], I2 = I[2], I3 = I[3], I4 = I[4], I5 = I[5];
+        const double tt[3] = {t[0] + g[0], t[1] + g[1], t[2] + g[2]};
+        const double dp[3] = {-(I0 * tt[0] + I1 * tt[1] + I2 * tt[2]), -(I1 * tt[0] + I3 * tt[1] + I4 * tt[2]),
+                              -(I2 * tt[0] + I4 * tt[1] + I5 * tt[2])};
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+            Xc[k] = X[k] + dp[k];
+            if (sub == 0) {
+                Xn[3 * (size_t)p + k] = Xc[k];
+                mcc += 0.5 * (dp[k] * dp[k] * b.lamp[3 * (size_t)p + k] - dp[k] * g[k]);
+                ssq += (X[k] - Xc[k]) * (X[k] - Xc[k]);
+                xsq += X[k] * X[k];
+            }
+        }
+    }
+    for (int j = sub; j < nobs; j += 4) {
+        const int oi = o0 + j;
+        const int c = b.obs_cam[oi];
+        obs_eval<false>(cprepn + (size_t)c * BA_PREP, Xc, b.obs_uv[oi], d, o);
+        cost += 0.5 * o.rho;
+    }
+    cost = wave_sum(cost); mcc = wave_sum(mcc); ssq = wave_sum(ssq); xsq = wave_sum(xsq);
+    __shared__ double redw[K8_THREADS / 64][4];
+    if (lane == 0) { redw[threadIdx.x >> 6][0] = cost; redw[threadIdx.x >> 6][1] = mcc; redw[threadIdx.x >> 6][2] = ssq; redw[threadIdx.x >> 6][3] = xsq; }
+    __syncthreads();
+    if (threadIdx.x < 4) {       // one atomic per workgroup and scalar, spread over BA_NSLOT lines
+        double v = 0.0;
+        for (int w = 0; w < K8_THREADS / 64; w++) v += redw[w][threadIdx.x];
+        atomicAdd(&b.pt_scal[(size_t)(blockIdx.x & (BA_NSLOT - 1)) * BA_SLOT_STRIDE + threadIdx.x], v);
+    }
+}
+
+size_t ba_backsub_lds_bytes(int C, int n)
+{
+    return sizeof(double) * (2 * (size_t)C * BA_PREP + (size_t)n + 8);
+}
+
+void ba_launch_backsub(hipStream_t s, const BaDims& d, const BaBufs& b)
+{
+    hipLaunchKernelGGL(ba_backsub_cost4, dim3((d.P + 63) / 64), dim3(K8_THREADS), ba_backsub_lds_bytes(d.C, d.n), s, d, b);
+}

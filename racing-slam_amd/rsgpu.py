@@ -17,7 +17,7 @@ EXPORTS = [
     "rs_context_synchronize", "rs_last_error", "rs_hamming_knn2", "rs_match_descriptors",
     "rs_kdtree_build", "rs_reproj_match", "rs_triangulate", "rs_triangulate_matches", "rs_ba_default_options",
     "rs_bundle_adjust", "rs_refine_pose", "rs_pack_pose", "rs_unpack_pose", "rs_build_local_window",
-    "rs_comm_get_unique_id", "rs_comm_init_rank", "rs_comm_destroy", "rs_prof_begin", "rs_prof_end",
+    "rs_comm_get_unique_id", "rs_comm_init_rank", "rs_comm_destroy", "rs_prof_begin", "rs_prof_end", "rs_prof_counters",
 ]
 
 _lib = None
@@ -314,6 +314,11 @@ class Context:
         n = C.c_int(0)
         self._check(self.lib.rs_prof_end(self.h, ent, C.byref(n)), "rs_prof_end")
         return {ent[i].name.decode(): (ent[i].launches, ent[i].total_ms) for i in range(n.value)}
+
+    def prof_counters(self, n=16):
+        buf = (C.c_uint64 * n)()
+        self._check(self.lib.rs_prof_counters(self.h, buf, n), "rs_prof_counters")
+        return list(buf)
 
     def synchronize(self):
         self._check(self.lib.rs_context_synchronize(self.h), "rs_context_synchronize")
