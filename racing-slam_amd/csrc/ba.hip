@@ -455,7 +455,8 @@ __global__ void ba_finalize(BaDims d, BaBufs b, double* __restrict__ cams_out, c
         const bool ok = st.termination != RS_BA_FAILURE && isfinite(st.x_cost) && st.x_cost <= st.initial_cost;
         usable = ok ? 1 : 0;
         cur = st.cur;
-        if (blockIdx.x == 0) { st.usable = usable; *b.st = st; }
+        st.usable = usable;
+        if (blockIdx.x == 0) b.st->usable = usable;     // only this field: other workgroups are reading the rest
     }
     __syncthreads();
     if (!usable) return;
@@ -647,7 +648,7 @@ extern "C" int rs_bundle_adjust(rs_context* ctx, int n_cameras, int n_points, in
     }
     {
         rs_prof_scope ps(ctx, "K10_ba_finalize");
-        hipLaunchKernelGGL(ba_finalize, dim3(1), dim3(1024), 0, s, d, b, d_cameras, (const uint8_t*)d_cam_free, d_points);
+        hipLaunchKernelGGL(ba_finalize, dim3(32), dim3(256), 0, s, d, b, d_cameras, (const uint8_t*)d_cam_free, d_points);
     }
     RS_HIP(ctx, hipMemcpyAsync(h_st, b.st, sizeof(BaState), hipMemcpyDeviceToHost, s));
     RS_HIP(ctx, hipStreamSynchronize(s));

@@ -38,37 +38,56 @@
 typedef __attribute__((ext_vector_type(4))) double d4;
 
 // ------------------------------------------------------------ setup kernels
-__global__ void ba_group_count(BaDims d, BaBufs b, BaGroup g)
+// Counting sort of the landmarks by (first, last) free-camera slot.  Histogram and cursors are
+// kept in GRP_REP replicas (workgroup w uses replica w % GRP_REP) and the histogram is first
+// accumulated in LDS: device-scope atomics on one 64-B line serialise (~12 ns each), and the
+// ~170 live buckets of a local window share a dozen lines.
+#define GRP_REP 8
+#define GRP_LDS_BINS 4096
+
+__global__ __launch_bounds__(256) void ba_group_count(BaDims d, BaBufs b, BaGroup g)
 {
+    __shared__ int lh[GRP_LDS_BINS];
+    const int nb = g.n_buckets + 1;
+    const bool use_lds = nb <= GRP_LDS_BINS;
+    if (use_lds) for (int i = threadIdx.x; i < nb; i += blockDim.x) lh[i] = 0;
+    __syncthreads();
     const int p = blockIdx.x * blockDim.x + threadIdx.x;
-    if (p >= d.P) return;
-    uint64_t m0 = 0, m1 = 0;
-    int first = 1 << 30, last = -1;
-    for (int o = b.obs_ptr[p]; o < b.obs_ptr[p + 1]; o++) {
-        const int s = b.slot[b.obs_cam[o]];
-        if (s < 0) continue;
-        if (s < 64) m0 |= 1ull << s; else m1 |= 1ull << (s - 64);
-        first = min(first, s);
-        last = max(last, s);
+    int* hist = g.hist + (size_t)(blockIdx.x & (GRP_REP - 1)) * nb;
+    if (p < d.P) {
+        uint64_t m0 = 0, m1 = 0;
+        int first = 1 << 30, last = -1;
+        for (int o = b.obs_ptr[p]; o < b.obs_ptr[p + 1]; o++) {
+            const int s = b.slot[b.obs_cam[o]];
+            if (s < 0) continue;
+            if (s < 64) m0 |= 1ull << s; else m1 |= 1ull << (s - 64);
+            first = min(first, s);
+            last = max(last, s);
+        }
+        g.mask[2 * (size_t)p] = m0;
+        g.mask[2 * (size_t)p + 1] = m1;
+        const int bk = last < 0 ? d.Cf * d.Cf : first * d.Cf + last;
+        g.bucket[p] = bk;
+        if (use_lds) atomicAdd(&lh[bk], 1); else atomicAdd(&hist[bk], 1);
     }
-    g.mask[2 * (size_t)p] = m0;
-    g.mask[2 * (size_t)p + 1] = m1;
-    const int bk = last < 0 ? d.Cf * d.Cf : first * d.Cf + last;
-    g.bucket[p] = bk;
-    atomicAdd(&g.hist[bk], 1);
+    __syncthreads();
+    if (use_lds)
+        for (int i = threadIdx.x; i < nb; i += blockDim.x) { const int v = lh[i]; if (v) atomicAdd(&hist[i], v); }
 }
 
 __global__ __launch_bounds__(1024) void ba_group_scan(BaGroup g)
 {
-    // exclusive scan of hist[0..n_buckets) into cursor (single workgroup)
+    // exclusive scan over (bucket-major, replica-minor) of hist[rep][bucket] into cursor[rep][bucket]
     __shared__ int wsum[16];
     __shared__ int carry;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int nb = g.n_buckets + 1, total = nb * GRP_REP;
     if (threadIdx.x == 0) carry = 0;
     __syncthreads();
-    for (int base = 0; base < g.n_buckets; base += 1024) {
+    for (int base = 0; base < total; base += 1024) {
         const int i = base + threadIdx.x;
-        const int v = i < g.n_buckets ? g.hist[i] : 0;
+        const int bk = i / GRP_REP, rep = i % GRP_REP;
+        const int v = i < total ? g.hist[(size_t)rep * nb + bk] : 0;
         int x = v;
 #pragma unroll
         for (int off = 1; off < 64; off <<= 1) {
@@ -79,35 +98,43 @@ __global__ __launch_bounds__(1024) void ba_group_scan(BaGroup g)
         __syncthreads();
         int pre = carry;
         for (int w = 0; w < wave; w++) pre += wsum[w];
-        if (i < g.n_buckets) g.cursor[i] = pre + x - v;
+        if (i < total) g.cursor[(size_t)rep * nb + bk] = pre + x - v;
         __syncthreads();
         if (threadIdx.x == 1023) carry = pre + x;
         __syncthreads();
     }
 }
 
-__global__ void ba_group_scatter(BaDims d, BaGroup g)
+__global__ __launch_bounds__(256) void ba_group_scatter(BaDims d, BaGroup g)
 {
     const int p = blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= d.P) return;
-    const int pos = atomicAdd(&g.cursor[g.bucket[p]], 1);
+    const int nb = g.n_buckets + 1;
+    const int pos = atomicAdd(&g.cursor[(size_t)(blockIdx.x & (GRP_REP - 1)) * nb + g.bucket[p]], 1);
     g.sorted[pos] = p;
 }
 
-__global__ void ba_group_items(BaDims d, BaGroup g)
+// one wave per item: lanes = the item's 64 landmarks, 128-bit OR across the wave
+__global__ __launch_bounds__(256) void ba_group_items(BaDims d, BaGroup g)
 {
-    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    const int t = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (t >= g.n_items) return;
+    const int q = t * IT_L + (threadIdx.x & 63);
     uint64_t m0 = 0, m1 = 0;
-    for (int l = 0; l < IT_L; l++) {
-        const int q = t * IT_L + l;
-        if (q >= d.P) break;
+    if (q < d.P) {
         const int p = g.sorted[q];
-        m0 |= g.mask[2 * (size_t)p];
-        m1 |= g.mask[2 * (size_t)p + 1];
+        m0 = g.mask[2 * (size_t)p];
+        m1 = g.mask[2 * (size_t)p + 1];
     }
-    g.item_mask[2 * (size_t)t] = m0;
-    g.item_mask[2 * (size_t)t + 1] = m1;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        m0 |= (uint64_t)__shfl_xor((unsigned long long)m0, off, 64);
+        m1 |= (uint64_t)__shfl_xor((unsigned long long)m1, off, 64);
+    }
+    if ((threadIdx.x & 63) == 0) {
+        g.item_mask[2 * (size_t)t] = m0;
+        g.item_mask[2 * (size_t)t + 1] = m1;
+    }
 }
 
 // ------------------------------------------------------------------ helpers
@@ -442,7 +469,7 @@ __global__ __launch_bounds__(64 * SCH_WAVES) void ba_schur_mfma(BaDims d, BaBufs
 // ------------------------------------------------------------------ host glue
 size_t ba_group_bytes(int P, int Cf)
 {
-    const size_t nb = (size_t)Cf * Cf + 2;
+    const size_t nb = ((size_t)Cf * Cf + 2) * GRP_REP;
     const size_t ni = ((size_t)P + IT_L - 1) / IT_L;
     return 256 * 8 + sizeof(int32_t) * (2 * (size_t)P + 2 * nb) + sizeof(uint64_t) * (2 * (size_t)P + 2 * ni);
 }
@@ -451,7 +478,7 @@ static size_t al256(size_t v) { return (v + 255) & ~(size_t)255; }
 
 void ba_group_carve(char* base, int P, int Cf, BaGroup* g)
 {
-    const size_t nb = (size_t)Cf * Cf + 2;
+    const size_t nb = ((size_t)Cf * Cf + 2) * GRP_REP;
     const size_t ni = ((size_t)P + IT_L - 1) / IT_L;
     size_t off = 0;
     g->sorted = (int32_t*)(base + off); off += al256(sizeof(int32_t) * P);
@@ -461,19 +488,19 @@ void ba_group_carve(char* base, int P, int Cf, BaGroup* g)
     g->mask = (uint64_t*)(base + off); off += al256(sizeof(uint64_t) * 2 * P);
     g->item_mask = (uint64_t*)(base + off); off += al256(sizeof(uint64_t) * 2 * ni);
     g->n_items = (int)ni;
-    g->n_buckets = (int)nb - 1;
+    g->n_buckets = Cf * Cf;           // + 1 bucket for landmarks without a free camera
 }
 
 int ba_launch_grouping(rs_context* ctx, const BaDims& d, const BaBufs& b, const BaGroup& g)
 {
     hipStream_t s = ctx->stream;
-    RS_HIP(ctx, hipMemsetAsync(g.hist, 0, sizeof(int32_t) * ((size_t)g.n_buckets + 1), s));
+    RS_HIP(ctx, hipMemsetAsync(g.hist, 0, sizeof(int32_t) * ((size_t)g.n_buckets + 1) * GRP_REP, s));
     rs_prof_scope ps(ctx, "K5s_group_landmarks");
     const int pb = (d.P + 255) / 256;
     hipLaunchKernelGGL(ba_group_count, dim3(pb), dim3(256), 0, s, d, b, g);
     hipLaunchKernelGGL(ba_group_scan, dim3(1), dim3(1024), 0, s, g);
     hipLaunchKernelGGL(ba_group_scatter, dim3(pb), dim3(256), 0, s, d, g);
-    hipLaunchKernelGGL(ba_group_items, dim3((g.n_items + 255) / 256), dim3(256), 0, s, d, g);
+    hipLaunchKernelGGL(ba_group_items, dim3((g.n_items + 3) / 4), dim3(256), 0, s, d, g);
     return RS_OK;
 }
 

@@ -19,8 +19,9 @@
 // Built with -ffp-contract=off so the f32 gates execute the oracle's operations.
 #include "common.h"
 
-#define K2_THREADS 256
+#define K2_THREADS 128
 #define K2_STACK 40
+#define K2_MAX_LDS_NODES 6144    // 16 B per node: the whole KD-tree of a frame (2000 keypoints = 32 KB) sits in LDS
 
 struct K2Frame {
     float T[16];
@@ -69,12 +70,24 @@ __device__ __forceinline__ int hamming256(const uint4 a0, const uint4 a1, const 
     return d;
 }
 
-__global__ __launch_bounds__(K2_THREADS) void k2_reproj_match(K2Frame f, K2Map m, int replace, int max_distance,
+__global__ __launch_bounds__(K2_THREADS) void k2_reproj_match(K2Frame f, K2Map m, int replace, int max_distance, int tree_in_lds,
                                                              int32_t* __restrict__ point_kp,
                                                              int32_t* __restrict__ point_dist,
                                                              unsigned long long* __restrict__ prop)
 {
-    __shared__ int stack[K2_STACK][K2_THREADS];
+    // dynamic LDS: [K2_STACK][K2_THREADS] traversal stacks, then the packed tree
+    // {x, y, left, right} per node (one ds_read_b128 per visited node instead of three
+    // dependent global loads)
+    extern __shared__ __attribute__((aligned(16))) int k2_lds[];
+    int (*stack)[K2_THREADS] = (int (*)[K2_THREADS])k2_lds;
+    float4* tree = (float4*)(k2_lds + K2_STACK * K2_THREADS);
+    if (tree_in_lds) {
+        for (int i = threadIdx.x; i < f.n_keypoints; i += blockDim.x) {
+            const float2 q = f.kp[f.kd_node_kp[i]];
+            tree[i] = make_float4(q.x, q.y, __int_as_float(f.kd_left[i]), __int_as_float(f.kd_right[i]));
+        }
+        __syncthreads();
+    }
     const int p = blockIdx.x * K2_THREADS + threadIdx.x;
     if (p >= m.n_points) return;
     int out_kp = -1, out_d = max_distance;
@@ -138,10 +151,18 @@ __global__ __launch_bounds__(K2_THREADS) void k2_reproj_match(K2Frame f, K2Map m
         while (sp > 0) {
             const int e = stack[--sp][threadIdx.x];
             const int node = e & 0x3FFFFFFF, odd = (e >> 30) & 1;
-            const int kp = f.kd_node_kp[node];
-            const float2 q = f.kp[kp];
-            const float dx = q.x - u, dy = q.y - v;
+            float qx, qy;
+            int l, r;
+            if (tree_in_lds) {
+                const float4 nd = tree[node];
+                qx = nd.x; qy = nd.y; l = __float_as_int(nd.z); r = __float_as_int(nd.w);
+            } else {
+                const float2 q = f.kp[f.kd_node_kp[node]];
+                qx = q.x; qy = q.y; l = f.kd_left[node]; r = f.kd_right[node];
+            }
+            const float dx = qx - u, dy = qy - v;
             const float d2 = dx * dx + dy * dy;
+            const int kp = d2 <= r2 ? f.kd_node_kp[node] : 0;
             if (d2 <= r2 && (replace || !f.kp_matched[kp])) {            // :65, :81
                 const uint4 a0 = f.desc[2 * (size_t)kp], a1 = f.desc[2 * (size_t)kp + 1];
                 for (int o = o0; o < o1; o++) {
@@ -151,7 +172,6 @@ __global__ __launch_bounds__(K2_THREADS) void k2_reproj_match(K2Frame f, K2Map m
                 }
             }
             const float delta = odd ? dy : dx;
-            const int l = f.kd_left[node], r = f.kd_right[node];
             const int near_child = (delta > 0) ? l : r;
             const int far_child = (delta > 0) ? r : l;
             const int child_tag = (odd ^ 1) << 30;
@@ -244,9 +264,13 @@ extern "C" int rs_reproj_match(rs_context* ctx, const rs_frame_view* fr, const r
         m.n_points = P; m.pos = mp->d_positions; m.eligible = mp->d_eligible; m.obs_ptr = mp->d_obs_ptr;
         m.obs_kf = mp->d_obs_kf; m.obs_desc = mp->d_obs_desc; m.kf_centers = mp->d_kf_centers;
         m.pool = (const uint4*)mp->d_desc_pool;
+        const int tree_in_lds = N <= K2_MAX_LDS_NODES ? 1 : 0;
+        const size_t lds = sizeof(int) * K2_STACK * K2_THREADS + (tree_in_lds ? sizeof(float4) * (size_t)N : 0);
+        if (lds > 48 * 1024)
+            RS_HIP(ctx, hipFuncSetAttribute((const void*)k2_reproj_match, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         rs_prof_scope ps(ctx, "K2_reproj_match");
-        hipLaunchKernelGGL(k2_reproj_match, dim3((P + K2_THREADS - 1) / K2_THREADS), dim3(K2_THREADS), 0,
-                           ctx->stream, f, m, replace, max_distance, d_point_kp, d_point_dist, prop);
+        hipLaunchKernelGGL(k2_reproj_match, dim3((P + K2_THREADS - 1) / K2_THREADS), dim3(K2_THREADS), lds,
+                           ctx->stream, f, m, replace, max_distance, tree_in_lds, d_point_kp, d_point_dist, prop);
     }
     {
         rs_prof_scope ps(ctx, "K3_accept");
