@@ -1,0 +1,96 @@
+#!/usr/bin/env python3
+"""Generates the golden fixtures under tests/golden/ (run from the repo root).
+
+The reference (GregVS/Racing-SLAM) ships no golden vectors for this path and
+cannot be built here (OpenCV / Eigen / Ceres absent) — PARITY UNPINNED.  These
+fixtures therefore pin the CPU oracle (oracle/*.c, validated against numpy /
+scipy in tests/test_oracle_cpu.py): seeded synthetic inputs and the oracle's
+outputs, small enough to commit.  tests/test_golden.py checks the oracle against
+them on the CPU (regression pin) and the HIP library against them on the GPU.
+
+    python tests/golden/make_golden.py
+"""
+import importlib
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path[:0] = [ROOT, os.path.join(ROOT, "oracle")]
+import pyoracle as O  # noqa: E402
+
+synth = importlib.import_module("racing-slam_amd.synth")
+OUT = os.path.dirname(os.path.abspath(__file__))
+
+
+def main():
+    O.build()
+    # -- a4: descriptor matching, 96 x 80 rows incl. exact ties and threshold boundaries
+    rng = np.random.default_rng(20261004)
+    t = rng.integers(0, 256, (80, 32), dtype=np.uint8)
+    q = np.zeros((96, 32), np.uint8)
+    for i in range(96):
+        bits = np.unpackbits(t[i % 80])
+        flip = rng.choice(256, size=[0, 5, 20, 48, 64, 65, 90, 128][i % 8], replace=False)
+        bits[flip] ^= 1
+        q[i] = np.packbits(bits)
+    t[40:44] = t[3]
+    i0, d0, i1, d1 = O.hamming_knn2(q, t)
+    mq, mt = O.match_descriptors(q, t)
+    np.savez_compressed(os.path.join(OUT, "match_descriptors.npz"), query=q, train=t, idx0=i0, dist0=d0, idx1=i1,
+                        dist1=d1, match_query=mq, match_train=mt)
+
+    # -- a6: triangulation, 64 correspondences of the cfg-1 pair (both gate settings)
+    pr = synth.make_pair(1)
+    a1, a2, ns = pr["truth12"]
+    uv1, uv2 = pr["kp1"][a1[:64]], pr["kp2"][a2[:64]]
+    uv2[5] += 40.0          # a bad correspondence
+    d = O.triangulate(uv1, uv2, pr["poses"], pr["K"])
+    m = O.triangulate(uv1, uv2, pr["poses"], pr["K"], min_parallax_cosine=1.0, max_reproj=4.0)
+    np.savez_compressed(os.path.join(OUT, "triangulate.npz"), uv1=uv1, uv2=uv2, poses=pr["poses"], K=pr["K"],
+                        xyz=d["xyz"], keep_default=d["keep"], out_index_default=d["out_index"],
+                        keep_mapper=m["keep"], out_index_mapper=m["out_index"])
+
+    # -- a2: reprojection-gated matching, 5 keyframes / 150 landmarks / 300 keypoints
+    w = synth.make_ba_window(n_kf=5, n_points=150, run_max=4)
+    frame, mp = synth.make_match_scene(w, n_keypoints=300, kdtree_build=O.kdtree_build)
+    r0 = O.reproj_match(frame, mp, replace=0)
+    r1 = O.reproj_match(frame, mp, replace=1)
+    blob = {f"frame_{k}": np.asarray(v) for k, v in frame.items()}
+    blob.update({f"map_{k}": np.asarray(v) for k, v in mp.items()})
+    for tag, r in (("r0", r0), ("r1", r1)):
+        blob.update({f"{tag}_{k}": v for k, v in r.items()})
+    np.savez_compressed(os.path.join(OUT, "reproj_match.npz"), **blob)
+
+    # -- a12: 4-camera / 50-landmark bundle adjustment, 10 LM iterations
+    b = synth.make_ba_window(n_kf=4, n_points=50, run_max=4, config_id=21, outlier_frac=0.05)
+    cams, pts, s = O.bundle_adjust(b["cams"], b["cam_free"], b["points"], b["obs_ptr"], b["obs_cam"], b["obs_uv"], b["K"])
+    np.savez_compressed(os.path.join(OUT, "bundle_adjust.npz"), cams=b["cams"], cam_free=b["cam_free"], points=b["points"],
+                        obs_ptr=b["obs_ptr"], obs_cam=b["obs_cam"], obs_uv=b["obs_uv"], K=b["K"], out_cams=cams,
+                        out_points=pts, summary=np.array([s["termination"], s["iterations"], s["successful_steps"],
+                                                          s["usable"]], np.int32),
+                        costs=np.array([s["initial_cost"], s["final_cost"], s["final_radius"]]))
+
+    # -- a13: pose-only refinement on 120 observations
+    sel = np.flatnonzero(b["obs_cam"] == 3)
+    obs_pt = np.repeat(np.arange(50), np.diff(b["obs_ptr"]))[sel]
+    rp_pts = b["points_true"][obs_pt]
+    cam, rs_ = O.refine_pose(b["cams"][3], rp_pts, b["obs_uv"][sel], b["K"])
+    np.savez_compressed(os.path.join(OUT, "refine_pose.npz"), cam=b["cams"][3], points=rp_pts, uv=b["obs_uv"][sel], K=b["K"],
+                        out_cam=cam, summary=np.array([rs_["termination"], rs_["iterations"], rs_["successful_steps"],
+                                                       rs_["usable"]], np.int32),
+                        costs=np.array([rs_["initial_cost"], rs_["final_cost"]]))
+
+    # -- a10: pose packing
+    poses = np.stack([synth.make_pose(synth.rodrigues(rng.normal(size=3) * 0.7).T, rng.normal(size=3) * 3) for _ in range(16)])
+    packed = np.stack([O.pack_pose(p) for p in poses])
+    unpacked = np.stack([O.unpack_pose(c) for c in packed])
+    np.savez_compressed(os.path.join(OUT, "pack_pose.npz"), poses=poses, packed=packed, unpacked=unpacked)
+    for f in sorted(os.listdir(OUT)):
+        if f.endswith(".npz"):
+            print(f, os.path.getsize(os.path.join(OUT, f)), "bytes")
+
+
+if __name__ == "__main__":
+    main()

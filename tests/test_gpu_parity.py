@@ -295,3 +295,75 @@ def test_profiling_names(ctx, synth):
     prof = ctx.prof_end()
     assert "K1_hamming_knn2" in prof and prof["K1_hamming_knn2"][0] == 1
     assert prof["K1_hamming_knn2"][1] > 0
+
+
+# ---------------------------------------------- BA: the less common code paths
+@pytest.mark.parametrize("n_kf,run_min,run_max,n_points", [
+    (22, 12, 20, 600),     # 20 free cameras: items with 11..21 cameras -> 8x8-tile (NT = 8) SYRK path, LDS solve (n = 120)
+    (30, 2, 28, 500),      # 28 free cameras: n = 168 -> global-memory reduced solve; unions > 21 -> per-landmark fallback
+    (100, 2, 10, 1500),    # cfg-5-shaped window (100 KF): n = 588, atomics Schur kernel + global solve + LDS back-substitution
+])
+def test_bundle_adjust_code_paths(ctx, oracle, synth, n_kf, run_min, run_max, n_points):
+    w = synth.make_ba_window(n_kf=n_kf, n_points=n_points, run_min=run_min, run_max=run_max, config_id=40 + n_kf)
+    c, p, s, rc, rp, rs_ = _ba_case(ctx, oracle, w)
+    assert s["usable"] == rs_["usable"] == 1
+    assert (s["iterations"], s["successful_steps"], s["termination"]) == \
+        (rs_["iterations"], rs_["successful_steps"], rs_["termination"])
+    assert np.isclose(s["final_cost"], rs_["final_cost"], rtol=1e-7)
+    assert np.allclose(c, rc, rtol=1e-6, atol=1e-8)
+    assert np.allclose(p, rp, rtol=1e-6, atol=1e-7)
+
+
+def test_bundle_adjust_arbitrary_covisibility(ctx, oracle, synth):
+    """observations of a landmark are NOT a consecutive run and not in camera order: exercises the
+    compact-row mapping (rank_in_mask / nth_set_bit) and the fixed-camera-only landmarks."""
+    w = synth.make_ba_window(n_kf=12, n_points=400, run_min=3, run_max=6, config_id=77)
+    rng = np.random.default_rng(77)
+    cams_of = []
+    for p in range(400):
+        k = w["obs_ptr"][p + 1] - w["obs_ptr"][p]
+        if p % 50 == 0:
+            cams_of.append(np.array([0, 1])[:max(2, min(k, 2))])       # seen by the two fixed cameras only
+        else:
+            cams_of.append(rng.permutation(12)[:k])                      # scattered, unsorted
+    obs_ptr = np.zeros(401, np.int32); obs_ptr[1:] = np.cumsum([len(c) for c in cams_of])
+    obs_cam = np.concatenate(cams_of).astype(np.int32)
+    obs_pt = np.repeat(np.arange(400), np.diff(obs_ptr))
+    uv = np.zeros((len(obs_cam), 2))
+    K = w["K"].astype(np.float64)
+    for o in range(len(obs_cam)):
+        uv[o] = synth.project(w["poses_true"][obs_cam[o]], K, w["points_true"][obs_pt[o]][None])[0][0]
+    uv += rng.normal(0, 0.5, uv.shape)
+    w.update(obs_ptr=obs_ptr, obs_cam=obs_cam, obs_uv=uv.astype(np.float32))
+    c, p, s, rc, rp, rs_ = _ba_case(ctx, oracle, w)
+    assert s["usable"] == rs_["usable"] == 1
+    assert (s["iterations"], s["successful_steps"]) == (rs_["iterations"], rs_["successful_steps"])
+    assert np.allclose(c, rc, rtol=1e-6, atol=1e-8)
+    assert np.allclose(p, rp, rtol=1e-6, atol=1e-7)
+
+
+def test_match_descriptors_cfg4_batch_properties(ctx, synth):
+    """BASELINE.json configs[3]: 64 pairs x 2k keypoints.  Size-independent properties: the batched
+    launch equals 64 single launches bit for bit, and matching a set against itself is the identity."""
+    import torch
+    rng = np.random.default_rng(4)
+    B, n = 64, 2000
+    base = rng.integers(0, 256, (B, n, 32), dtype=np.uint8)
+    noise = (rng.random((B, n, 32 * 8)) < 0.05)
+    q = np.packbits(np.unpackbits(base, axis=2) ^ noise, axis=2)
+    dq, dt = ctx.dev(q), ctx.dev(base)
+    m = ctx.match_descriptors(dq, dt, n, n, batch=B, raw=True)
+    cnt = to_np(m["cnt"])
+    assert cnt.min() > 0.95 * n
+    for b in (0, 17, 63):
+        one = ctx.match_descriptors(dq[b].contiguous(), dt[b].contiguous(), n, n, raw=True)
+        c = int(to_np(one["cnt"])[0])
+        assert c == cnt[b]
+        assert torch.equal(one["mq"][0, :c], m["mq"][b, :c]) and torch.equal(one["mt"][0, :c], m["mt"][b, :c])
+        for a, bb in zip(one["raw"], m["raw"]):
+            assert torch.equal(a[0], bb[b])
+        # true correspondence i <-> i (5 % bit flips: distance ~13, impostors ~128)
+        assert (to_np(m["mq"])[b, :c] == to_np(m["mt"])[b, :c]).mean() > 0.999
+    ident = ctx.match_descriptors(dt[0].contiguous(), dt[0].contiguous(), n, n, raw=True)
+    assert int(to_np(ident["cnt"])[0]) == n
+    assert np.array_equal(to_np(ident["raw"][0])[0], np.arange(n)) and to_np(ident["raw"][1])[0].max() == 0
