@@ -242,14 +242,20 @@ __global__ __launch_bounds__(256) void ba_reduced_solve(BaDims d, BaBufs b, BaOp
         y[i] = yy;
     }
     __syncthreads();
+    // S is accumulated in its upper triangle.  Two phases because S may BE b.S (in place):
+    // first mirror upper -> lower, then add the block diagonal and the damping.
     for (int idx = tid; idx < n * n; idx += nt) {
         const int i = idx / n, j = idx % n;
-        double v = (i <= j) ? b.S[idx] : b.S[(size_t)j * n + i];   // S is accumulated in its upper triangle
-        if (i / 6 == j / 6) {
-            const int a = i % 6, e = j % 6;
-            v += (a <= e) ? b.U[(i / 6) * 36 + a * 6 + e] : b.U[(i / 6) * 36 + e * 6 + a];
-            if (i == j) v += lam[i];
-        }
+        if (i > j) S[idx] = b.S[(size_t)j * n + i];
+        else if (S != b.S) S[idx] = b.S[idx];
+    }
+    __syncthreads();
+    for (int idx = tid; idx < n * n; idx += nt) {
+        const int i = idx / n, j = idx % n;
+        if (i / 6 != j / 6) continue;
+        const int a = i % 6, e = j % 6;
+        double v = S[idx] + ((a <= e) ? b.U[(i / 6) * 36 + a * 6 + e] : b.U[(i / 6) * 36 + e * 6 + a]);
+        if (i == j) v += lam[i];
         S[idx] = v;
     }
     __syncthreads();

@@ -12,26 +12,22 @@
 #include "ba_common.h"
 
 #define K8_THREADS 256
-#define K8_MAXC 64
 
 __global__ __launch_bounds__(K8_THREADS) void ba_backsub_cost4(BaDims d, BaBufs b)
 {
     extern __shared__ __attribute__((aligned(16))) double lds[];
     const BaState st = *b.st;
     if (st.done || st.solver_failed) return;
-    const bool stage = d.C <= K8_MAXC;
     double* cprep = lds;                                    // [C][BA_PREP] current
-    double* cprepn = lds + (stage ? (size_t)d.C * BA_PREP : 0);   // [C][BA_PREP] candidate
-    double* dcl = cprepn + (stage ? (size_t)d.C * BA_PREP : 0);   // [n] delta_c
+    double* cprepn = lds + (size_t)d.C * BA_PREP;           // [C][BA_PREP] candidate
+    double* dcl = cprepn + (size_t)d.C * BA_PREP;           // [n] delta_c
     const double* gprep = b.prep + (size_t)st.cur * d.C * BA_PREP;
     double* gprepn = b.prep + (size_t)(st.cur ^ 1) * d.C * BA_PREP;
-    const double* Xcn = b.Xc + (size_t)(st.cur ^ 1) * d.C * 6;
     // K7 wrote the candidate cameras' blocks (prep[cur^1]); both sets are staged in LDS
     for (int i = threadIdx.x; i < d.C * BA_PREP; i += blockDim.x) { cprep[i] = gprep[i]; cprepn[i] = gprepn[i]; }
     for (int i = threadIdx.x; i < d.n; i += blockDim.x) dcl[i] = b.dc[i];
     __syncthreads();
     const double* prep = cprep;
-    (void)Xcn; (void)stage;
 
     const double* Xp = b.Xp + (size_t)st.cur * d.P * 3;
     double* Xn = b.Xp + (size_t)(st.cur ^ 1) * d.P * 3;
