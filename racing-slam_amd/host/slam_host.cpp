@@ -1,0 +1,449 @@
+// slam_host.cpp — marshalling of the host mirror (slam_host.h) onto the C-ABI of librsgpu.so.
+// Pointer graph -> SoA, upload, ONE C-ABI call per interface function, download.
+#include "slam_host.h"
+
+#include <hip/hip_runtime_api.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <stdexcept>
+#include <unordered_map>
+
+namespace slam {
+
+// ------------------------------------------------------------------ device helpers
+namespace {
+
+void hip_ok(hipError_t e, const char* what)
+{
+    if (e != hipSuccess) throw std::runtime_error(std::string(what) + ": " + hipGetErrorString(e));
+}
+
+template <typename T>
+class DevBuf {
+  public:
+    DevBuf() = default;
+    explicit DevBuf(size_t n) { resize(n); }
+    explicit DevBuf(const std::vector<T>& h) { upload(h); }
+    DevBuf(const DevBuf&) = delete;
+    DevBuf& operator=(const DevBuf&) = delete;
+    ~DevBuf() { if (m_p) (void)hipFree(m_p); }
+    void resize(size_t n)
+    {
+        if (m_p) (void)hipFree(m_p);
+        m_p = nullptr;
+        m_n = n;
+        hip_ok(hipMalloc((void**)&m_p, sizeof(T) * (n ? n : 1)), "hipMalloc");
+    }
+    void upload(const std::vector<T>& h)
+    {
+        resize(h.size());
+        if (!h.empty()) hip_ok(hipMemcpy(m_p, h.data(), sizeof(T) * h.size(), hipMemcpyHostToDevice), "H2D");
+    }
+    std::vector<T> download(size_t n) const
+    {
+        std::vector<T> h(n);
+        if (n) hip_ok(hipMemcpy(h.data(), m_p, sizeof(T) * n, hipMemcpyDeviceToHost), "D2H");
+        return h;
+    }
+    T* get() const { return m_p; }
+    size_t size() const { return m_n; }
+
+  private:
+    T* m_p = nullptr;
+    size_t m_n = 0;
+};
+
+// The reference has no error codes: a failed C-ABI call is logged to stdout like the
+// reference logs, and the interface function returns "empty / false".  Nothing throws across it.
+bool rs_ok(int rc, const char* what)
+{
+    if (rc == RS_OK) return true;
+    std::printf("%s failed (status %d): %s\n", what, rc, rs_last_error(Session::get().ctx()));
+    return false;
+}
+
+rs_ba_summary g_summary{};
+
+}  // namespace
+
+Session::Session()
+{
+    const int rc = rs_context_create(0, &m_ctx);
+    if (rc != RS_OK) throw std::runtime_error("rs_context_create failed (no gfx950 GPU? there is no CPU fallback)");
+}
+Session::~Session() { rs_context_destroy(m_ctx); }
+Session& Session::get()
+{
+    static Session s;
+    return s;
+}
+
+// ------------------------------------------------------------------------ data model
+Frame::Frame(int index, ExtractedFeatures features) : m_index((size_t)index), m_features(std::move(features))
+{
+    const size_t n = m_features.keypoints.size();
+    m_map_matches.assign(n, nullptr);
+    std::vector<float> kp(2 * n);
+    for (size_t i = 0; i < n; i++) { kp[2 * i] = m_features.keypoints[i].pt.x; kp[2 * i + 1] = m_features.keypoints[i].pt.y; }
+    m_kd_node_kp.resize(n); m_kd_left.resize(n); m_kd_right.resize(n);
+    int32_t root = -1;
+    rs_kdtree_build(kp.data(), (int)n, m_kd_node_kp.data(), m_kd_left.data(), m_kd_right.data(), &root);   // src/Frame.cpp:8-15
+    m_kd_root = root;
+}
+
+Vec3f Frame::camera_center() const
+{
+    const Mat4f& T = m_pose;
+    Vec3f c;
+    c.x = (-T[0] * T[3] + -T[4] * T[7]) + -T[8] * T[11];
+    c.y = (-T[1] * T[3] + -T[5] * T[7]) + -T[9] * T[11];
+    c.z = (-T[2] * T[3] + -T[6] * T[7]) + -T[10] * T[11];
+    return c;
+}
+
+void Frame::add_map_match(const MapPointMatch& m)
+{
+    MapPoint* previous = m_map_matches[m.keypoint_index];
+    if (previous == &m.point) return;
+    if (previous == nullptr) m_num++;
+    for (size_t i = 0; i < m_map_matches.size(); i++) {
+        if (m_map_matches[i] != &m.point || i == m.keypoint_index) continue;
+        m_map_matches[i] = nullptr;
+        if (m_num > 0) m_num--;
+    }
+    m_map_matches[m.keypoint_index] = &m.point;
+}
+
+bool Frame::is_matched(const MapPoint& p) const
+{
+    for (MapPoint* q : m_map_matches)
+        if (q == &p) return true;
+    return false;
+}
+
+std::vector<MapPointMatch> Frame::map_matches() const
+{
+    std::vector<MapPointMatch> out;
+    for (size_t i = 0; i < m_map_matches.size(); i++)
+        if (m_map_matches[i]) out.push_back(MapPointMatch{*m_map_matches[i], i});
+    return out;
+}
+
+bool MapPoint::is_observed_by(const KeyFrame* kf) const
+{
+    for (const auto& o : m_obs)
+        if (o.first == kf) return true;
+    return false;
+}
+
+void Map::associate(KeyFrame& kf, MapPoint& point, size_t keypoint_index)
+{
+    bool found = false;
+    for (auto& o : point.m_obs)
+        if (o.first == &kf) { o.second = keypoint_index; found = true; }
+    if (!found) point.m_obs.emplace_back(&kf, keypoint_index);
+    kf.add_map_match(MapPointMatch{point, keypoint_index});
+}
+
+// ------------------------------------------------------------------------ MapMatcher
+MapMatcher::MapMatcher(const Camera& camera, float max_descriptor_distance, NormTypes norm_type)
+    : m_camera(camera), m_max_descriptor_distance(max_descriptor_distance), m_norm_type(norm_type)
+{
+}
+
+std::vector<MapPointMatch> MapMatcher::match_map(const Frame& frame, Map& map) const
+{
+    std::vector<MapPoint*> pts(map.size());
+    for (size_t i = 0; i < map.size(); i++) pts[i] = &map[i];
+    return match(frame, pts, nullptr, false);
+}
+
+std::vector<MapPointMatch> MapMatcher::match_key_frame(const Frame& frame, Map& map, KeyFrame* key_frame) const
+{
+    std::vector<MapPoint*> pts(map.size());
+    for (size_t i = 0; i < map.size(); i++) pts[i] = &map[i];
+    return match(frame, pts, key_frame, false);
+}
+
+std::vector<MapPointMatch> MapMatcher::match_for_fuse(const Frame& frame, const std::vector<MapPoint*>& points) const
+{
+    return match(frame, points, nullptr, true);
+}
+
+// src/MapMatcher.cpp:45-98,117-127,165-175 -> rs_reproj_match
+std::vector<MapPointMatch> MapMatcher::match(const Frame& frame, const std::vector<MapPoint*>& points,
+                                             const KeyFrame* required_observer, bool replace) const
+{
+    rs_context* ctx = Session::get().ctx();
+    const size_t N = frame.features().keypoints.size(), P = points.size();
+    if (N == 0) return {};
+    // frame side
+    std::vector<float> kp(2 * N);
+    std::vector<uint8_t> matched(N);
+    for (size_t i = 0; i < N; i++) {
+        kp[2 * i] = frame.keypoint(i).pt.x; kp[2 * i + 1] = frame.keypoint(i).pt.y;
+        matched[i] = frame.is_matched(i) ? 1 : 0;
+    }
+    // map side: positions, eligibility (the pointer-set tests of :53, :121-123, :169), observation CSR,
+    // keyframe table and descriptor pool
+    std::vector<float> pos(3 * P), centers;
+    std::vector<uint8_t> eligible(P), pool;
+    std::vector<int32_t> obs_ptr(P + 1, 0), obs_kf, obs_desc;
+    std::unordered_map<const KeyFrame*, int> kf_id;
+    std::vector<int> kf_pool_off;
+    for (size_t p = 0; p < P; p++) {
+        const MapPoint* mp = points[p];
+        bool ok = mp != nullptr;
+        if (ok && frame.is_matched(*mp)) ok = false;
+        if (ok && required_observer && !mp->is_observed_by(required_observer)) ok = false;
+        eligible[p] = ok ? 1 : 0;
+        if (mp) { pos[3 * p] = mp->position().x; pos[3 * p + 1] = mp->position().y; pos[3 * p + 2] = mp->position().z; }
+        if (ok) {
+            for (const auto& o : mp->observations()) {
+                auto it = kf_id.find(o.first);
+                if (it == kf_id.end()) {
+                    it = kf_id.emplace(o.first, (int)kf_id.size()).first;
+                    const Vec3f c = o.first->camera_center();
+                    centers.insert(centers.end(), {c.x, c.y, c.z});
+                    kf_pool_off.push_back((int)(pool.size() / 32));
+                    const auto& d = o.first->features().descriptors;
+                    pool.insert(pool.end(), d.begin(), d.end());
+                }
+                obs_kf.push_back(it->second);
+                obs_desc.push_back(kf_pool_off[it->second] + (int)o.second);
+            }
+        }
+        obs_ptr[p + 1] = (int32_t)obs_kf.size();
+    }
+    DevBuf<float> d_kp(kp), d_pos(pos), d_centers(centers);
+    DevBuf<uint8_t> d_desc(frame.features().descriptors), d_matched(matched), d_elig(eligible), d_pool(pool);
+    DevBuf<int32_t> d_nk(frame.kd_node_kp()), d_l(frame.kd_left()), d_r(frame.kd_right()), d_optr(obs_ptr), d_okf(obs_kf),
+        d_odesc(obs_desc);
+    rs_frame_view fv{};
+    std::memcpy(fv.pose, frame.pose().data(), sizeof fv.pose);
+    fv.fx = m_camera.fx(); fv.fy = m_camera.fy(); fv.cx = m_camera.cx(); fv.cy = m_camera.cy();
+    fv.width = m_camera.get_width(); fv.height = m_camera.get_height();
+    fv.n_keypoints = (int)N; fv.d_keypoints = d_kp.get(); fv.d_descriptors = d_desc.get(); fv.d_kp_matched = d_matched.get();
+    fv.d_kd_node_kp = d_nk.get(); fv.d_kd_left = d_l.get(); fv.d_kd_right = d_r.get(); fv.kd_root = frame.kd_root();
+    rs_map_view mv{};
+    mv.n_points = (int)P; mv.d_positions = d_pos.get(); mv.d_eligible = d_elig.get(); mv.d_obs_ptr = d_optr.get();
+    mv.d_obs_kf = d_okf.get(); mv.d_obs_desc = d_odesc.get(); mv.d_kf_centers = d_centers.get(); mv.d_desc_pool = d_pool.get();
+    DevBuf<int32_t> pk(P), pd(P), pp(N), pdist(N), mkp(N), mpt(N), cnt(1);
+    if (!rs_ok(rs_reproj_match(ctx, &fv, &mv, replace ? 1 : 0, (int)m_max_descriptor_distance, pk.get(), pd.get(), pp.get(),
+                               pdist.get(), mkp.get(), mpt.get(), cnt.get()), "rs_reproj_match"))
+        return {};
+    rs_context_synchronize(ctx);
+    const int n = cnt.download(1)[0];
+    const auto hk = mkp.download((size_t)n), hp = mpt.download((size_t)n);
+    std::vector<MapPointMatch> out;
+    for (int i = 0; i < n; i++) out.push_back(MapPointMatch{*points[(size_t)hp[i]], (size_t)hk[i]});
+    return out;
+}
+
+// src/MapMatcher.cpp:129-163 -> rs_match_descriptors
+std::vector<MapPointMatch> MapMatcher::match_descriptors(const Frame& frame, const KeyFrame& key_frame) const
+{
+    rs_context* ctx = Session::get().ctx();
+    const auto km = key_frame.map_matches();                  // ascending keypoint order
+    std::vector<uint8_t> train;
+    for (const auto& m : km) {
+        const uint8_t* row = key_frame.features().descriptors.data() + 32 * m.keypoint_index;
+        train.insert(train.end(), row, row + 32);
+    }
+    const int nq = (int)frame.features().keypoints.size(), nt = (int)km.size();
+    if (nt == 0 || nq == 0) return {};                        // :139-141
+    DevBuf<uint8_t> dq(frame.features().descriptors), dt(train);
+    DevBuf<int32_t> mq((size_t)nq), mt((size_t)nq), cnt(1);
+    if (!rs_ok(rs_match_descriptors(ctx, dq.get(), nq, dt.get(), nt, 1, (int)m_max_descriptor_distance, mq.get(), mt.get(),
+                                    cnt.get(), nullptr, nullptr, nullptr, nullptr), "rs_match_descriptors"))
+        return {};
+    rs_context_synchronize(ctx);
+    const int n = cnt.download(1)[0];
+    const auto hq = mq.download((size_t)n), ht = mt.download((size_t)n);
+    std::vector<MapPointMatch> out;
+    for (int i = 0; i < n; i++) out.push_back(MapPointMatch{km[(size_t)ht[i]].point, (size_t)hq[i]});   // :159-160
+    return out;
+}
+
+// --------------------------------------------------------------------- triangulation
+namespace triangulation {
+
+std::pair<std::vector<Vec2f>, std::vector<Vec2f>> get_matching_points(const ExtractedFeatures& f1, const ExtractedFeatures& f2,
+                                                                      const std::vector<FeatureMatch>& matches)
+{
+    std::vector<Vec2f> p1, p2;
+    for (const auto& m : matches) {                            // src/Triangulation.cpp:11-26
+        p1.push_back(f1.keypoints[m.train_index].pt);
+        p2.push_back(f2.keypoints[m.query_index].pt);
+    }
+    return {p1, p2};
+}
+
+std::vector<TriangulatedPoint> triangulate_points(const std::vector<Vec2f>& points1, const std::vector<Vec2f>& points2,
+                                                  const Mat4f& pose1, const Mat4f& pose2, const Camera& camera,
+                                                  float min_parallax_cosine, float max_reprojection_error)
+{
+    if (points1.empty() || points2.empty()) return {};         // :46-48
+    rs_context* ctx = Session::get().ctx();
+    const size_t n = points1.size();
+    std::vector<float> uv1(2 * n), uv2(2 * n), poses(32);
+    for (size_t i = 0; i < n; i++) { uv1[2 * i] = points1[i].x; uv1[2 * i + 1] = points1[i].y; uv2[2 * i] = points2[i].x; uv2[2 * i + 1] = points2[i].y; }
+    std::memcpy(poses.data(), pose1.data(), 64);
+    std::memcpy(poses.data() + 16, pose2.data(), 64);
+    DevBuf<float> d1(uv1), d2(uv2), dp(poses), xyz(3 * n), oxyz(3 * n);
+    DevBuf<uint8_t> keep(n);
+    DevBuf<int32_t> oidx(n), cnt(1);
+    const float K[4] = {camera.fx(), camera.fy(), camera.cx(), camera.cy()};
+    if (!rs_ok(rs_triangulate(ctx, d1.get(), d2.get(), (int)n, dp.get(), 2, nullptr, nullptr, K, min_parallax_cosine,
+                              max_reprojection_error, xyz.get(), keep.get(), oidx.get(), oxyz.get(), cnt.get()), "rs_triangulate"))
+        return {};
+    rs_context_synchronize(ctx);
+    const int m = cnt.download(1)[0];
+    const auto hi = oidx.download((size_t)m);
+    const auto hx = oxyz.download(3 * (size_t)m);
+    std::vector<TriangulatedPoint> out((size_t)m);
+    for (int i = 0; i < m; i++) out[(size_t)i] = TriangulatedPoint{Vec3f{hx[3 * i], hx[3 * i + 1], hx[3 * i + 2]}, hi[(size_t)i]};
+    return out;
+}
+
+std::vector<TriangulatedPoint> triangulate_points(const Frame& frame1, const Frame& frame2,
+                                                  const std::vector<FeatureMatch>& matches, const Camera& camera)
+{
+    auto pts = get_matching_points(frame1.features(), frame2.features(), matches);   // :28-35
+    return triangulate_points(pts.first, pts.second, frame1.pose(), frame2.pose(), camera);
+}
+
+}  // namespace triangulation
+
+// ---------------------------------------------------------------------- optimisation
+namespace optimization {
+
+const rs_ba_summary& last_summary() { return g_summary; }
+
+// src/Optimization.cpp:194-267 (vision-only) -> rs_refine_pose
+bool refine_pose(Frame& frame, const Camera& camera)
+{
+    rs_context* ctx = Session::get().ctx();
+    std::vector<double> pts;
+    std::vector<float> uv;
+    for (const auto& m : frame.map_matches()) {
+        if (m.point.observations().size() < 2) continue;       // MIN_OBSERVATIONS_TO_OPTIMIZE, :98,:206
+        pts.insert(pts.end(), {m.point.position().x, m.point.position().y, m.point.position().z});
+        uv.insert(uv.end(), {frame.keypoint(m.keypoint_index).pt.x, frame.keypoint(m.keypoint_index).pt.y});
+    }
+    if (uv.empty()) return false;                              // :227-229
+    double cam[6];
+    rs_pack_pose(frame.pose().data(), cam);
+    DevBuf<double> dp(pts);
+    DevBuf<float> duv(uv);
+    const float K[4] = {camera.fx(), camera.fy(), camera.cx(), camera.cy()};
+    if (!rs_ok(rs_refine_pose(ctx, cam, dp.get(), duv.get(), (int)(uv.size() / 2), K, nullptr, &g_summary), "rs_refine_pose")) return false;
+    std::printf("refine_pose: iterations %d, cost %.6e -> %.6e, termination %d\n", g_summary.iterations,
+                g_summary.initial_cost, g_summary.final_cost, g_summary.termination);
+    if (!g_summary.usable) { std::printf("Optimization rejected, unusable or non-improving solution\n"); return false; }
+    Mat4f T;
+    rs_unpack_pose(cam, T.data());
+    frame.set_pose(T);
+    return true;
+}
+
+// src/Optimization.cpp:269-374 (vision-only) -> rs_bundle_adjust
+bool bundle_adjust(const std::vector<FrameConfig>& frames, const Camera& camera, Map&)
+{
+    rs_context* ctx = Session::get().ctx();
+    const size_t C = frames.size();
+    std::vector<double> cams(6 * C);
+    std::vector<uint8_t> cam_free(C);
+    for (size_t c = 0; c < C; c++) { rs_pack_pose(frames[c].frame->pose().data(), &cams[6 * c]); cam_free[c] = frames[c].optimize ? 1 : 0; }
+    // free points: matched by an optimised frame, >= 2 observations (:287-302), in first-seen order
+    std::vector<MapPoint*> free_pts;
+    std::unordered_map<const MapPoint*, int> pid;
+    for (size_t c = 0; c < C; c++) {
+        if (!frames[c].optimize) continue;
+        for (const auto& m : frames[c].frame->map_matches()) {
+            if (m.point.observations().size() < 2) continue;
+            if (pid.emplace(&m.point, (int)free_pts.size()).second) free_pts.push_back(&m.point);
+        }
+    }
+    const size_t P = free_pts.size();
+    // residual blocks: every listed frame (free or fixed) x its matched free points (:304-315), CSR by point
+    std::vector<std::vector<std::pair<int, Vec2f>>> per_point(P);
+    for (size_t c = 0; c < C; c++)
+        for (const auto& m : frames[c].frame->map_matches()) {
+            auto it = pid.find(&m.point);
+            if (it != pid.end()) per_point[(size_t)it->second].emplace_back((int)c, frames[c].frame->keypoint(m.keypoint_index).pt);
+        }
+    std::vector<int32_t> obs_ptr(P + 1, 0), obs_cam;
+    std::vector<float> obs_uv;
+    std::vector<double> pts(3 * P);
+    for (size_t p = 0; p < P; p++) {
+        pts[3 * p] = free_pts[p]->position().x; pts[3 * p + 1] = free_pts[p]->position().y; pts[3 * p + 2] = free_pts[p]->position().z;
+        for (const auto& o : per_point[p]) { obs_cam.push_back(o.first); obs_uv.insert(obs_uv.end(), {o.second.x, o.second.y}); }
+        obs_ptr[p + 1] = (int32_t)obs_cam.size();
+    }
+    if (P == 0 || obs_cam.empty()) return false;
+    DevBuf<double> dc(cams), dp(pts);
+    DevBuf<int32_t> dptr(obs_ptr), dcam(obs_cam);
+    DevBuf<float> duv(obs_uv);
+    const float K[4] = {camera.fx(), camera.fy(), camera.cx(), camera.cy()};
+    if (!rs_ok(rs_bundle_adjust(ctx, (int)C, (int)P, (int)obs_cam.size(), dc.get(), cam_free.data(), dp.get(), dptr.get(), dcam.get(),
+                                duv.get(), K, nullptr, &g_summary), "rs_bundle_adjust"))
+        return false;
+    std::printf("bundle_adjust: iterations %d, cost %.6e -> %.6e, termination %d\n", g_summary.iterations,
+                g_summary.initial_cost, g_summary.final_cost, g_summary.termination);
+    if (!g_summary.usable) { std::printf("Optimization rejected, unusable or non-improving solution\n"); return false; }
+    const auto hc = dc.download(6 * C);
+    const auto hp = dp.download(3 * P);
+    for (size_t c = 0; c < C; c++)
+        if (frames[c].optimize) { Mat4f T; rs_unpack_pose(&hc[6 * c], T.data()); frames[c].frame->set_pose(T); }   // :363-368
+    for (size_t p = 0; p < P; p++) free_pts[p]->set_position(Vec3f{(float)hp[3 * p], (float)hp[3 * p + 1], (float)hp[3 * p + 2]});
+    return true;
+}
+
+// src/LocalWindow.cpp:10-52 -> rs_build_local_window
+std::vector<FrameConfig> build_local_window(const std::vector<std::shared_ptr<KeyFrame>>& key_frames, Frame& new_frame,
+                                            size_t window_size, bool fix_oldest)
+{
+    const int n = (int)key_frames.size();
+    int new_index = -1;
+    std::unordered_map<const Frame*, int> fid;
+    for (int i = 0; i < n; i++) { fid[key_frames[(size_t)i].get()] = i; if (key_frames[(size_t)i].get() == &new_frame) new_index = i; }
+    std::unordered_map<const MapPoint*, int> pid;
+    std::vector<const MapPoint*> pts;
+    std::vector<int32_t> frame_ptr((size_t)n + 2, 0), frame_pt;
+    auto add_frame = [&](const Frame& f, int slot) {
+        for (const auto& m : f.map_matches()) {
+            auto it = pid.find(&m.point);
+            if (it == pid.end()) { it = pid.emplace(&m.point, (int)pts.size()).first; pts.push_back(&m.point); }
+            frame_pt.push_back(it->second);
+        }
+        frame_ptr[(size_t)slot + 1] = (int32_t)frame_pt.size();
+    };
+    for (int i = 0; i < n; i++) add_frame(*key_frames[(size_t)i], i);
+    if (new_index < 0) add_frame(new_frame, n); else frame_ptr[(size_t)n + 1] = frame_ptr[(size_t)n];
+    std::vector<int32_t> pt_ptr(pts.size() + 1, 0), pt_obs;
+    for (size_t p = 0; p < pts.size(); p++) {
+        for (const auto& o : pts[p]->observations()) {
+            auto it = fid.find(o.first);
+            if (it != fid.end()) pt_obs.push_back(it->second);
+        }
+        pt_ptr[p + 1] = (int32_t)pt_obs.size();
+    }
+    std::vector<int32_t> of((size_t)n + 1);
+    std::vector<uint8_t> oo((size_t)n + 1);
+    int32_t cnt = 0;
+    if (rs_build_local_window(n, new_index, (int)window_size, fix_oldest ? 1 : 0, frame_ptr.data(), frame_pt.data(), pt_ptr.data(),
+                              pt_obs.data(), of.data(), oo.data(), &cnt) != RS_OK)
+        return {};
+    std::vector<FrameConfig> out;
+    for (int i = 0; i < cnt; i++) {
+        Frame* f = of[(size_t)i] == n ? &new_frame : key_frames[(size_t)of[(size_t)i]].get();
+        out.push_back(FrameConfig{oo[(size_t)i] != 0, f});
+    }
+    return out;
+}
+
+}  // namespace optimization
+}  // namespace slam

@@ -1,0 +1,39 @@
+"""The C++ host mirror (racing-slam_amd/host/) over the C-ABI: compile on the CPU (always),
+run its self-test against the oracle on the GPU."""
+import os
+import shutil
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BIN = os.path.join(ROOT, "tests", "host_cpp", "test_host.bin")
+
+
+def build_host_test(rs, oracle):
+    rs.load()
+    oracle.lib()
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    srcs = [os.path.join(ROOT, "tests", "host_cpp", "test_host.cpp"), os.path.join(ROOT, "racing-slam_amd", "host", "slam_host.cpp")]
+    deps = srcs + [os.path.join(ROOT, "racing-slam_amd", "host", "slam_host.h"), os.path.join(ROOT, "include", "rsgpu.h"),
+                   os.path.join(ROOT, "racing-slam_amd", "librsgpu.so"), os.path.join(ROOT, "oracle", "liboracle.so")]
+    if os.path.exists(BIN) and all(os.path.getmtime(d) <= os.path.getmtime(BIN) for d in deps):
+        return BIN
+    cmd = [hipcc, "-O2", "-std=c++17", "-Wall", "-o", BIN] + srcs + [
+        "-L" + os.path.join(ROOT, "racing-slam_amd"), "-lrsgpu", "-L" + os.path.join(ROOT, "oracle"), "-loracle",
+        "-Wl,-rpath," + os.path.join(ROOT, "racing-slam_amd"), "-Wl,-rpath," + os.path.join(ROOT, "oracle"), "-lm"]
+    subprocess.check_call(cmd)
+    return BIN
+
+
+def test_host_mirror_compiles_and_links(rs, oracle):
+    assert os.path.exists(build_host_test(rs, oracle))
+
+
+@pytest.mark.gpu
+def test_host_mirror_selftest(rs, oracle):
+    exe = build_host_test(rs, oracle)
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    print(r.stdout[-3000:], r.stderr[-2000:])
+    assert r.returncode == 0, r.stdout[-3000:]
+    assert "all checks passed" in r.stdout
