@@ -1,0 +1,132 @@
+// Drop-in replacement of the reference's src/Optimization.cpp (keeps src/Optimization.h).
+// NOT COMPILED IN THIS REPO; see rs_shim_common.h.  Vision-only: when InertialInput::usable() or an
+// InertialConstraint is set the IMU residual blocks (src/Optimization.cpp:237-258,317-346) are not
+// yet supported by the GPU solver — the shim then logs and returns false, and
+// pose_graph (a14) is left to the reference's own Ceres implementation (keep that function from the
+// original file).
+#include "Optimization.h"
+
+#include <unordered_map>
+
+#include "Camera.h"
+#include "Frame.h"
+#include "Map.h"
+#include "MapPoint.h"
+#include "rs_shim_common.h"
+
+namespace slam::optimization {
+
+namespace {
+constexpr size_t MIN_OBSERVATIONS_TO_OPTIMIZE = 2;
+
+void intrinsics(const Camera& camera, float K[4])
+{
+    const Eigen::Matrix3f& M = camera.get_intrinsic_matrix();
+    K[0] = M(0, 0); K[1] = M(1, 1); K[2] = M(0, 2); K[3] = M(1, 2);
+}
+
+bool report(const char* what, const rs_ba_summary& s)
+{
+    std::printf("%s: iterations %d, cost %.6e -> %.6e, termination %d\n", what, s.iterations, s.initial_cost, s.final_cost, s.termination);
+    if (!s.usable) std::printf("Optimization rejected, unusable or non-improving solution\n");
+    return s.usable != 0;
+}
+}  // namespace
+
+bool refine_pose(Frame& frame, const Camera& camera, const InertialConstraint& inertial)
+{
+    using namespace rs_shim;
+    if (!std::holds_alternative<std::monostate>(inertial)) {
+        std::printf("refine_pose: inertial constraints are not supported by the GPU path yet\n");
+        return false;
+    }
+    std::vector<double> pts;
+    std::vector<float> uv;
+    for (const auto& m : frame.map_matches()) {
+        if (m.point.observations().size() < MIN_OBSERVATIONS_TO_OPTIMIZE) continue;
+        for (int k = 0; k < 3; k++) pts.push_back((double)m.point.position()[k]);
+        uv.push_back(frame.keypoint(m.keypoint_index).pt.x);
+        uv.push_back(frame.keypoint(m.keypoint_index).pt.y);
+    }
+    if (uv.empty()) return false;
+    float T[16], K[4];
+    double cam[6];
+    pose_to_row_major(frame.pose(), T);
+    rs_pack_pose(T, cam);
+    intrinsics(camera, K);
+    DevBuf<double> dp(pts);
+    DevBuf<float> duv(uv);
+    rs_ba_summary s{};
+    if (!ok(rs_refine_pose(context(), cam, dp.p, duv.p, (int)(uv.size() / 2), K, nullptr, &s), "rs_refine_pose")) return false;
+    if (!report("refine_pose", s)) return false;
+    rs_unpack_pose(cam, T);
+    frame.set_pose(pose_from_row_major(T));
+    return true;
+}
+
+bool bundle_adjust(const std::vector<FrameConfig>& frames, const Camera& camera, Map&, const InertialInput& inertial)
+{
+    using namespace rs_shim;
+    if (inertial.usable()) {
+        std::printf("bundle_adjust: IMU factors are not supported by the GPU path yet\n");
+        return false;
+    }
+    const size_t C = frames.size();
+    std::vector<double> cams(6 * C);
+    std::vector<uint8_t> cam_free(C);
+    for (size_t c = 0; c < C; c++) {
+        float T[16];
+        pose_to_row_major(frames[c].frame->pose(), T);
+        rs_pack_pose(T, &cams[6 * c]);
+        cam_free[c] = frames[c].optimize;
+    }
+    std::vector<MapPoint*> free_pts;
+    std::unordered_map<const MapPoint*, int> pid;
+    for (const auto& fc : frames) {
+        if (!fc.optimize) continue;
+        for (auto m : fc.frame->map_matches()) {
+            if (m.point.observations().size() < MIN_OBSERVATIONS_TO_OPTIMIZE) continue;
+            if (pid.emplace(&m.point, (int)free_pts.size()).second) free_pts.push_back(&m.point);
+        }
+    }
+    const size_t P = free_pts.size();
+    std::vector<std::vector<std::pair<int, cv::Point2f>>> per_point(P);
+    for (size_t c = 0; c < C; c++)
+        for (const auto& m : frames[c].frame->map_matches()) {
+            auto it = pid.find(&m.point);
+            if (it != pid.end()) per_point[it->second].emplace_back((int)c, frames[c].frame->keypoint(m.keypoint_index).pt);
+        }
+    std::vector<int32_t> obs_ptr(P + 1, 0), obs_cam;
+    std::vector<float> obs_uv;
+    std::vector<double> pts(3 * P);
+    for (size_t p = 0; p < P; p++) {
+        for (int k = 0; k < 3; k++) pts[3 * p + k] = (double)free_pts[p]->position()[k];
+        for (const auto& [c, px] : per_point[p]) { obs_cam.push_back(c); obs_uv.push_back(px.x); obs_uv.push_back(px.y); }
+        obs_ptr[p + 1] = (int32_t)obs_cam.size();
+    }
+    if (P == 0 || obs_cam.empty()) return false;
+    float K[4];
+    intrinsics(camera, K);
+    DevBuf<double> dc(cams), dp(pts);
+    DevBuf<int32_t> dptr(obs_ptr), dcam(obs_cam);
+    DevBuf<float> duv(obs_uv);
+    rs_ba_summary s{};
+    if (!ok(rs_bundle_adjust(context(), (int)C, (int)P, (int)obs_cam.size(), dc.p, cam_free.data(), dp.p, dptr.p, dcam.p, duv.p, K,
+                             nullptr, &s), "rs_bundle_adjust"))
+        return false;
+    if (!report("bundle_adjust", s)) return false;
+    const auto hc = dc.download(6 * C);
+    const auto hp = dp.download(3 * P);
+    for (size_t c = 0; c < C; c++)
+        if (frames[c].optimize) {
+            float T[16];
+            rs_unpack_pose(&hc[6 * c], T);
+            frames[c].frame->set_pose(pose_from_row_major(T));
+        }
+    for (size_t p = 0; p < P; p++) free_pts[p]->set_position(Eigen::Vector3f((float)hp[3 * p], (float)hp[3 * p + 1], (float)hp[3 * p + 2]));
+    return true;
+}
+
+// pose_graph(...): keep the reference's implementation (src/Optimization.cpp:376-639) in this file.
+
+}  // namespace slam::optimization

@@ -1,0 +1,62 @@
+// Drop-in replacement of the reference's src/Triangulation.cpp (keeps src/Triangulation.h).
+// NOT COMPILED IN THIS REPO; see rs_shim_common.h.
+#include "Triangulation.h"
+
+#include "Frame.h"
+#include "rs_shim_common.h"
+
+namespace slam::triangulation {
+
+std::pair<std::vector<Eigen::Vector2f>, std::vector<Eigen::Vector2f>>
+get_matching_points(const ExtractedFeatures& features1, const ExtractedFeatures& features2, const std::vector<FeatureMatch>& matches)
+{
+    std::vector<Eigen::Vector2f> p1, p2;
+    for (const auto& m : matches) {
+        p1.emplace_back(features1.keypoints[m.train_index].pt.x, features1.keypoints[m.train_index].pt.y);
+        p2.emplace_back(features2.keypoints[m.query_index].pt.x, features2.keypoints[m.query_index].pt.y);
+    }
+    return {p1, p2};
+}
+
+std::vector<TriangulatedPoint> triangulate_points(const Frame& frame1, const Frame& frame2,
+                                                  const std::vector<FeatureMatch>& matches, const Camera& camera)
+{
+    auto [p1, p2] = get_matching_points(frame1.features(), frame2.features(), matches);
+    return triangulate_points(p1, p2, frame1.pose(), frame2.pose(), camera);
+}
+
+std::vector<TriangulatedPoint> triangulate_points(const std::vector<Eigen::Vector2f>& points1,
+                                                  const std::vector<Eigen::Vector2f>& points2,
+                                                  const Eigen::Matrix4f& pose1, const Eigen::Matrix4f& pose2,
+                                                  const Camera& camera, float min_parallax_cosine,
+                                                  float max_reprojection_error)
+{
+    using namespace rs_shim;
+    if (points1.empty() || points2.empty()) return {};
+    const size_t n = points1.size();
+    std::vector<float> uv1(2 * n), uv2(2 * n), poses(32);
+    for (size_t i = 0; i < n; i++) { uv1[2 * i] = points1[i].x(); uv1[2 * i + 1] = points1[i].y(); uv2[2 * i] = points2[i].x(); uv2[2 * i + 1] = points2[i].y(); }
+    pose_to_row_major(pose1, poses.data());
+    pose_to_row_major(pose2, poses.data() + 16);
+    const Eigen::Matrix3f& Km = camera.get_intrinsic_matrix();
+    const float K[4] = {Km(0, 0), Km(1, 1), Km(0, 2), Km(1, 2)};
+    DevBuf<float> d1(uv1), d2(uv2), dp(poses), xyz(3 * n), oxyz(3 * n);
+    DevBuf<uint8_t> keep(n);
+    DevBuf<int32_t> oidx(n), cnt(1);
+    if (!ok(rs_triangulate(context(), d1.p, d2.p, (int)n, dp.p, 2, nullptr, nullptr, K, min_parallax_cosine, max_reprojection_error,
+                           xyz.p, keep.p, oidx.p, oxyz.p, cnt.p), "rs_triangulate"))
+        return {};
+    rs_context_synchronize(context());
+    const int m = cnt.download(1)[0];
+    const auto hi = oidx.download(m);
+    const auto hx = oxyz.download(3 * (size_t)m);
+    std::vector<TriangulatedPoint> out;
+    for (int i = 0; i < m; i++) out.push_back(TriangulatedPoint{Eigen::Vector3f(hx[3 * i], hx[3 * i + 1], hx[3 * i + 2]), hi[i]});
+    return out;
+}
+
+}  // namespace slam::triangulation
+// Mapper::triangulate_tracks (src/Mapper.cpp:246-259) calls the function above once per track with
+// N = 1.  It keeps working unchanged; to get one launch per keyframe instead of <= 2000, gather the
+// tracks' (first sighting pixel, keyframe pixel, first pose) and call rs_triangulate once with
+// per-item pose indices (d_pose_idx1[i] = track's first pose, d_pose_idx2[i] = keyframe pose).
