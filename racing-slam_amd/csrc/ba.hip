@@ -621,7 +621,7 @@ extern "C" int rs_bundle_adjust(rs_context* ctx, int n_cameras, int n_points, in
             rs_prof_scope ps(ctx, "K5_ba_linearize_schur");
             hipLaunchKernelGGL(ba_linearize_schur, dim3(pblocks), dim3(BA_THREADS), k5_lds, s, d, b, opt);
         }
-        if (ctx->n_ranks > 1) {
+        if (ctx->comm) {
             rs_prof_scope ps(ctx, "C1_allreduce_system");
             rc = rs_allreduce_f64(ctx, b.acc, b.acc_count, false);
             if (rc) return rc;
@@ -642,7 +642,7 @@ extern "C" int rs_bundle_adjust(rs_context* ctx, int n_cameras, int n_points, in
             rs_prof_scope ps(ctx, "K8_ba_backsub_cost_global");
             hipLaunchKernelGGL(ba_backsub_cost, dim3(pblocks), dim3(BA_THREADS), 0, s, d, b);
         }
-        if (ctx->n_ranks > 1) {
+        if (ctx->comm) {
             rs_prof_scope ps(ctx, "C2_allreduce_cost");
             rc = rs_allreduce_f64(ctx, b.pt_scal, BA_NSLOT * BA_SLOT_STRIDE, false);
             if (rc) return rc;

@@ -251,7 +251,7 @@ extern "C" int rs_comm_destroy(rs_context* ctx)
 
 int rs_allreduce_f64(rs_context* ctx, double* d_buf, size_t count, bool is_max)
 {
-    if (ctx->n_ranks <= 1 || !ctx->comm) return RS_OK;
+    if (!ctx->comm) return RS_OK;     // a 1-rank communicator still goes through RCCL (exercised by the tests)
     // ncclFloat64 = 8, ncclSum = 0, ncclMax = 2
     int e = g_rccl.allreduce(d_buf, d_buf, count, 8, is_max ? 2 : 0, ctx->comm, ctx->stream);
     if (e != 0) return rs_fail(ctx, RS_ERR_RCCL, "ncclAllReduce: %s", g_rccl.errstr ? g_rccl.errstr(e) : "?");

@@ -305,6 +305,9 @@ class Context:
         buf = (C.c_uint8 * 128).from_buffer_copy(uid)
         self._check(self.lib.rs_comm_init_rank(self.h, buf, int(n_ranks), int(rank)), "rs_comm_init_rank")
 
+    def comm_destroy(self):
+        self._check(self.lib.rs_comm_destroy(self.h), "rs_comm_destroy")
+
     # -- profiling
     def prof_begin(self):
         self._check(self.lib.rs_prof_begin(self.h), "rs_prof_begin")

@@ -367,3 +367,25 @@ def test_match_descriptors_cfg4_batch_properties(ctx, synth):
     ident = ctx.match_descriptors(dt[0].contiguous(), dt[0].contiguous(), n, n, raw=True)
     assert int(to_np(ident["cnt"])[0]) == n
     assert np.array_equal(to_np(ident["raw"][0])[0], np.arange(n)) and to_np(ident["raw"][1])[0].max() == 0
+
+
+def test_bundle_adjust_through_rccl_single_rank(ctx, rs, synth):
+    """The multi-GPU code path on one GPU: a 1-rank RCCL communicator (dlopen of librccl,
+    ncclCommInitRank, sum and max ncclAllReduce of the reduced system / scalar slots on the library
+    stream every LM step) must leave the solve unchanged."""
+    w = synth.make_ba_window(n_kf=8, n_points=500, run_max=6, config_id=61)
+    def run():
+        dc, dp = ctx.dev(w["cams"]), ctx.dev(w["points"])
+        s = ctx.bundle_adjust(dc, w["cam_free"], dp, ctx.dev(w["obs_ptr"]), ctx.dev(w["obs_cam"]), ctx.dev(w["obs_uv"]), w["K"])
+        return to_np(dc), to_np(dp), s
+    c0, p0, s0 = run()
+    ctx.comm_init(rs.Context.comm_unique_id(), 1, 0)
+    try:
+        ctx.prof_begin()
+        c1, p1, s1 = run()
+        prof = ctx.prof_end()
+    finally:
+        ctx.comm_destroy()
+    assert prof["C1_allreduce_system"][0] == 10 and prof["C2_allreduce_cost"][0] == 10
+    assert (s0["iterations"], s0["successful_steps"], s0["termination"]) == (s1["iterations"], s1["successful_steps"], s1["termination"])
+    assert np.allclose(c0, c1, rtol=1e-9, atol=1e-12) and np.allclose(p0, p1, rtol=1e-9, atol=1e-11)
