@@ -209,7 +209,7 @@ def main():
             "per_kernel_us": {k: round(v["avg_us"], 2) for k, v in sorted(per_kernel.items())},
             "per_kernel_launches_per_pass": {k: v["launches"] / max(args.steps, 1) for k, v in sorted(per_kernel.items())},
             "ba_summary": last.get("ba"),
-            "ba_phase_cycles": ctx.prof_counters(16),
+            "ba_phase_cycles": ctx.prof_counters(48),
             "speedup_vs_cpu_baseline": (value / cpu["value"]) if cpu else None,
         }
         print(json.dumps(out))

@@ -25,6 +25,8 @@
 //                          model-cost terms, robust cost at the candidate
 //   [RCCL all-reduce of 4 scalars]
 //   K9 ba_decide           accept / reject, radius update, termination tests
+#include <stdlib.h>
+
 #include "ba_common.h"
 
 // ---------------------------------------------------------------------- K0
@@ -541,6 +543,7 @@ extern "C" int rs_bundle_adjust(rs_context* ctx, int n_cameras, int n_points, in
     opt.min_rel = options->min_relative_decrease; opt.dmin = options->min_lm_diagonal;
     opt.dmax = options->max_lm_diagonal; opt.ftol = options->function_tolerance;
     opt.gtol = options->gradient_tolerance; opt.ptol = options->parameter_tolerance;
+    opt.dbg = getenv("RS_K7_DEBUG") ? atoi(getenv("RS_K7_DEBUG")) : 0;
     if (opt.max_iter < 0 || opt.max_iter > 1000) return rs_fail(ctx, RS_ERR_INVALID, "max_num_iterations out of range");
     if (d.Cf * 42 * sizeof(double) > 60 * 1024) return rs_fail(ctx, RS_ERR_UNSUPPORTED, "more than 182 free cameras");
 
@@ -868,6 +871,7 @@ extern "C" int rs_refine_pose(rs_context* ctx, double h_camera[6], const double*
     opt.min_rel = options->min_relative_decrease; opt.dmin = options->min_lm_diagonal;
     opt.dmax = options->max_lm_diagonal; opt.ftol = options->function_tolerance;
     opt.gtol = options->gradient_tolerance; opt.ptol = options->parameter_tolerance;
+    opt.dbg = 0;
     void* wsv = nullptr;
     int rc = rs_workspace(ctx, 1024, &wsv);
     if (rc) return rc;

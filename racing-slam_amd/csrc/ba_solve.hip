@@ -27,7 +27,16 @@
 #include "ba_common.h"
 
 #define K7_THREADS 256
-#define K7_TPW 9       // lower-triangle tiles per wave: 8*9/2 = 36 tiles / 4 waves
+#if RS_STAMPS
+#define W7_DECL unsigned long long w7_acc[8] = {0,0,0,0,0,0,0,0}; unsigned long long w7_t = clock64()
+#define W7(idx) do { if ((threadIdx.x & 63) == 0) { const unsigned long long t__ = clock64(); w7_acc[idx] += t__ - w7_t; w7_t = t__; } } while (0)
+#define W7_FLUSH(b) do { if ((threadIdx.x & 63) == 0) { _Pragma("unroll") for (int q__ = 0; q__ < 8; q__++) (b).dbg[16 + (threadIdx.x >> 6) * 8 + q__] += w7_acc[q__]; } } while (0)
+#else
+#define W7_DECL do { } while (0)
+#define W7(idx) do { } while (0)
+#define W7_FLUSH(b) do { } while (0)
+#endif
+#define K7_TPW 12      // tiles per wave: tile rows w (<= 4 tiles) and NTL-1-w (<= 8 tiles)
 
 typedef __attribute__((ext_vector_type(4))) double d4;
 
@@ -39,6 +48,14 @@ __device__ __forceinline__ double fast_rsqrt(double x)
     y = y * (1.5 - h * y * y);
     y = y * (1.5 - h * y * y);
     return y;
+}
+
+// 1/x from v_rcp_f64 + one Newton step
+__device__ __forceinline__ double fast_rcp(double x)
+{
+    double r = __builtin_amdgcn_rcp(x);
+    const double e = fma(-x, r, 1.0);
+    return fma(r, e, r);
 }
 
 __global__ __launch_bounds__(K7_THREADS) void ba_reduced_solve_lds(BaDims d, BaBufs b, BaOpt opt)
@@ -53,6 +70,7 @@ __global__ __launch_bounds__(K7_THREADS) void ba_reduced_solve_lds(BaDims d, BaB
     double* Us = Minv + 6 * n;                     // [Cf*36] U folded over the BA_UREP replicas
     double* gcs = Us + 6 * n;                      // [n] gc folded
     double* grs = gcs + n;                         // [n] gc + rhs folded: the reduced right-hand side
+    double* dvals = grs + n;                       // [n] the pivots D of L D L^T
     __shared__ BaState st;
     __shared__ int s_fail;
     __shared__ double red[4];
@@ -119,21 +137,23 @@ __global__ __launch_bounds__(K7_THREADS) void ba_reduced_solve_lds(BaDims d, BaB
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lr = lane & 15, lq = lane >> 4;
     const int NTL = (n + 1 + 15) / 16;             // tile rows/cols
-    const int ntiles = NTL * (NTL + 1) / 2;
+    // Tile ownership: wave w owns the two tile ROWS  rowA = w  and  rowB = NTL-1-w  (balanced: w+1 and
+    // NTL-w tiles).  Slot s < 4 is tile (rowA, s); slot 4+c is tile (rowB, c).  The column index of a slot
+    // is a compile-time constant, so the column operands of the trailing update are indexed statically and
+    // the row operands are just two registers — one code path for all waves (a per-wave template
+    // instantiation was 2x slower: four instruction streams thrash the instruction cache).
+    const int rowA = wave, rowB = (NTL - 1 - wave > wave) ? NTL - 1 - wave : -1;
     d4 acc[K7_TPW];
-    int tr[K7_TPW], tc[K7_TPW];
 #pragma unroll
     for (int s = 0; s < K7_TPW; s++) {
-        // lower-triangle tiles in row-major order: t -> (r, c), c <= r
-        const int t = wave + 4 * s;
-        int r = 0, rem = t;
-        while (rem > r) { rem -= r + 1; r++; }
-        tr[s] = (t < ntiles) ? r : -1;
-        tc[s] = rem;
-        const int k = 16 * rem + lr;
+        const int c = s < 4 ? s : s - 4;
+        const int r = s < 4 ? rowA : rowB;
+        const bool tile_ok = r >= 0 && r < NTL && c <= r;
+        const int rr = max(r, 0);
+        const int k = 16 * c + lr;
 #pragma unroll
         for (int q = 0; q < 4; q++) {
-            const int i = 16 * r + lq + 4 * q;
+            const int i = 16 * rr + lq + 4 * q;
             // unconditional loads from clamped addresses, then selects
             const int kc = min(k, n - 1), ic = min(i, n - 1);
             const int klo = min(kc, ic), khi = max(kc, ic);
@@ -142,33 +162,47 @@ __global__ __launch_bounds__(K7_THREADS) void ba_reduced_solve_lds(BaDims d, BaB
             const double gv = grs[kc];
             double val = sv + ((klo / 6 == khi / 6) ? uv : 0.0) + ((i == k) ? lam[ic] : 0.0);
             val = (k < n && i < n && k <= i) ? val : ((i == n && k < n) ? gv : 0.0);
-            acc[s][q] = (t < ntiles) ? val : 0.0;
+            acc[s][q] = tile_ok ? val : 0.0;
         }
     }
     BA_STAMP(b, 1);
 
+    // J-invariant addressing of the trailing update's operands
+    int rowoff[8];
+    bool rowok[8];
+#pragma unroll
+    for (int c = 0; c < 8; c++) { rowoff[c] = min(16 * c + lr, n) * LD; rowok[c] = 16 * c + lr <= n; }
+    const int rowoffA = min(16 * rowA + lr, n) * LD, rowoffB = min(16 * max(rowB, 0) + lr, n) * LD;
+    const bool rowokA = 16 * rowA + lr <= n, rowokB = rowB >= 0 && 16 * rowB + lr <= n;
+
     // (3) block Cholesky
     const int NB = n / 6;
+    W7_DECL;
     for (int J = 0; J < NB; J++) {
         const int c0 = 6 * J, r0 = c0 + 6;
         // publish block column J (k in [c0, c0+6), i >= k) from the owning tiles
 #pragma unroll
         for (int s = 0; s < K7_TPW; s++) {
-            if (tr[s] < 0 || 16 * tc[s] + 15 < c0 || 16 * tc[s] >= r0) continue;       // wave-uniform
-            const int k = 16 * tc[s] + lr;
+            const int c = s < 4 ? s : s - 4;
+            const int r = s < 4 ? rowA : rowB;
+            if (r < 0 || c > r || 16 * c + 15 < c0 || 16 * c >= r0) continue;       // wave-uniform
+            const int k = 16 * c + lr;
             if (k < c0 || k >= r0) continue;
 #pragma unroll
             for (int q = 0; q < 4; q++) {
-                const int i = 16 * tr[s] + lq + 4 * q;
-                if (i >= k && i <= n) A[(size_t)i * LD + k] = acc[s][q];
+                const int i = 16 * r + lq + 4 * q;
+                if (i >= k && i <= n) A[i * LD + k] = acc[s][q];
             }
         }
+        W7(0);
         __syncthreads();
+        W7(1);
         BA_STAMP(b, 2);
-        // (a) diagonal block: every lane factors and inverts it in registers
-        double M[6][6];
+        // (a) diagonal block: every lane factors it in registers as L D L^T (unit lower L, no square roots:
+        // the per-pivot dependency chain is one v_rcp_f64 + one Newton step) and inverts L.
+        double M[6][6], dinv[6], dpiv[6];      // M = L_JJ^-1 (unit lower), dinv = 1 / D, dpiv = D
         {
-            double L[6][6], iv[6];
+            double L[6][6];
 #pragma unroll
             for (int a = 0; a < 6; a++)
 #pragma unroll
@@ -178,38 +212,47 @@ __global__ __launch_bounds__(K7_THREADS) void ba_reduced_solve_lds(BaDims d, BaB
             for (int c = 0; c < 6; c++) {
                 const double piv = L[c][c];
                 if (!(piv > 0.0) || !isfinite(piv)) bad = true;
-                const double rs = fast_rsqrt(piv);
-                iv[c] = rs;
+                const double rd = fast_rcp(piv);
+                dinv[c] = rd;
+                dpiv[c] = piv;
+                double lc[6];
 #pragma unroll
-                for (int a = c + 1; a < 6; a++) L[a][c] *= rs;
+                for (int a = c + 1; a < 6; a++) lc[a] = L[a][c] * rd;              // l_ac; L[a][c] still holds l_ac * d_c
 #pragma unroll
                 for (int a = c + 1; a < 6; a++)
 #pragma unroll
-                    for (int e = c + 1; e <= a; e++) L[a][e] -= L[a][c] * L[e][c];
+                    for (int e = c + 1; e <= a; e++) L[a][e] -= lc[a] * L[e][c];   // a_ae -= l_ac d_c l_ec
+#pragma unroll
+                for (int a = c + 1; a < 6; a++) L[a][c] = lc[a];
             }
 #pragma unroll
             for (int e = 0; e < 6; e++) {
 #pragma unroll
                 for (int a = 0; a < e; a++) M[a][e] = 0.0;
-                M[e][e] = iv[e];
+                M[e][e] = 1.0;
 #pragma unroll
                 for (int a = e + 1; a < 6; a++) {
-                    double s = 0.0;
+                    double sacc = 0.0;
 #pragma unroll
-                    for (int k = e; k < a; k++) s -= L[a][k] * M[k][e];
-                    M[a][e] = s * iv[a];
+                    for (int k = e; k < a; k++) sacc -= L[a][k] * M[k][e];
+                    M[a][e] = sacc;
                 }
             }
             if (tid == 255) {        // off the critical path: only the backward substitution reads it
 #pragma unroll
                 for (int a = 0; a < 6; a++)
 #pragma unroll
-                    for (int e = 0; e < 6; e++) Minv[J * 36 + a * 6 + e] = (e <= a) ? M[a][e] : 0.0;
+                    for (int e = 0; e < 6; e++) Minv[J * 36 + a * 6 + e] = M[a][e];
                 if (bad) s_fail = 1;
             }
         }
+        W7(2);
         BA_STAMP(b, 3);
-        // (b) panel rows i > c0+5 (incl. the rhs row n): row_i <- row_i * L_JJ^-T
+        // (b) panel rows i > c0+5 (incl. the rhs row n): F_i = row_i L_JJ^-T D_J^-1  (the L factor of L D L^T)
+        if (tid == 254) {
+#pragma unroll
+            for (int e = 0; e < 6; e++) dvals[c0 + e] = dpiv[e];            // off the critical path (read by (c) after the barrier)
+        }
         for (int i = r0 + tid; i <= n; i += nt) {
             double* row = A + (size_t)i * LD + c0;
             double x[6], rr[6];
@@ -217,34 +260,54 @@ __global__ __launch_bounds__(K7_THREADS) void ba_reduced_solve_lds(BaDims d, BaB
             for (int e = 0; e < 6; e++) rr[e] = row[e];
 #pragma unroll
             for (int r = 0; r < 6; r++) {
-                double s = 0.0;
+                double sacc = rr[r];
 #pragma unroll
-                for (int e = 0; e <= r; e++) s += rr[e] * M[r][e];
-                x[r] = s;
+                for (int e = 0; e < r; e++) sacc += rr[e] * M[r][e];
+                x[r] = sacc * dinv[r];
             }
 #pragma unroll
             for (int r = 0; r < 6; r++) row[r] = x[r];
         }
+        W7(3);
         __syncthreads();
+        W7(4);
         BA_STAMP(b, 4);
-        // (c) trailing update on the matrix cores: tile(tr,tc) -= P[tr rows] P[tc rows]^T, K = 6 (+2 zero)
-#pragma unroll
-        for (int s = 0; s < K7_TPW; s++) {
-            if (tr[s] < 0 || 16 * tr[s] + 15 < r0 || 16 * tc[s] + 15 < r0) continue;  // wave-uniform
-            const int ra = 16 * tr[s] + lr, rb = 16 * tc[s] + lr;
+        // (c) trailing update on the matrix cores: tile(r,c) -= P_r P_c^T, K = 6 (+2 zero columns).  The
+        // panel operand of every tile COLUMN is loaded once per step (static index), the two owned rows
+        // once (negated).
+        {
+            double Pc[8][2], PnA[2], PnB[2];
 #pragma unroll
             for (int kc = 0; kc < 2; kc++) {
                 const int kk = 4 * kc + lq;
-                const int kcl = min(kk, 5);
-                const double ta = A[min(ra, n) * LD + c0 + kcl];
-                const double tb = A[min(rb, n) * LD + c0 + kcl];
-                const double a = (ra >= r0 && ra <= n && kk < 6) ? -ta : 0.0;
-                const double bb = (rb >= r0 && rb <= n && kk < 6) ? tb : 0.0;
-                acc[s] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, bb, acc[s], 0, 0, 0);
+                const int kcl = c0 + min(kk, 5);
+                const bool kv = kk < 6;
+                const double dk = dvals[kcl];
+                // branch-free: unconditional reads from clamped (hoisted) row offsets, then selects
+#pragma unroll
+                for (int c = 0; c < 8; c++) {
+                    const double t = A[rowoff[c] + kcl];
+                    Pc[c][kc] = (kv && rowok[c] && 16 * c + lr >= r0) ? t * dk : 0.0;      // B operand = P = F D
+                }
+                const double ta = A[rowoffA + kcl], tb = A[rowoffB + kcl];
+                PnA[kc] = (kv && rowokA && 16 * rowA + lr >= r0) ? -ta : 0.0;
+                PnB[kc] = (kv && rowokB && 16 * rowB + lr >= r0) ? -tb : 0.0;
+            }
+            const bool actA = 16 * rowA + 15 >= r0, actB = rowB >= 0 && 16 * rowB + 15 >= r0;
+#pragma unroll
+            for (int kc = 0; kc < 2; kc++) {
+#pragma unroll
+                for (int c = 0; c < 8; c++) {
+                    if (16 * c + 15 < r0) continue;                                     // wave-uniform
+                    if (c < 4 && actA && c <= rowA) acc[c] = __builtin_amdgcn_mfma_f64_16x16x4f64(PnA[kc], Pc[c][kc], acc[c], 0, 0, 0);
+                    if (actB && c <= rowB) acc[4 + c] = __builtin_amdgcn_mfma_f64_16x16x4f64(PnB[kc], Pc[c][kc], acc[4 + c], 0, 0, 0);
+                }
             }
         }
+        W7(5);
         BA_STAMP(b, 5);
     }
+    W7_FLUSH(b);
     __syncthreads();
     if (tid < 64) { const double f = slot_sum(b.scal, 1); if (f > 0.0 && tid == 0) s_fail = 1; }
     __syncthreads();
@@ -316,7 +379,7 @@ __global__ __launch_bounds__(K7_THREADS) void ba_reduced_solve_lds(BaDims d, BaB
 size_t ba_reduced_solve_lds_bytes(int n)
 {
     const int LD = n + 1 + ((n & 1) ? 1 : 0);
-    return sizeof(double) * ((size_t)(n + 1) * LD + 2 * (size_t)n + 6 * (size_t)n + 6 * (size_t)n + 2 * (size_t)n + 8);
+    return sizeof(double) * ((size_t)(n + 1) * LD + 2 * (size_t)n + 6 * (size_t)n + 6 * (size_t)n + 3 * (size_t)n + 8);
 }
 
 void ba_launch_reduced_solve_lds(hipStream_t s, const BaDims& d, const BaBufs& b, const BaOpt& opt)
