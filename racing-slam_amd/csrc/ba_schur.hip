@@ -26,7 +26,8 @@
 #include "ba_common.h"
 
 #define IT_L 64                 // landmarks per item (= per workgroup; 16 per wave)
-#define SCH_WAVES 4             // waves per workgroup
+#define SCH_WAVES 8             // waves per workgroup (2 per SIMD: latency hiding; <= 2 SYRK tiles per wave)
+#define SCH_SUBS 8              // lanes sharing one landmark (8 landmarks per wave)
 #define YT_STRIDE4 81           // doubles per K-column, NT = 4: 64 rows + 17 (17 mod 32 keeps the two
                                 // half-wave column groups of a ds_read_b64 on disjoint banks; 3*81*2 = 6 mod 32
                                 // spreads the 16 producer lanes over 16 bank pairs)
@@ -213,6 +214,7 @@ __device__ __forceinline__ void syrk_scatter(const double* yt, int nchunks, int 
         if (wave + SCH_WAVES * t < NT * (NT + 1) / 2) tile_rc(wave + SCH_WAVES * t, NT, r, c);
         tr[t] = r; tc[t] = c;               // c >= nt_used marks an unused slot
     }
+#pragma unroll 4
     for (int kc = 0; kc < nchunks; kc++) {
         const double* col = yt + (size_t)(kc * 4 + lk) * STRIDE + lr;
 #pragma unroll
@@ -271,8 +273,8 @@ __global__ __launch_bounds__(64 * SCH_WAVES) void ba_schur_mfma(BaDims d, BaBufs
     const size_t rep_off = (size_t)(blockIdx.x & (BA_UREP - 1)) * b.cam_stride;
     double* rhs_rep = b.rhs + rep_off;
     double cost = 0.0, gmax = 0.0, fail = 0.0;
-    const int l = lane & 15, sub = lane >> 4;
-    const int wl = 16 * wave + l;                    // landmark slot inside the item
+    const int l = lane & 7, sub = lane >> 3;         // 8 landmarks per wave, 8 lanes each
+    const int wl = 8 * wave + l;                     // landmark slot inside the item
     const int q = item * IT_L + wl;
     const int p = q < d.P ? g.sorted[q] : -1;
 
@@ -286,7 +288,7 @@ __global__ __launch_bounds__(64 * SCH_WAVES) void ba_schur_mfma(BaDims d, BaBufs
     // ---- pass 1: V, g, cost, U/gc
     double V[6] = {0, 0, 0, 0, 0, 0}, gv[3] = {0, 0, 0};
     ObsLin o;
-    for (int j = sub; j < nobs; j += 4) {
+    for (int j = sub; j < nobs; j += SCH_SUBS) {
         int jj = j + l; while (jj >= nobs) jj -= nobs;     // staggered: lanes of one round hit different cameras
         const int oi = o0 + jj;
         const int c = b.obs_cam[oi];
@@ -314,11 +316,11 @@ __global__ __launch_bounds__(64 * SCH_WAVES) void ba_schur_mfma(BaDims d, BaBufs
         }
     }
     BA_STAMP(b, 1);
-    // the 4 sub-lanes of a landmark (lanes l, l+16, l+32, l+48) combine their partial sums
+    // the 8 sub-lanes of a landmark (lanes l + 8 s) combine their partial sums
 #pragma unroll
-    for (int k = 0; k < 6; k++) { V[k] += __shfl_xor(V[k], 16, 64); V[k] += __shfl_xor(V[k], 32, 64); }
+    for (int k = 0; k < 6; k++) { V[k] += __shfl_xor(V[k], 8, 64); V[k] += __shfl_xor(V[k], 16, 64); V[k] += __shfl_xor(V[k], 32, 64); }
 #pragma unroll
-    for (int k = 0; k < 3; k++) { gv[k] += __shfl_xor(gv[k], 16, 64); gv[k] += __shfl_xor(gv[k], 32, 64); }
+    for (int k = 0; k < 3; k++) { gv[k] += __shfl_xor(gv[k], 8, 64); gv[k] += __shfl_xor(gv[k], 16, 64); gv[k] += __shfl_xor(gv[k], 32, 64); }
 
     double Li[6] = {0, 0, 0, 0, 0, 0}, I[6] = {0, 0, 0, 0, 0, 0};
     bool ok = false;
@@ -370,7 +372,7 @@ __global__ __launch_bounds__(64 * SCH_WAVES) void ba_schur_mfma(BaDims d, BaBufs
             BA_STAMP(b, 3);
             const int lb = wl - bt * lb_n;
             if (p >= 0 && ok && lb >= 0 && lb < lb_n) {
-                for (int j = sub; j < nobs; j += 4) {
+                for (int j = sub; j < nobs; j += SCH_SUBS) {
                     const int oi = o0 + j;
                     const int c = b.obs_cam[oi];
                     const float2 uvv = b.obs_uv[oi];
@@ -397,8 +399,8 @@ __global__ __launch_bounds__(64 * SCH_WAVES) void ba_schur_mfma(BaDims d, BaBufs
             }
             __syncthreads();
             BA_STAMP(b, 4);
-            if (big) syrk_scatter<8, 9, YT_STRIDE8>(yt, ncol / 4, ns, gslot, d.n, wave, b.S, rhs_rep);
-            else syrk_scatter<4, 3, YT_STRIDE4>(yt, ncol / 4, ns, gslot, d.n, wave, b.S, rhs_rep);
+            if (big) syrk_scatter<8, 5, YT_STRIDE8>(yt, ncol / 4, ns, gslot, d.n, wave, b.S, rhs_rep);
+            else syrk_scatter<4, 2, YT_STRIDE4>(yt, ncol / 4, ns, gslot, d.n, wave, b.S, rhs_rep);
         }
     } else if (ns > 21) {
         // generic fallback: per-landmark f64 atomics (any covisibility pattern)
