@@ -38,7 +38,8 @@ __global__ void ba_init(BaDims d, BaBufs b, BaOpt opt, const double* __restrict_
     for (int i = tid; i < d.P * 3; i += nth) b.Xp[i] = pts_in[i];
     for (int c = tid; c < d.C; c += nth) cam_prepare(cams_in + 6 * c, b.prep + (size_t)c * BA_PREP);
     for (size_t i = tid; i < b.acc_count; i += nth) b.acc[i] = 0.0;
-    for (int i = tid; i < BA_NSLOT * BA_SLOT_STRIDE; i += nth) { b.pt_scal[i] = 0.0; b.gmax[i] = 0.0; }
+    for (int i = tid; i < 2 * BA_NSLOT * BA_SLOT_STRIDE; i += nth) b.pt_scal[i] = 0.0;
+    for (int i = tid; i < BA_NSLOT * BA_SLOT_STRIDE; i += nth) b.gmax[i] = 0.0;
     if (tid == 0) {
         BaState s;
         s.radius = opt.r0; s.decrease_factor = 2.0; s.x_cost = 0.0; s.initial_cost = 0.0;
@@ -46,15 +47,16 @@ __global__ void ba_init(BaDims d, BaBufs b, BaOpt opt, const double* __restrict_
         s.iter = 0; s.successful = 0; s.invalid_steps = 0; s.done = 0;
         s.termination = 0; s.cur = 0; s.have_scale = 0; s.solver_failed = 0;
         s.fresh = 1; s.usable = 0; s.pad0 = 0; s.pad1 = 0;
-        *b.st = s;
+        b.st[1] = s;      // the state iteration 0 starts from (st[(0 + 1) & 1])
     }
 }
 
 // ---------------------------------------------------------------------- K5
-__global__ __launch_bounds__(BA_THREADS) void ba_linearize_schur(BaDims d, BaBufs b, BaOpt opt)
+__global__ __launch_bounds__(BA_THREADS) void ba_linearize_schur(BaDims d, BaBufs b, BaOpt opt, int it)
 {
     extern __shared__ __attribute__((aligned(16))) double lds[];   // [Cf][42]: U(36) gc(6)
-    const BaState st = *b.st;
+    __shared__ BaState st_sh;
+    const BaState st = ba_state_for_iteration(b, opt, it, &st_sh);
     if (st.done) return;
     const int nlds = d.Cf * 42;
     for (int i = threadIdx.x; i < nlds; i += blockDim.x) lds[i] = 0.0;
@@ -189,6 +191,7 @@ __global__ __launch_bounds__(256) void ba_reduced_solve(BaDims d, BaBufs b, BaOp
     if (tid == 0) { st = *b.st; s_fail = 0; }
     __syncthreads();
     if (st.done) return;
+    for (int i = tid; i < BA_NSLOT * BA_SLOT_STRIDE; i += nt) b.pt_scal[i] = 0.0;     // K8 of this iteration accumulates here
     // fold the BA_UREP replicas of the camera-side accumulators into replica 0
     for (size_t i = tid; i < b.cam_stride; i += nt) {
         double v = 0.0;
@@ -345,7 +348,10 @@ __global__ __launch_bounds__(256) void ba_reduced_solve(BaDims d, BaBufs b, BaOp
 __global__ __launch_bounds__(BA_THREADS) void ba_backsub_cost(BaDims d, BaBufs b)
 {
     const BaState st = *b.st;
-    if (st.done || st.solver_failed) return;
+    if (st.done) return;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < b.acc_count; i += (size_t)gridDim.x * blockDim.x) b.acc[i] = 0.0;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < BA_NSLOT * BA_SLOT_STRIDE; i += gridDim.x * blockDim.x) b.gmax[i] = 0.0;
+    if (st.solver_failed) return;
     const double* prep = b.prep + (size_t)st.cur * d.C * BA_PREP;
     const double* prepn = b.prep + (size_t)(st.cur ^ 1) * d.C * BA_PREP;
     const double* Xp = b.Xp + (size_t)st.cur * d.P * 3;
@@ -396,75 +402,31 @@ __global__ __launch_bounds__(BA_THREADS) void ba_backsub_cost(BaDims d, BaBufs b
     }
 }
 
-// ---------------------------------------------------------------------- K9
-__global__ __launch_bounds__(256) void ba_decide(BaDims d, BaBufs b, BaOpt opt)
+// -------------------------------------------------------------------- finalize
+__global__ void ba_finalize(BaDims d, BaBufs b, BaOpt opt, int it, double* __restrict__ cams_out,
+                            const uint8_t* __restrict__ cam_free, double* __restrict__ pts_out)
 {
-    __shared__ int was_done;
-    double ps0 = 0.0, ps1 = 0.0, ps2 = 0.0, ps3 = 0.0;
-    if (threadIdx.x < 64) { ps0 = slot_sum(b.pt_scal, 0); ps1 = slot_sum(b.pt_scal, 1); ps2 = slot_sum(b.pt_scal, 2); ps3 = slot_sum(b.pt_scal, 3); }
-    if (threadIdx.x == 0) {
-        BaState st = *b.st;
-        was_done = st.done;
-        if (!st.done) {
-            st.iter++;
-            const double cand = ps0;
-            const double mcc = ps1 + st.cam_scal[0];
-            const double step_norm = sqrt(ps2 + st.cam_scal[1]);
-            const double x_norm = sqrt(ps3 + st.cam_scal[2]);
-            st.fresh = 0;
-            if (st.solver_failed || !(mcc > 0.0)) {
-                // TrustRegionMinimizer::HandleInvalidStep
-                if (++st.invalid_steps >= opt.max_invalid) { st.done = 1; st.termination = RS_BA_FAILURE; }
-                else { st.radius /= st.decrease_factor; st.decrease_factor *= 2.0; }
-            } else {
-                st.invalid_steps = 0;
-                if (step_norm <= opt.ptol * (x_norm + opt.ptol)) { st.done = 1; st.termination = RS_BA_CONVERGENCE_PARAMETER; }
-                else if (fabs(st.x_cost - cand) <= opt.ftol * st.x_cost) { st.done = 1; st.termination = RS_BA_CONVERGENCE_FUNCTION; }
-                else {
-                    const double rel = (st.x_cost - cand) / mcc;
-                    if (rel > opt.min_rel && isfinite(cand)) {
-                        st.cur ^= 1;
-                        st.successful++;
-                        const double t = 2.0 * rel - 1.0;
-                        st.radius = st.radius / fmax(1.0 / 3.0, 1.0 - t * t * t);
-                        st.radius = fmin(opt.rmax, st.radius);
-                        st.decrease_factor = 2.0;
-                        st.fresh = 1;
-                        st.x_cost = cand;   // replaced by K5's evaluation at the new point
-                    } else {
-                        st.radius /= st.decrease_factor;
-                        st.decrease_factor *= 2.0;
-                        if (st.radius < opt.rmin) { st.done = 1; st.termination = RS_BA_CONVERGENCE_RADIUS; }
-                    }
-                }
-            }
-            st.solver_failed = 0;
-            st.have_scale = 1;
-            if (!st.done && st.iter >= opt.max_iter) { st.done = 1; st.termination = RS_BA_NO_CONVERGENCE; }
-            *b.st = st;
+    __shared__ int usable, cur;
+    __shared__ BaState st_fin;
+    // the decision of the last iteration (every workgroup recomputes it; b.st_prev / b.pt_prev are immutable here)
+    if (threadIdx.x < 64) {
+        double p0 = 0.0, p1 = 0.0, p2 = 0.0, p3 = 0.0;
+        if (it > 0) { p0 = slot_sum(b.pt_prev, 0); p1 = slot_sum(b.pt_prev, 1); p2 = slot_sum(b.pt_prev, 2); p3 = slot_sum(b.pt_prev, 3); }
+        if (threadIdx.x == 0) {
+            BaState s0 = *b.st_prev;
+            if (it > 0) ba_apply_decision(s0, p0, p1, p2, p3, opt);
+            st_fin = s0;
         }
     }
     __syncthreads();
-    if (was_done) return;
-    // reset the accumulators for the next linearisation
-    const int tid = blockIdx.x * blockDim.x + threadIdx.x, nth = gridDim.x * blockDim.x;
-    for (size_t i = tid; i < b.acc_count; i += nth) b.acc[i] = 0.0;
-    for (int i = tid; i < BA_NSLOT * BA_SLOT_STRIDE; i += nth) { b.pt_scal[i] = 0.0; b.gmax[i] = 0.0; }
-}
-
-// -------------------------------------------------------------------- finalize
-__global__ void ba_finalize(BaDims d, BaBufs b, double* __restrict__ cams_out, const uint8_t* __restrict__ cam_free,
-                            double* __restrict__ pts_out)
-{
-    __shared__ int usable, cur;
     if (threadIdx.x == 0) {
-        BaState st = *b.st;
+        BaState st = st_fin;
         // after a successful step the cost at the new point is K5's value if it ran, else the candidate cost
         const bool ok = st.termination != RS_BA_FAILURE && isfinite(st.x_cost) && st.x_cost <= st.initial_cost;
         usable = ok ? 1 : 0;
         cur = st.cur;
         st.usable = usable;
-        if (blockIdx.x == 0) b.st->usable = usable;     // only this field: other workgroups are reading the rest
+        if (blockIdx.x == 0) *b.st = st;
     }
     __syncthreads();
     if (!usable) return;
@@ -559,8 +521,8 @@ extern "C" int rs_bundle_adjust(rs_context* ctx, int n_cameras, int n_points, in
     const size_t cam_stride = (size_t)d.Cf * 36 + 2 * n;
     const size_t acc_count = n * n + (size_t)BA_UREP * cam_stride + (size_t)BA_NSLOT * BA_SLOT_STRIDE;
     const size_t o_acc = carve(sizeof(double) * acc_count);
-    const size_t o_gmax = carve(sizeof(double) * BA_NSLOT * BA_SLOT_STRIDE), o_pts = carve(sizeof(double) * BA_NSLOT * BA_SLOT_STRIDE), o_dc = carve(sizeof(double) * (n + 1));
-    const size_t o_st = carve(sizeof(BaState));
+    const size_t o_gmax = carve(sizeof(double) * BA_NSLOT * BA_SLOT_STRIDE), o_pts = carve(sizeof(double) * 2 * BA_NSLOT * BA_SLOT_STRIDE), o_dc = carve(sizeof(double) * (n + 1));
+    const size_t o_st = carve(sizeof(BaState) * 2);
     const size_t o_dbg = carve(sizeof(unsigned long long) * 64);
     const size_t o_free = carve(C);
     const bool use_mfma = d.Cf >= 1 && d.Cf <= 128 && ba_schur_lds_bytes(d.C, d.Cf) <= 160 * 1024;
@@ -580,6 +542,10 @@ extern "C" int rs_bundle_adjust(rs_context* ctx, int n_cameras, int n_points, in
     b.cam_stride = cam_stride; b.scal = b.rhs + (size_t)BA_UREP * cam_stride;
     b.gmax = (double*)(ws + o_gmax); b.pt_scal = (double*)(ws + o_pts); b.dc = (double*)(ws + o_dc);
     b.st = (BaState*)(ws + o_st);
+    b.st_prev = b.st;
+    b.pt_prev = b.pt_scal;
+    BaState* const st_base = b.st;
+    double* const pts_base = b.pt_scal;
     b.dbg = (unsigned long long*)(ws + o_dbg);
     RS_HIP(ctx, hipMemsetAsync(b.dbg, 0, sizeof(unsigned long long) * 64, ctx->stream));
     ctx->ba_cache = b.dbg;
@@ -617,12 +583,16 @@ extern "C" int rs_bundle_adjust(rs_context* ctx, int n_cameras, int n_points, in
         if (rc) return rc;
     }
     for (int it = 0; it < opt.max_iter; it++) {
+        // double-buffered state / step-scalar blocks: iteration `it` works on [it & 1] and reads [(it + 1) & 1]
+        b.st = st_base + (it & 1); b.st_prev = st_base + ((it + 1) & 1);
+        b.pt_scal = pts_base + (size_t)(it & 1) * BA_NSLOT * BA_SLOT_STRIDE;
+        b.pt_prev = pts_base + (size_t)((it + 1) & 1) * BA_NSLOT * BA_SLOT_STRIDE;
         if (use_mfma) {
             rs_prof_scope ps(ctx, "K5_ba_schur_mfma");
-            ba_launch_schur(s, d, b, opt, grp);
+            ba_launch_schur(s, d, b, opt, grp, it);
         } else {
             rs_prof_scope ps(ctx, "K5_ba_linearize_schur");
-            hipLaunchKernelGGL(ba_linearize_schur, dim3(pblocks), dim3(BA_THREADS), k5_lds, s, d, b, opt);
+            hipLaunchKernelGGL(ba_linearize_schur, dim3(pblocks), dim3(BA_THREADS), k5_lds, s, d, b, opt, it);
         }
         if (ctx->comm) {
             rs_prof_scope ps(ctx, "C1_allreduce_system");
@@ -650,14 +620,14 @@ extern "C" int rs_bundle_adjust(rs_context* ctx, int n_cameras, int n_points, in
             rc = rs_allreduce_f64(ctx, b.pt_scal, BA_NSLOT * BA_SLOT_STRIDE, false);
             if (rc) return rc;
         }
-        {
-            rs_prof_scope ps(ctx, "K9_ba_decide");
-            hipLaunchKernelGGL(ba_decide, dim3(1), dim3(256), 0, s, d, b, opt);
-        }
     }
     {
         rs_prof_scope ps(ctx, "K10_ba_finalize");
-        hipLaunchKernelGGL(ba_finalize, dim3(32), dim3(256), 0, s, d, b, d_cameras, (const uint8_t*)d_cam_free, d_points);
+        // the last decision: iteration index max_iter reads the blocks of iteration max_iter - 1
+        const int itf = opt.max_iter;
+        b.st = st_base + (itf & 1); b.st_prev = st_base + ((itf + 1) & 1);
+        b.pt_prev = pts_base + (size_t)((itf + 1) & 1) * BA_NSLOT * BA_SLOT_STRIDE;
+        hipLaunchKernelGGL(ba_finalize, dim3(32), dim3(256), 0, s, d, b, opt, itf, d_cameras, (const uint8_t*)d_cam_free, d_points);
     }
     RS_HIP(ctx, hipMemcpyAsync(h_st, b.st, sizeof(BaState), hipMemcpyDeviceToHost, s));
     RS_HIP(ctx, hipStreamSynchronize(s));

@@ -48,10 +48,12 @@ struct BaBufs {
     size_t cam_stride;       // doubles per replica = Cf*36 + 2n
     double* scal;    // [BA_NSLOT][8] per slot: cost_x, fail_count (summed by K7)
     double* gmax;    // [BA_NSLOT][8] per slot: bits of a non-negative double (max; K7 folds)
-    double* pt_scal; // [BA_NSLOT][8] per slot, K8: cand_cost, mcc_p, step_sq_p, x_sq_p (summed by K9)
+    double* pt_scal; // [BA_NSLOT][8] per slot, K8 of THIS iteration: cand_cost, mcc_p, step_sq_p, x_sq_p
+    const double* pt_prev;   // the same block of the PREVIOUS iteration (read by the next linearisation's decision)
     double* dc;      // [n]
     unsigned long long* dbg;   // [64] in-kernel phase cycle counters (diagnostic; rs_prof_counters)
-    BaState* st;
+    BaState* st;             // state of THIS iteration (st[it & 1])
+    const BaState* st_prev;  // state the previous iteration ended with (st[(it + 1) & 1])
 };
 
 struct BaOpt {
@@ -180,6 +182,53 @@ __device__ __forceinline__ void atomic_max_nonneg(double* addr, double v)
 
 __device__ __forceinline__ double clampd(double v, double lo, double hi) { return fmin(fmax(v, lo), hi); }
 
+__device__ __forceinline__ double slot_sum(const double* base, int field);
+
+// ---- the accept / reject decision of one LM step (TrustRegionMinimizer / LevenbergMarquardtStrategy,
+// see oracle/ba.c).  There is no separate "decide" launch: the first kernel of iteration `it`
+// applies the decision of iteration it-1 itself — every workgroup redundantly, from the previous
+// state block and the previous slot sums (both immutable during this launch); workgroup 0 stores
+// the result as this iteration's state.
+__device__ __forceinline__ void ba_apply_decision(BaState& st, double cand, double mcc_p, double ssq_p, double xsq_p,
+                                                  const BaOpt& opt)
+{
+    if (st.done) return;
+    st.iter++;
+    const double mcc = mcc_p + st.cam_scal[0];
+    const double step_norm = sqrt(ssq_p + st.cam_scal[1]);
+    const double x_norm = sqrt(xsq_p + st.cam_scal[2]);
+    st.fresh = 0;
+    if (st.solver_failed || !(mcc > 0.0)) {
+        // TrustRegionMinimizer::HandleInvalidStep
+        if (++st.invalid_steps >= opt.max_invalid) { st.done = 1; st.termination = RS_BA_FAILURE; }
+        else { st.radius /= st.decrease_factor; st.decrease_factor *= 2.0; }
+    } else {
+        st.invalid_steps = 0;
+        if (step_norm <= opt.ptol * (x_norm + opt.ptol)) { st.done = 1; st.termination = RS_BA_CONVERGENCE_PARAMETER; }
+        else if (fabs(st.x_cost - cand) <= opt.ftol * st.x_cost) { st.done = 1; st.termination = RS_BA_CONVERGENCE_FUNCTION; }
+        else {
+            const double rel = (st.x_cost - cand) / mcc;
+            if (rel > opt.min_rel && isfinite(cand)) {
+                st.cur ^= 1;
+                st.successful++;
+                const double t = 2.0 * rel - 1.0;
+                st.radius = st.radius / fmax(1.0 / 3.0, 1.0 - t * t * t);
+                st.radius = fmin(opt.rmax, st.radius);
+                st.decrease_factor = 2.0;
+                st.fresh = 1;
+                st.x_cost = cand;   // replaced by the evaluation at the new point
+            } else {
+                st.radius /= st.decrease_factor;
+                st.decrease_factor *= 2.0;
+                if (st.radius < opt.rmin) { st.done = 1; st.termination = RS_BA_CONVERGENCE_RADIUS; }
+            }
+        }
+    }
+    st.solver_failed = 0;
+    st.have_scale = 1;
+    if (!st.done && st.iter >= opt.max_iter) { st.done = 1; st.termination = RS_BA_NO_CONVERGENCE; }
+}
+
 // fold the BA_NSLOT partial slots (one wave, lane = slot); result valid in every lane
 __device__ __forceinline__ double slot_sum(const double* base, int field)
 {
@@ -200,6 +249,23 @@ __device__ __forceinline__ double slot_max_bits(const double* base)
 // phase stamps: thread 0 of block 0 accumulates s_memtime deltas per phase in REGISTERS
 // (static slot indices) and flushes them once at kernel end, so the stamps do not add
 // global-memory round trips to the phases they measure.
+// state of iteration `it` (called by all threads of the first kernel of the iteration; one barrier)
+__device__ __forceinline__ BaState ba_state_for_iteration(const BaBufs& b, const BaOpt& opt, int it, BaState* sh)
+{
+    if (threadIdx.x < 64) {
+        double p0 = 0.0, p1 = 0.0, p2 = 0.0, p3 = 0.0;
+        if (it > 0) { p0 = slot_sum(b.pt_prev, 0); p1 = slot_sum(b.pt_prev, 1); p2 = slot_sum(b.pt_prev, 2); p3 = slot_sum(b.pt_prev, 3); }
+        if (threadIdx.x == 0) {
+            BaState s = *b.st_prev;
+            if (it > 0) ba_apply_decision(s, p0, p1, p2, p3, opt);
+            *sh = s;
+            if (blockIdx.x == 0) *b.st = s;
+        }
+    }
+    __syncthreads();
+    return *sh;
+}
+
 #ifndef RS_STAMPS
 #define RS_STAMPS 0
 #endif
@@ -246,7 +312,7 @@ void ba_group_carve(char* base, int P, int Cf, BaGroup* g);
 int ba_launch_grouping(rs_context* ctx, const BaDims& d, const BaBufs& b, const BaGroup& g);
 size_t ba_schur_lds_bytes(int C, int Cf);
 int ba_prepare_schur(int C, int Cf);
-void ba_launch_schur(hipStream_t s, const BaDims& d, const BaBufs& b, const BaOpt& opt, const BaGroup& g);
+void ba_launch_schur(hipStream_t s, const BaDims& d, const BaBufs& b, const BaOpt& opt, const BaGroup& g, int it);
 // ---- LDS-resident reduced solve (ba_solve.hip), n = 6*Cf <= BA_MAX_LDS_N
 size_t ba_reduced_solve_lds_bytes(int n);
 int ba_prepare_reduced_solve_lds(int n);

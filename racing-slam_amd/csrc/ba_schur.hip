@@ -243,11 +243,12 @@ __device__ __forceinline__ void syrk_scatter(const double* yt, int nchunks, int 
 
 // ---------------------------------------------------------------------- K5
 // One workgroup = one item of IT_L = 64 sorted landmarks (16 per wave).
-__global__ __launch_bounds__(64 * SCH_WAVES) void ba_schur_mfma(BaDims d, BaBufs b, BaOpt opt, BaGroup g)
+__global__ __launch_bounds__(64 * SCH_WAVES) void ba_schur_mfma(BaDims d, BaBufs b, BaOpt opt, BaGroup g, int it)
 {
     extern __shared__ __attribute__((aligned(16))) double lds[];
     BA_STAMP_DECL;
-    const BaState st = *b.st;
+    __shared__ BaState st_sh;
+    const BaState st = ba_state_for_iteration(b, opt, it, &st_sh);
     if (st.done) return;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -518,7 +519,7 @@ int ba_prepare_schur(int C, int Cf)
                                     (int)ba_schur_lds_bytes(C, Cf));
 }
 
-void ba_launch_schur(hipStream_t s, const BaDims& d, const BaBufs& b, const BaOpt& opt, const BaGroup& g)
+void ba_launch_schur(hipStream_t s, const BaDims& d, const BaBufs& b, const BaOpt& opt, const BaGroup& g, int it)
 {
-    hipLaunchKernelGGL(ba_schur_mfma, dim3(g.n_items), dim3(64 * SCH_WAVES), ba_schur_lds_bytes(d.C, d.Cf), s, d, b, opt, g);
+    hipLaunchKernelGGL(ba_schur_mfma, dim3(g.n_items), dim3(64 * SCH_WAVES), ba_schur_lds_bytes(d.C, d.Cf), s, d, b, opt, g, it);
 }

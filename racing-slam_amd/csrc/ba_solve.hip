@@ -79,6 +79,7 @@ __global__ __launch_bounds__(K7_THREADS) void ba_reduced_solve_lds(BaDims d, BaB
     if (tid == 0) { st = *b.st; s_fail = 0; }
     __syncthreads();
     if (st.done) return;
+    for (int i = tid; i < BA_NSLOT * BA_SLOT_STRIDE; i += nt) b.pt_scal[i] = 0.0;     // K8 of this iteration accumulates here
     // fold the replicas of the camera-side accumulators (replica layout: rhs[n] U[Cf*36] gc[n])
     for (int i = tid; i < (int)b.cam_stride; i += nt) {
         double v = 0.0;

@@ -17,7 +17,11 @@ __global__ __launch_bounds__(K8_THREADS) void ba_backsub_cost4(BaDims d, BaBufs 
 {
     extern __shared__ __attribute__((aligned(16))) double lds[];
     const BaState st = *b.st;
-    if (st.done || st.solver_failed) return;
+    if (st.done) return;
+    // K7 has consumed the accumulators: clear them for the next linearisation (no separate launch)
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < b.acc_count; i += (size_t)gridDim.x * blockDim.x) b.acc[i] = 0.0;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < BA_NSLOT * BA_SLOT_STRIDE; i += gridDim.x * blockDim.x) b.gmax[i] = 0.0;
+    if (st.solver_failed) return;
     double* cprep = lds;                                    // [C][BA_PREP] current
     double* cprepn = lds + (size_t)d.C * BA_PREP;           // [C][BA_PREP] candidate
     double* dcl = cprepn + (size_t)d.C * BA_PREP;           // [n] delta_c
