@@ -26,17 +26,17 @@
 // Phase timings (s_memtime stamps) are in DESIGN.md.
 #include "ba_common.h"
 
-#define K7_THREADS 256
+#define K7_THREADS 512
 #if RS_STAMPS
 #define W7_DECL unsigned long long w7_acc[8] = {0,0,0,0,0,0,0,0}; unsigned long long w7_t = clock64()
 #define W7(idx) do { if ((threadIdx.x & 63) == 0) { const unsigned long long t__ = clock64(); w7_acc[idx] += t__ - w7_t; w7_t = t__; } } while (0)
-#define W7_FLUSH(b) do { if ((threadIdx.x & 63) == 0) { _Pragma("unroll") for (int q__ = 0; q__ < 8; q__++) (b).dbg[16 + (threadIdx.x >> 6) * 8 + q__] += w7_acc[q__]; } } while (0)
+#define W7_FLUSH(b) do { if ((threadIdx.x & 63) == 0) { _Pragma("unroll") for (int q__ = 0; q__ < 8; q__++) if ((threadIdx.x >> 6) < 4) (b).dbg[16 + (threadIdx.x >> 6) * 8 + q__] += w7_acc[q__]; } } while (0)
 #else
 #define W7_DECL do { } while (0)
 #define W7(idx) do { } while (0)
 #define W7_FLUSH(b) do { } while (0)
 #endif
-#define K7_TPW 12      // tiles per wave: tile rows w (<= 4 tiles) and NTL-1-w (<= 8 tiles)
+#define K7_TPW 6       // tiles per tile wave: 6 tile waves x 6 = the 36 lower-triangle tiles of a 128 x 128 matrix
 
 typedef __attribute__((ext_vector_type(4))) double d4;
 
@@ -58,6 +58,7 @@ __device__ __forceinline__ double fast_rcp(double x)
     return fma(r, e, r);
 }
 
+
 __global__ __launch_bounds__(K7_THREADS) void ba_reduced_solve_lds(BaDims d, BaBufs b, BaOpt opt)
 {
     extern __shared__ __attribute__((aligned(16))) double sm[];
@@ -71,15 +72,20 @@ __global__ __launch_bounds__(K7_THREADS) void ba_reduced_solve_lds(BaDims d, BaB
     double* gcs = Us + 6 * n;                      // [n] gc folded
     double* grs = gcs + n;                         // [n] gc + rhs folded: the reduced right-hand side
     double* dvals = grs + n;                       // [n] the pivots D of L D L^T
+    // MFMA operand panels of the current step, k-major: Pd[e][i] = F[i][e] d_e, Nf[e][i] = -F[i][e];
+    // rows e = 6, 7 stay zero (K = 6 padded to 8).  16-byte aligned.
+    double* Pd = sm + (((size_t)(n + 1) * LD + 17 * (size_t)n + 1) & ~(size_t)1);
+    double* Nf = Pd + 8 * 128;
     __shared__ BaState st;
     __shared__ int s_fail;
-    __shared__ double red[4];
-    __shared__ double red3[4][3];
+    __shared__ double red[K7_THREADS / 64];
+    __shared__ double red3[K7_THREADS / 64][3];
     BA_STAMP_DECL;
     if (tid == 0) { st = *b.st; s_fail = 0; }
     __syncthreads();
     if (st.done) return;
     for (int i = tid; i < BA_NSLOT * BA_SLOT_STRIDE; i += nt) b.pt_scal[i] = 0.0;     // K8 of this iteration accumulates here
+    for (int i = tid; i < 2 * 8 * 128; i += nt) Pd[i] = 0.0;
     // fold the replicas of the camera-side accumulators (replica layout: rhs[n] U[Cf*36] gc[n])
     for (int i = tid; i < (int)b.cam_stride; i += nt) {
         double v = 0.0;
@@ -138,23 +144,32 @@ __global__ __launch_bounds__(K7_THREADS) void ba_reduced_solve_lds(BaDims d, BaB
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lr = lane & 15, lq = lane >> 4;
     const int NTL = (n + 1 + 15) / 16;             // tile rows/cols
-    // Tile ownership: wave w owns the two tile ROWS  rowA = w  and  rowB = NTL-1-w  (balanced: w+1 and
-    // NTL-w tiles).  Slot s < 4 is tile (rowA, s); slot 4+c is tile (rowB, c).  The column index of a slot
-    // is a compile-time constant, so the column operands of the trailing update are indexed statically and
-    // the row operands are just two registers — one code path for all waves (a per-wave template
-    // instantiation was 2x slower: four instruction streams thrash the instruction cache).
-    const int rowA = wave, rowB = (NTL - 1 - wave > wave) ? NTL - 1 - wave : -1;
+    // Roles.  f64 MFMA and f64 VALU share one datapath per SIMD (measured: they do not overlap, neither
+    // within a wave nor between two waves of one SIMD), and waves w, w+4 of a workgroup land on the same
+    // SIMD.  So the latency chain of the factorisation (diagonal block -> panel -> next diagonal block)
+    // gets a SIMD of its own: waves 0 and 4 are the CHAIN waves (one matrix row per lane, 128 >= n+1-6
+    // rows), waves 1,2,3,5,6,7 are the TILE waves that keep the trailing matrix in MFMA accumulators.
+    const bool chain = (wave & 3) == 0;
+    const int tw = wave - 1 - (wave >> 2);         // tile wave index 0..5
+    // slot s of tile wave tw holds lower-triangle tile number t = 6 s + tw, tiles numbered row by row
+    int tr[K7_TPW], tc[K7_TPW];
+    bool tv[K7_TPW];
     d4 acc[K7_TPW];
 #pragma unroll
     for (int s = 0; s < K7_TPW; s++) {
-        const int c = s < 4 ? s : s - 4;
-        const int r = s < 4 ? rowA : rowB;
-        const bool tile_ok = r >= 0 && r < NTL && c <= r;
-        const int rr = max(r, 0);
-        const int k = 16 * c + lr;
+        const int t = 6 * s + max(tw, 0);
+        int r = 0;
+#pragma unroll
+        for (int q = 1; q < 8; q++) r += (t >= q * (q + 1) / 2) ? 1 : 0;
+        tr[s] = r;
+        tc[s] = t - r * (r + 1) / 2;
+        tv[s] = !chain && r < NTL;
+        acc[s] = d4{0.0, 0.0, 0.0, 0.0};
+        if (!tv[s]) continue;                       // wave-uniform
+        const int k = 16 * tc[s] + lr;
 #pragma unroll
         for (int q = 0; q < 4; q++) {
-            const int i = 16 * rr + lq + 4 * q;
+            const int i = 16 * r + lq + 4 * q;
             // unconditional loads from clamped addresses, then selects
             const int kc = min(k, n - 1), ic = min(i, n - 1);
             const int klo = min(kc, ic), khi = max(kc, ic);
@@ -163,150 +178,178 @@ __global__ __launch_bounds__(K7_THREADS) void ba_reduced_solve_lds(BaDims d, BaB
             const double gv = grs[kc];
             double val = sv + ((klo / 6 == khi / 6) ? uv : 0.0) + ((i == k) ? lam[ic] : 0.0);
             val = (k < n && i < n && k <= i) ? val : ((i == n && k < n) ? gv : 0.0);
-            acc[s][q] = tile_ok ? val : 0.0;
+            acc[s][q] = val;
         }
     }
     BA_STAMP(b, 1);
 
-    // J-invariant addressing of the trailing update's operands
-    int rowoff[8];
-    bool rowok[8];
-#pragma unroll
-    for (int c = 0; c < 8; c++) { rowoff[c] = min(16 * c + lr, n) * LD; rowok[c] = 16 * c + lr <= n; }
-    const int rowoffA = min(16 * rowA + lr, n) * LD, rowoffB = min(16 * max(rowB, 0) + lr, n) * LD;
-    const bool rowokA = 16 * rowA + lr <= n, rowokB = rowB >= 0 && 16 * rowB + lr <= n;
-
-    // (3) block Cholesky
+    // (3) block L D L^T, one camera (6 columns) per step, two barriers per step:
+    //   phase 1 (after barrier A: block column J is final in LDS)
+    //       chain: (a) factor + invert the 6x6 diagonal block (per lane, redundantly: no cross-lane traffic)
+    //              (b) one lane per row: F_i = row_i L^-T D^-1 -> LDS (factor panel + the MFMA operand panels)
+    //       tiles: rank-6 trailing update of step J-1 (operands in registers) on the live tiles, then
+    //              publish block column J+1 RAW (it has the updates of steps <= J-1)
+    //   phase 2 (after barrier B)
+    //       chain: apply step J's update to the 6 entries of block column J+1 of its row (36 FMAs), so
+    //              the next diagonal block never waits for the matrix cores
+    //       tiles: load the MFMA operands of step J
     const int NB = n / 6;
     W7_DECL;
+    double opA[K7_TPW][2], opB[K7_TPW][2];
+#pragma unroll
+    for (int s = 0; s < K7_TPW; s++) { opA[s][0] = opA[s][1] = opB[s][0] = opB[s][1] = 0.0; }
+    const int crow = (wave >> 2) * 64 + lane;      // chain waves: row slot 0..127
+    const bool chain_rows = chain && wave < 8;
+    // publish block column 0 (raw == final)
+#pragma unroll
+    for (int s = 0; s < K7_TPW; s++) {
+        if (!tv[s] || tc[s] != 0) continue;
+        const int k = lr;
+        if (k >= 6) continue;
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const int i = 16 * tr[s] + lq + 4 * q;
+            if (i >= k && i <= n) A[i * LD + k] = acc[s][q];
+        }
+    }
+    __syncthreads();
     for (int J = 0; J < NB; J++) {
         const int c0 = 6 * J, r0 = c0 + 6;
-        // publish block column J (k in [c0, c0+6), i >= k) from the owning tiles
-#pragma unroll
-        for (int s = 0; s < K7_TPW; s++) {
-            const int c = s < 4 ? s : s - 4;
-            const int r = s < 4 ? rowA : rowB;
-            if (r < 0 || c > r || 16 * c + 15 < c0 || 16 * c >= r0) continue;       // wave-uniform
-            const int k = 16 * c + lr;
-            if (k < c0 || k >= r0) continue;
-#pragma unroll
-            for (int q = 0; q < 4; q++) {
-                const int i = 16 * r + lq + 4 * q;
-                if (i >= k && i <= n) A[i * LD + k] = acc[s][q];
-            }
-        }
+        const int irow = r0 + crow;
+        const bool has_row = chain_rows && irow <= n;
+        double M[6][6], dinv[6], dpiv[6], F[6] = {0, 0, 0, 0, 0, 0};
+        bool fbad = false;
         W7(0);
-        __syncthreads();
-        W7(1);
-        BA_STAMP(b, 2);
-        // (a) diagonal block: every lane factors it in registers as L D L^T (unit lower L, no square roots:
-        // the per-pivot dependency chain is one v_rcp_f64 + one Newton step) and inverts L.
-        double M[6][6], dinv[6], dpiv[6];      // M = L_JJ^-1 (unit lower), dinv = 1 / D, dpiv = D
-        {
-            double L[6][6];
-#pragma unroll
-            for (int a = 0; a < 6; a++)
-#pragma unroll
-                for (int e = 0; e <= a; e++) L[a][e] = A[(size_t)(c0 + a) * LD + c0 + e];
-            bool bad = false;
-#pragma unroll
-            for (int c = 0; c < 6; c++) {
-                const double piv = L[c][c];
-                if (!(piv > 0.0) || !isfinite(piv)) bad = true;
-                const double rd = fast_rcp(piv);
-                dinv[c] = rd;
-                dpiv[c] = piv;
-                double lc[6];
-#pragma unroll
-                for (int a = c + 1; a < 6; a++) lc[a] = L[a][c] * rd;              // l_ac; L[a][c] still holds l_ac * d_c
-#pragma unroll
-                for (int a = c + 1; a < 6; a++)
-#pragma unroll
-                    for (int e = c + 1; e <= a; e++) L[a][e] -= lc[a] * L[e][c];   // a_ae -= l_ac d_c l_ec
-#pragma unroll
-                for (int a = c + 1; a < 6; a++) L[a][c] = lc[a];
-            }
-#pragma unroll
-            for (int e = 0; e < 6; e++) {
-#pragma unroll
-                for (int a = 0; a < e; a++) M[a][e] = 0.0;
-                M[e][e] = 1.0;
-#pragma unroll
-                for (int a = e + 1; a < 6; a++) {
-                    double sacc = 0.0;
-#pragma unroll
-                    for (int k = e; k < a; k++) sacc -= L[a][k] * M[k][e];
-                    M[a][e] = sacc;
-                }
-            }
-            if (tid == 255) {        // off the critical path: only the backward substitution reads it
+        if (chain_rows) {
+            {   // wave 4 always factors too: its last lane stores the inverse blocks
+                // (a) L D L^T of the diagonal block + inverse of the unit-lower factor, in every lane
+                double L[6][6];
 #pragma unroll
                 for (int a = 0; a < 6; a++)
 #pragma unroll
-                    for (int e = 0; e < 6; e++) Minv[J * 36 + a * 6 + e] = M[a][e];
-                if (bad) s_fail = 1;
-            }
-        }
-        W7(2);
-        BA_STAMP(b, 3);
-        // (b) panel rows i > c0+5 (incl. the rhs row n): F_i = row_i L_JJ^-T D_J^-1  (the L factor of L D L^T)
-        if (tid == 254) {
+                    for (int e = 0; e <= a; e++) L[a][e] = A[(c0 + a) * LD + c0 + e];
 #pragma unroll
-            for (int e = 0; e < 6; e++) dvals[c0 + e] = dpiv[e];            // off the critical path (read by (c) after the barrier)
-        }
-        for (int i = r0 + tid; i <= n; i += nt) {
-            double* row = A + (size_t)i * LD + c0;
-            double x[6], rr[6];
+                for (int c = 0; c < 6; c++) {
+                    const double piv = L[c][c];
+                    if (!(piv > 0.0) || !isfinite(piv)) fbad = true;
+                    const double rd = fast_rcp(piv);
+                    dinv[c] = rd;
+                    dpiv[c] = piv;
+                    double lc[6];
 #pragma unroll
-            for (int e = 0; e < 6; e++) rr[e] = row[e];
+                    for (int a = c + 1; a < 6; a++) lc[a] = L[a][c] * rd;              // l_ac; L[a][c] still holds l_ac * d_c
 #pragma unroll
-            for (int r = 0; r < 6; r++) {
-                double sacc = rr[r];
+                    for (int a = c + 1; a < 6; a++)
 #pragma unroll
-                for (int e = 0; e < r; e++) sacc += rr[e] * M[r][e];
-                x[r] = sacc * dinv[r];
-            }
+                        for (int e = c + 1; e <= a; e++) L[a][e] -= lc[a] * L[e][c];   // a_ae -= l_ac d_c l_ec
 #pragma unroll
-            for (int r = 0; r < 6; r++) row[r] = x[r];
-        }
-        W7(3);
-        __syncthreads();
-        W7(4);
-        BA_STAMP(b, 4);
-        // (c) trailing update on the matrix cores: tile(r,c) -= P_r P_c^T, K = 6 (+2 zero columns).  The
-        // panel operand of every tile COLUMN is loaded once per step (static index), the two owned rows
-        // once (negated).
-        {
-            double Pc[8][2], PnA[2], PnB[2];
-#pragma unroll
-            for (int kc = 0; kc < 2; kc++) {
-                const int kk = 4 * kc + lq;
-                const int kcl = c0 + min(kk, 5);
-                const bool kv = kk < 6;
-                const double dk = dvals[kcl];
-                // branch-free: unconditional reads from clamped (hoisted) row offsets, then selects
-#pragma unroll
-                for (int c = 0; c < 8; c++) {
-                    const double t = A[rowoff[c] + kcl];
-                    Pc[c][kc] = (kv && rowok[c] && 16 * c + lr >= r0) ? t * dk : 0.0;      // B operand = P = F D
+                    for (int a = c + 1; a < 6; a++) L[a][c] = lc[a];
                 }
-                const double ta = A[rowoffA + kcl], tb = A[rowoffB + kcl];
-                PnA[kc] = (kv && rowokA && 16 * rowA + lr >= r0) ? -ta : 0.0;
-                PnB[kc] = (kv && rowokB && 16 * rowB + lr >= r0) ? -tb : 0.0;
+#pragma unroll
+                for (int e = 0; e < 6; e++) {
+#pragma unroll
+                    for (int a = 0; a < e; a++) M[a][e] = 0.0;
+                    M[e][e] = 1.0;
+#pragma unroll
+                    for (int a = e + 1; a < 6; a++) {
+                        double sacc = 0.0;
+#pragma unroll
+                        for (int k = e; k < a; k++) sacc -= L[a][k] * M[k][e];
+                        M[a][e] = sacc;
+                    }
+                }
             }
-            const bool actA = 16 * rowA + 15 >= r0, actB = rowB >= 0 && 16 * rowB + 15 >= r0;
+            W7(2);
+            // (b) panel row of this lane
+            if (has_row) {
+                double* row = A + irow * LD + c0;
+                double rr[6];
 #pragma unroll
-            for (int kc = 0; kc < 2; kc++) {
+                for (int e = 0; e < 6; e++) rr[e] = row[e];
 #pragma unroll
-                for (int c = 0; c < 8; c++) {
-                    if (16 * c + 15 < r0) continue;                                     // wave-uniform
-                    if (c < 4 && actA && c <= rowA) acc[c] = __builtin_amdgcn_mfma_f64_16x16x4f64(PnA[kc], Pc[c][kc], acc[c], 0, 0, 0);
-                    if (actB && c <= rowB) acc[4 + c] = __builtin_amdgcn_mfma_f64_16x16x4f64(PnB[kc], Pc[c][kc], acc[4 + c], 0, 0, 0);
+                for (int r = 0; r < 6; r++) {
+                    double sacc = rr[r];
+#pragma unroll
+                    for (int e = 0; e < r; e++) sacc += rr[e] * M[r][e];
+                    F[r] = sacc * dinv[r];
+                }
+#pragma unroll
+                for (int r = 0; r < 6; r++) {
+                    row[r] = F[r];
+                    Nf[r * 128 + irow] = -F[r];
+                    Pd[r * 128 + irow] = F[r] * dpiv[r];
+                }
+            }
+            W7(3);
+        } else if (!chain) {
+            // trailing update of step J-1: its live region is rows/cols >= c0
+            if (J > 0) {
+#pragma unroll
+                for (int s = 0; s < K7_TPW; s++) {
+                    if (!tv[s] || 16 * tc[s] + 15 < c0) continue;                  // wave-uniform
+                    acc[s] = __builtin_amdgcn_mfma_f64_16x16x4f64(opA[s][0], opB[s][0], acc[s], 0, 0, 0);
+                    acc[s] = __builtin_amdgcn_mfma_f64_16x16x4f64(opA[s][1], opB[s][1], acc[s], 0, 0, 0);
+                }
+            }
+            W7(2);
+            // publish block column J+1 raw (k in [r0, r0+6), rows i >= k) from the owning tiles
+            if (J + 1 < NB) {
+#pragma unroll
+                for (int s = 0; s < K7_TPW; s++) {
+                    if (!tv[s] || 16 * tc[s] + 15 < r0 || 16 * tc[s] >= r0 + 6) continue;   // wave-uniform
+                    const int k = 16 * tc[s] + lr;
+                    if (k < r0 || k >= r0 + 6) continue;
+#pragma unroll
+                    for (int q = 0; q < 4; q++) {
+                        const int i = 16 * tr[s] + lq + 4 * q;
+                        if (i >= k && i <= n) A[i * LD + k] = acc[s][q];
+                    }
+                }
+            }
+            W7(3);
+        }
+        __syncthreads();                                                   // barrier B
+        W7(1);
+        if (chain_rows) {
+            if (has_row && J + 1 < NB) {
+                // step J's update of block column J+1: A[i][r0+k] -= sum_e F_i[e] d_e F[r0+k][c0+e]
+                double* nxt = A + irow * LD + r0;
+                double x[6];
+#pragma unroll
+                for (int k = 0; k < 6; k++) x[k] = nxt[k];
+#pragma unroll
+                for (int e = 0; e < 6; e++) {
+                    const double2* g2 = reinterpret_cast<const double2*>(Pd + e * 128 + r0);
+                    const double2 g01 = g2[0], g23 = g2[1], g45 = g2[2];
+                    x[0] -= F[e] * g01.x; x[1] -= F[e] * g01.y;
+                    x[2] -= F[e] * g23.x; x[3] -= F[e] * g23.y;
+                    x[4] -= F[e] * g45.x; x[5] -= F[e] * g45.y;
+                }
+#pragma unroll
+                for (int k = 0; k < 6; k++) nxt[k] = x[k];
+            }
+            if (tid == 319) {        // last lane of chain wave 4 (never the busier one): only the backward substitution reads these
+#pragma unroll
+                for (int a = 1; a < 6; a++)
+#pragma unroll
+                    for (int e = 0; e < a; e++) Minv[J * 36 + a * 6 + e] = M[a][e];
+                if (fbad) s_fail = 1;
+            }
+        } else if (!chain && J + 1 < NB) {
+            // operands of step J for the matrix cores.  No masks: rows that are already factored only
+            // put garbage into accumulator entries that are never read again.
+#pragma unroll
+            for (int s = 0; s < K7_TPW; s++) {
+                if (!tv[s] || 16 * tc[s] + 15 < r0) continue;                      // wave-uniform
+#pragma unroll
+                for (int kc = 0; kc < 2; kc++) {
+                    opA[s][kc] = Nf[(4 * kc + lq) * 128 + 16 * tr[s] + lr];
+                    opB[s][kc] = Pd[(4 * kc + lq) * 128 + 16 * tc[s] + lr];
                 }
             }
         }
         W7(5);
-        BA_STAMP(b, 5);
+        __syncthreads();                                                   // barrier A of step J+1
     }
     W7_FLUSH(b);
     __syncthreads();
@@ -321,9 +364,9 @@ __global__ __launch_bounds__(K7_THREADS) void ba_reduced_solve_lds(BaDims d, BaB
     for (int J = NB - 1; J >= 0; J--) {
         const int c0 = 6 * J;
         if (tid < 6) {      // x_J = L_JJ^-T y_J as a mat-vec with the stored inverse block
-            double sacc = 0.0;
+            double sacc = y[c0 + tid];
 #pragma unroll
-            for (int e = 0; e < 6; e++) sacc += Minv[J * 36 + e * 6 + tid] * y[c0 + e];
+            for (int e = 1; e < 6; e++) sacc += (e > tid ? Minv[J * 36 + e * 6 + tid] : 0.0) * y[c0 + e];
             xs[c0 + tid] = sacc;
         }
         __syncthreads();
@@ -380,7 +423,7 @@ __global__ __launch_bounds__(K7_THREADS) void ba_reduced_solve_lds(BaDims d, BaB
 size_t ba_reduced_solve_lds_bytes(int n)
 {
     const int LD = n + 1 + ((n & 1) ? 1 : 0);
-    return sizeof(double) * ((size_t)(n + 1) * LD + 2 * (size_t)n + 6 * (size_t)n + 6 * (size_t)n + 3 * (size_t)n + 8);
+    return sizeof(double) * ((size_t)(n + 1) * LD + 2 * (size_t)n + 6 * (size_t)n + 6 * (size_t)n + 3 * (size_t)n + 8 + 2 * 8 * 128);
 }
 
 void ba_launch_reduced_solve_lds(hipStream_t s, const BaDims& d, const BaBufs& b, const BaOpt& opt)
