@@ -27,15 +27,6 @@
 #include "ba_common.h"
 
 #define K7_THREADS 512
-#if RS_STAMPS
-#define W7_DECL unsigned long long w7_acc[8] = {0,0,0,0,0,0,0,0}; unsigned long long w7_t = clock64()
-#define W7(idx) do { if ((threadIdx.x & 63) == 0) { const unsigned long long t__ = clock64(); w7_acc[idx] += t__ - w7_t; w7_t = t__; } } while (0)
-#define W7_FLUSH(b) do { if ((threadIdx.x & 63) == 0) { _Pragma("unroll") for (int q__ = 0; q__ < 8; q__++) if ((threadIdx.x >> 6) < 4) (b).dbg[16 + (threadIdx.x >> 6) * 8 + q__] += w7_acc[q__]; } } while (0)
-#else
-#define W7_DECL do { } while (0)
-#define W7(idx) do { } while (0)
-#define W7_FLUSH(b) do { } while (0)
-#endif
 #define K7_TPW 6       // tiles per tile wave: 6 tile waves x 6 = the 36 lower-triangle tiles of a 128 x 128 matrix
 
 typedef __attribute__((ext_vector_type(4))) double d4;
@@ -149,41 +140,11 @@ __global__ __launch_bounds__(K7_THREADS) void ba_reduced_solve_lds(BaDims d, BaB
     // SIMD.  So the latency chain of the factorisation (diagonal block -> panel -> next diagonal block)
     // gets a SIMD of its own: waves 0 and 4 are the CHAIN waves (one matrix row per lane, 128 >= n+1-6
     // rows), waves 1,2,3,5,6,7 are the TILE waves that keep the trailing matrix in MFMA accumulators.
-    const bool chain = (wave & 3) == 0;
-    const int tw = wave - 1 - (wave >> 2);         // tile wave index 0..5
-    // slot s of tile wave tw holds lower-triangle tile number t = 6 s + tw, tiles numbered row by row
-    int tr[K7_TPW], tc[K7_TPW];
-    bool tv[K7_TPW];
-    d4 acc[K7_TPW];
-#pragma unroll
-    for (int s = 0; s < K7_TPW; s++) {
-        const int t = 6 * s + max(tw, 0);
-        int r = 0;
-#pragma unroll
-        for (int q = 1; q < 8; q++) r += (t >= q * (q + 1) / 2) ? 1 : 0;
-        tr[s] = r;
-        tc[s] = t - r * (r + 1) / 2;
-        tv[s] = !chain && r < NTL;
-        acc[s] = d4{0.0, 0.0, 0.0, 0.0};
-        if (!tv[s]) continue;                       // wave-uniform
-        const int k = 16 * tc[s] + lr;
-#pragma unroll
-        for (int q = 0; q < 4; q++) {
-            const int i = 16 * r + lq + 4 * q;
-            // unconditional loads from clamped addresses, then selects
-            const int kc = min(k, n - 1), ic = min(i, n - 1);
-            const int klo = min(kc, ic), khi = max(kc, ic);
-            const double sv = b.S[(size_t)klo * n + khi];     // S is accumulated in its upper triangle
-            const double uv = Us[(klo / 6) * 36 + (klo % 6) * 6 + (khi % 6)];
-            const double gv = grs[kc];
-            double val = sv + ((klo / 6 == khi / 6) ? uv : 0.0) + ((i == k) ? lam[ic] : 0.0);
-            val = (k < n && i < n && k <= i) ? val : ((i == n && k < n) ? gv : 0.0);
-            acc[s][q] = val;
-        }
-    }
-    BA_STAMP(b, 1);
-
-    // (3) block L D L^T, one camera (6 columns) per step, two barriers per step:
+    const bool chain = (wave & 3) == 0;            // waves 0 and 4
+    const int NB = n / 6;
+    // (3) block L D L^T, one camera (6 columns) per step, two barriers per step.  The two roles run
+    // DIFFERENT loops with the same barrier count (s_barrier only counts arrivals), so neither role's
+    // registers are live in the other's code:
     //   phase 1 (after barrier A: block column J is final in LDS)
     //       chain: (a) factor + invert the 6x6 diagonal block (per lane, redundantly: no cross-lane traffic)
     //              (b) one lane per row: F_i = row_i L^-T D^-1 -> LDS (factor panel + the MFMA operand panels)
@@ -193,86 +154,65 @@ __global__ __launch_bounds__(K7_THREADS) void ba_reduced_solve_lds(BaDims d, BaB
     //       chain: apply step J's update to the 6 entries of block column J+1 of its row (36 FMAs), so
     //              the next diagonal block never waits for the matrix cores
     //       tiles: load the MFMA operands of step J
-    const int NB = n / 6;
-    W7_DECL;
-    double opA[K7_TPW][2], opB[K7_TPW][2];
+    if (chain) {
+        BA_STAMP(b, 1);
+        const int crow = (wave >> 2) * 64 + lane;  // row slot 0..127 (n + 1 - 6 <= 121 rows)
+        __syncthreads();                           // block column 0 published by the tile waves
+        for (int J = 0; J < NB; J++) {
+            const int c0 = 6 * J, r0 = c0 + 6;
+            const int irow = r0 + crow;
+            const bool has_row = irow <= n;
+            double* row = A + min(irow, n) * LD + c0;
+            // loads first: the diagonal block and this lane's panel row (clamped address, no branch)
+            double L[6][6], rr[6];
 #pragma unroll
-    for (int s = 0; s < K7_TPW; s++) { opA[s][0] = opA[s][1] = opB[s][0] = opB[s][1] = 0.0; }
-    const int crow = (wave >> 2) * 64 + lane;      // chain waves: row slot 0..127
-    const bool chain_rows = chain && wave < 8;
-    // publish block column 0 (raw == final)
+            for (int a = 0; a < 6; a++)
 #pragma unroll
-    for (int s = 0; s < K7_TPW; s++) {
-        if (!tv[s] || tc[s] != 0) continue;
-        const int k = lr;
-        if (k >= 6) continue;
+                for (int e = 0; e <= a; e++) L[a][e] = A[(c0 + a) * LD + c0 + e];
 #pragma unroll
-        for (int q = 0; q < 4; q++) {
-            const int i = 16 * tr[s] + lq + 4 * q;
-            if (i >= k && i <= n) A[i * LD + k] = acc[s][q];
-        }
-    }
-    __syncthreads();
-    for (int J = 0; J < NB; J++) {
-        const int c0 = 6 * J, r0 = c0 + 6;
-        const int irow = r0 + crow;
-        const bool has_row = chain_rows && irow <= n;
-        double M[6][6], dinv[6], dpiv[6], F[6] = {0, 0, 0, 0, 0, 0};
-        bool fbad = false;
-        W7(0);
-        if (chain_rows) {
-            {   // wave 4 always factors too: its last lane stores the inverse blocks
-                // (a) L D L^T of the diagonal block + inverse of the unit-lower factor, in every lane
-                double L[6][6];
+            for (int e = 0; e < 6; e++) rr[e] = row[e];
+            // (a) L D L^T of the diagonal block + inverse M of the unit-lower factor
+            double M[6][6], dinv[6], dpiv[6], F[6];
+            bool fbad = false;
 #pragma unroll
-                for (int a = 0; a < 6; a++)
+            for (int c = 0; c < 6; c++) {
+                const double piv = L[c][c];
+                if (!(piv > 0.0) || !isfinite(piv)) fbad = true;
+                const double rd = fast_rcp(piv);
+                dinv[c] = rd;
+                dpiv[c] = piv;
+                double lc[6];
 #pragma unroll
-                    for (int e = 0; e <= a; e++) L[a][e] = A[(c0 + a) * LD + c0 + e];
+                for (int a = c + 1; a < 6; a++) lc[a] = L[a][c] * rd;              // l_ac; L[a][c] still holds l_ac * d_c
 #pragma unroll
-                for (int c = 0; c < 6; c++) {
-                    const double piv = L[c][c];
-                    if (!(piv > 0.0) || !isfinite(piv)) fbad = true;
-                    const double rd = fast_rcp(piv);
-                    dinv[c] = rd;
-                    dpiv[c] = piv;
-                    double lc[6];
+                for (int a = c + 1; a < 6; a++)
 #pragma unroll
-                    for (int a = c + 1; a < 6; a++) lc[a] = L[a][c] * rd;              // l_ac; L[a][c] still holds l_ac * d_c
+                    for (int e = c + 1; e <= a; e++) L[a][e] -= lc[a] * L[e][c];   // a_ae -= l_ac d_c l_ec
 #pragma unroll
-                    for (int a = c + 1; a < 6; a++)
+                for (int a = c + 1; a < 6; a++) L[a][c] = lc[a];
+            }
 #pragma unroll
-                        for (int e = c + 1; e <= a; e++) L[a][e] -= lc[a] * L[e][c];   // a_ae -= l_ac d_c l_ec
+            for (int e = 0; e < 6; e++) {
 #pragma unroll
-                    for (int a = c + 1; a < 6; a++) L[a][c] = lc[a];
-                }
+                for (int a = 0; a < e; a++) M[a][e] = 0.0;
+                M[e][e] = 1.0;
 #pragma unroll
-                for (int e = 0; e < 6; e++) {
+                for (int a = e + 1; a < 6; a++) {
+                    double sacc = 0.0;
 #pragma unroll
-                    for (int a = 0; a < e; a++) M[a][e] = 0.0;
-                    M[e][e] = 1.0;
-#pragma unroll
-                    for (int a = e + 1; a < 6; a++) {
-                        double sacc = 0.0;
-#pragma unroll
-                        for (int k = e; k < a; k++) sacc -= L[a][k] * M[k][e];
-                        M[a][e] = sacc;
-                    }
+                    for (int k = e; k < a; k++) sacc -= L[a][k] * M[k][e];
+                    M[a][e] = sacc;
                 }
             }
-            W7(2);
-            // (b) panel row of this lane
+            // (b) panel row: F = row L^-T D^-1
+#pragma unroll
+            for (int r = 0; r < 6; r++) {
+                double sacc = rr[r];
+#pragma unroll
+                for (int e = 0; e < r; e++) sacc += rr[e] * M[r][e];
+                F[r] = sacc * dinv[r];
+            }
             if (has_row) {
-                double* row = A + irow * LD + c0;
-                double rr[6];
-#pragma unroll
-                for (int e = 0; e < 6; e++) rr[e] = row[e];
-#pragma unroll
-                for (int r = 0; r < 6; r++) {
-                    double sacc = rr[r];
-#pragma unroll
-                    for (int e = 0; e < r; e++) sacc += rr[e] * M[r][e];
-                    F[r] = sacc * dinv[r];
-                }
 #pragma unroll
                 for (int r = 0; r < 6; r++) {
                     row[r] = F[r];
@@ -280,8 +220,84 @@ __global__ __launch_bounds__(K7_THREADS) void ba_reduced_solve_lds(BaDims d, BaB
                     Pd[r * 128 + irow] = F[r] * dpiv[r];
                 }
             }
-            W7(3);
-        } else if (!chain) {
+            __syncthreads();                                               // barrier B
+            if (J + 1 < NB) {
+                // step J's update of block column J+1: A[i][r0+k] -= sum_e F_i[e] d_e F[r0+k][c0+e]
+                double* nxt = row + 6;
+                double x[6];
+#pragma unroll
+                for (int k = 0; k < 6; k++) x[k] = nxt[k];
+#pragma unroll
+                for (int e = 0; e < 6; e++) {
+                    const double2* g2 = reinterpret_cast<const double2*>(Pd + e * 128 + r0);
+                    const double2 g01 = g2[0], g23 = g2[1], g45 = g2[2];
+                    x[0] -= F[e] * g01.x; x[1] -= F[e] * g01.y;
+                    x[2] -= F[e] * g23.x; x[3] -= F[e] * g23.y;
+                    x[4] -= F[e] * g45.x; x[5] -= F[e] * g45.y;
+                }
+                if (has_row) {
+#pragma unroll
+                    for (int k = 0; k < 6; k++) nxt[k] = x[k];
+                }
+            }
+            if (tid == 319) {        // last lane of wave 4 (the less busy chain wave); only the backward substitution reads these
+#pragma unroll
+                for (int a = 1; a < 6; a++)
+#pragma unroll
+                    for (int e = 0; e < a; e++) Minv[J * 36 + a * 6 + e] = M[a][e];
+                if (fbad) s_fail = 1;
+            }
+            __syncthreads();                                               // barrier A of step J+1
+        }
+    } else {
+        const int tw = wave - 1 - (wave >> 2);     // tile wave index 0..5
+        // slot s of tile wave tw holds lower-triangle tile number t = 6 s + tw, tiles numbered row by row
+        int tr[K7_TPW], tc[K7_TPW];
+        bool tv[K7_TPW];
+        d4 acc[K7_TPW];
+        double opA[K7_TPW][2], opB[K7_TPW][2];
+#pragma unroll
+        for (int s = 0; s < K7_TPW; s++) {
+            const int t = 6 * s + tw;
+            int r = 0;
+#pragma unroll
+            for (int q = 1; q < 8; q++) r += (t >= q * (q + 1) / 2) ? 1 : 0;
+            tr[s] = r;
+            tc[s] = t - r * (r + 1) / 2;
+            tv[s] = r < NTL;
+            acc[s] = d4{0.0, 0.0, 0.0, 0.0};
+            opA[s][0] = opA[s][1] = opB[s][0] = opB[s][1] = 0.0;
+            if (!tv[s]) continue;                       // wave-uniform
+            const int k = 16 * tc[s] + lr;
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const int i = 16 * r + lq + 4 * q;
+                // unconditional loads from clamped addresses, then selects
+                const int kc = min(k, n - 1), ic = min(i, n - 1);
+                const int klo = min(kc, ic), khi = max(kc, ic);
+                const double sv = b.S[(size_t)klo * n + khi];     // S is accumulated in its upper triangle
+                const double uv = Us[(klo / 6) * 36 + (klo % 6) * 6 + (khi % 6)];
+                const double gv = grs[kc];
+                double val = sv + ((klo / 6 == khi / 6) ? uv : 0.0) + ((i == k) ? lam[ic] : 0.0);
+                val = (k < n && i < n && k <= i) ? val : ((i == n && k < n) ? gv : 0.0);
+                acc[s][q] = val;
+            }
+        }
+        // publish block column 0 (raw == final)
+#pragma unroll
+        for (int s = 0; s < K7_TPW; s++) {
+            if (!tv[s] || tc[s] != 0) continue;
+            const int k = lr;
+            if (k >= 6) continue;
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const int i = 16 * tr[s] + lq + 4 * q;
+                if (i >= k && i <= n) A[i * LD + k] = acc[s][q];
+            }
+        }
+        __syncthreads();
+        for (int J = 0; J < NB; J++) {
+            const int c0 = 6 * J, r0 = c0 + 6;
             // trailing update of step J-1: its live region is rows/cols >= c0
             if (J > 0) {
 #pragma unroll
@@ -291,7 +307,6 @@ __global__ __launch_bounds__(K7_THREADS) void ba_reduced_solve_lds(BaDims d, BaB
                     acc[s] = __builtin_amdgcn_mfma_f64_16x16x4f64(opA[s][1], opB[s][1], acc[s], 0, 0, 0);
                 }
             }
-            W7(2);
             // publish block column J+1 raw (k in [r0, r0+6), rows i >= k) from the owning tiles
             if (J + 1 < NB) {
 #pragma unroll
@@ -306,52 +321,23 @@ __global__ __launch_bounds__(K7_THREADS) void ba_reduced_solve_lds(BaDims d, BaB
                     }
                 }
             }
-            W7(3);
-        }
-        __syncthreads();                                                   // barrier B
-        W7(1);
-        if (chain_rows) {
-            if (has_row && J + 1 < NB) {
-                // step J's update of block column J+1: A[i][r0+k] -= sum_e F_i[e] d_e F[r0+k][c0+e]
-                double* nxt = A + irow * LD + r0;
-                double x[6];
+            __syncthreads();                                               // barrier B
+            if (J + 1 < NB) {
+                // operands of step J for the matrix cores.  No masks: rows that are already factored only
+                // put garbage into accumulator entries that are never read again.
 #pragma unroll
-                for (int k = 0; k < 6; k++) x[k] = nxt[k];
+                for (int s = 0; s < K7_TPW; s++) {
+                    if (!tv[s] || 16 * tc[s] + 15 < r0) continue;                  // wave-uniform
 #pragma unroll
-                for (int e = 0; e < 6; e++) {
-                    const double2* g2 = reinterpret_cast<const double2*>(Pd + e * 128 + r0);
-                    const double2 g01 = g2[0], g23 = g2[1], g45 = g2[2];
-                    x[0] -= F[e] * g01.x; x[1] -= F[e] * g01.y;
-                    x[2] -= F[e] * g23.x; x[3] -= F[e] * g23.y;
-                    x[4] -= F[e] * g45.x; x[5] -= F[e] * g45.y;
-                }
-#pragma unroll
-                for (int k = 0; k < 6; k++) nxt[k] = x[k];
-            }
-            if (tid == 319) {        // last lane of chain wave 4 (never the busier one): only the backward substitution reads these
-#pragma unroll
-                for (int a = 1; a < 6; a++)
-#pragma unroll
-                    for (int e = 0; e < a; e++) Minv[J * 36 + a * 6 + e] = M[a][e];
-                if (fbad) s_fail = 1;
-            }
-        } else if (!chain && J + 1 < NB) {
-            // operands of step J for the matrix cores.  No masks: rows that are already factored only
-            // put garbage into accumulator entries that are never read again.
-#pragma unroll
-            for (int s = 0; s < K7_TPW; s++) {
-                if (!tv[s] || 16 * tc[s] + 15 < r0) continue;                      // wave-uniform
-#pragma unroll
-                for (int kc = 0; kc < 2; kc++) {
-                    opA[s][kc] = Nf[(4 * kc + lq) * 128 + 16 * tr[s] + lr];
-                    opB[s][kc] = Pd[(4 * kc + lq) * 128 + 16 * tc[s] + lr];
+                    for (int kc = 0; kc < 2; kc++) {
+                        opA[s][kc] = Nf[(4 * kc + lq) * 128 + 16 * tr[s] + lr];
+                        opB[s][kc] = Pd[(4 * kc + lq) * 128 + 16 * tc[s] + lr];
+                    }
                 }
             }
+            __syncthreads();                                               // barrier A of step J+1
         }
-        W7(5);
-        __syncthreads();                                                   // barrier A of step J+1
     }
-    W7_FLUSH(b);
     __syncthreads();
     if (tid < 64) { const double f = slot_sum(b.scal, 1); if (f > 0.0 && tid == 0) s_fail = 1; }
     __syncthreads();
