@@ -162,6 +162,11 @@ __global__ __launch_bounds__(K7_THREADS) void ba_reduced_solve_lds(BaDims d, BaB
             const int c0 = 6 * J, r0 = c0 + 6;
             const int irow = r0 + crow;
             const bool has_row = irow <= n;
+            if (wave != 0 && r0 + 64 > n) {        // wave 4 has no rows left: leave the SIMD to wave 0
+                __syncthreads();
+                __syncthreads();
+                continue;
+            }
             double* row = A + min(irow, n) * LD + c0;
             // loads first: the diagonal block and this lane's panel row (clamped address, no branch)
             double L[6][6], rr[6];
@@ -171,8 +176,8 @@ __global__ __launch_bounds__(K7_THREADS) void ba_reduced_solve_lds(BaDims d, BaB
                 for (int e = 0; e <= a; e++) L[a][e] = A[(c0 + a) * LD + c0 + e];
 #pragma unroll
             for (int e = 0; e < 6; e++) rr[e] = row[e];
-            // (a) L D L^T of the diagonal block + inverse M of the unit-lower factor
-            double M[6][6], dinv[6], dpiv[6], F[6];
+            // (a) L D L^T of the diagonal block
+            double dinv[6], dpiv[6], F[6];
             bool fbad = false;
 #pragma unroll
             for (int c = 0; c < 6; c++) {
@@ -191,26 +196,18 @@ __global__ __launch_bounds__(K7_THREADS) void ba_reduced_solve_lds(BaDims d, BaB
 #pragma unroll
                 for (int a = c + 1; a < 6; a++) L[a][c] = lc[a];
             }
+            // (b) panel row: t = row L^-T by forward substitution (unit lower L), F = t D^-1
+            {
+                double t[6];
 #pragma unroll
-            for (int e = 0; e < 6; e++) {
+                for (int r = 0; r < 6; r++) {
+                    double sacc = rr[r];
 #pragma unroll
-                for (int a = 0; a < e; a++) M[a][e] = 0.0;
-                M[e][e] = 1.0;
-#pragma unroll
-                for (int a = e + 1; a < 6; a++) {
-                    double sacc = 0.0;
-#pragma unroll
-                    for (int k = e; k < a; k++) sacc -= L[a][k] * M[k][e];
-                    M[a][e] = sacc;
+                    for (int e = 0; e < r; e++) sacc -= t[e] * L[r][e];
+                    t[r] = sacc;
                 }
-            }
-            // (b) panel row: F = row L^-T D^-1
 #pragma unroll
-            for (int r = 0; r < 6; r++) {
-                double sacc = rr[r];
-#pragma unroll
-                for (int e = 0; e < r; e++) sacc += rr[e] * M[r][e];
-                F[r] = sacc * dinv[r];
+                for (int r = 0; r < 6; r++) F[r] = t[r] * dinv[r];
             }
             if (has_row) {
 #pragma unroll
@@ -240,11 +237,11 @@ __global__ __launch_bounds__(K7_THREADS) void ba_reduced_solve_lds(BaDims d, BaB
                     for (int k = 0; k < 6; k++) nxt[k] = x[k];
                 }
             }
-            if (tid == 319) {        // last lane of wave 4 (the less busy chain wave); only the backward substitution reads these
+            if (tid == 63) {         // the unit-lower diagonal blocks, for the backward substitution
 #pragma unroll
                 for (int a = 1; a < 6; a++)
 #pragma unroll
-                    for (int e = 0; e < a; e++) Minv[J * 36 + a * 6 + e] = M[a][e];
+                    for (int e = 0; e < a; e++) Minv[J * 36 + a * 6 + e] = L[a][e];
                 if (fbad) s_fail = 1;
             }
             __syncthreads();                                               // barrier A of step J+1
@@ -272,13 +269,14 @@ __global__ __launch_bounds__(K7_THREADS) void ba_reduced_solve_lds(BaDims d, BaB
 #pragma unroll
             for (int q = 0; q < 4; q++) {
                 const int i = 16 * r + lq + 4 * q;
-                // unconditional loads from clamped addresses, then selects
+                // unconditional loads from clamped addresses, then selects.  Only k <= i is ever used, so
+                // (k, i) is already the (low, high) pair of S's upper triangle.
                 const int kc = min(k, n - 1), ic = min(i, n - 1);
-                const int klo = min(kc, ic), khi = max(kc, ic);
-                const double sv = b.S[(size_t)klo * n + khi];     // S is accumulated in its upper triangle
-                const double uv = Us[(klo / 6) * 36 + (klo % 6) * 6 + (khi % 6)];
+                const double sv = b.S[(size_t)kc * n + ic];
+                const int kb = kc / 6;
+                const double uv = Us[kb * 36 + (kc - 6 * kb) * 6 + ic % 6];
                 const double gv = grs[kc];
-                double val = sv + ((klo / 6 == khi / 6) ? uv : 0.0) + ((i == k) ? lam[ic] : 0.0);
+                double val = sv + ((kb == ic / 6) ? uv : 0.0) + ((i == k) ? lam[ic] : 0.0);
                 val = (k < n && i < n && k <= i) ? val : ((i == n && k < n) ? gv : 0.0);
                 acc[s][q] = val;
             }
@@ -349,11 +347,17 @@ __global__ __launch_bounds__(K7_THREADS) void ba_reduced_solve_lds(BaDims d, BaB
     double* y = A + (size_t)n * LD;
     for (int J = NB - 1; J >= 0; J--) {
         const int c0 = 6 * J;
-        if (tid < 6) {      // x_J = L_JJ^-T y_J as a mat-vec with the stored inverse block
-            double sacc = y[c0 + tid];
+        if (tid == 0) {     // x_J = L_JJ^-T y_J by back substitution with the stored unit-lower block
+            double x[6];
 #pragma unroll
-            for (int e = 1; e < 6; e++) sacc += (e > tid ? Minv[J * 36 + e * 6 + tid] : 0.0) * y[c0 + e];
-            xs[c0 + tid] = sacc;
+            for (int t = 5; t >= 0; t--) {
+                double sacc = y[c0 + t];
+#pragma unroll
+                for (int e = 5; e > t; e--) sacc -= Minv[J * 36 + e * 6 + t] * x[e];
+                x[t] = sacc;
+            }
+#pragma unroll
+            for (int t = 0; t < 6; t++) xs[c0 + t] = x[t];
         }
         __syncthreads();
         for (int i = tid; i < c0; i += nt) {
