@@ -41,6 +41,14 @@ __device__ __forceinline__ double fast_rsqrt(double x)
     return y;
 }
 
+// broadcast one lane's double to the wave (lane is wave-uniform)
+__device__ __forceinline__ double readlane_f64(double v, int lane)
+{
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), lane);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
+    return __hiloint2double(hi, lo);
+}
+
 // 1/x from v_rcp_f64 + one Newton step
 __device__ __forceinline__ double fast_rcp(double x)
 {
@@ -343,31 +351,43 @@ __global__ __launch_bounds__(K7_THREADS) void ba_reduced_solve_lds(BaDims d, BaB
         if (tid == 0) { st.solver_failed = 1; *b.st = st; }
         return;
     }
-    // (4) backward substitution L^T x = y (y = row n of the panels), block column by block column
-    double* y = A + (size_t)n * LD;
-    for (int J = NB - 1; J >= 0; J--) {
-        const int c0 = 6 * J;
-        if (tid == 0) {     // x_J = L_JJ^-T y_J by back substitution with the stored unit-lower block
+    // (4) backward substitution L^T x = y in ONE wave without block barriers: y (row n of the panels)
+    // lives in registers, two entries per lane; per block column the 6 entries of y_J are broadcast with
+    // v_readlane, every lane solves the 6x6 unit-lower block redundantly, and each lane updates its own
+    // entries with the panel column loaded ahead of the dependency chain.
+    if (wave == 0) {
+        const double* yrow = A + (size_t)n * LD;
+        double y0 = yrow[min(lane, n)], y1 = yrow[min(64 + lane, n)];
+        for (int J = NB - 1; J >= 0; J--) {
+            const int c0 = 6 * J;
+            double Lb[6][6], p0[6], p1[6];
+#pragma unroll
+            for (int e = 1; e < 6; e++)
+#pragma unroll
+                for (int t = 0; t < e; t++) Lb[e][t] = Minv[J * 36 + e * 6 + t];
+#pragma unroll
+            for (int e = 0; e < 6; e++) {
+                p0[e] = A[(c0 + e) * LD + min(lane, n)];        // only columns i < c0 matter; the rest feeds
+                p1[e] = A[(c0 + e) * LD + min(64 + lane, n)];   // entries of y that are already consumed
+            }
             double x[6];
 #pragma unroll
             for (int t = 5; t >= 0; t--) {
-                double sacc = y[c0 + t];
+                const int idx = c0 + t;                          // wave-uniform
+                double sacc = readlane_f64(idx >= 64 ? y1 : y0, idx & 63);
 #pragma unroll
-                for (int e = 5; e > t; e--) sacc -= Minv[J * 36 + e * 6 + t] * x[e];
+                for (int e = 5; e > t; e--) sacc -= Lb[e][t] * x[e];
                 x[t] = sacc;
             }
 #pragma unroll
-            for (int t = 0; t < 6; t++) xs[c0 + t] = x[t];
-        }
-        __syncthreads();
-        for (int i = tid; i < c0; i += nt) {
-            double s = y[i];
+            for (int e = 0; e < 6; e++) { y0 -= p0[e] * x[e]; y1 -= p1[e] * x[e]; }
+            if (lane == 0) {
 #pragma unroll
-            for (int e = 0; e < 6; e++) s -= A[(size_t)(c0 + e) * LD + i] * xs[c0 + e];
-            y[i] = s;
+                for (int t = 0; t < 6; t++) xs[c0 + t] = x[t];
+            }
         }
-        __syncthreads();
     }
+    __syncthreads();
     BA_STAMP(b, 6);
     // (5) delta_c = -x, candidate cameras, camera part of the step scalars
     double mcc = 0.0, ssq = 0.0, xsq = 0.0;
