@@ -301,13 +301,31 @@ __global__ __launch_bounds__(K7_THREADS) void ba_reduced_solve_lds(BaDims d, BaB
                 if (i >= k && i <= n) A[i * LD + k] = acc[s][q];
             }
         }
+        // loop-invariant publish addressing: LDS index of this lane's first entry of slot s and the
+        // mask of its 4 rows that lie in the stored lower triangle
+        int paddr[K7_TPW];
+        unsigned pmask[K7_TPW];
+#pragma unroll
+        for (int s = 0; s < K7_TPW; s++) {
+            const int k = 16 * tc[s] + lr;
+            paddr[s] = (16 * tr[s] + lq) * LD + k;
+            unsigned m = 0;
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const int i = 16 * tr[s] + lq + 4 * q;
+                m |= (i >= k && i <= n) ? (1u << q) : 0u;
+            }
+            pmask[s] = m;
+        }
+        const int LD4 = 4 * LD;
         __syncthreads();
         for (int J = 0; J < NB; J++) {
             const int c0 = 6 * J, r0 = c0 + 6;
-            // trailing update of step J-1: its live region is rows/cols >= c0
+            // phase 1: the odd slots' half of the trailing update of step J-1 (the even slots' half ran
+            // in phase 2 of step J-1, while the chain did its fix-up); live region: rows/cols >= c0
             if (J > 0) {
 #pragma unroll
-                for (int s = 0; s < K7_TPW; s++) {
+                for (int s = 1; s < K7_TPW; s += 2) {
                     if (!tv[s] || 16 * tc[s] + 15 < c0) continue;                  // wave-uniform
                     acc[s] = __builtin_amdgcn_mfma_f64_16x16x4f64(opA[s][0], opB[s][0], acc[s], 0, 0, 0);
                     acc[s] = __builtin_amdgcn_mfma_f64_16x16x4f64(opA[s][1], opB[s][1], acc[s], 0, 0, 0);
@@ -321,10 +339,8 @@ __global__ __launch_bounds__(K7_THREADS) void ba_reduced_solve_lds(BaDims d, BaB
                     const int k = 16 * tc[s] + lr;
                     if (k < r0 || k >= r0 + 6) continue;
 #pragma unroll
-                    for (int q = 0; q < 4; q++) {
-                        const int i = 16 * tr[s] + lq + 4 * q;
-                        if (i >= k && i <= n) A[i * LD + k] = acc[s][q];
-                    }
+                    for (int q = 0; q < 4; q++)
+                        if (pmask[s] >> q & 1) A[paddr[s] + q * LD4] = acc[s][q];
                 }
             }
             __syncthreads();                                               // barrier B
@@ -339,6 +355,13 @@ __global__ __launch_bounds__(K7_THREADS) void ba_reduced_solve_lds(BaDims d, BaB
                         opA[s][kc] = Nf[(4 * kc + lq) * 128 + 16 * tr[s] + lr];
                         opB[s][kc] = Pd[(4 * kc + lq) * 128 + 16 * tc[s] + lr];
                     }
+                }
+                // phase 2: the even slots' half of the trailing update of step J
+#pragma unroll
+                for (int s = 0; s < K7_TPW; s += 2) {
+                    if (!tv[s] || 16 * tc[s] + 15 < r0) continue;                  // wave-uniform
+                    acc[s] = __builtin_amdgcn_mfma_f64_16x16x4f64(opA[s][0], opB[s][0], acc[s], 0, 0, 0);
+                    acc[s] = __builtin_amdgcn_mfma_f64_16x16x4f64(opA[s][1], opB[s][1], acc[s], 0, 0, 0);
                 }
             }
             __syncthreads();                                               // barrier A of step J+1
@@ -358,17 +381,29 @@ __global__ __launch_bounds__(K7_THREADS) void ba_reduced_solve_lds(BaDims d, BaB
     if (wave == 0) {
         const double* yrow = A + (size_t)n * LD;
         double y0 = yrow[min(lane, n)], y1 = yrow[min(64 + lane, n)];
-        for (int J = NB - 1; J >= 0; J--) {
-            const int c0 = 6 * J;
-            double Lb[6][6], p0[6], p1[6];
+        const int i0 = min(lane, n), i1 = min(64 + lane, n);
+        // operands of a step do not depend on the chain: they are loaded one step ahead
+        double Lb[6][6], p0[6], p1[6];
+        {
+            const int J = NB - 1, c0 = 6 * J;
 #pragma unroll
             for (int e = 1; e < 6; e++)
 #pragma unroll
                 for (int t = 0; t < e; t++) Lb[e][t] = Minv[J * 36 + e * 6 + t];
 #pragma unroll
-            for (int e = 0; e < 6; e++) {
-                p0[e] = A[(c0 + e) * LD + min(lane, n)];        // only columns i < c0 matter; the rest feeds
-                p1[e] = A[(c0 + e) * LD + min(64 + lane, n)];   // entries of y that are already consumed
+            for (int e = 0; e < 6; e++) { p0[e] = A[(c0 + e) * LD + i0]; p1[e] = A[(c0 + e) * LD + i1]; }
+        }
+        for (int J = NB - 1; J >= 0; J--) {
+            const int c0 = 6 * J;
+            double nL[6][6], np0[6], np1[6];
+            {
+                const int Jn = max(J - 1, 0), cn = 6 * Jn;
+#pragma unroll
+                for (int e = 1; e < 6; e++)
+#pragma unroll
+                    for (int t = 0; t < e; t++) nL[e][t] = Minv[Jn * 36 + e * 6 + t];
+#pragma unroll
+                for (int e = 0; e < 6; e++) { np0[e] = A[(cn + e) * LD + i0]; np1[e] = A[(cn + e) * LD + i1]; }
             }
             double x[6];
 #pragma unroll
@@ -379,11 +414,18 @@ __global__ __launch_bounds__(K7_THREADS) void ba_reduced_solve_lds(BaDims d, BaB
                 for (int e = 5; e > t; e--) sacc -= Lb[e][t] * x[e];
                 x[t] = sacc;
             }
+            // only columns i < c0 matter; the other lanes update entries of y that are already consumed
 #pragma unroll
             for (int e = 0; e < 6; e++) { y0 -= p0[e] * x[e]; y1 -= p1[e] * x[e]; }
             if (lane == 0) {
 #pragma unroll
                 for (int t = 0; t < 6; t++) xs[c0 + t] = x[t];
+            }
+#pragma unroll
+            for (int e = 0; e < 6; e++) {
+                p0[e] = np0[e]; p1[e] = np1[e];
+#pragma unroll
+                for (int t = 0; t < e; t++) Lb[e][t] = nL[e][t];
             }
         }
     }
