@@ -31,15 +31,22 @@
 
 // ---------------------------------------------------------------------- K0
 __global__ void ba_init(BaDims d, BaBufs b, BaOpt opt, const double* __restrict__ cams_in,
-                        const double* __restrict__ pts_in)
+                        const double* __restrict__ pts_in, unsigned long long free_mask, int from_mask,
+                        uint8_t* __restrict__ cam_free, int32_t* __restrict__ zero_i32, int zero_n)
 {
     const int tid = blockIdx.x * blockDim.x + threadIdx.x, nth = gridDim.x * blockDim.x;
+    if (from_mask && tid < d.C) {     // C <= 64: the free-camera table arrives as a kernel argument, not as two copies
+        const int fr = (int)(free_mask >> tid & 1ull);
+        b.slot[tid] = fr ? __popcll(free_mask & ((1ull << tid) - 1ull)) : -1;
+        cam_free[tid] = (uint8_t)fr;
+    }
     for (int i = tid; i < d.C * 6; i += nth) { b.Xc[i] = cams_in[i]; b.Xc[d.C * 6 + i] = cams_in[i]; }
     for (int i = tid; i < d.P * 3; i += nth) b.Xp[i] = pts_in[i];
     for (int c = tid; c < d.C; c += nth) cam_prepare(cams_in + 6 * c, b.prep + (size_t)c * BA_PREP);
     for (size_t i = tid; i < b.acc_count; i += nth) b.acc[i] = 0.0;
     for (int i = tid; i < 2 * BA_NSLOT * BA_SLOT_STRIDE; i += nth) b.pt_scal[i] = 0.0;
     for (int i = tid; i < BA_NSLOT * BA_SLOT_STRIDE; i += nth) b.gmax[i] = 0.0;
+    for (int i = tid; i < zero_n; i += nth) zero_i32[i] = 0;      // histogram of the landmark grouping
     if (tid == 0) {
         BaState s;
         s.radius = opt.r0; s.decrease_factor = 2.0; s.x_cost = 0.0; s.initial_cost = 0.0;
@@ -547,7 +554,9 @@ extern "C" int rs_bundle_adjust(rs_context* ctx, int n_cameras, int n_points, in
     BaState* const st_base = b.st;
     double* const pts_base = b.pt_scal;
     b.dbg = (unsigned long long*)(ws + o_dbg);
+#if RS_STAMPS
     RS_HIP(ctx, hipMemsetAsync(b.dbg, 0, sizeof(unsigned long long) * 64, ctx->stream));
+#endif
     ctx->ba_cache = b.dbg;
 
     void* pin = nullptr;
@@ -556,11 +565,17 @@ extern "C" int rs_bundle_adjust(rs_context* ctx, int n_cameras, int n_points, in
     BaState* h_st = (BaState*)pin;
     int32_t* h_slot = (int32_t*)((char*)pin + sizeof(BaState));
     uint8_t* h_free = (uint8_t*)(h_slot + C);
-    memcpy(h_slot, slot.data(), sizeof(int32_t) * C);
-    memcpy(h_free, h_cam_free, C);
-    RS_HIP(ctx, hipMemcpyAsync(b.slot, h_slot, sizeof(int32_t) * C, hipMemcpyHostToDevice, ctx->stream));
     uint8_t* d_cam_free = (uint8_t*)(ws + o_free);
-    RS_HIP(ctx, hipMemcpyAsync(d_cam_free, h_free, C, hipMemcpyHostToDevice, ctx->stream));
+    unsigned long long free_mask = 0;
+    const int from_mask = C <= 64 ? 1 : 0;
+    if (from_mask) {
+        for (size_t c = 0; c < C; c++) if (h_cam_free[c]) free_mask |= 1ull << c;
+    } else {
+        memcpy(h_slot, slot.data(), sizeof(int32_t) * C);
+        memcpy(h_free, h_cam_free, C);
+        RS_HIP(ctx, hipMemcpyAsync(b.slot, h_slot, sizeof(int32_t) * C, hipMemcpyHostToDevice, ctx->stream));
+        RS_HIP(ctx, hipMemcpyAsync(d_cam_free, h_free, C, hipMemcpyHostToDevice, ctx->stream));
+    }
 
     const bool solve_lds = d.n >= 6 && d.n <= BA_MAX_LDS_N;
     if (solve_lds && ba_prepare_reduced_solve_lds(d.n) != 0) return rs_fail(ctx, RS_ERR_HIP, "LDS attribute (K7)");
@@ -573,10 +588,14 @@ extern "C" int rs_bundle_adjust(rs_context* ctx, int n_cameras, int n_points, in
     if (use_mfma) ba_group_carve(ws + o_grp, d.P, d.Cf, &grp);
 
     const int pblocks = (d.P + BA_THREADS - 1) / BA_THREADS;
+    int32_t* zero_ptr = nullptr;
+    int zero_n = 0;
+    if (use_mfma) ba_group_zero_range(grp, &zero_ptr, &zero_n);
     hipStream_t s = ctx->stream;
     {
         rs_prof_scope ps(ctx, "K0_ba_init");
-        hipLaunchKernelGGL(ba_init, dim3(64), dim3(256), 0, s, d, b, opt, (const double*)d_cameras, (const double*)d_points);
+        hipLaunchKernelGGL(ba_init, dim3(64), dim3(256), 0, s, d, b, opt, (const double*)d_cameras, (const double*)d_points,
+                           free_mask, from_mask, d_cam_free, zero_ptr, zero_n);
     }
     if (use_mfma) {
         rc = ba_launch_grouping(ctx, d, b, grp);

@@ -309,6 +309,7 @@ struct BaGroup {
 
 size_t ba_group_bytes(int P, int Cf);
 void ba_group_carve(char* base, int P, int Cf, BaGroup* g);
+void ba_group_zero_range(const BaGroup& g, int32_t** ptr, int* count);
 int ba_launch_grouping(rs_context* ctx, const BaDims& d, const BaBufs& b, const BaGroup& g);
 size_t ba_schur_lds_bytes(int C, int Cf);
 int ba_prepare_schur(int C, int Cf);

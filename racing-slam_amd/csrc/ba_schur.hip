@@ -46,7 +46,7 @@ typedef __attribute__((ext_vector_type(4))) double d4;
 #define GRP_REP 8
 #define GRP_LDS_BINS 4096
 
-__global__ __launch_bounds__(256) void ba_group_count(BaDims d, BaBufs b, BaGroup g)
+__global__ __launch_bounds__(256) void ba_group_count(BaDims d, BaBufs b, BaGroup g, int* ticket)
 {
     __shared__ int lh[GRP_LDS_BINS];
     const int nb = g.n_buckets + 1;
@@ -74,6 +74,20 @@ __global__ __launch_bounds__(256) void ba_group_count(BaDims d, BaBufs b, BaGrou
     __syncthreads();
     if (use_lds)
         for (int i = threadIdx.x; i < nb; i += blockDim.x) { const int v = lh[i]; if (v) atomicAdd(&hist[i], v); }
+    // the last workgroup scans: exclusive prefix over (bucket-major, replica-minor) of hist into cursor
+    if (rs_last_workgroup(ticket)) {
+        const int total = nb * GRP_REP, T = blockDim.x, chunk = (total + T - 1) / T;
+        const int lo = min((int)threadIdx.x * chunk, total), hi = min(lo + chunk, total);
+        int sum = 0;
+        for (int i = lo; i < hi; i++) sum += __builtin_nontemporal_load(&g.hist[(size_t)(i % GRP_REP) * nb + i / GRP_REP]);
+        int tot;
+        int off = rs_block_exclusive_scan(sum, &tot);
+        for (int i = lo; i < hi; i++) {
+            const size_t a = (size_t)(i % GRP_REP) * nb + i / GRP_REP;
+            g.cursor[a] = off;
+            off += __builtin_nontemporal_load(&g.hist[a]);
+        }
+    }
 }
 
 __global__ __launch_bounds__(1024) void ba_group_scan(BaGroup g)
@@ -477,6 +491,86 @@ size_t ba_group_bytes(int P, int Cf)
     return 256 * 8 + sizeof(int32_t) * (2 * (size_t)P + 2 * nb) + sizeof(uint64_t) * (2 * (size_t)P + 2 * ni);
 }
 
+// The whole grouping in ONE workgroup (a launch costs ~4 us on this GPU; a local window has ~10^4
+// landmarks): histogram and cursors in LDS, landmarks strided over the 1024 threads.
+#define GRP_SMALL_P 2048
+__global__ __launch_bounds__(1024) void ba_group_small(BaDims d, BaBufs b, BaGroup g)
+{
+    __shared__ int lh[GRP_LDS_BINS];
+    __shared__ int wsum[16];
+    __shared__ int carry;
+    const int nb = g.n_buckets + 1;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int i = threadIdx.x; i < nb; i += 1024) lh[i] = 0;
+    if (threadIdx.x == 0) carry = 0;
+    __syncthreads();
+    for (int p = threadIdx.x; p < d.P; p += 1024) {
+        uint64_t m0 = 0, m1 = 0;
+        int first = 1 << 30, last = -1;
+        for (int o = b.obs_ptr[p]; o < b.obs_ptr[p + 1]; o++) {
+            const int s = b.slot[b.obs_cam[o]];
+            if (s < 0) continue;
+            if (s < 64) m0 |= 1ull << s; else m1 |= 1ull << (s - 64);
+            first = min(first, s);
+            last = max(last, s);
+        }
+        g.mask[2 * (size_t)p] = m0;
+        g.mask[2 * (size_t)p + 1] = m1;
+        const int bk = last < 0 ? d.Cf * d.Cf : first * d.Cf + last;
+        g.bucket[p] = bk;
+        atomicAdd(&lh[bk], 1);
+    }
+    __syncthreads();
+    // exclusive scan of lh in place
+    for (int base = 0; base < nb; base += 1024) {
+        const int i = base + threadIdx.x;
+        const int v = i < nb ? lh[i] : 0;
+        int x = v;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const int t = __shfl_up(x, off, 64);
+            if (lane >= off) x += t;
+        }
+        if (lane == 63) wsum[wave] = x;
+        __syncthreads();
+        int pre = carry;
+        for (int w = 0; w < wave; w++) pre += wsum[w];
+        if (i < nb) lh[i] = pre + x - v;
+        __syncthreads();
+        if (threadIdx.x == 1023) carry = pre + x;
+        __syncthreads();
+    }
+    for (int p = threadIdx.x; p < d.P; p += 1024) {
+        const int pos = atomicAdd(&lh[g.bucket[p]], 1);
+        g.sorted[pos] = p;
+    }
+    __syncthreads();
+    for (int t = wave; t < g.n_items; t += 16) {
+        const int q = t * IT_L + lane;
+        uint64_t m0 = 0, m1 = 0;
+        if (q < d.P) {
+            const int p = g.sorted[q];
+            m0 = g.mask[2 * (size_t)p];
+            m1 = g.mask[2 * (size_t)p + 1];
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            m0 |= (uint64_t)__shfl_xor((unsigned long long)m0, off, 64);
+            m1 |= (uint64_t)__shfl_xor((unsigned long long)m1, off, 64);
+        }
+        if (lane == 0) {
+            g.item_mask[2 * (size_t)t] = m0;
+            g.item_mask[2 * (size_t)t + 1] = m1;
+        }
+    }
+}
+
+void ba_group_zero_range(const BaGroup& g, int32_t** ptr, int* count)
+{
+    *ptr = g.hist;
+    *count = (g.n_buckets + 1) * GRP_REP;
+}
+
 static size_t al256(size_t v) { return (v + 255) & ~(size_t)255; }
 
 void ba_group_carve(char* base, int P, int Cf, BaGroup* g)
@@ -497,11 +591,14 @@ void ba_group_carve(char* base, int P, int Cf, BaGroup* g)
 int ba_launch_grouping(rs_context* ctx, const BaDims& d, const BaBufs& b, const BaGroup& g)
 {
     hipStream_t s = ctx->stream;
-    RS_HIP(ctx, hipMemsetAsync(g.hist, 0, sizeof(int32_t) * ((size_t)g.n_buckets + 1) * GRP_REP, s));
     rs_prof_scope ps(ctx, "K5s_group_landmarks");
+    if (d.P <= GRP_SMALL_P && g.n_buckets + 1 <= GRP_LDS_BINS) {
+        hipLaunchKernelGGL(ba_group_small, dim3(1), dim3(1024), 0, s, d, b, g);
+        return RS_OK;
+    }
+    // g.hist was zeroed by ba_init (ba_group_zero_range)
     const int pb = (d.P + 255) / 256;
-    hipLaunchKernelGGL(ba_group_count, dim3(pb), dim3(256), 0, s, d, b, g);
-    hipLaunchKernelGGL(ba_group_scan, dim3(1), dim3(1024), 0, s, g);
+    hipLaunchKernelGGL(ba_group_count, dim3(pb), dim3(256), 0, s, d, b, g, ctx->tickets + RS_TICKET_GROUP);
     hipLaunchKernelGGL(ba_group_scatter, dim3(pb), dim3(256), 0, s, d, g);
     hipLaunchKernelGGL(ba_group_items, dim3((g.n_items + 3) / 4), dim3(256), 0, s, d, g);
     return RS_OK;

@@ -38,7 +38,31 @@ struct rs_context {
     int rank = 0;
     // cached BA graph / buffers live in ba.hip
     void* ba_cache = nullptr;
+    // "last workgroup runs the tail" tickets (one int per fused kernel pair; always left at 0)
+    int* tickets = nullptr;
+    // proposal table of rs_reproj_match: persistent, always left at all-ones by the accept tail
+    unsigned long long* prop = nullptr;
+    size_t prop_cap = 0;
 };
+enum { RS_TICKET_K2 = 0, RS_TICKET_K4 = 1, RS_TICKET_K1 = 2, RS_TICKET_K5 = 3, RS_TICKET_GROUP = 4, RS_TICKETS = 16 };
+
+// Grid-wide "am I the last workgroup to get here": every thread's global writes are released first;
+// the last workgroup acquires (L1 invalidate) and resets the ticket for the next launch on the stream.
+__device__ __forceinline__ bool rs_last_workgroup(int* ticket)
+{
+    __shared__ int rs_is_last;
+    __threadfence();
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const int t = atomicAdd(ticket, 1);
+        rs_is_last = (t == (int)gridDim.x - 1);
+        if (rs_is_last) *ticket = 0;
+    }
+    __syncthreads();
+    const bool last = rs_is_last != 0;
+    if (last) __threadfence();
+    return last;
+}
 
 int rs_fail(rs_context* ctx, int code, const char* fmt, ...);
 
@@ -64,6 +88,27 @@ struct rs_prof_scope {
     rs_prof_scope(rs_context* ctx, const char* name) : c(ctx), n(name) { if (c->prof_on) rs_prof_start(c, n); }
     ~rs_prof_scope() { if (c->prof_on) rs_prof_stop(c, n); }
 };
+
+// Exclusive prefix sum of one int per thread over the workgroup (any size up to 1024, multiple of 64);
+// returns this thread's offset and the workgroup total.
+__device__ __forceinline__ int rs_block_exclusive_scan(int v, int* total)
+{
+    __shared__ int rs_scan_w[16];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+    int x = v;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const int t = __shfl_up(x, off, 64);
+        if (lane >= off) x += t;
+    }
+    if (lane == 63) rs_scan_w[wave] = x;
+    __syncthreads();
+    int pre = 0, tot = 0;
+    for (int w = 0; w < nw; w++) { const int c = rs_scan_w[w]; if (w < wave) pre += c; tot += c; }
+    __syncthreads();
+    *total = tot;
+    return pre + x - v;
+}
 
 // comm.hip: sum / max all-reduce of f64 on the context stream (no-op when n_ranks == 1)
 int rs_allreduce_f64(rs_context* ctx, double* d_buf, size_t count, bool is_max);

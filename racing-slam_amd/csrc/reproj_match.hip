@@ -70,10 +70,60 @@ __device__ __forceinline__ int hamming256(const uint4 a0, const uint4 a1, const 
     return d;
 }
 
+// Ordered acceptance of the proposal table (accepted_matches, src/MapMatcher.cpp:34-43) by ONE workgroup
+// of any size; resets the table to all-ones for the next call.
+__device__ __forceinline__ void k3_accept_body(unsigned long long* __restrict__ prop, int n, int max_distance,
+                                               int32_t* __restrict__ prop_point, int32_t* __restrict__ prop_dist,
+                                               int32_t* __restrict__ match_kp, int32_t* __restrict__ match_point,
+                                               int32_t* __restrict__ match_count)
+{
+    // every thread owns a contiguous chunk of keypoints: count, one workgroup scan, ordered write.
+    // Loads go out in batches of 8 (clamped addresses, no branches) so that their latencies overlap.
+    const int T = blockDim.x, chunk = (n + T - 1) / T;
+    const int lo = min((int)threadIdx.x * chunk, n), hi = min(lo + chunk, n);
+    int cnt = 0;
+    for (int i0 = lo; i0 < hi; i0 += 8) {
+        unsigned long long v[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) v[u] = __builtin_nontemporal_load(&prop[min(i0 + u, hi - 1)]);
+#pragma unroll
+        for (int u = 0; u < 8; u++) cnt += (i0 + u < hi && v[u] != ~0ull) ? 1 : 0;
+    }
+    int total;
+    int off = rs_block_exclusive_scan(cnt, &total);
+    for (int i0 = lo; i0 < hi; i0 += 8) {
+        unsigned long long v[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) v[u] = __builtin_nontemporal_load(&prop[min(i0 + u, hi - 1)]);
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            const int i = i0 + u;
+            if (i >= hi) break;
+            int pt = -1, dist = max_distance;
+            if (v[u] != ~0ull) {
+                pt = (int)(unsigned)(v[u] & 0xFFFFFFFFull);
+                dist = (int)(v[u] >> 32);
+                match_kp[off] = i;                                       // accepted_matches :34-43
+                match_point[off] = pt;
+                off++;
+                prop[i] = ~0ull;
+            }
+            prop_point[i] = pt;
+            prop_dist[i] = dist;
+        }
+    }
+    if (threadIdx.x == 0) *match_count = total;
+}
+
 __global__ __launch_bounds__(K2_THREADS) void k2_reproj_match(K2Frame f, K2Map m, int replace, int max_distance, int tree_in_lds,
                                                              int32_t* __restrict__ point_kp,
                                                              int32_t* __restrict__ point_dist,
-                                                             unsigned long long* __restrict__ prop)
+                                                             unsigned long long* __restrict__ prop, int* ticket,
+                                                             int32_t* __restrict__ prop_point,
+                                                             int32_t* __restrict__ prop_dist,
+                                                             int32_t* __restrict__ match_kp,
+                                                             int32_t* __restrict__ match_point,
+                                                             int32_t* __restrict__ match_count)
 {
     // dynamic LDS: [K2_STACK][K2_THREADS] traversal stacks, then the packed tree
     // {x, y, left, right} per node (one ds_read_b128 per visited node instead of three
@@ -89,9 +139,8 @@ __global__ __launch_bounds__(K2_THREADS) void k2_reproj_match(K2Frame f, K2Map m
         __syncthreads();
     }
     const int p = blockIdx.x * K2_THREADS + threadIdx.x;
-    if (p >= m.n_points) return;
     int out_kp = -1, out_d = max_distance;
-    do {
+    if (p < m.n_points) do {
         if (!m.eligible[p]) break;
         const float X[3] = {m.pos[3 * (size_t)p], m.pos[3 * (size_t)p + 1], m.pos[3 * (size_t)p + 2]};
         const float* T = f.T;
@@ -185,46 +234,22 @@ __global__ __launch_bounds__(K2_THREADS) void k2_reproj_match(K2Frame f, K2Map m
             atomicMin(&prop[best_kp], ((unsigned long long)(unsigned)best_d << 32) | (unsigned)p);
         }
     } while (0);
-    point_kp[p] = out_kp;
-    point_dist[p] = out_d;
+    if (p < m.n_points) {
+        point_kp[p] = out_kp;
+        point_dist[p] = out_d;
+    }
+    // K3 fused: the last workgroup to finish accepts the proposals (a separate launch costs ~4 us)
+    if (rs_last_workgroup(ticket))
+        k3_accept_body(prop, f.n_keypoints, max_distance, prop_point, prop_dist, match_kp, match_point, match_count);
 }
 
-__global__ __launch_bounds__(1024) void k3_accept(const unsigned long long* __restrict__ prop, int n,
+// stand-alone acceptance (no map points: nothing was proposed)
+__global__ __launch_bounds__(1024) void k3_accept(unsigned long long* __restrict__ prop, int n,
                                                   int max_distance, int32_t* __restrict__ prop_point,
                                                   int32_t* __restrict__ prop_dist, int32_t* __restrict__ match_kp,
                                                   int32_t* __restrict__ match_point, int32_t* __restrict__ match_count)
 {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    __shared__ int wave_count[16];
-    __shared__ int running;
-    if (threadIdx.x == 0) running = 0;
-    __syncthreads();
-    for (int base = 0; base < n; base += 1024) {
-        const int i = base + threadIdx.x;
-        bool ok = false;
-        int pt = -1, dist = max_distance;
-        if (i < n) {
-            const unsigned long long v = prop[i];
-            if (v != ~0ull) { ok = true; pt = (int)(unsigned)(v & 0xFFFFFFFFull); dist = (int)(v >> 32); }
-            prop_point[i] = pt;
-            prop_dist[i] = dist;
-        }
-        const unsigned long long mk = __ballot(ok);
-        if (lane == 0) wave_count[wave] = __popcll(mk);
-        __syncthreads();
-        int off = running;
-        for (int w = 0; w < wave; ++w) off += wave_count[w];
-        off += __popcll(mk & ((1ull << lane) - 1ull));
-        if (ok) { match_kp[off] = i; match_point[off] = pt; }            // accepted_matches :34-43
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            int tot = 0;
-            for (int w = 0; w < 16; ++w) tot += wave_count[w];
-            running += tot;
-        }
-        __syncthreads();
-    }
-    if (threadIdx.x == 0) *match_count = running;
+    k3_accept_body(prop, n, max_distance, prop_point, prop_dist, match_kp, match_point, match_count);
 }
 
 extern "C" int rs_reproj_match(rs_context* ctx, const rs_frame_view* fr, const rs_map_view* mp, int replace,
@@ -247,11 +272,17 @@ extern "C" int rs_reproj_match(rs_context* ctx, const rs_frame_view* fr, const r
         return rs_fail(ctx, RS_ERR_INVALID, "null output");
     if (P > 0 && (!d_point_kp || !d_point_dist || !mp->d_positions || !mp->d_eligible || !mp->d_obs_ptr))
         return rs_fail(ctx, RS_ERR_INVALID, "null map pointer");
-    void* ws = nullptr;
-    int rc = rs_workspace(ctx, sizeof(unsigned long long) * (size_t)N, &ws);
-    if (rc) return rc;
-    unsigned long long* prop = (unsigned long long*)ws;
-    RS_HIP(ctx, hipMemsetAsync(prop, 0xFF, sizeof(unsigned long long) * (size_t)N, ctx->stream));
+    if ((size_t)N > ctx->prop_cap) {     // grow-only; all-ones once, every call leaves it all-ones again
+        RS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        if (ctx->prop) RS_HIP(ctx, hipFree(ctx->prop));
+        ctx->prop = nullptr; ctx->prop_cap = 0;
+        const size_t cap = ((size_t)N + 4095) & ~(size_t)4095;
+        if (hipMalloc(&ctx->prop, sizeof(unsigned long long) * cap) != hipSuccess)
+            return rs_fail(ctx, RS_ERR_NOMEM, "proposal table of %zu entries", cap);
+        RS_HIP(ctx, hipMemsetAsync(ctx->prop, 0xFF, sizeof(unsigned long long) * cap, ctx->stream));
+        ctx->prop_cap = cap;
+    }
+    unsigned long long* prop = ctx->prop;
     if (P > 0) {
         K2Frame f;
         memcpy(f.T, fr->pose, sizeof f.T);
@@ -270,9 +301,10 @@ extern "C" int rs_reproj_match(rs_context* ctx, const rs_frame_view* fr, const r
             RS_HIP(ctx, hipFuncSetAttribute((const void*)k2_reproj_match, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         rs_prof_scope ps(ctx, "K2_reproj_match");
         hipLaunchKernelGGL(k2_reproj_match, dim3((P + K2_THREADS - 1) / K2_THREADS), dim3(K2_THREADS), lds,
-                           ctx->stream, f, m, replace, max_distance, tree_in_lds, d_point_kp, d_point_dist, prop);
-    }
-    {
+                           ctx->stream, f, m, replace, max_distance, tree_in_lds, d_point_kp, d_point_dist, prop,
+                           ctx->tickets + RS_TICKET_K2, d_prop_point, d_prop_dist, d_match_kp, d_match_point,
+                           d_match_count);
+    } else {
         rs_prof_scope ps(ctx, "K3_accept");
         hipLaunchKernelGGL(k3_accept, dim3(1), dim3(1024), 0, ctx->stream, prop, N, max_distance, d_prop_point,
                            d_prop_dist, d_match_kp, d_match_point, d_match_count);

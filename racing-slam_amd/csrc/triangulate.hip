@@ -100,7 +100,7 @@ __device__ __forceinline__ void projection_rows(const TriParams& k, const float*
         }                                                                                      \
     }
 
-__global__ __launch_bounds__(64) void k4_triangulate(
+__device__ __forceinline__ void k4_triangulate_body(
     const float2* __restrict__ uv1, const float2* __restrict__ uv2, int n,
     const float* __restrict__ poses, const int32_t* __restrict__ idx1, const int32_t* __restrict__ idx2,
     const int32_t* __restrict__ gather1, const int32_t* __restrict__ gather2, const int32_t* __restrict__ d_n,
@@ -212,42 +212,60 @@ __global__ __launch_bounds__(64) void k4_triangulate(
     keep[i] = ok ? 1 : 0;
 }
 
-// Single workgroup: ordered compaction of the kept correspondences (:102).
-__global__ __launch_bounds__(1024) void k4_compact(const uint8_t* __restrict__ keep, const float* __restrict__ xyz,
-                                                   int n, const int32_t* __restrict__ d_n,
-                                                   int32_t* __restrict__ out_index,
-                                                   float* __restrict__ out_xyz, int32_t* __restrict__ out_count)
+// Ordered compaction of the kept correspondences (:102) by ONE workgroup of any size.
+__device__ __forceinline__ void k4_compact_body(const uint8_t* __restrict__ keep, const float* __restrict__ xyz,
+                                                int n, const int32_t* __restrict__ d_n,
+                                                int32_t* __restrict__ out_index, float* __restrict__ out_xyz,
+                                                int32_t* __restrict__ out_count)
 {
     if (d_n) n = min(n, *d_n);
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    __shared__ int wave_count[16];
-    __shared__ int running;
-    if (threadIdx.x == 0) running = 0;
-    __syncthreads();
-    for (int base = 0; base < n; base += 1024) {
-        const int i = base + threadIdx.x;
-        const bool ok = i < n && keep[i] != 0;
-        const unsigned long long m = __ballot(ok);
-        if (lane == 0) wave_count[wave] = __popcll(m);
-        __syncthreads();
-        int off = running;
-        for (int w = 0; w < wave; ++w) off += wave_count[w];
-        off += __popcll(m & ((1ull << lane) - 1ull));
-        if (ok) {
-            out_index[off] = i;
-            out_xyz[3 * (size_t)off + 0] = xyz[3 * (size_t)i + 0];
-            out_xyz[3 * (size_t)off + 1] = xyz[3 * (size_t)i + 1];
-            out_xyz[3 * (size_t)off + 2] = xyz[3 * (size_t)i + 2];
-        }
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            int tot = 0;
-            for (int w = 0; w < 16; ++w) tot += wave_count[w];
-            running += tot;
-        }
-        __syncthreads();
+    // every thread owns a contiguous chunk: count, one workgroup scan, ordered write.  Loads go out in
+    // batches (clamped addresses, no branches) so that their latencies overlap.
+    const int T = blockDim.x, chunk = (n + T - 1) / T;
+    const int lo = min((int)threadIdx.x * chunk, n), hi = min(lo + chunk, n);
+    int cnt = 0;
+    for (int i0 = lo; i0 < hi; i0 += 16) {
+        uint8_t k[16];
+#pragma unroll
+        for (int u = 0; u < 16; u++) k[u] = keep[min(i0 + u, hi - 1)];
+#pragma unroll
+        for (int u = 0; u < 16; u++) cnt += (i0 + u < hi && k[u] != 0) ? 1 : 0;
     }
-    if (threadIdx.x == 0) *out_count = running;
+    int total;
+    int off = rs_block_exclusive_scan(cnt, &total);
+    for (int i0 = lo; i0 < hi; i0 += 8) {
+        uint8_t k[8];
+        float x[8][3];
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            const int i = min(i0 + u, hi - 1);
+            k[u] = keep[i];
+            x[u][0] = xyz[3 * (size_t)i + 0]; x[u][1] = xyz[3 * (size_t)i + 1]; x[u][2] = xyz[3 * (size_t)i + 2];
+        }
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            if (i0 + u >= hi || k[u] == 0) continue;
+            out_index[off] = i0 + u;
+            out_xyz[3 * (size_t)off + 0] = x[u][0];
+            out_xyz[3 * (size_t)off + 1] = x[u][1];
+            out_xyz[3 * (size_t)off + 2] = x[u][2];
+            off++;
+        }
+    }
+    if (threadIdx.x == 0) *out_count = total;
+}
+
+// K4 + K4b: every workgroup triangulates 64 correspondences; the last one to finish compacts
+// (a separate single-workgroup launch costs ~4 us).
+__global__ __launch_bounds__(64) void k4_triangulate(
+    const float2* __restrict__ uv1, const float2* __restrict__ uv2, int n,
+    const float* __restrict__ poses, const int32_t* __restrict__ idx1, const int32_t* __restrict__ idx2,
+    const int32_t* __restrict__ gather1, const int32_t* __restrict__ gather2, const int32_t* __restrict__ d_n,
+    TriParams prm, float* __restrict__ xyz, uint8_t* __restrict__ keep, int* ticket,
+    int32_t* __restrict__ out_index, float* __restrict__ out_xyz, int32_t* __restrict__ out_count)
+{
+    k4_triangulate_body(uv1, uv2, n, poses, idx1, idx2, gather1, gather2, d_n, prm, xyz, keep);
+    if (rs_last_workgroup(ticket)) k4_compact_body(keep, xyz, n, d_n, out_index, out_xyz, out_count);
 }
 
 static int tri_launch(rs_context* ctx, const float* d_uv1, const float* d_uv2, int n, const float* d_poses,
@@ -273,12 +291,8 @@ static int tri_launch(rs_context* ctx, const float* d_uv1, const float* d_uv2, i
     {
         rs_prof_scope ps(ctx, "K4_triangulate_dlt");
         hipLaunchKernelGGL(k4_triangulate, dim3((n + 63) / 64), dim3(64), 0, ctx->stream, (const float2*)d_uv1,
-                           (const float2*)d_uv2, n, d_poses, d_pose_idx1, d_pose_idx2, g1, g2, d_n, prm, d_xyz, d_keep);
-    }
-    {
-        rs_prof_scope ps(ctx, "K4b_compact");
-        hipLaunchKernelGGL(k4_compact, dim3(1), dim3(1024), 0, ctx->stream, d_keep, d_xyz, n, d_n, d_out_index,
-                           d_out_xyz, d_out_count);
+                           (const float2*)d_uv2, n, d_poses, d_pose_idx1, d_pose_idx2, g1, g2, d_n, prm, d_xyz, d_keep,
+                           ctx->tickets + RS_TICKET_K4, d_out_index, d_out_xyz, d_out_count);
     }
     RS_HIP(ctx, hipGetLastError());
     return RS_OK;
