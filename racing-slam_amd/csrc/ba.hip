@@ -1,7 +1,9 @@
-// ba.hip — K5..K9: local-window bundle adjustment (Levenberg-Marquardt with
-// point-block Schur elimination) and pose-only refinement, all in f64, with
-// the whole LM schedule resident on the device (no host round trip until the
-// summary is read).
+// ba.hip — local-window bundle adjustment (Levenberg-Marquardt with point-block
+// Schur elimination) and pose-only refinement, all in f64, with the whole LM
+// schedule resident on the device (no host round trip until the summary is
+// read): host orchestration, K0 init, K10 finalize, the generic (any size)
+// fallback kernels and refine_pose.  The fast paths live in ba_schur.hip (K5),
+// ba_solve.hip (K7) and ba_update.hip (K8).
 //
 // Replaces optimization::bundle_adjust / refine_pose's ceres::Solve
 // (reference src/Optimization.cpp:21-72,127-142,194-267,269-374).  The Ceres
@@ -12,19 +14,21 @@
 //     s_i = 1 / (1 + sqrt(H_ii at the first linearisation)),
 //     model_cost_change = 1/2 (delta' Lambda delta - delta' g).
 //
-// Kernel chain per LM iteration (all launches unconditional; each kernel
+// Kernel chain per LM iteration (three launches, all unconditional; each kernel
 // returns at once when state.done is set):
-//   K5 ba_linearize_schur  one lane per landmark: analytic Jacobians (left
-//                          Jacobian of SO(3), Jacobians never stored), Huber
-//                          weights, V/gp, U/gc (LDS-reduced), damped V^-1,
-//                          Schur products into S and the reduced rhs
+//   K5 linearise + Schur   applies the accept / reject decision of the PREVIOUS
+//                          iteration first (every workgroup redundantly, from the
+//                          previous state block and slot sums: no "decide" launch),
+//                          then analytic Jacobians (left Jacobian of SO(3), never
+//                          stored), Huber weights, V/gp, U/gc, damped V^-1, Schur
+//                          products into S and the reduced rhs
 //   [RCCL all-reduce of the accumulators when landmark-sharded]
-//   K7 ba_reduced_solve    one workgroup: S = U + Lambda_c - sum Y W', dense
-//                          Cholesky in LDS, delta_c, candidate cameras
-//   K8 ba_backsub_cost     one lane per landmark: delta_p, candidate points,
-//                          model-cost terms, robust cost at the candidate
-//   [RCCL all-reduce of 4 scalars]
-//   K9 ba_decide           accept / reject, radius update, termination tests
+//   K7 reduced solve       one workgroup: (U + Lambda_c - sum Y Y') y = rhs by block
+//                          L D L', delta_c, candidate cameras
+//   K8 back-substitution   delta_p, candidate points, model-cost terms, robust cost
+//                          at the candidate; clears the accumulators for the next K5
+//   [RCCL all-reduce of the step scalars]
+// K10 applies the last decision and writes the result back.
 #include <stdlib.h>
 
 #include "ba_common.h"
@@ -512,7 +516,7 @@ extern "C" int rs_bundle_adjust(rs_context* ctx, int n_cameras, int n_points, in
     opt.min_rel = options->min_relative_decrease; opt.dmin = options->min_lm_diagonal;
     opt.dmax = options->max_lm_diagonal; opt.ftol = options->function_tolerance;
     opt.gtol = options->gradient_tolerance; opt.ptol = options->parameter_tolerance;
-    opt.dbg = getenv("RS_K7_DEBUG") ? atoi(getenv("RS_K7_DEBUG")) : 0;
+    opt.dbg = 0;
     if (opt.max_iter < 0 || opt.max_iter > 1000) return rs_fail(ctx, RS_ERR_INVALID, "max_num_iterations out of range");
     if (d.Cf * 42 * sizeof(double) > 60 * 1024) return rs_fail(ctx, RS_ERR_UNSUPPORTED, "more than 182 free cameras");
 

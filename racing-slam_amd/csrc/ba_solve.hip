@@ -80,65 +80,6 @@ __global__ __launch_bounds__(K7_THREADS) void ba_reduced_solve_lds(BaDims d, BaB
     __shared__ double red[K7_THREADS / 64];
     __shared__ double red3[K7_THREADS / 64][3];
     BA_STAMP_DECL;
-    if (tid == 0) { st = *b.st; s_fail = 0; }
-    __syncthreads();
-    if (st.done) return;
-    for (int i = tid; i < BA_NSLOT * BA_SLOT_STRIDE; i += nt) b.pt_scal[i] = 0.0;     // K8 of this iteration accumulates here
-    for (int i = tid; i < 2 * 8 * 128; i += nt) Pd[i] = 0.0;
-    // fold the replicas of the camera-side accumulators (replica layout: rhs[n] U[Cf*36] gc[n])
-    for (int i = tid; i < (int)b.cam_stride; i += nt) {
-        double v = 0.0;
-#pragma unroll
-        for (int r = 0; r < BA_UREP; r++) v += b.rhs[(size_t)r * b.cam_stride + i];
-        if (i < n) grs[i] = v;                      // rhs part
-        else if (i < n + 6 * n) Us[i - n] = v;
-        else gcs[i - 7 * n] = v;
-    }
-    __syncthreads();
-    for (int i = tid; i < n; i += nt) grs[i] += gcs[i];
-    __syncthreads();
-
-    // (1) fresh linearisation: cost at x, Jacobi scaling of the camera blocks, gradient test
-    if (st.fresh) {
-        if (tid < 64) {
-            const double c = slot_sum(b.scal, 0);
-            if (tid == 0) {
-                st.x_cost = c;
-                if (st.iter == 0) st.initial_cost = st.x_cost;
-            }
-        }
-        if (!st.have_scale)
-            for (int i = tid; i < n; i += nt) {
-                const double h = Us[(i / 6) * 36 + (i % 6) * 7];
-                b.sc[i] = opt.jacobi ? 1.0 / (1.0 + sqrt(h)) : 1.0;
-            }
-        double gm = 0.0;
-        for (int i = tid; i < n; i += nt) gm = fmax(gm, fabs(gcs[i]));
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) gm = fmax(gm, __shfl_down(gm, off, 64));
-        if ((tid & 63) == 0) red[tid >> 6] = gm;
-        __syncthreads();
-        double gslots = 0.0;
-        if (tid < 64) gslots = slot_max_bits(b.gmax);
-        if (tid == 0) {
-            double g = gslots;
-            for (int w = 0; w < nt / 64; w++) g = fmax(g, red[w]);
-            if (!isfinite(st.x_cost)) { st.done = 1; st.termination = RS_BA_FAILURE; }
-            else if (g <= opt.gtol) { st.done = 1; st.termination = RS_BA_CONVERGENCE_GRADIENT; }
-        }
-        __syncthreads();
-        if (st.done) { if (tid == 0) *b.st = st; return; }
-    }
-    BA_STAMP(b, 0);
-
-    // (2) load the lower triangle + rhs row into the accumulator tiles
-    const double radius = st.radius;
-    for (int i = tid; i < n; i += nt) {
-        const double h = Us[(i / 6) * 36 + (i % 6) * 7];
-        const double s2 = b.sc[i] * b.sc[i];
-        lam[i] = clampd(s2 * h, opt.dmin, opt.dmax) / (radius * s2);
-    }
-    __syncthreads();
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lr = lane & 15, lq = lane >> 4;
@@ -149,6 +90,112 @@ __global__ __launch_bounds__(K7_THREADS) void ba_reduced_solve_lds(BaDims d, BaB
     // gets a SIMD of its own: waves 0 and 4 are the CHAIN waves (one matrix row per lane, 128 >= n+1-6
     // rows), waves 1,2,3,5,6,7 are the TILE waves that keep the trailing matrix in MFMA accumulators.
     const bool chain = (wave & 3) == 0;            // waves 0 and 4
+    const int tw = chain ? 0 : wave - 1 - (wave >> 2);     // tile wave index 0..5
+    // slot s of tile wave tw holds lower-triangle tile number t = 6 s + tw, tiles numbered row by row
+    int tr[K7_TPW], tc[K7_TPW];
+    bool tv[K7_TPW];
+#pragma unroll
+    for (int s = 0; s < K7_TPW; s++) {
+        const int t = 6 * s + tw;
+        int r = 0;
+#pragma unroll
+        for (int q = 1; q < 8; q++) r += (t >= q * (q + 1) / 2) ? 1 : 0;
+        tr[s] = r;
+        tc[s] = t - r * (r + 1) / 2;
+        tv[s] = !chain && r < NTL;
+    }
+
+    // ---- every global load of the prologue is issued here, up front, so that the ~1 us latencies of the
+    // state block, K5's slot sums, the Jacobi scale, the accumulator replicas and S overlap
+    if (tid == 0) { st = *b.st; s_fail = 0; }
+    double pre_cost = 0.0, pre_fail = 0.0, pre_gm = 0.0;
+    if (tid < 64) {
+        pre_cost = b.scal[(size_t)tid * BA_SLOT_STRIDE + 0];
+        pre_fail = b.scal[(size_t)tid * BA_SLOT_STRIDE + 1];
+        pre_gm = __longlong_as_double((long long)((const unsigned long long*)b.gmax)[(size_t)tid * BA_SLOT_STRIDE]);
+    }
+    const double pre_sc = tid < n ? b.sc[tid] : 1.0;                   // n <= 126: one entry per thread
+    double fold[2] = {0.0, 0.0};                                       // cam_stride = 8 n <= 1008: two entries per thread
+#pragma unroll
+    for (int h = 0; h < 2; h++) {
+        const int i = tid + h * nt;
+        if (i < (int)b.cam_stride) {
+#pragma unroll
+            for (int r = 0; r < BA_UREP; r++) fold[h] += b.rhs[(size_t)r * b.cam_stride + i];
+        }
+    }
+    double sv[K7_TPW][4];                                              // tile waves: their entries of S
+#pragma unroll
+    for (int s = 0; s < K7_TPW; s++) {
+#pragma unroll
+        for (int q = 0; q < 4; q++) sv[s][q] = 0.0;
+        if (!tv[s]) continue;                                          // wave-uniform
+        const int kc = min(16 * tc[s] + lr, n - 1);
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const int ic = min(16 * tr[s] + lq + 4 * q, n - 1);
+            sv[s][q] = b.S[(size_t)kc * n + ic];                       // only k <= i is used: (k, i) is S's upper triangle
+        }
+    }
+    __syncthreads();
+    if (st.done) return;
+    BA_STAMP(b, 2);
+    for (int i = tid; i < BA_NSLOT * BA_SLOT_STRIDE; i += nt) b.pt_scal[i] = 0.0;     // K8 of this iteration accumulates here
+    for (int i = tid; i < 2 * 8 * 128; i += nt) Pd[i] = 0.0;
+    // fold the replicas of the camera-side accumulators (replica layout: rhs[n] U[Cf*36] gc[n])
+#pragma unroll
+    for (int h = 0; h < 2; h++) {
+        const int i = tid + h * nt;
+        if (i < (int)b.cam_stride) {
+            if (i < n) grs[i] = fold[h];                   // rhs part
+            else if (i < n + 6 * n) Us[i - n] = fold[h];
+            else gcs[i - 7 * n] = fold[h];
+        }
+    }
+    __syncthreads();
+    for (int i = tid; i < n; i += nt) grs[i] += gcs[i];
+    // Jacobi scaling of the camera blocks (first iteration) and the LM damping
+    if (tid < n) {
+        const double h = Us[(tid / 6) * 36 + (tid % 6) * 7];
+        double sc = pre_sc;
+        if (!st.have_scale) {
+            sc = opt.jacobi ? 1.0 / (1.0 + sqrt(h)) : 1.0;
+            b.sc[tid] = sc;
+        }
+        const double s2 = sc * sc;
+        lam[tid] = clampd(s2 * h, opt.dmin, opt.dmax) / (st.radius * s2);
+    }
+    BA_STAMP(b, 3);
+
+    // (1) fresh linearisation: cost at x, gradient test
+    const double fail_sum = wave_sum(pre_fail);          // only wave 0 holds real values
+    if (st.fresh) {
+        const double c = wave_sum(pre_cost);
+        double gslots = pre_gm;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) gslots = fmax(gslots, __shfl_xor(gslots, off, 64));
+        double gm = 0.0;
+        for (int i = tid; i < n; i += nt) gm = fmax(gm, fabs(gcs[i]));
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) gm = fmax(gm, __shfl_down(gm, off, 64));
+        if ((tid & 63) == 0) red[tid >> 6] = gm;
+        __syncthreads();
+        if (tid == 0) {
+            st.x_cost = c;
+            if (st.iter == 0) st.initial_cost = st.x_cost;
+            double g = gslots;
+            for (int w = 0; w < nt / 64; w++) g = fmax(g, red[w]);
+            if (!isfinite(st.x_cost)) { st.done = 1; st.termination = RS_BA_FAILURE; }
+            else if (g <= opt.gtol) { st.done = 1; st.termination = RS_BA_CONVERGENCE_GRADIENT; }
+        }
+        __syncthreads();
+        if (st.done) { if (tid == 0) *b.st = st; return; }
+    } else {
+        __syncthreads();
+    }
+    if (tid == 0 && fail_sum > 0.0) s_fail = 1;          // K5 saw a non-finite landmark block
+    BA_STAMP(b, 0);
+
     const int NB = n / 6;
     // (3) block L D L^T, one camera (6 columns) per step, two barriers per step.  The two roles run
     // DIFFERENT loops with the same barrier count (s_barrier only counts arrivals), so neither role's
@@ -255,36 +302,23 @@ __global__ __launch_bounds__(K7_THREADS) void ba_reduced_solve_lds(BaDims d, BaB
             __syncthreads();                                               // barrier A of step J+1
         }
     } else {
-        const int tw = wave - 1 - (wave >> 2);     // tile wave index 0..5
-        // slot s of tile wave tw holds lower-triangle tile number t = 6 s + tw, tiles numbered row by row
-        int tr[K7_TPW], tc[K7_TPW];
-        bool tv[K7_TPW];
+        // (2) the lower triangle + rhs row in the accumulator tiles: S (prefetched) + U + damping
         d4 acc[K7_TPW];
         double opA[K7_TPW][2], opB[K7_TPW][2];
 #pragma unroll
         for (int s = 0; s < K7_TPW; s++) {
-            const int t = 6 * s + tw;
-            int r = 0;
-#pragma unroll
-            for (int q = 1; q < 8; q++) r += (t >= q * (q + 1) / 2) ? 1 : 0;
-            tr[s] = r;
-            tc[s] = t - r * (r + 1) / 2;
-            tv[s] = r < NTL;
             acc[s] = d4{0.0, 0.0, 0.0, 0.0};
             opA[s][0] = opA[s][1] = opB[s][0] = opB[s][1] = 0.0;
             if (!tv[s]) continue;                       // wave-uniform
             const int k = 16 * tc[s] + lr;
+            const int kc = min(k, n - 1), kb = kc / 6;
+            const double gv = grs[kc];
 #pragma unroll
             for (int q = 0; q < 4; q++) {
-                const int i = 16 * r + lq + 4 * q;
-                // unconditional loads from clamped addresses, then selects.  Only k <= i is ever used, so
-                // (k, i) is already the (low, high) pair of S's upper triangle.
-                const int kc = min(k, n - 1), ic = min(i, n - 1);
-                const double sv = b.S[(size_t)kc * n + ic];
-                const int kb = kc / 6;
+                const int i = 16 * tr[s] + lq + 4 * q;
+                const int ic = min(i, n - 1);
                 const double uv = Us[kb * 36 + (kc - 6 * kb) * 6 + ic % 6];
-                const double gv = grs[kc];
-                double val = sv + ((kb == ic / 6) ? uv : 0.0) + ((i == k) ? lam[ic] : 0.0);
+                double val = sv[s][q] + ((kb == ic / 6) ? uv : 0.0) + ((i == k) ? lam[ic] : 0.0);
                 val = (k < n && i < n && k <= i) ? val : ((i == n && k < n) ? gv : 0.0);
                 acc[s][q] = val;
             }
@@ -367,8 +401,6 @@ __global__ __launch_bounds__(K7_THREADS) void ba_reduced_solve_lds(BaDims d, BaB
             __syncthreads();                                               // barrier A of step J+1
         }
     }
-    __syncthreads();
-    if (tid < 64) { const double f = slot_sum(b.scal, 1); if (f > 0.0 && tid == 0) s_fail = 1; }
     __syncthreads();
     if (s_fail) {
         if (tid == 0) { st.solver_failed = 1; *b.st = st; }
