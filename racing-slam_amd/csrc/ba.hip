@@ -538,7 +538,7 @@ extern "C" int rs_bundle_adjust(rs_context* ctx, int n_cameras, int n_points, in
     const size_t o_free = carve(C);
     const bool use_mfma = d.Cf >= 1 && d.Cf <= 128 && ba_schur_lds_bytes(d.C, d.Cf) <= 160 * 1024;
     const bool k8_lds = ba_backsub_lds_bytes(d.C, d.n) <= 64 * 1024;
-    const size_t o_grp = carve(use_mfma ? ba_group_bytes(d.P, d.Cf) : 16);
+    const size_t o_grp = carve(use_mfma ? ba_group_bytes(d.P, d.Cf, d.M) : 16);
     void* wsv = nullptr;
     int rc = rs_workspace(ctx, off, &wsv);
     if (rc) return rc;
@@ -589,7 +589,8 @@ extern "C" int rs_bundle_adjust(rs_context* ctx, int n_cameras, int n_points, in
     if (use_mfma && ba_prepare_schur(d.C, d.Cf) != 0) return rs_fail(ctx, RS_ERR_HIP, "LDS attribute (K5)");
     BaGroup grp;
     memset(&grp, 0, sizeof grp);
-    if (use_mfma) ba_group_carve(ws + o_grp, d.P, d.Cf, &grp);
+    if (use_mfma) ba_group_carve(ws + o_grp, d.P, d.Cf, d.M, &grp);
+    b.obs_cs = use_mfma ? grp.obs_cs : nullptr;
 
     const int pblocks = (d.P + BA_THREADS - 1) / BA_THREADS;
     int32_t* zero_ptr = nullptr;

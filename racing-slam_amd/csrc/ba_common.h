@@ -32,6 +32,7 @@ struct BaBufs {
     const int32_t* obs_ptr;   // [P+1]
     const int32_t* obs_cam;   // [M]
     const float2* obs_uv;     // [M]
+    const int32_t* obs_cs;    // [M] cam | (slot + 1) << 16, built by the landmark grouping (null on the generic path)
     double* Xc;      // [2][C][6]
     double* Xp;      // [2][P][3]
     double* prep;    // [2][C][BA_PREP]
@@ -297,6 +298,8 @@ __device__ __forceinline__ BaState ba_state_for_iteration(const BaBufs& b, const
 // ---- landmark grouping for the MFMA Schur kernel (ba_schur.hip)
 struct BaGroup {
     int32_t* sorted;        // [P] landmark order
+    int4* lm;               // [P] per sorted position: {landmark, first observation, observation count, 0}
+    int32_t* obs_cs;        // [M] cam | (slot + 1) << 16 per observation
     int32_t* bucket;        // [P]
     uint64_t* mask;         // [P][2] free-slot bitmask of the landmark
     int32_t* hist;          // [Cf*Cf + 2] histogram / offsets
@@ -307,8 +310,8 @@ struct BaGroup {
 };
 
 
-size_t ba_group_bytes(int P, int Cf);
-void ba_group_carve(char* base, int P, int Cf, BaGroup* g);
+size_t ba_group_bytes(int P, int Cf, int M);
+void ba_group_carve(char* base, int P, int Cf, int M, BaGroup* g);
 void ba_group_zero_range(const BaGroup& g, int32_t** ptr, int* count);
 int ba_launch_grouping(rs_context* ctx, const BaDims& d, const BaBufs& b, const BaGroup& g);
 size_t ba_schur_lds_bytes(int C, int Cf);

@@ -59,7 +59,9 @@ __global__ __launch_bounds__(256) void ba_group_count(BaDims d, BaBufs b, BaGrou
         uint64_t m0 = 0, m1 = 0;
         int first = 1 << 30, last = -1;
         for (int o = b.obs_ptr[p]; o < b.obs_ptr[p + 1]; o++) {
-            const int s = b.slot[b.obs_cam[o]];
+            const int c = b.obs_cam[o];
+            const int s = b.slot[c];
+            g.obs_cs[o] = c | ((s + 1) << 16);
             if (s < 0) continue;
             if (s < 64) m0 |= 1ull << s; else m1 |= 1ull << (s - 64);
             first = min(first, s);
@@ -120,13 +122,15 @@ __global__ __launch_bounds__(1024) void ba_group_scan(BaGroup g)
     }
 }
 
-__global__ __launch_bounds__(256) void ba_group_scatter(BaDims d, BaGroup g)
+__global__ __launch_bounds__(256) void ba_group_scatter(BaDims d, BaBufs b, BaGroup g)
 {
     const int p = blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= d.P) return;
     const int nb = g.n_buckets + 1;
     const int pos = atomicAdd(&g.cursor[(size_t)(blockIdx.x & (GRP_REP - 1)) * nb + g.bucket[p]], 1);
     g.sorted[pos] = p;
+    const int o0 = b.obs_ptr[p];
+    g.lm[pos] = make_int4(p, o0, b.obs_ptr[p + 1] - o0, 0);
 }
 
 // one wave per item: lanes = the item's 64 landmarks, 128-bit OR across the wave
@@ -171,20 +175,29 @@ __device__ __forceinline__ int nth_set_bit(uint64_t m0, uint64_t m1, int r)
 }
 
 // cholesky of the damped point block; Li = L^-1 (lower, row-major 6 entries: 00 10 11 20 21 22)
+// 1/sqrt(x) from v_rsq_f64 + two Newton steps (no f64 sqrt / divide sequences on the chain)
+__device__ __forceinline__ double rsqrt_nr(double x)
+{
+    double y = __builtin_amdgcn_rsq(x);
+    const double h = 0.5 * x;
+    y = y * (1.5 - h * y * y);
+    y = y * (1.5 - h * y * y);
+    return y;
+}
+
 __device__ __forceinline__ bool chol3_inv(const double V[6], double Li[6], double I[6])
 {
     const double l00s = V[0];
     if (!(l00s > 0.0)) return false;
-    const double l00 = sqrt(l00s);
-    const double l10 = V[1] / l00, l20 = V[2] / l00;
+    const double i00 = rsqrt_nr(l00s);
+    const double l10 = V[1] * i00, l20 = V[2] * i00;
     const double l11s = V[3] - l10 * l10;
     if (!(l11s > 0.0)) return false;
-    const double l11 = sqrt(l11s);
-    const double l21 = (V[4] - l20 * l10) / l11;
+    const double i11 = rsqrt_nr(l11s);
+    const double l21 = (V[4] - l20 * l10) * i11;
     const double l22s = V[5] - l20 * l20 - l21 * l21;
     if (!(l22s > 0.0)) return false;
-    const double l22 = sqrt(l22s);
-    const double i00 = 1.0 / l00, i11 = 1.0 / l11, i22 = 1.0 / l22;
+    const double i22 = rsqrt_nr(l22s);
     const double i10 = -l10 * i00 * i11;
     const double i21 = -l21 * i11 * i22;
     const double i20 = -(l20 * i00 + l21 * i10) * i22;
@@ -262,8 +275,6 @@ __global__ __launch_bounds__(64 * SCH_WAVES) void ba_schur_mfma(BaDims d, BaBufs
     extern __shared__ __attribute__((aligned(16))) double lds[];
     BA_STAMP_DECL;
     __shared__ BaState st_sh;
-    const BaState st = ba_state_for_iteration(b, opt, it, &st_sh);
-    if (st.done) return;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     double* yt = lds;                                            // WG tile
@@ -271,43 +282,52 @@ __global__ __launch_bounds__(64 * SCH_WAVES) void ba_schur_mfma(BaDims d, BaBufs
     double* cprep = ulds + (size_t)d.Cf * 42;                    // [C][BA_PREP] camera block staged in LDS (C <= 64)
     int* gslot = (int*)(cprep + (size_t)d.C * BA_PREP);   // [24]
     const int nlds = d.Cf * 42;
+    // ---- everything that does not depend on the LM state goes out before the state barrier: the item's
+    // camera mask, this lane's landmark record {landmark, first observation, count} (one 16-byte load
+    // instead of the chain sorted -> obs_ptr), LDS zeroing
+    const int item = blockIdx.x;
+    const uint64_t um0 = g.item_mask[2 * (size_t)item], um1 = g.item_mask[2 * (size_t)item + 1];
+    const int l = lane & 7, sub = lane >> 3;         // 8 landmarks per wave, 8 lanes each
+    const int wl = 8 * wave + l;                     // landmark slot inside the item
+    const int q = item * IT_L + wl;
+    const int4 lmq = q < d.P ? g.lm[q] : make_int4(-1, 0, 0, 0);
+    const int p = lmq.x, o0 = lmq.y, nobs = lmq.z;
     for (int i = threadIdx.x; i < nlds; i += blockDim.x) ulds[i] = 0.0;
     for (int i = threadIdx.x; i < YT_DOUBLES; i += blockDim.x) yt[i] = 0.0;   // first batch's tile, under the load latency
+    const BaState st = ba_state_for_iteration(b, opt, it, &st_sh);
+    if (st.done) return;
+    // ---- one more round trip: camera blocks -> LDS, the landmark, the first observation of every lane
     const double* gprep = b.prep + (size_t)st.cur * d.C * BA_PREP;
     for (int i = threadIdx.x; i < d.C * BA_PREP; i += blockDim.x) cprep[i] = gprep[i];
     const double* prep = cprep;       // pure LDS pointer: ds_read, not flat_load
-
-    const int item = blockIdx.x;
-    const uint64_t um0 = g.item_mask[2 * (size_t)item], um1 = g.item_mask[2 * (size_t)item + 1];
+    const double* Xp = b.Xp + (size_t)st.cur * d.P * 3;
+    double X[3] = {0, 0, 0};
+    if (p >= 0) { X[0] = Xp[3 * (size_t)p]; X[1] = Xp[3 * (size_t)p + 1]; X[2] = Xp[3 * (size_t)p + 2]; }
+    // observation j of the lane's landmark, staggered so that the lanes of one round hit different cameras
+    int jj0 = sub + l; while (nobs > 0 && jj0 >= nobs) jj0 -= nobs;
+    int cs0 = 0;
+    float2 uv0 = make_float2(0.f, 0.f);
+    if (sub < nobs) { cs0 = g.obs_cs[o0 + jj0]; uv0 = b.obs_uv[o0 + jj0]; }
     const int ns = __popcll(um0) + __popcll(um1);
     if (threadIdx.x < 24) gslot[threadIdx.x] = (int)threadIdx.x < ns ? nth_set_bit(um0, um1, threadIdx.x) : 0;
     __syncthreads();
 
     BA_STAMP(b, 0);
-    const double* Xp = b.Xp + (size_t)st.cur * d.P * 3;
     const size_t rep_off = (size_t)(blockIdx.x & (BA_UREP - 1)) * b.cam_stride;
     double* rhs_rep = b.rhs + rep_off;
     double cost = 0.0, gmax = 0.0, fail = 0.0;
-    const int l = lane & 7, sub = lane >> 3;         // 8 landmarks per wave, 8 lanes each
-    const int wl = 8 * wave + l;                     // landmark slot inside the item
-    const int q = item * IT_L + wl;
-    const int p = q < d.P ? g.sorted[q] : -1;
-
-    double X[3] = {0, 0, 0};
-    int o0 = 0, nobs = 0;
-    if (p >= 0) {
-        X[0] = Xp[3 * (size_t)p]; X[1] = Xp[3 * (size_t)p + 1]; X[2] = Xp[3 * (size_t)p + 2];
-        o0 = b.obs_ptr[p];
-        nobs = b.obs_ptr[p + 1] - o0;
-    }
     // ---- pass 1: V, g, cost, U/gc
     double V[6] = {0, 0, 0, 0, 0, 0}, gv[3] = {0, 0, 0};
     ObsLin o;
     for (int j = sub; j < nobs; j += SCH_SUBS) {
-        int jj = j + l; while (jj >= nobs) jj -= nobs;     // staggered: lanes of one round hit different cameras
-        const int oi = o0 + jj;
-        const int c = b.obs_cam[oi];
-        const float2 uvv = b.obs_uv[oi];
+        int cs = cs0;
+        float2 uvv = uv0;
+        if (j != sub) {
+            int jj = j + l; while (jj >= nobs) jj -= nobs;
+            cs = g.obs_cs[o0 + jj];
+            uvv = b.obs_uv[o0 + jj];
+        }
+        const int c = cs & 0xFFFF;
         obs_eval<true>(prep + (size_t)c * BA_PREP, X, uvv, d, o);
         cost += 0.5 * o.rho;
         const double w = o.w;
@@ -319,7 +339,7 @@ __global__ __launch_bounds__(64 * SCH_WAVES) void ba_schur_mfma(BaDims d, BaBufs
         V[5] += w * (o.jp[2] * o.jp[2] + o.jp[5] * o.jp[5]);
 #pragma unroll
         for (int k = 0; k < 3; k++) gv[k] += w * (o.jp[k] * o.r0 + o.jp[3 + k] * o.r1);
-        const int s = b.slot[c];
+        const int s = (cs >> 16) - 1;
         if (s >= 0) {
             double* u = ulds + s * 42;
 #pragma unroll
@@ -388,10 +408,15 @@ __global__ __launch_bounds__(64 * SCH_WAVES) void ba_schur_mfma(BaDims d, BaBufs
             const int lb = wl - bt * lb_n;
             if (p >= 0 && ok && lb >= 0 && lb < lb_n) {
                 for (int j = sub; j < nobs; j += SCH_SUBS) {
-                    const int oi = o0 + j;
-                    const int c = b.obs_cam[oi];
-                    const float2 uvv = b.obs_uv[oi];
-                    const int s = b.slot[c];
+                    int cs = cs0;
+                    float2 uvv = uv0;                          // round 0 is still in registers
+                    if (j != sub) {
+                        int jj = j + l; while (jj >= nobs) jj -= nobs;
+                        cs = g.obs_cs[o0 + jj];
+                        uvv = b.obs_uv[o0 + jj];
+                    }
+                    const int c = cs & 0xFFFF;
+                    const int s = (cs >> 16) - 1;
                     if (s < 0) continue;
                     obs_eval<true>(prep + (size_t)c * BA_PREP, X, uvv, d, o);
                     const int pos = rank_in_mask(um0, um1, s);
@@ -484,11 +509,12 @@ __global__ __launch_bounds__(64 * SCH_WAVES) void ba_schur_mfma(BaDims d, BaBufs
 }
 
 // ------------------------------------------------------------------ host glue
-size_t ba_group_bytes(int P, int Cf)
+size_t ba_group_bytes(int P, int Cf, int M)
 {
     const size_t nb = ((size_t)Cf * Cf + 2) * GRP_REP;
     const size_t ni = ((size_t)P + IT_L - 1) / IT_L;
-    return 256 * 8 + sizeof(int32_t) * (2 * (size_t)P + 2 * nb) + sizeof(uint64_t) * (2 * (size_t)P + 2 * ni);
+    return 256 * 10 + sizeof(int32_t) * (2 * (size_t)P + 2 * nb + (size_t)M) + sizeof(int4) * (size_t)P +
+           sizeof(uint64_t) * (2 * (size_t)P + 2 * ni);
 }
 
 // The whole grouping in ONE workgroup (a launch costs ~4 us on this GPU; a local window has ~10^4
@@ -508,7 +534,9 @@ __global__ __launch_bounds__(1024) void ba_group_small(BaDims d, BaBufs b, BaGro
         uint64_t m0 = 0, m1 = 0;
         int first = 1 << 30, last = -1;
         for (int o = b.obs_ptr[p]; o < b.obs_ptr[p + 1]; o++) {
-            const int s = b.slot[b.obs_cam[o]];
+            const int c = b.obs_cam[o];
+            const int s = b.slot[c];
+            g.obs_cs[o] = c | ((s + 1) << 16);
             if (s < 0) continue;
             if (s < 64) m0 |= 1ull << s; else m1 |= 1ull << (s - 64);
             first = min(first, s);
@@ -543,6 +571,8 @@ __global__ __launch_bounds__(1024) void ba_group_small(BaDims d, BaBufs b, BaGro
     for (int p = threadIdx.x; p < d.P; p += 1024) {
         const int pos = atomicAdd(&lh[g.bucket[p]], 1);
         g.sorted[pos] = p;
+        const int o0 = b.obs_ptr[p];
+        g.lm[pos] = make_int4(p, o0, b.obs_ptr[p + 1] - o0, 0);
     }
     __syncthreads();
     for (int t = wave; t < g.n_items; t += 16) {
@@ -573,7 +603,7 @@ void ba_group_zero_range(const BaGroup& g, int32_t** ptr, int* count)
 
 static size_t al256(size_t v) { return (v + 255) & ~(size_t)255; }
 
-void ba_group_carve(char* base, int P, int Cf, BaGroup* g)
+void ba_group_carve(char* base, int P, int Cf, int M, BaGroup* g)
 {
     const size_t nb = ((size_t)Cf * Cf + 2) * GRP_REP;
     const size_t ni = ((size_t)P + IT_L - 1) / IT_L;
@@ -584,6 +614,8 @@ void ba_group_carve(char* base, int P, int Cf, BaGroup* g)
     g->cursor = (int32_t*)(base + off); off += al256(sizeof(int32_t) * nb);
     g->mask = (uint64_t*)(base + off); off += al256(sizeof(uint64_t) * 2 * P);
     g->item_mask = (uint64_t*)(base + off); off += al256(sizeof(uint64_t) * 2 * ni);
+    g->lm = (int4*)(base + off); off += al256(sizeof(int4) * P);
+    g->obs_cs = (int32_t*)(base + off); off += al256(sizeof(int32_t) * M);
     g->n_items = (int)ni;
     g->n_buckets = Cf * Cf;           // + 1 bucket for landmarks without a free camera
 }
@@ -599,7 +631,7 @@ int ba_launch_grouping(rs_context* ctx, const BaDims& d, const BaBufs& b, const 
     // g.hist was zeroed by ba_init (ba_group_zero_range)
     const int pb = (d.P + 255) / 256;
     hipLaunchKernelGGL(ba_group_count, dim3(pb), dim3(256), 0, s, d, b, g, ctx->tickets + RS_TICKET_GROUP);
-    hipLaunchKernelGGL(ba_group_scatter, dim3(pb), dim3(256), 0, s, d, g);
+    hipLaunchKernelGGL(ba_group_scatter, dim3(pb), dim3(256), 0, s, d, b, g);
     hipLaunchKernelGGL(ba_group_items, dim3((g.n_items + 3) / 4), dim3(256), 0, s, d, g);
     return RS_OK;
 }

@@ -16,6 +16,25 @@
 __global__ __launch_bounds__(K8_THREADS) void ba_backsub_cost4(BaDims d, BaBufs b)
 {
     extern __shared__ __attribute__((aligned(16))) double lds[];
+    // ---- loads that depend on nothing but the landmark index go out first, together with the state block
+    const int lane = threadIdx.x & 63, l = lane & 15, sub = lane >> 4;
+    const int p = blockIdx.x * 64 + (threadIdx.x >> 6) * 16 + l;
+    const bool valid = p < d.P;
+    int o0 = 0, nobs = 0;
+    double g[3] = {0, 0, 0}, I[6] = {0, 0, 0, 0, 0, 0}, lamp[3] = {0, 0, 0}, Xa[3] = {0, 0, 0}, Xb[3] = {0, 0, 0};
+    if (valid) {
+        o0 = b.obs_ptr[p];
+        nobs = b.obs_ptr[p + 1] - o0;
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+            g[k] = b.gp[3 * (size_t)p + k];
+            lamp[k] = b.lamp[3 * (size_t)p + k];
+            Xa[k] = b.Xp[3 * (size_t)p + k];
+            Xb[k] = b.Xp[(size_t)d.P * 3 + 3 * (size_t)p + k];
+        }
+#pragma unroll
+        for (int k = 0; k < 6; k++) I[k] = b.Vinv[6 * (size_t)p + k];
+    }
     const BaState st = *b.st;
     if (st.done) return;
     // K7 has consumed the accumulators: clear them for the next linearisation (no separate launch)
@@ -27,33 +46,45 @@ __global__ __launch_bounds__(K8_THREADS) void ba_backsub_cost4(BaDims d, BaBufs 
     double* dcl = cprepn + (size_t)d.C * BA_PREP;           // [n] delta_c
     const double* gprep = b.prep + (size_t)st.cur * d.C * BA_PREP;
     double* gprepn = b.prep + (size_t)(st.cur ^ 1) * d.C * BA_PREP;
-    // K7 wrote the candidate cameras' blocks (prep[cur^1]); both sets are staged in LDS
+    // second round trip: K7's candidate camera blocks (prep[cur^1]) and the current ones -> LDS, and the
+    // first two observations of every lane (later rounds load on demand)
+    int cs_pre[2] = {0, 0};
+    float2 uv_pre[2] = {make_float2(0.f, 0.f), make_float2(0.f, 0.f)};
+#pragma unroll
+    for (int r = 0; r < 2; r++) {
+        const int j = sub + 4 * r;
+        if (j < nobs) {
+            const int oi = o0 + j;
+            if (b.obs_cs) cs_pre[r] = b.obs_cs[oi];
+            else { const int c = b.obs_cam[oi]; cs_pre[r] = c | ((b.slot[c] + 1) << 16); }
+            uv_pre[r] = b.obs_uv[oi];
+        }
+    }
     for (int i = threadIdx.x; i < d.C * BA_PREP; i += blockDim.x) { cprep[i] = gprep[i]; cprepn[i] = gprepn[i]; }
     for (int i = threadIdx.x; i < d.n; i += blockDim.x) dcl[i] = b.dc[i];
     __syncthreads();
     const double* prep = cprep;
 
-    const double* Xp = b.Xp + (size_t)st.cur * d.P * 3;
     double* Xn = b.Xp + (size_t)(st.cur ^ 1) * d.P * 3;
-    const int lane = threadIdx.x & 63, l = lane & 15, sub = lane >> 4;
-    const int p = blockIdx.x * 64 + (threadIdx.x >> 6) * 16 + l;
     double cost = 0.0, mcc = 0.0, ssq = 0.0, xsq = 0.0;
-    const bool valid = p < d.P;
-    double X[3] = {0, 0, 0};
-    int o0 = 0, nobs = 0;
-    if (valid) {
-        X[0] = Xp[3 * (size_t)p]; X[1] = Xp[3 * (size_t)p + 1]; X[2] = Xp[3 * (size_t)p + 2];
-        o0 = b.obs_ptr[p];
-        nobs = b.obs_ptr[p + 1] - o0;
-    }
+    double X[3];
+#pragma unroll
+    for (int k = 0; k < 3; k++) X[k] = st.cur ? Xb[k] : Xa[k];
     double t[3] = {0, 0, 0};
     ObsLin o;
-    for (int j = sub; j < nobs; j += 4) {
-        const int oi = o0 + j;
-        const int c = b.obs_cam[oi];
-        const int s = b.slot[c];
+    for (int j = sub, r = 0; j < nobs; j += 4, r++) {
+        int cs;
+        float2 uvv;
+        if (r < 2) { cs = cs_pre[r & 1]; uvv = uv_pre[r & 1]; }
+        else {
+            const int oi = o0 + j;
+            if (b.obs_cs) cs = b.obs_cs[oi];
+            else { const int c = b.obs_cam[oi]; cs = c | ((b.slot[c] + 1) << 16); }
+            uvv = b.obs_uv[oi];
+        }
+        const int c = cs & 0xFFFF, s = (cs >> 16) - 1;
         if (s < 0) continue;
-        obs_eval<true>(prep + (size_t)c * BA_PREP, X, b.obs_uv[oi], d, o);
+        obs_eval<true>(prep + (size_t)c * BA_PREP, X, uvv, d, o);
         double m0 = 0.0, m1 = 0.0;
 #pragma unroll
         for (int a = 0; a < 6; a++) { const double dc = dcl[6 * s + a]; m0 += o.jc[a] * dc; m1 += o.jc[6 + a] * dc; }
@@ -64,8 +95,6 @@ __global__ __launch_bounds__(K8_THREADS) void ba_backsub_cost4(BaDims d, BaBufs 
     for (int k = 0; k < 3; k++) { t[k] += __shfl_xor(t[k], 16, 64); t[k] += __shfl_xor(t[k], 32, 64); }
     double Xc[3] = {0, 0, 0};
     if (valid) {
-        const double g[3] = {b.gp[3 * (size_t)p], b.gp[3 * (size_t)p + 1], b.gp[3 * (size_t)p + 2]};
-        const double* I = b.Vinv + 6 * (size_t)p;
         const double I0 = I[0], I1 = I[1], I2 = I[2], I3 = I[3], I4 = I[4], I5 = I[5];
         const double tt[3] = {t[0] + g[0], t[1] + g[1], t[2] + g[2]};
         const double dp[3] = {-(I0 * tt[0] + I1 * tt[1] + I2 * tt[2]), -(I1 * tt[0] + I3 * tt[1] + I4 * tt[2]),
@@ -75,16 +104,18 @@ __global__ __launch_bounds__(K8_THREADS) void ba_backsub_cost4(BaDims d, BaBufs 
             Xc[k] = X[k] + dp[k];
             if (sub == 0) {
                 Xn[3 * (size_t)p + k] = Xc[k];
-                mcc += 0.5 * (dp[k] * dp[k] * b.lamp[3 * (size_t)p + k] - dp[k] * g[k]);
+                mcc += 0.5 * (dp[k] * dp[k] * lamp[k] - dp[k] * g[k]);
                 ssq += (X[k] - Xc[k]) * (X[k] - Xc[k]);
                 xsq += X[k] * X[k];
             }
         }
     }
-    for (int j = sub; j < nobs; j += 4) {
-        const int oi = o0 + j;
-        const int c = b.obs_cam[oi];
-        obs_eval<false>(cprepn + (size_t)c * BA_PREP, Xc, b.obs_uv[oi], d, o);
+    for (int j = sub, r = 0; j < nobs; j += 4, r++) {
+        int c;
+        float2 uvv;
+        if (r < 2) { c = cs_pre[r & 1] & 0xFFFF; uvv = uv_pre[r & 1]; }
+        else { c = b.obs_cam[o0 + j]; uvv = b.obs_uv[o0 + j]; }
+        obs_eval<false>(cprepn + (size_t)c * BA_PREP, Xc, uvv, d, o);
         cost += 0.5 * o.rho;
     }
     cost = wave_sum(cost); mcc = wave_sum(mcc); ssq = wave_sum(ssq); xsq = wave_sum(xsq);
