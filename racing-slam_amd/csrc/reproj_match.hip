@@ -21,6 +21,7 @@
 
 #define K2_THREADS 128
 #define K2_STACK 40
+#define K2_PRE 8         // observations of a map point whose centre / descriptor row are preloaded
 #define K2_MAX_LDS_NODES 6144    // 16 B per node: the whole KD-tree of a frame (2000 keypoints = 32 KB) sits in LDS
 
 struct K2Frame {
@@ -131,18 +132,48 @@ __global__ __launch_bounds__(K2_THREADS) void k2_reproj_match(K2Frame f, K2Map m
     extern __shared__ __attribute__((aligned(16))) int k2_lds[];
     int (*stack)[K2_THREADS] = (int (*)[K2_THREADS])k2_lds;
     float4* tree = (float4*)(k2_lds + K2_STACK * K2_THREADS);
+    int* tree_kp = (int*)(tree + (tree_in_lds ? f.n_keypoints : 0));
+    // this lane's map point: every load that needs only p goes out before the tree is staged
+    const int p = blockIdx.x * K2_THREADS + threadIdx.x;
+    const bool have = p < m.n_points;
+    const int pc = have ? p : 0;
+    const bool elig = have && m.n_points > 0 && m.eligible[pc] != 0;
+    const int o0 = m.n_points > 0 ? m.obs_ptr[pc] : 0, o1 = m.n_points > 0 ? m.obs_ptr[pc + 1] : 0;
+    const int nobs = o1 - o0;
+    float X[3] = {0.f, 0.f, 0.f};
+    if (m.n_points > 0) { X[0] = m.pos[3 * (size_t)pc]; X[1] = m.pos[3 * (size_t)pc + 1]; X[2] = m.pos[3 * (size_t)pc + 2]; }
+    // the first K2_PRE observations of the point: keyframe centre and descriptor row, loaded as two
+    // batches (not as nobs dependent pairs inside the loops below); further observations load on demand
+    int rowv[K2_PRE];
+    float Cv[K2_PRE][3];
+    {
+        int kfv[K2_PRE];
+#pragma unroll
+        for (int j = 0; j < K2_PRE; j++) {
+            kfv[j] = 0; rowv[j] = 0;
+            if (elig && j < nobs) { kfv[j] = m.obs_kf[o0 + j]; rowv[j] = m.obs_desc[o0 + j]; }
+        }
+#pragma unroll
+        for (int j = 0; j < K2_PRE; j++) {
+            Cv[j][0] = Cv[j][1] = Cv[j][2] = 0.f;
+            if (elig && j < nobs) {
+                const float* C = m.kf_centers + 3 * (size_t)kfv[j];
+                Cv[j][0] = C[0]; Cv[j][1] = C[1]; Cv[j][2] = C[2];
+            }
+        }
+    }
     if (tree_in_lds) {
         for (int i = threadIdx.x; i < f.n_keypoints; i += blockDim.x) {
-            const float2 q = f.kp[f.kd_node_kp[i]];
+            const int kpi = f.kd_node_kp[i];
+            const float2 q = f.kp[kpi];
             tree[i] = make_float4(q.x, q.y, __int_as_float(f.kd_left[i]), __int_as_float(f.kd_right[i]));
+            tree_kp[i] = kpi;
         }
         __syncthreads();
     }
-    const int p = blockIdx.x * K2_THREADS + threadIdx.x;
     int out_kp = -1, out_d = max_distance;
-    if (p < m.n_points) do {
-        if (!m.eligible[p]) break;
-        const float X[3] = {m.pos[3 * (size_t)p], m.pos[3 * (size_t)p + 1], m.pos[3 * (size_t)p + 2]};
+    if (have) do {
+        if (!elig) break;
         const float* T = f.T;
         // Camera::project (src/Camera.cpp:25-32): K * pose.block<3,4> first, then * homogeneous
         float uvw[3];
@@ -172,18 +203,23 @@ __global__ __launch_bounds__(K2_THREADS) void k2_reproj_match(K2Frame f, K2Map m
             center[i] = dot3f(a, t);
         }
         const float ray[3] = {X[0] - center[0], X[1] - center[1], X[2] - center[2]};
-        const int o0 = m.obs_ptr[p], o1 = m.obs_ptr[p + 1];
         float normal[3] = {0.0f, 0.0f, 0.0f};
         float nearest = 3.402823466e+38f, furthest = 0.0f;
-        for (int o = o0; o < o1; o++) {                                  // src/MapPoint.cpp:24-45
-            const float* C = m.kf_centers + 3 * (size_t)m.obs_kf[o];
-            float d[3] = {X[0] - C[0], X[1] - C[1], X[2] - C[2]};
+        auto add_obs = [&](const float Cx, const float Cy, const float Cz) {   // src/MapPoint.cpp:24-45
+            float d[3] = {X[0] - Cx, X[1] - Cy, X[2] - Cz};
             const float dist = sqrtf(dot3f(d, d));
             nearest = dist < nearest ? dist : nearest;
             furthest = furthest < dist ? dist : furthest;
             normalize3f(d);
             normalize3f(d);
             normal[0] += d[0]; normal[1] += d[1]; normal[2] += d[2];
+        };
+#pragma unroll
+        for (int j = 0; j < K2_PRE; j++)
+            if (j < nobs) add_obs(Cv[j][0], Cv[j][1], Cv[j][2]);
+        for (int o = o0 + K2_PRE; o < o1; o++) {
+            const float* C = m.kf_centers + 3 * (size_t)m.obs_kf[o];
+            add_obs(C[0], C[1], C[2]);
         }
         normalize3f(normal);
         float rn[3] = {ray[0], ray[1], ray[2]};
@@ -211,13 +247,26 @@ __global__ __launch_bounds__(K2_THREADS) void k2_reproj_match(K2Frame f, K2Map m
             }
             const float dx = qx - u, dy = qy - v;
             const float d2 = dx * dx + dy * dy;
-            const int kp = d2 <= r2 ? f.kd_node_kp[node] : 0;
+            const int kp = d2 <= r2 ? (tree_in_lds ? tree_kp[node] : f.kd_node_kp[node]) : 0;
             if (d2 <= r2 && (replace || !f.kp_matched[kp])) {            // :65, :81
                 const uint4 a0 = f.desc[2 * (size_t)kp], a1 = f.desc[2 * (size_t)kp + 1];
-                for (int o = o0; o < o1; o++) {
+                // the point's descriptors: rows are already in registers, the loads of one candidate go out together
+                uint4 b0[K2_PRE], b1[K2_PRE];
+#pragma unroll
+                for (int j = 0; j < K2_PRE; j++) {
+                    b0[j] = make_uint4(0, 0, 0, 0); b1[j] = b0[j];
+                    if (j < nobs) { const size_t row = (size_t)rowv[j]; b0[j] = m.pool[2 * row]; b1[j] = m.pool[2 * row + 1]; }
+                }
+#pragma unroll
+                for (int j = 0; j < K2_PRE; j++) {
+                    if (j >= nobs) break;
+                    const int hd = hamming256(a0, a1, b0[j], b1[j]);
+                    if (hd < best_d) { best_d = hd; best_kp = kp; }       // :88-91
+                }
+                for (int o = o0 + K2_PRE; o < o1; o++) {
                     const size_t row = (size_t)m.obs_desc[o];
                     const int hd = hamming256(a0, a1, m.pool[2 * row], m.pool[2 * row + 1]);
-                    if (hd < best_d) { best_d = hd; best_kp = kp; }       // :88-91
+                    if (hd < best_d) { best_d = hd; best_kp = kp; }
                 }
             }
             const float delta = odd ? dy : dx;
@@ -296,7 +345,7 @@ extern "C" int rs_reproj_match(rs_context* ctx, const rs_frame_view* fr, const r
         m.obs_kf = mp->d_obs_kf; m.obs_desc = mp->d_obs_desc; m.kf_centers = mp->d_kf_centers;
         m.pool = (const uint4*)mp->d_desc_pool;
         const int tree_in_lds = N <= K2_MAX_LDS_NODES ? 1 : 0;
-        const size_t lds = sizeof(int) * K2_STACK * K2_THREADS + (tree_in_lds ? sizeof(float4) * (size_t)N : 0);
+        const size_t lds = sizeof(int) * K2_STACK * K2_THREADS + (tree_in_lds ? (sizeof(float4) + sizeof(int)) * (size_t)N : 0);
         if (lds > 48 * 1024)
             RS_HIP(ctx, hipFuncSetAttribute((const void*)k2_reproj_match, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         rs_prof_scope ps(ctx, "K2_reproj_match");
