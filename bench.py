@@ -47,6 +47,29 @@ def algorithmic_work(w, n_free):
                 lin_bytes=lin_bytes, cost_bytes=cost_bytes)
 
 
+PMC_FILE = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "round1_v3_pmc.csv")
+PMC_NAMES = {"K5_ba_schur_mfma": "ba_schur_mfma", "K7_ba_reduced_solve": "ba_reduced_solve_lds",
+             "K8_ba_backsub_cost": "ba_backsub_cost4", "K1_hamming_knn2": "k1_hamming_knn2",
+             "K1b_merge_filter": "k1_merge_filter", "K2_reproj_match": "k2_reproj_match",
+             "K4_triangulate_dlt": "k4_triangulate"}
+
+
+def pmc_traffic():
+    """HBM-side bytes per launch from the committed rocprofv3 PMC passes (FETCH_SIZE and WRITE_SIZE collected in
+    separate runs of this same benchmark; FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950).  The
+    counters cannot be collected from inside bench.py; the file is the record of the last collection."""
+    out = {}
+    try:
+        with open(PMC_FILE) as fh:
+            next(fh)
+            for line in fh:
+                f = line.strip().split(",")
+                out[f[0]] = float(f[4])
+    except OSError:
+        pass
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -172,6 +195,32 @@ def main():
         roofline["frac"] = roofline["achieved"] / roofline["peak"]
         roofline["avg_launch_us"] = per_kernel[dom]["avg_us"]
         roofline["timing"] = "hip events per launch on the library stream, %d instrumented passes" % args.steps
+        pmc = pmc_traffic()
+        if PMC_NAMES.get(dom) in pmc:
+            roofline["traffic"] = pmc[PMC_NAMES[dom]]
+            roofline["traffic_source"] = "profiles/round1_v3_pmc.csv (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes; 2*FETCH+WRITE bytes per launch)"
+        if dom.startswith("K7"):
+            roofline["note"] = ("latency-bound single-workgroup factorisation (18 dependent block steps); neither the "
+                                "MFMA nor the HBM roof applies, see DESIGN.md 4.2")
+
+    # every hot kernel against its roof (same event timings)
+    roofline_all = {}
+    pmc_all = pmc_traffic()
+    def add(name, bound, work_amount):
+        if name not in per_kernel:
+            return
+        t = per_kernel[name]["avg_us"] * 1e-6
+        peak = FP64_PEAK_TFLOPS if bound == "mfma" else HBM_PEAK_GBS
+        ach = work_amount / t / (1e12 if bound == "mfma" else 1e9)
+        roofline_all[name] = dict(bound=bound, achieved=ach, peak=peak, unit="TFLOP/s" if bound == "mfma" else "GB/s",
+                                  frac=ach / peak, avg_launch_us=per_kernel[name]["avg_us"],
+                                  traffic=pmc_all.get(PMC_NAMES.get(name)))
+    add("K5_ba_schur_mfma", "mfma", work["lin_flops"] + work["schur_flops"])
+    add("K7_ba_reduced_solve", "mfma", work["solve_flops"])
+    add("K8_ba_backsub_cost", "hbm", work["cost_bytes"] + 16 * work["M"] + 2 * 24 * work["P"])
+    add("K1_hamming_knn2", "hbm", 32.0 * (nq + nt) + 12.0 * nq)
+    add("K4_triangulate_dlt", "mfma", 2500.0 * nq)
+    add("K2_reproj_match", "hbm", 13.0 * len(mp["positions"]) + 4.0 * len(mp["obs_kf"]) * 2 + 32.0 * len(mp["obs_kf"]) + 48.0 * nq)
 
     # ------------------------------------------------- CPU baseline (rank 0)
     cpu = None
@@ -209,7 +258,7 @@ def main():
             "per_kernel_us": {k: round(v["avg_us"], 2) for k, v in sorted(per_kernel.items())},
             "per_kernel_launches_per_pass": {k: v["launches"] / max(args.steps, 1) for k, v in sorted(per_kernel.items())},
             "ba_summary": last.get("ba"),
-            "ba_phase_cycles": ctx.prof_counters(48),
+            "roofline_all": roofline_all,
             "speedup_vs_cpu_baseline": (value / cpu["value"]) if cpu else None,
         }
         print(json.dumps(out))
