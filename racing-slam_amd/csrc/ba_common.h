@@ -307,6 +307,7 @@ struct BaGroup {
     uint64_t* item_mask;    // [n_items][2]
     int n_items;
     int n_buckets;
+    int it_l;               // landmarks per item (40 or 64)
 };
 
 

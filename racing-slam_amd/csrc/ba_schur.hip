@@ -25,7 +25,9 @@
 // f64 atomics (correct for any covisibility, slow).
 #include "ba_common.h"
 
-#define IT_L 64                 // landmarks per item (= per workgroup; 16 per wave)
+#define IT_L 64                 // landmarks per item, upper bound (= per workgroup; 8 per wave); the actual
+                                // count g.it_l is 40 when that puts every item on its own CU (P <= 256 * 40)
+#define IT_L_SMALL 40
 #define SCH_WAVES 8             // waves per workgroup (2 per SIMD: latency hiding; <= 2 SYRK tiles per wave)
 #define SCH_SUBS 8              // lanes sharing one landmark (8 landmarks per wave)
 #define YT_STRIDE4 81           // doubles per K-column, NT = 4: 64 rows + 17 (17 mod 32 keeps the two
@@ -138,9 +140,9 @@ __global__ __launch_bounds__(256) void ba_group_items(BaDims d, BaGroup g)
 {
     const int t = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (t >= g.n_items) return;
-    const int q = t * IT_L + (threadIdx.x & 63);
+    const int q = t * g.it_l + (threadIdx.x & 63);
     uint64_t m0 = 0, m1 = 0;
-    if (q < d.P) {
+    if ((int)(threadIdx.x & 63) < g.it_l && q < d.P) {
         const int p = g.sorted[q];
         m0 = g.mask[2 * (size_t)p];
         m1 = g.mask[2 * (size_t)p + 1];
@@ -226,7 +228,7 @@ __device__ __forceinline__ void tile_rc(int t, int NT, int& r, int& c)
 //   yt : LDS tile, column-major [col][STRIDE]; rows [0, 6*ns] used (row 6*ns = rhs row)
 template <int NT, int TPW, int STRIDE>
 __device__ __forceinline__ void syrk_scatter(const double* yt, int nchunks, int ns, const int* gslot, int n,
-                                             int wave, double* __restrict__ S, double* __restrict__ rhs)
+                                             int wave, int nw, double* __restrict__ S, double* __restrict__ rhs)
 {
     const int lane = threadIdx.x & 63;
     const int lr = lane & 15, lk = lane >> 4;
@@ -238,7 +240,7 @@ __device__ __forceinline__ void syrk_scatter(const double* yt, int nchunks, int 
     for (int t = 0; t < TPW; t++) {
         acc[t] = (d4){0.0, 0.0, 0.0, 0.0};
         int r = 0, c = NT;
-        if (wave + SCH_WAVES * t < NT * (NT + 1) / 2) tile_rc(wave + SCH_WAVES * t, NT, r, c);
+        if (wave + nw * t < NT * (NT + 1) / 2) tile_rc(wave + nw * t, NT, r, c);
         tr[t] = r; tc[t] = c;               // c >= nt_used marks an unused slot
     }
 #pragma unroll 4
@@ -289,7 +291,7 @@ __global__ __launch_bounds__(64 * SCH_WAVES) void ba_schur_mfma(BaDims d, BaBufs
     const uint64_t um0 = g.item_mask[2 * (size_t)item], um1 = g.item_mask[2 * (size_t)item + 1];
     const int l = lane & 7, sub = lane >> 3;         // 8 landmarks per wave, 8 lanes each
     const int wl = 8 * wave + l;                     // landmark slot inside the item
-    const int q = item * IT_L + wl;
+    const int q = item * g.it_l + wl;
     const int4 lmq = q < d.P ? g.lm[q] : make_int4(-1, 0, 0, 0);
     const int p = lmq.x, o0 = lmq.y, nobs = lmq.z;
     for (int i = threadIdx.x; i < nlds; i += blockDim.x) ulds[i] = 0.0;
@@ -395,7 +397,7 @@ __global__ __launch_bounds__(64 * SCH_WAVES) void ba_schur_mfma(BaDims d, BaBufs
     // ---- pass 2: Y into the LDS tile (compact rows), SYRK on the matrix cores, scatter
     if (ns > 0 && ns <= 21) {
         const bool big = ns > 10;
-        const int nbatch = big ? 2 : 1, lb_n = big ? 32 : 64;
+        const int nbatch = big ? 2 : 1, lb_n = big ? g.it_l / 2 : g.it_l;
         const int stride = big ? YT_STRIDE8 : YT_STRIDE4;
         for (int bt = 0; bt < nbatch; bt++) {
             const int ncol = 3 * lb_n;
@@ -439,8 +441,13 @@ __global__ __launch_bounds__(64 * SCH_WAVES) void ba_schur_mfma(BaDims d, BaBufs
             }
             __syncthreads();
             BA_STAMP(b, 4);
-            if (big) syrk_scatter<8, 5, YT_STRIDE8>(yt, ncol / 4, ns, gslot, d.n, wave, b.S, rhs_rep);
-            else syrk_scatter<4, 2, YT_STRIDE4>(yt, ncol / 4, ns, gslot, d.n, wave, b.S, rhs_rep);
+            const int nw = (int)(blockDim.x >> 6);            // 8 (64 landmarks) or 5 (40 landmarks)
+            if (big) {
+                if (nw >= 8) syrk_scatter<8, 5, YT_STRIDE8>(yt, ncol / 4, ns, gslot, d.n, wave, nw, b.S, rhs_rep);
+                else syrk_scatter<8, 8, YT_STRIDE8>(yt, ncol / 4, ns, gslot, d.n, wave, nw, b.S, rhs_rep);
+            } else {
+                syrk_scatter<4, 2, YT_STRIDE4>(yt, ncol / 4, ns, gslot, d.n, wave, nw, b.S, rhs_rep);
+            }
         }
     } else if (ns > 21) {
         // generic fallback: per-landmark f64 atomics (any covisibility pattern)
@@ -486,11 +493,12 @@ __global__ __launch_bounds__(64 * SCH_WAVES) void ba_schur_mfma(BaDims d, BaBufs
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) gmax = fmax(gmax, __shfl_down(gmax, off, 64));
     __shared__ double redw[SCH_WAVES][3];
+    const int nwaves = (int)(blockDim.x >> 6);
     if (lane == 0) { redw[wave][0] = cost; redw[wave][1] = fail; redw[wave][2] = gmax; }
     __syncthreads();
     if (threadIdx.x == 0) {      // one atomic per workgroup, spread over BA_NSLOT lines
         double c = 0.0, f = 0.0, gm = 0.0;
-        for (int w = 0; w < SCH_WAVES; w++) { c += redw[w][0]; f += redw[w][1]; gm = fmax(gm, redw[w][2]); }
+        for (int w = 0; w < nwaves; w++) { c += redw[w][0]; f += redw[w][1]; gm = fmax(gm, redw[w][2]); }
         const size_t slot = (size_t)(blockIdx.x & (BA_NSLOT - 1)) * BA_SLOT_STRIDE;
         if (c != 0.0) atomicAdd(&b.scal[slot], c);
         if (f > 0.0) atomicAdd(&b.scal[slot + 1], f);
@@ -512,7 +520,7 @@ __global__ __launch_bounds__(64 * SCH_WAVES) void ba_schur_mfma(BaDims d, BaBufs
 size_t ba_group_bytes(int P, int Cf, int M)
 {
     const size_t nb = ((size_t)Cf * Cf + 2) * GRP_REP;
-    const size_t ni = ((size_t)P + IT_L - 1) / IT_L;
+    const size_t ni = ((size_t)P + IT_L_SMALL - 1) / IT_L_SMALL;
     return 256 * 10 + sizeof(int32_t) * (2 * (size_t)P + 2 * nb + (size_t)M) + sizeof(int4) * (size_t)P +
            sizeof(uint64_t) * (2 * (size_t)P + 2 * ni);
 }
@@ -576,9 +584,9 @@ __global__ __launch_bounds__(1024) void ba_group_small(BaDims d, BaBufs b, BaGro
     }
     __syncthreads();
     for (int t = wave; t < g.n_items; t += 16) {
-        const int q = t * IT_L + lane;
+        const int q = t * g.it_l + lane;
         uint64_t m0 = 0, m1 = 0;
-        if (q < d.P) {
+        if (lane < g.it_l && q < d.P) {
             const int p = g.sorted[q];
             m0 = g.mask[2 * (size_t)p];
             m1 = g.mask[2 * (size_t)p + 1];
@@ -606,14 +614,16 @@ static size_t al256(size_t v) { return (v + 255) & ~(size_t)255; }
 void ba_group_carve(char* base, int P, int Cf, int M, BaGroup* g)
 {
     const size_t nb = ((size_t)Cf * Cf + 2) * GRP_REP;
-    const size_t ni = ((size_t)P + IT_L - 1) / IT_L;
+    const size_t ni_max = ((size_t)P + IT_L_SMALL - 1) / IT_L_SMALL;
+    g->it_l = P <= 256 * IT_L_SMALL ? IT_L_SMALL : IT_L;
+    const size_t ni = ((size_t)P + g->it_l - 1) / g->it_l;
     size_t off = 0;
     g->sorted = (int32_t*)(base + off); off += al256(sizeof(int32_t) * P);
     g->bucket = (int32_t*)(base + off); off += al256(sizeof(int32_t) * P);
     g->hist = (int32_t*)(base + off); off += al256(sizeof(int32_t) * nb);
     g->cursor = (int32_t*)(base + off); off += al256(sizeof(int32_t) * nb);
     g->mask = (uint64_t*)(base + off); off += al256(sizeof(uint64_t) * 2 * P);
-    g->item_mask = (uint64_t*)(base + off); off += al256(sizeof(uint64_t) * 2 * ni);
+    g->item_mask = (uint64_t*)(base + off); off += al256(sizeof(uint64_t) * 2 * ni_max);
     g->lm = (int4*)(base + off); off += al256(sizeof(int4) * P);
     g->obs_cs = (int32_t*)(base + off); off += al256(sizeof(int32_t) * M);
     g->n_items = (int)ni;
@@ -650,5 +660,5 @@ int ba_prepare_schur(int C, int Cf)
 
 void ba_launch_schur(hipStream_t s, const BaDims& d, const BaBufs& b, const BaOpt& opt, const BaGroup& g, int it)
 {
-    hipLaunchKernelGGL(ba_schur_mfma, dim3(g.n_items), dim3(64 * SCH_WAVES), ba_schur_lds_bytes(d.C, d.Cf), s, d, b, opt, g, it);
+    hipLaunchKernelGGL(ba_schur_mfma, dim3(g.n_items), dim3(8 * g.it_l), ba_schur_lds_bytes(d.C, d.Cf), s, d, b, opt, g, it);
 }
