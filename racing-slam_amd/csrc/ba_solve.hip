@@ -70,7 +70,6 @@ __global__ __launch_bounds__(K7_THREADS) void ba_reduced_solve_lds(BaDims d, BaB
     double* Us = Minv + 6 * n;                     // [Cf*36] U folded over the BA_UREP replicas
     double* gcs = Us + 6 * n;                      // [n] gc folded
     double* grs = gcs + n;                         // [n] gc + rhs folded: the reduced right-hand side
-    double* dvals = grs + n;                       // [n] the pivots D of L D L^T
     // MFMA operand panels of the current step, k-major: Pd[e][i] = F[i][e] d_e, Nf[e][i] = -F[i][e];
     // rows e = 6, 7 stay zero (K = 6 padded to 8).  16-byte aligned.
     double* Pd = sm + (((size_t)(n + 1) * LD + 17 * (size_t)n + 1) & ~(size_t)1);
@@ -414,52 +413,44 @@ __global__ __launch_bounds__(K7_THREADS) void ba_reduced_solve_lds(BaDims d, BaB
         const double* yrow = A + (size_t)n * LD;
         double y0 = yrow[min(lane, n)], y1 = yrow[min(64 + lane, n)];
         const int i0 = min(lane, n), i1 = min(64 + lane, n);
-        // operands of a step do not depend on the chain: they are loaded one step ahead
-        double Lb[6][6], p0[6], p1[6];
-        {
-            const int J = NB - 1, c0 = 6 * J;
-#pragma unroll
-            for (int e = 1; e < 6; e++)
-#pragma unroll
-                for (int t = 0; t < e; t++) Lb[e][t] = Minv[J * 36 + e * 6 + t];
-#pragma unroll
-            for (int e = 0; e < 6; e++) { p0[e] = A[(c0 + e) * LD + i0]; p1[e] = A[(c0 + e) * LD + i1]; }
-        }
-        for (int J = NB - 1; J >= 0; J--) {
-            const int c0 = 6 * J;
-            double nL[6][6], np0[6], np1[6];
-            {
-                const int Jn = max(J - 1, 0), cn = 6 * Jn;
-#pragma unroll
-                for (int e = 1; e < 6; e++)
-#pragma unroll
-                    for (int t = 0; t < e; t++) nL[e][t] = Minv[Jn * 36 + e * 6 + t];
-#pragma unroll
-                for (int e = 0; e < 6; e++) { np0[e] = A[(cn + e) * LD + i0]; np1[e] = A[(cn + e) * LD + i1]; }
-            }
-            double x[6];
-#pragma unroll
-            for (int t = 5; t >= 0; t--) {
-                const int idx = c0 + t;                          // wave-uniform
-                double sacc = readlane_f64(idx >= 64 ? y1 : y0, idx & 63);
-#pragma unroll
-                for (int e = 5; e > t; e--) sacc -= Lb[e][t] * x[e];
-                x[t] = sacc;
-            }
-            // only columns i < c0 matter; the other lanes update entries of y that are already consumed
-#pragma unroll
-            for (int e = 0; e < 6; e++) { y0 -= p0[e] * x[e]; y1 -= p1[e] * x[e]; }
-            if (lane == 0) {
-#pragma unroll
-                for (int t = 0; t < 6; t++) xs[c0 + t] = x[t];
-            }
-#pragma unroll
-            for (int e = 0; e < 6; e++) {
-                p0[e] = np0[e]; p1[e] = np1[e];
-#pragma unroll
-                for (int t = 0; t < e; t++) Lb[e][t] = nL[e][t];
+        // One step.  Operands (the unit-lower diagonal block and this lane's two entries of the panel
+        // column) do not depend on the chain: the caller loads them one step ahead into the other register
+        // set (the loop is unrolled by two so that the sets never have to be copied).  The second entry
+        // (rows 64..) is only touched while the block column lies beyond row 64.
+#define K7_BS_LOAD(J_, L_, P0_, P1_)                                                                       \
+    {                                                                                                      \
+        const int jj_ = max((J_), 0), cc_ = 6 * jj_;                                                       \
+        _Pragma("unroll") for (int e = 1; e < 6; e++)                                                      \
+            _Pragma("unroll") for (int t = 0; t < e; t++) L_[e][t] = Minv[jj_ * 36 + e * 6 + t];           \
+        _Pragma("unroll") for (int e = 0; e < 6; e++) P0_[e] = A[(cc_ + e) * LD + i0];                     \
+        if (cc_ > 64) { _Pragma("unroll") for (int e = 0; e < 6; e++) P1_[e] = A[(cc_ + e) * LD + i1]; }   \
+    }
+#define K7_BS_STEP(J_, L_, P0_, P1_)                                                                       \
+    {                                                                                                      \
+        const int c0_ = 6 * (J_);                                                                          \
+        double x[6];                                                                                       \
+        _Pragma("unroll") for (int t = 5; t >= 0; t--) {                                                   \
+            const int idx = c0_ + t;                                                                       \
+            double sacc = readlane_f64(idx >= 64 ? y1 : y0, idx & 63);                                     \
+            _Pragma("unroll") for (int e = 5; e > t; e--) sacc -= L_[e][t] * x[e];                         \
+            x[t] = sacc;                                                                                   \
+        }                                                                                                  \
+        _Pragma("unroll") for (int e = 0; e < 6; e++) y0 -= P0_[e] * x[e];                                 \
+        if (c0_ > 64) { _Pragma("unroll") for (int e = 0; e < 6; e++) y1 -= P1_[e] * x[e]; }               \
+        if (lane == 0) { _Pragma("unroll") for (int t = 0; t < 6; t++) xs[c0_ + t] = x[t]; }               \
+    }
+        double La[6][6], Pa0[6], Pa1[6], Lb[6][6], Pb0[6], Pb1[6];
+        K7_BS_LOAD(NB - 1, La, Pa0, Pa1);
+        for (int J = NB - 1; J >= 0; J -= 2) {
+            K7_BS_LOAD(J - 1, Lb, Pb0, Pb1);
+            K7_BS_STEP(J, La, Pa0, Pa1);
+            if (J - 1 >= 0) {
+                K7_BS_LOAD(J - 2, La, Pa0, Pa1);
+                K7_BS_STEP(J - 1, Lb, Pb0, Pb1);
             }
         }
+#undef K7_BS_LOAD
+#undef K7_BS_STEP
     }
     __syncthreads();
     BA_STAMP(b, 6);
