@@ -214,6 +214,34 @@ int rs_triangulate_matches(rs_context* ctx,
                            float* d_xyz, uint8_t* d_keep,
                            int32_t* d_out_index, float* d_out_xyz, int32_t* d_out_count);
 
+/* §8(f) rank 1 — the body of Mapper::triangulate_tracks (reference src/Mapper.cpp:246-305):
+ * per track t (track-id order, the order of the reference's std::map<TrackId, Track>,
+ * src/TrackStore.h:38) with sightings CSR d_sight_ptr[t] .. d_sight_ptr[t+1] (pose index into
+ * d_poses = Trajectory::pose_at(frame_index), and pixel), key-frame pixel d_track_uv[t]:
+ *   - d_skip[t] != 0 or no sightings: nothing (the host-side filters of :247-250);
+ *   - triangulate (first sighting, key-frame pixel) under (pose of the first sighting, d_poses[kf_pose])
+ *     with gates (any_parallax_cosine = 1.0, max_reprojection_error = 4.0), :252-262;
+ *   - reproject into every sighting's pose, first error > max_reprojection_error => inconsistent,
+ *     :264-275 (the caller erases those tracks, :332-334);
+ *   - parallax cosine and required = min(min_parallax_cosine, cos(rotation_parallax_factor * turn)),
+ *     :277-288;
+ * then the selection :291-304: candidates with parallax <= required in track order, and, while
+ * fewer than min_new_points, the remaining candidates by parallax cosine ascending (ties: track
+ * order; std::sort leaves them unspecified upstream).
+ * Outputs, all device: d_status[t] 0 none / 1 candidate / 2 inconsistent; d_xyz[t][3];
+ * d_parallax_cos[t]; d_required_cos[t]; d_accepted[0..counts[0]) track indices in creation order
+ * (the last counts[1] of them are the top-up); d_inconsistent[0..counts[2]); d_counts[3].
+ * Point creation / association (:306-330) is pointer work and stays with the caller. */
+int rs_triangulate_tracks(rs_context* ctx, int n_tracks, const float* d_track_uv /*[T][2]*/,
+                          const uint8_t* d_skip /*[T] or NULL*/, const int32_t* d_sight_ptr /*[T+1]*/,
+                          const int32_t* d_sight_pose /*[S]*/, const float* d_sight_uv /*[S][2]*/,
+                          const float* d_poses /*[n_poses][16]*/, int n_poses, int kf_pose,
+                          const float h_intrinsics[4], float any_parallax_cosine,
+                          float max_reprojection_error, float min_parallax_cosine,
+                          float rotation_parallax_factor, int min_new_points, uint8_t* d_status,
+                          float* d_xyz, float* d_parallax_cos, float* d_required_cos,
+                          int32_t* d_accepted, int32_t* d_inconsistent, int32_t* d_counts /*[3]*/);
+
 /* ----------------------------------------------------- a9-a13: optimisation */
 
 typedef enum rs_ba_termination {

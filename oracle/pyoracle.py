@@ -202,6 +202,41 @@ def triangulate(uv1, uv2, poses, K, idx1=None, idx2=None, min_parallax_cosine=0.
     return dict(xyz=xyz[:n], keep=keep[:n], out_index=oi[:m].copy(), out_xyz=ox[:m].copy())
 
 
+def triangulate_tracks(track_uv, sight_ptr, sight_pose, sight_uv, poses, kf_pose, K, skip=None,
+                       any_parallax_cosine=1.0, max_reproj=4.0, min_parallax_cosine=0.999848,
+                       rotation_parallax_factor=0.20, min_new_points=100):
+    track_uv = np.ascontiguousarray(track_uv, np.float32).reshape(-1, 2)
+    sight_ptr = np.ascontiguousarray(sight_ptr, np.int32)
+    sight_pose = np.ascontiguousarray(sight_pose, np.int32)
+    sight_uv = np.ascontiguousarray(sight_uv, np.float32).reshape(-1, 2)
+    poses = np.ascontiguousarray(poses, np.float32).reshape(-1, 16)
+    n = len(track_uv)
+    m = max(n, 1)
+    Kc = (C.c_float * 4)(*[float(v) for v in K])
+    status = np.zeros(m, np.uint8)
+    xyz = np.zeros((m, 3), np.float32)
+    pc = np.zeros(m, np.float32)
+    rc_ = np.zeros(m, np.float32)
+    acc = np.zeros(m, np.int32)
+    inc = np.zeros(m, np.int32)
+    cnt = np.zeros(3, np.int32)
+    sk = None if skip is None else np.ascontiguousarray(skip, np.uint8)
+    L = lib()
+    L.orc_triangulate_tracks.argtypes = [C.c_int, f32p, u8p, i32p, i32p, f32p, f32p, C.c_int, C.c_int, C.c_float * 4,
+                                         C.c_float, C.c_float, C.c_float, C.c_float, C.c_int, u8p, f32p, f32p, f32p,
+                                         i32p, i32p, i32p, i32p, i32p]
+    rc = L.orc_triangulate_tracks(n, _p(track_uv, f32p), _p(sk, u8p), _p(sight_ptr, i32p), _p(sight_pose, i32p),
+                                  _p(sight_uv, f32p), _p(poses, f32p), len(poses), int(kf_pose), Kc,
+                                  float(any_parallax_cosine), float(max_reproj), float(min_parallax_cosine),
+                                  float(rotation_parallax_factor), int(min_new_points), _p(status, u8p), _p(xyz, f32p),
+                                  _p(pc, f32p), _p(rc_, f32p), _p(acc, i32p),
+                                  cnt[0:1].ctypes.data_as(i32p), cnt[1:2].ctypes.data_as(i32p), _p(inc, i32p),
+                                  cnt[2:3].ctypes.data_as(i32p))
+    assert rc == 0
+    return dict(status=status[:n], xyz=xyz[:n], parallax_cos=pc[:n], required_cos=rc_[:n],
+                accepted=acc[:int(cnt[0])].copy(), n_topped_up=int(cnt[1]), inconsistent=inc[:int(cnt[2])].copy())
+
+
 def null_vector4(A):
     A = np.ascontiguousarray(A, np.float64).reshape(16)
     v = np.zeros(4)

@@ -78,6 +78,14 @@ int orc_triangulate(const float* uv1, const float* uv2, int n, const float* pose
                     const float intrinsics[4], float min_parallax_cosine,
                     float max_reprojection_error, float* xyz, uint8_t* keep,
                     int32_t* out_index, float* out_xyz, int32_t* out_count);
+/* -- tracks.c: the body of Mapper::triangulate_tracks (src/Mapper.cpp:246-305) ------------- */
+int orc_triangulate_tracks(int n_tracks, const float* track_uv, const uint8_t* skip, const int32_t* sight_ptr,
+                           const int32_t* sight_pose, const float* sight_uv, const float* poses, int n_poses,
+                           int kf_pose, const float intrinsics[4], float any_parallax_cosine,
+                           float max_reprojection_error, float min_parallax_cosine,
+                           float rotation_parallax_factor, int min_new_points, uint8_t* status, float* xyz,
+                           float* parallax_cos, float* required_cos, int32_t* accepted, int32_t* n_accepted,
+                           int32_t* n_topped_up, int32_t* inconsistent, int32_t* n_inconsistent);
 /* 4x4 f64 one-sided Jacobi SVD null vector (exposed for tests): v = right
  * singular vector of the smallest singular value of row-major A. */
 void orc_null_vector4(const double A[16], double v[4], double sigma[4]);

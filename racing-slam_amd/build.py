@@ -21,6 +21,7 @@ SOURCES = [
     ("hamming.hip", []),
     ("triangulate.hip", ["-ffp-contract=off"]),
     ("reproj_match.hip", ["-ffp-contract=off"]),
+    ("tracks.hip", ["-ffp-contract=off"]),
     ("ba.hip", ["-munsafe-fp-atomics"]),
     ("ba_solve.hip", ["-munsafe-fp-atomics"]),
     ("ba_schur.hip", ["-munsafe-fp-atomics"]),
@@ -49,7 +50,7 @@ def build(force=False, verbose=False):
     cc = hipcc()
     objdir = os.path.join(HERE, "build")
     os.makedirs(objdir, exist_ok=True)
-    headers = [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "ba_common.h"), os.path.join(HERE, "..", "include", "rsgpu.h"), __file__]
+    headers = [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "tri_core.h"), os.path.join(CSRC, "ba_common.h"), os.path.join(HERE, "..", "include", "rsgpu.h"), __file__]
     objs = []
     rebuilt = False
     for src, extra in SOURCES:

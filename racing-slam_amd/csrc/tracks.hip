@@ -1,0 +1,209 @@
+// tracks.hip — K6: the body of Mapper::triangulate_tracks (reference src/Mapper.cpp:246-305) as two
+// launches: per-track triangulation + sighting consistency + parallax terms (one lane per track), then the
+// selection (threshold, quota top-up) by one workgroup.  SURVEY.md §8(f) rank 1: it replaces ~2000
+// one-correspondence cv::triangulatePoints calls per key frame.
+//
+// Per track (track-id order = input order): triangulate (first sighting, key-frame pixel) with the loose
+// gates (:252-262, through dlt_one of tri_core.h), reproject into every sighting's pose, first error > 4 px
+// makes the track inconsistent (:264-275), parallax cosine and the rotation-dependent requirement
+// (:277-288).  Selection (:291-304): candidates at or below their requirement in order, then — below the
+// quota — the best of the rest by parallax cosine ascending (ties: candidate order; the reference's
+// std::sort leaves them unspecified).  Built with -ffp-contract=off; acosf / cosf are the device libm's
+// (last-ulp differences to glibc only move `required`).
+#include "tri_core.h"
+
+struct TrackParams {
+    TriParams tri;               // loose gates of the per-track triangulation
+    float min_parallax_cosine;   // TRACK_MIN_PARALLAX_COSINE
+    float rotation_factor;       // ROTATION_PARALLAX_FACTOR
+    int kf_pose;
+};
+
+__device__ __forceinline__ void load_pose(const float* __restrict__ poses, int idx, float* T)
+{
+    const float4* a = (const float4*)(poses + 16 * (size_t)idx);
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+        const float4 v = a[r];
+        T[4 * r] = v.x; T[4 * r + 1] = v.y; T[4 * r + 2] = v.z; T[4 * r + 3] = v.w;
+    }
+}
+
+// Camera::project, src/Camera.cpp:25-32: K * pose.block<3,4> first, then * homogeneous
+__device__ __forceinline__ float2 project_f32(const TriParams& k, const float* T, const float* X)
+{
+    float KP[12];
+    projection_rows(k, T, KP);
+    float uvw[3];
+#pragma unroll
+    for (int i = 0; i < 3; i++)
+        uvw[i] = (KP[4 * i] * X[0] + KP[4 * i + 1] * X[1]) + (KP[4 * i + 2] * X[2] + KP[4 * i + 3] * 1.0f);
+    if (uvw[2] < 0.0f) return make_float2(-1.0f, -1.0f);
+    return make_float2(uvw[0] / uvw[2], uvw[1] / uvw[2]);
+}
+
+// -R^T t, src/MotionModel.cpp:8-11, src/Frame.cpp:39-42
+__device__ __forceinline__ void camera_center_f32(const float* T, float* c)
+{
+    const float t[3] = {T[3], T[7], T[11]};
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+        const float a[3] = {-T[0 * 4 + i], -T[1 * 4 + i], -T[2 * 4 + i]};
+        c[i] = dot3f(a, t);
+    }
+}
+
+__global__ __launch_bounds__(64) void k6_tracks(const float2* __restrict__ track_uv, const uint8_t* __restrict__ skip,
+                                               const int32_t* __restrict__ sight_ptr,
+                                               const int32_t* __restrict__ sight_pose,
+                                               const float2* __restrict__ sight_uv, const float* __restrict__ poses,
+                                               int n_tracks, TrackParams prm, uint8_t* __restrict__ status,
+                                               float* __restrict__ xyz, float* __restrict__ parallax_cos,
+                                               float* __restrict__ required_cos)
+{
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n_tracks) return;
+    const int s0 = sight_ptr[t], s1 = sight_ptr[t + 1];
+    uint8_t st = 0;
+    float X[3] = {0.f, 0.f, 0.f}, pc = 0.f, rc = 0.f;
+    if (s1 > s0 && !(skip && skip[t])) {                                   // :248-250
+        float Tf[16], Tk[16];
+        load_pose(poses, sight_pose[s0], Tf);
+        load_pose(poses, prm.kf_pose, Tk);
+        const bool ok = dlt_one(sight_uv[s0], track_uv[t], Tf, Tk, prm.tri, X);   // :254-263
+        if (ok) {
+            bool consistent = true;
+            for (int s = s0; s < s1; s++) {                                // :265-271
+                float Ts[16];
+                load_pose(poses, sight_pose[s], Ts);
+                const float2 pr = project_f32(prm.tri, Ts, X);
+                const float2 px = sight_uv[s];
+                const float dx = pr.x - px.x, dy = pr.y - px.y;
+                if (sqrtf(dx * dx + dy * dy) > prm.tri.max_reprojection_error) { consistent = false; break; }
+            }
+            if (!consistent) {
+                st = 2;                                                    // :272-275
+            } else {
+                float cf[3], ck[3];
+                camera_center_f32(Tf, cf);
+                camera_center_f32(Tk, ck);
+                float a[3] = {cf[0] - X[0], cf[1] - X[1], cf[2] - X[2]};
+                float b[3] = {ck[0] - X[0], ck[1] - X[1], ck[2] - X[2]};
+                normalize3f(a);                                            // :278-279
+                normalize3f(b);
+                float tr[3];
+#pragma unroll
+                for (int i = 0; i < 3; i++) {                              // trace(R_kf R_first^T), :281-282
+                    const float rk[3] = {Tk[4 * i], Tk[4 * i + 1], Tk[4 * i + 2]};
+                    const float rf[3] = {Tf[4 * i], Tf[4 * i + 1], Tf[4 * i + 2]};
+                    tr[i] = dot3f(rk, rf);
+                }
+                const float trace = (tr[0] + tr[1]) + tr[2];
+                float cosine = (trace - 1.0f) / 2.0f;
+                cosine = cosine < -1.0f ? -1.0f : cosine;
+                cosine = cosine > 1.0f ? 1.0f : cosine;
+                const float turned = acosf(cosine);
+                const float need = cosf(prm.rotation_factor * turned);
+                st = 1;
+                pc = dot3f(a, b);                                          // :287
+                rc = prm.min_parallax_cosine < need ? prm.min_parallax_cosine : need;   // :288
+            }
+        }
+    }
+    status[t] = st;
+    xyz[3 * (size_t)t + 0] = X[0]; xyz[3 * (size_t)t + 1] = X[1]; xyz[3 * (size_t)t + 2] = X[2];
+    parallax_cos[t] = pc;
+    required_cos[t] = rc;
+}
+
+// Selection by ONE workgroup (:291-304): ordered compaction of the accepted and of the inconsistent tracks,
+// then the quota top-up by rank counting over the rejected candidates (n_rej^2 comparisons; key = (cosine,
+// candidate order), NaN cosines sort last).
+__global__ __launch_bounds__(1024) void k6_select(const uint8_t* __restrict__ status, const float* __restrict__ pcs,
+                                                  const float* __restrict__ rcs, int n_tracks, int min_new_points,
+                                                  int32_t* __restrict__ accepted, int32_t* __restrict__ inconsistent,
+                                                  int32_t* __restrict__ rejected, int32_t* __restrict__ counts)
+{
+    const int T = blockDim.x, chunk = (n_tracks + T - 1) / T;
+    const int lo = min((int)threadIdx.x * chunk, n_tracks), hi = min(lo + chunk, n_tracks);
+    int na = 0, nr = 0, ni = 0;
+    for (int t = lo; t < hi; t++) {
+        const int st = status[t];
+        if (st == 2) ni++;
+        else if (st == 1) { if (pcs[t] <= rcs[t]) na++; else nr++; }
+    }
+    int tot_a, tot_r, tot_i;
+    int oa = rs_block_exclusive_scan(na, &tot_a);
+    int orj = rs_block_exclusive_scan(nr, &tot_r);
+    int oi = rs_block_exclusive_scan(ni, &tot_i);
+    for (int t = lo; t < hi; t++) {
+        const int st = status[t];
+        if (st == 2) inconsistent[oi++] = t;
+        else if (st == 1) { if (pcs[t] <= rcs[t]) accepted[oa++] = t; else rejected[orj++] = t; }
+    }
+    __threadfence_block();
+    __syncthreads();
+    int top = 0;
+    if (tot_a < min_new_points && tot_r > 0) {
+        top = min(min_new_points - tot_a, tot_r);
+        for (int i = threadIdx.x; i < tot_r; i += T) {
+            const int ti = rejected[i];
+            const float ki = pcs[ti];
+            int rank = 0;
+            for (int j = 0; j < tot_r; j++) {
+                const float kj = pcs[rejected[j]];
+                // kj sorts before ki:  kj < ki, or equal (or both unordered) and earlier; NaN after everything
+                const bool before = (kj < ki) || (!(ki < kj) && !(kj < ki) && ((kj == kj) == (ki == ki)) && j < i) ||
+                                    ((kj == kj) && !(ki == ki));
+                rank += before ? 1 : 0;
+            }
+            if (rank < top) accepted[tot_a + rank] = ti;
+        }
+    }
+    if (threadIdx.x == 0) { counts[0] = tot_a + top; counts[1] = top; counts[2] = tot_i; }
+}
+
+extern "C" int rs_triangulate_tracks(rs_context* ctx, int n_tracks, const float* d_track_uv, const uint8_t* d_skip,
+                                     const int32_t* d_sight_ptr, const int32_t* d_sight_pose,
+                                     const float* d_sight_uv, const float* d_poses, int n_poses, int kf_pose,
+                                     const float h_intrinsics[4], float any_parallax_cosine,
+                                     float max_reprojection_error, float min_parallax_cosine,
+                                     float rotation_parallax_factor, int min_new_points, uint8_t* d_status,
+                                     float* d_xyz, float* d_parallax_cos, float* d_required_cos,
+                                     int32_t* d_accepted, int32_t* d_inconsistent, int32_t* d_counts)
+{
+    if (!ctx) return RS_ERR_INVALID;
+    if (n_tracks < 0 || n_poses < 0) return rs_fail(ctx, RS_ERR_INVALID, "negative size");
+    if (!d_counts) return rs_fail(ctx, RS_ERR_INVALID, "null counts");
+    RS_HIP(ctx, hipSetDevice(ctx->device));
+    if (n_tracks == 0) {
+        RS_HIP(ctx, hipMemsetAsync(d_counts, 0, 3 * sizeof(int32_t), ctx->stream));
+        return RS_OK;
+    }
+    if (!d_track_uv || !d_sight_ptr || !d_sight_pose || !d_sight_uv || !d_poses || !h_intrinsics || !d_status ||
+        !d_xyz || !d_parallax_cos || !d_required_cos || !d_accepted || !d_inconsistent)
+        return rs_fail(ctx, RS_ERR_INVALID, "null pointer");
+    if (kf_pose < 0 || kf_pose >= n_poses) return rs_fail(ctx, RS_ERR_INVALID, "key-frame pose index out of range");
+    if ((uintptr_t)d_poses & 15) return rs_fail(ctx, RS_ERR_INVALID, "poses must be 16-byte aligned");
+    void* ws = nullptr;
+    int rc = rs_workspace(ctx, sizeof(int32_t) * (size_t)n_tracks, &ws);
+    if (rc) return rc;
+    TrackParams prm;
+    prm.tri = {h_intrinsics[0], h_intrinsics[1], h_intrinsics[2], h_intrinsics[3], any_parallax_cosine, max_reprojection_error};
+    prm.min_parallax_cosine = min_parallax_cosine;
+    prm.rotation_factor = rotation_parallax_factor;
+    prm.kf_pose = kf_pose;
+    {
+        rs_prof_scope ps(ctx, "K6_tracks");
+        hipLaunchKernelGGL(k6_tracks, dim3((n_tracks + 63) / 64), dim3(64), 0, ctx->stream, (const float2*)d_track_uv,
+                           d_skip, d_sight_ptr, d_sight_pose, (const float2*)d_sight_uv, d_poses, n_tracks, prm,
+                           d_status, d_xyz, d_parallax_cos, d_required_cos);
+    }
+    {
+        rs_prof_scope ps(ctx, "K6b_select");
+        hipLaunchKernelGGL(k6_select, dim3(1), dim3(1024), 0, ctx->stream, d_status, d_parallax_cos, d_required_cos,
+                           n_tracks, min_new_points, d_accepted, d_inconsistent, (int32_t*)ws, d_counts);
+    }
+    RS_HIP(ctx, hipGetLastError());
+    return RS_OK;
+}

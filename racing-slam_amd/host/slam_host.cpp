@@ -317,6 +317,61 @@ std::vector<TriangulatedPoint> triangulate_points(const Frame& frame1, const Fra
 
 }  // namespace triangulation
 
+// ---------------------------------------------------------------------- track triangulation
+namespace tracks {
+
+// src/Mapper.cpp:246-305 -> rs_triangulate_tracks
+Selection select_track_points(const KeyFrame& key_frame, const std::vector<Track>& tracks,
+                              const std::vector<Mat4f>& trajectory_poses, const Camera& camera, size_t min_new_points)
+{
+    Selection out;
+    const size_t T = tracks.size();
+    if (T == 0) return out;
+    rs_context* ctx = Session::get().ctx();
+    std::vector<float> track_uv(2 * T), sight_uv, poses(16 * (trajectory_poses.size() + 1));
+    std::vector<uint8_t> skip(T);
+    std::vector<int32_t> sight_ptr(T + 1, 0), sight_pose;
+    for (size_t t = 0; t < T; t++) {
+        const Track& tr = tracks[t];
+        skip[t] = (key_frame.is_matched(tr.keypoint_index) || tr.sightings.empty()) ? 1 : 0;     // :248-250
+        const Vec2f px = key_frame.keypoint(tr.keypoint_index).pt;
+        track_uv[2 * t] = px.x; track_uv[2 * t + 1] = px.y;
+        for (const auto& sg : tr.sightings) {
+            sight_pose.push_back((int32_t)sg.frame_index);
+            sight_uv.push_back(sg.pixel.x); sight_uv.push_back(sg.pixel.y);
+        }
+        sight_ptr[t + 1] = (int32_t)sight_pose.size();
+    }
+    for (size_t i = 0; i < trajectory_poses.size(); i++) std::memcpy(&poses[16 * i], trajectory_poses[i].data(), 64);
+    const int kf_pose = (int)trajectory_poses.size();                                         // key_frame.pose(), :257
+    std::memcpy(&poses[16 * (size_t)kf_pose], key_frame.pose().data(), 64);
+    if (sight_pose.empty()) { sight_pose.push_back(0); sight_uv.resize(2); }
+    DevBuf<float> d_tuv(track_uv), d_suv(sight_uv), d_poses(poses), d_xyz(3 * T), d_pc(T), d_rc(T);
+    DevBuf<uint8_t> d_skip(skip), d_status(T);
+    DevBuf<int32_t> d_sptr(sight_ptr), d_spose(sight_pose), d_acc(T), d_inc(T), d_cnt(3);
+    const float K[4] = {camera.fx(), camera.fy(), camera.cx(), camera.cy()};
+    if (!rs_ok(rs_triangulate_tracks(ctx, (int)T, d_tuv.get(), d_skip.get(), d_sptr.get(), d_spose.get(), d_suv.get(),
+                                     d_poses.get(), kf_pose + 1, kf_pose, K, ANY_PARALLAX_COSINE,
+                                     TRACK_MAX_REPROJECTION_ERROR, TRACK_MIN_PARALLAX_COSINE, ROTATION_PARALLAX_FACTOR,
+                                     (int)min_new_points, d_status.get(), d_xyz.get(), d_pc.get(), d_rc.get(), d_acc.get(),
+                                     d_inc.get(), d_cnt.get()), "rs_triangulate_tracks"))
+        return out;
+    rs_context_synchronize(ctx);
+    const auto cnt = d_cnt.download(3);
+    const auto acc = d_acc.download((size_t)cnt[0]);
+    const auto inc = d_inc.download((size_t)cnt[2]);
+    const auto xyz = d_xyz.download(3 * T);
+    const auto pc = d_pc.download(T), rc = d_rc.download(T);
+    for (int32_t t : acc)
+        out.accepted.push_back(Candidate{(size_t)t, Vec3f{xyz[3 * (size_t)t], xyz[3 * (size_t)t + 1], xyz[3 * (size_t)t + 2]},
+                                         tracks[(size_t)t].keypoint_index, pc[(size_t)t], rc[(size_t)t]});
+    out.topped_up = (size_t)cnt[1];
+    for (int32_t t : inc) out.inconsistent.push_back((size_t)t);
+    return out;
+}
+
+}  // namespace tracks
+
 // ---------------------------------------------------------------------- optimisation
 namespace optimization {
 

@@ -158,6 +158,33 @@ std::vector<TriangulatedPoint> triangulate_points(const Frame& frame1, const Fra
                                                   const std::vector<FeatureMatch>& matches, const Camera& camera);
 }  // namespace triangulation
 
+namespace tracks {
+// The arithmetic body of Mapper::triangulate_tracks (src/Mapper.cpp:246-305) on the types of
+// src/TrackStore.h:17-29.  The Mapper keeps the pointer work (window membership, create_point /
+// associate, :306-330): it passes the tracks in std::map<TrackId, Track> order together with the
+// trajectory poses its sightings refer to and gets back what to create and what to erase.
+struct TrackSighting { size_t frame_index = 0; Vec2f pixel; };
+struct Track { std::vector<TrackSighting> sightings; size_t keypoint_index = 0; };
+struct Candidate {
+    size_t track;            // index into the input vector
+    Vec3f position;
+    size_t keypoint_index;
+    float parallax_cosine, required_cosine;
+};
+struct Selection {
+    std::vector<Candidate> accepted;      // creation order: above-threshold in track order, then the quota top-up
+    size_t topped_up = 0;
+    std::vector<size_t> inconsistent;     // tracks to erase (:332-334)
+};
+static const float TRACK_MIN_PARALLAX_COSINE = 0.999848f, ROTATION_PARALLAX_FACTOR = 0.20f;
+static const float ANY_PARALLAX_COSINE = 1.0f, TRACK_MAX_REPROJECTION_ERROR = 4.0f;
+static const size_t MIN_NEW_POINTS_PER_KEY_FRAME = 100;
+// `trajectory_poses[i]` = Trajectory::pose_at(i); the key frame contributes its pose and keypoints.
+Selection select_track_points(const KeyFrame& key_frame, const std::vector<Track>& tracks,
+                              const std::vector<Mat4f>& trajectory_poses, const Camera& camera,
+                              size_t min_new_points = MIN_NEW_POINTS_PER_KEY_FRAME);
+}  // namespace tracks
+
 namespace optimization {
 // src/Optimization.h:23-26, 76-81; src/LocalWindow.h:13-19 (vision-only: InertialInput{} default)
 struct FrameConfig { bool optimize; Frame* frame; };

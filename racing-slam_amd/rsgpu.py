@@ -15,7 +15,7 @@ LIB_PATH = os.path.join(_HERE, "librsgpu.so")
 EXPORTS = [
     "rs_abi_version", "rs_context_create", "rs_context_destroy", "rs_context_set_stream",
     "rs_context_synchronize", "rs_last_error", "rs_hamming_knn2", "rs_match_descriptors",
-    "rs_kdtree_build", "rs_reproj_match", "rs_triangulate", "rs_triangulate_matches", "rs_ba_default_options",
+    "rs_kdtree_build", "rs_reproj_match", "rs_triangulate", "rs_triangulate_matches", "rs_triangulate_tracks", "rs_ba_default_options",
     "rs_bundle_adjust", "rs_refine_pose", "rs_pack_pose", "rs_unpack_pose", "rs_build_local_window",
     "rs_comm_get_unique_id", "rs_comm_init_rank", "rs_comm_destroy", "rs_prof_begin", "rs_prof_end", "rs_prof_counters",
 ]
@@ -267,6 +267,28 @@ class Context:
                                                     C.c_float(max_reproj), _dp(out["xyz"]), _dp(out["keep"]),
                                                     _dp(out["out_index"]), _dp(out["out_xyz"]), _dp(out["count"])),
                     "rs_triangulate_matches")
+        return out
+
+    # -- §8(f) rank 1: Mapper::triangulate_tracks body
+    def triangulate_tracks(self, d_track_uv, d_sight_ptr, d_sight_pose, d_sight_uv, d_poses, kf_pose, K, d_skip=None,
+                           any_parallax_cosine=1.0, max_reproj=4.0, min_parallax_cosine=0.999848,
+                           rotation_parallax_factor=0.20, min_new_points=100, out=None):
+        t = self.torch
+        n = int(d_track_uv.shape[0])
+        m = max(n, 1)
+        if out is None:
+            out = dict(status=self.empty((m,), t.uint8), xyz=self.empty((m, 3), t.float32),
+                       parallax_cos=self.empty((m,), t.float32), required_cos=self.empty((m,), t.float32),
+                       accepted=self.empty((m,), t.int32), inconsistent=self.empty((m,), t.int32),
+                       counts=self.empty((3,), t.int32))
+        Kc = (C.c_float * 4)(*[float(v) for v in K])
+        self._check(self.lib.rs_triangulate_tracks(
+            self.h, n, _dp(d_track_uv), None if d_skip is None else _dp(d_skip), _dp(d_sight_ptr), _dp(d_sight_pose),
+            _dp(d_sight_uv), _dp(d_poses), int(d_poses.shape[0]), int(kf_pose), Kc, C.c_float(any_parallax_cosine),
+            C.c_float(max_reproj), C.c_float(min_parallax_cosine), C.c_float(rotation_parallax_factor),
+            int(min_new_points), _dp(out["status"]), _dp(out["xyz"]), _dp(out["parallax_cos"]),
+            _dp(out["required_cos"]), _dp(out["accepted"]), _dp(out["inconsistent"]), _dp(out["counts"])),
+            "rs_triangulate_tracks")
         return out
 
     # -- a9-a13

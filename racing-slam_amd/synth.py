@@ -247,3 +247,57 @@ def make_match_scene(window=None, n_keypoints=2000, config_id=3, seed_stream=7, 
               obs_ptr=window["obs_ptr"], obs_kf=window["obs_cam"], obs_desc=obs_desc,
               kf_centers=kf_centers, desc_pool=pool)
     return frame, mp
+
+
+def make_tracks(n_tracks=2000, n_frames=12, config_id=6, outlier_frac=0.05, noise_px=0.5, far_frac=0.3,
+                max_sightings=10, image=(1920, 1080), K=(1000.0, 1000.0, 960.0, 540.0)):
+    """Synthetic input of Mapper::triangulate_tracks (reference src/Mapper.cpp:222-305): a forward-moving,
+    gently turning camera (`n_frames` trajectory poses, the last one is the key frame), `n_tracks` feature
+    tracks, each sighted in a run of consecutive frames ending at the key frame.  `far_frac` of the landmarks
+    are far away (low parallax: they exercise the requirement / quota top-up), `outlier_frac` of the tracks
+    get one corrupted sighting (inconsistent)."""
+    rng = np.random.default_rng(0x5EED0000 + config_id)
+    fx, fy, cx, cy = K
+    W, H = image
+    poses = np.zeros((n_frames, 16), np.float32)
+    for f in range(n_frames):
+        yaw = np.deg2rad(0.4 * f)
+        R = np.array([[np.cos(yaw), 0, np.sin(yaw)], [0, 1, 0], [-np.sin(yaw), 0, np.cos(yaw)]])
+        c = np.array([0.03 * f, 0.0, 0.12 * f])
+        T = np.eye(4)
+        T[:3, :3] = R
+        T[:3, 3] = -R @ c
+        poses[f] = T.astype(np.float32).reshape(16)
+    kf = n_frames - 1
+    Tk = poses[kf].reshape(4, 4).astype(np.float64)
+    # landmarks in the key frame's frustum
+    depth = np.where(rng.random(n_tracks) < far_frac, rng.uniform(60, 400, n_tracks), rng.uniform(3, 25, n_tracks))
+    u = rng.uniform(50, W - 50, n_tracks)
+    v = rng.uniform(50, H - 50, n_tracks)
+    Xc = np.stack([(u - cx) / fx * depth, (v - cy) / fy * depth, depth], 1)
+    Xw = (Xc - Tk[:3, 3]) @ Tk[:3, :3]          # R^T (Xc - t)
+    track_uv = np.zeros((n_tracks, 2), np.float32)
+    sight_ptr = [0]
+    sight_pose, sight_uv = [], []
+    skip = (rng.random(n_tracks) < 0.03).astype(np.uint8)
+    for t in range(n_tracks):
+        ns = int(rng.integers(0, max_sightings + 1)) if rng.random() < 0.03 else int(rng.integers(2, max_sightings + 1))
+        ns = min(ns, kf)
+        frames = list(range(kf - ns, kf))           # sightings in the frames before the key frame
+        bad = rng.random() < outlier_frac and ns >= 2
+        bad_at = int(rng.integers(1, ns)) if bad else -1
+        for j, f in enumerate(frames):
+            T = poses[f].reshape(4, 4).astype(np.float64)
+            pc = T[:3, :3] @ Xw[t] + T[:3, 3]
+            px = np.array([fx * pc[0] / pc[2] + cx, fy * pc[1] / pc[2] + cy]) + rng.normal(0, noise_px, 2)
+            if j == bad_at:
+                px += rng.uniform(8, 30, 2) * rng.choice([-1, 1], 2)
+            sight_pose.append(f)
+            sight_uv.append(px)
+        pk = Tk[:3, :3] @ Xw[t] + Tk[:3, 3]
+        track_uv[t] = np.array([fx * pk[0] / pk[2] + cx, fy * pk[1] / pk[2] + cy]) + rng.normal(0, noise_px, 2)
+        sight_ptr.append(len(sight_pose))
+    return dict(track_uv=track_uv, skip=skip, sight_ptr=np.array(sight_ptr, np.int32),
+                sight_pose=np.array(sight_pose, np.int32).reshape(-1),
+                sight_uv=np.array(sight_uv, np.float32).reshape(-1, 2), poses=poses, kf_pose=kf,
+                K=np.array(K, np.float32))

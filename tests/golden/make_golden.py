@@ -52,6 +52,16 @@ def main():
                         xyz=d["xyz"], keep_default=d["keep"], out_index_default=d["out_index"],
                         keep_mapper=m["keep"], out_index_mapper=m["out_index"])
 
+    # -- §8(f)1: Mapper::triangulate_tracks body, 160 tracks over 10 frames; quota 24 so that the top-up runs
+    tk = synth.make_tracks(n_tracks=160, n_frames=10, config_id=8, far_frac=0.85)
+    tr = O.triangulate_tracks(tk["track_uv"], tk["sight_ptr"], tk["sight_pose"], tk["sight_uv"], tk["poses"],
+                              tk["kf_pose"], tk["K"], skip=tk["skip"], min_new_points=24)
+    np.savez_compressed(os.path.join(OUT, "triangulate_tracks.npz"), **{k: tk[k] for k in
+                        ("track_uv", "skip", "sight_ptr", "sight_pose", "sight_uv", "poses", "K")},
+                        kf_pose=np.int32(tk["kf_pose"]), min_new_points=np.int32(24), status=tr["status"], xyz=tr["xyz"],
+                        parallax_cos=tr["parallax_cos"], required_cos=tr["required_cos"], accepted=tr["accepted"],
+                        n_topped_up=np.int32(tr["n_topped_up"]), inconsistent=tr["inconsistent"])
+
     # -- a2: reprojection-gated matching, 5 keyframes / 150 landmarks / 300 keypoints
     w = synth.make_ba_window(n_kf=5, n_points=150, run_max=4)
     frame, mp = synth.make_match_scene(w, n_keypoints=300, kdtree_build=O.kdtree_build)

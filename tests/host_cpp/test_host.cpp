@@ -200,6 +200,62 @@ int main()
         std::printf("refine_pose: max pose error %.4f\n", err);
     }
 
+    // ---- §8(f)1: the body of Mapper::triangulate_tracks vs oracle
+    {
+        // tracks = the landmarks the new frame sees that are NOT map points yet would be the real case; here every
+        // landmark seen by the last key frame and by >= 2 earlier frames forms a track ending at that key frame
+        // a copy of the last key frame whose key points are still unmatched (except a few, to exercise the skip rule)
+        static std::shared_ptr<KeyFrame> kf_keep;        // the map keeps observer pointers: outlive this block
+        kf_keep = std::make_shared<KeyFrame>(Frame(99, kfs[NKF - 1]->features()));
+        KeyFrame& kf = *kf_keep;
+        kf.set_pose(kfs[NKF - 1]->pose());
+        for (size_t j = 0; j < 8 && j < kp_landmark[NKF - 1].size(); j++)
+            if (point_of[kp_landmark[NKF - 1][j]] >= 0) map.associate(kf, map[(size_t)point_of[kp_landmark[NKF - 1][j]]], j);
+        std::vector<tracks::Track> tr;
+        for (size_t j = 0; j < kp_landmark[NKF - 1].size(); j++) {
+            tracks::Track t;
+            t.keypoint_index = j;
+            for (int k = 0; k < NKF - 1; k++)
+                for (size_t i = 0; i < kp_landmark[k].size(); i++)
+                    if (kp_landmark[k][i] == kp_landmark[NKF - 1][j])
+                        t.sightings.push_back(tracks::TrackSighting{(size_t)k, kfs[k]->keypoint(i).pt});
+            tr.push_back(t);
+        }
+        std::vector<Mat4f> traj(poses.begin(), poses.begin() + NKF - 1);
+        auto sel = tracks::select_track_points(kf, tr, traj, camera, 40);
+        // oracle on the same marshalled arrays
+        const int T = (int)tr.size();
+        std::vector<float> tuv(2 * T), suv, ps(16 * NKF);
+        std::vector<uint8_t> skip(T), status(T);
+        std::vector<int32_t> sptr(T + 1, 0), spose, acc(T), inc(T);
+        for (int t = 0; t < T; t++) {
+            skip[t] = (kf.is_matched(tr[t].keypoint_index) || tr[t].sightings.empty()) ? 1 : 0;
+            tuv[2 * t] = kf.keypoint(tr[t].keypoint_index).pt.x; tuv[2 * t + 1] = kf.keypoint(tr[t].keypoint_index).pt.y;
+            for (auto& sg : tr[t].sightings) { spose.push_back((int32_t)sg.frame_index); suv.push_back(sg.pixel.x); suv.push_back(sg.pixel.y); }
+            sptr[t + 1] = (int32_t)spose.size();
+        }
+        for (int k = 0; k < NKF - 1; k++) for (int i = 0; i < 16; i++) ps[16 * k + i] = traj[k][i];
+        for (int i = 0; i < 16; i++) ps[16 * (NKF - 1) + i] = kf.pose()[i];
+        std::vector<float> xyz(3 * T), pc(T), rc(T);
+        int32_t na = 0, ntop = 0, ninc = 0;
+        const float K[4] = {500.f, 500.f, 320.f, 240.f};
+        orc_triangulate_tracks(T, tuv.data(), skip.data(), sptr.data(), spose.data(), suv.data(), ps.data(), NKF, NKF - 1, K,
+                               1.0f, 4.0f, 0.999848f, 0.20f, 40, status.data(), xyz.data(), pc.data(), rc.data(), acc.data(),
+                               &na, &ntop, inc.data(), &ninc);
+        CHECK((int)sel.accepted.size() == na);
+        CHECK((int)sel.inconsistent.size() == ninc);
+        CHECK(na >= 20);
+        for (int i = 0; i < na && i < (int)sel.accepted.size(); i++) {
+            CHECK((int)sel.accepted[i].track == acc[i]);
+            CHECK(sel.accepted[i].position.x == xyz[3 * acc[i]] && sel.accepted[i].position.z == xyz[3 * acc[i] + 2]);
+            CHECK(sel.accepted[i].keypoint_index == tr[(size_t)acc[i]].keypoint_index);
+        }
+        // matched key points were skipped: every accepted track's key point is unmatched in the key frame
+        for (auto& c : sel.accepted) CHECK(!kf.is_matched(c.keypoint_index));
+        CHECK(tracks::select_track_points(kf, {}, traj, camera).accepted.empty());
+        std::printf("select_track_points: %d tracks, %d accepted (%zu topped up), %d inconsistent\n", T, na, sel.topped_up, ninc);
+    }
+
     // ---- a8 + a12: build_local_window + bundle_adjust
     {
         auto window = optimization::build_local_window(kfs, new_frame, 20);

@@ -148,6 +148,53 @@ def test_triangulate_tracks_per_item_poses(ctx, oracle, synth):
     del rng
 
 
+@pytest.mark.parametrize("kw,quota", [(dict(n_tracks=2000, config_id=6), 100),
+                                      (dict(n_tracks=300, far_frac=0.9, config_id=7), 100),
+                                      (dict(n_tracks=5000, n_frames=16, max_sightings=14, config_id=9), 100),
+                                      (dict(n_tracks=37, config_id=10), 1000)])
+def test_triangulate_tracks_body(ctx, oracle, synth, kw, quota):
+    """K6 (body of Mapper::triangulate_tracks, src/Mapper.cpp:246-305) vs the oracle: statuses, points and parallax
+    cosines bit for bit; `required` within device-libm ulps (acosf / cosf); the accepted / inconsistent lists
+    identical unless a candidate sits within an ulp of its requirement."""
+    sc = synth.make_tracks(**kw)
+    ref = oracle.triangulate_tracks(sc["track_uv"], sc["sight_ptr"], sc["sight_pose"], sc["sight_uv"], sc["poses"],
+                                    sc["kf_pose"], sc["K"], skip=sc["skip"], min_new_points=quota)
+    d = ctx.triangulate_tracks(ctx.dev(sc["track_uv"]), ctx.dev(sc["sight_ptr"]), ctx.dev(sc["sight_pose"]),
+                               ctx.dev(sc["sight_uv"]), ctx.dev(sc["poses"]), sc["kf_pose"], sc["K"],
+                               d_skip=ctx.dev(sc["skip"]), min_new_points=quota)
+    n = len(sc["track_uv"])
+    assert np.array_equal(to_np(d["status"])[:n], ref["status"])
+    assert np.array_equal(to_np(d["xyz"])[:n].view(np.uint32), ref["xyz"].view(np.uint32))
+    assert np.array_equal(to_np(d["parallax_cos"])[:n].view(np.uint32), ref["parallax_cos"].view(np.uint32))
+    req = to_np(d["required_cos"])[:n]
+    assert np.allclose(req, ref["required_cos"], rtol=0, atol=3e-7)
+    cnt = to_np(d["counts"])
+    assert np.array_equal(to_np(d["inconsistent"])[:cnt[2]], ref["inconsistent"])
+    cand = ref["status"] == 1
+    boundary = cand & (np.abs(ref["parallax_cos"] - ref["required_cos"]) <= 3e-7)
+    if not boundary.any():
+        assert cnt[1] == ref["n_topped_up"]
+        assert np.array_equal(to_np(d["accepted"])[:cnt[0]], ref["accepted"])
+    else:       # decisions may differ only on the boundary tracks
+        diff = set(to_np(d["accepted"])[:cnt[0]].tolist()) ^ set(ref["accepted"].tolist())
+        assert len(diff) <= 2 * int(boundary.sum())
+
+
+def test_triangulate_tracks_body_edge_cases(ctx, synth):
+    sc = synth.make_tracks(n_tracks=64, config_id=11)
+    e = ctx.triangulate_tracks(ctx.dev(np.zeros((0, 2), np.float32)), ctx.dev(np.zeros(1, np.int32)),
+                               ctx.dev(np.zeros(1, np.int32)), ctx.dev(np.zeros((1, 2), np.float32)), ctx.dev(sc["poses"]),
+                               0, sc["K"])
+    assert to_np(e["counts"]).tolist() == [0, 0, 0]
+    z = ctx.triangulate_tracks(ctx.dev(sc["track_uv"]), ctx.dev(sc["sight_ptr"]), ctx.dev(sc["sight_pose"]),
+                               ctx.dev(sc["sight_uv"]), ctx.dev(sc["poses"]), sc["kf_pose"], sc["K"],
+                               d_skip=ctx.dev(np.ones(64, np.uint8)))
+    assert to_np(z["counts"]).tolist() == [0, 0, 0] and not to_np(z["status"])[:64].any()
+    with pytest.raises(Exception):
+        ctx.triangulate_tracks(ctx.dev(sc["track_uv"]), ctx.dev(sc["sight_ptr"]), ctx.dev(sc["sight_pose"]),
+                               ctx.dev(sc["sight_uv"]), ctx.dev(sc["poses"]), 99, sc["K"])
+
+
 def test_triangulate_empty_and_degenerate(ctx, oracle, synth):
     pr = synth.make_pair(1)
     d = ctx.triangulate(ctx.dev(pr["kp1"]), ctx.dev(pr["kp2"]), 0, ctx.dev(pr["poses"]), 2, pr["K"])

@@ -210,6 +210,72 @@ def test_triangulate_recovers_points_and_gates(oracle, synth):
 
 
 # ------------------------------------------------------------------ rotation
+def test_triangulate_tracks_vs_numpy(oracle, synth):
+    """Body of Mapper::triangulate_tracks (src/Mapper.cpp:246-305) against an independent float64 numpy
+    formulation: same statuses away from the thresholds, same parallax terms, and the selection rule
+    (threshold, quota top-up by ascending cosine, ties in track order) recomputed from the per-track values."""
+    for kw, quota in ((dict(n_tracks=600, config_id=6), 100), (dict(n_tracks=260, far_frac=0.9, config_id=7), 100)):
+        sc = synth.make_tracks(**kw)
+        d = oracle.triangulate_tracks(sc["track_uv"], sc["sight_ptr"], sc["sight_pose"], sc["sight_uv"], sc["poses"],
+                                      sc["kf_pose"], sc["K"], skip=sc["skip"], min_new_points=quota)
+        fx, fy, cx, cy = [float(v) for v in sc["K"]]
+        P = sc["poses"].reshape(-1, 4, 4).astype(np.float64)
+        Tk = P[sc["kf_pose"]]
+        ck = -Tk[:3, :3].T @ Tk[:3, 3]
+        n = len(sc["track_uv"])
+        first = sc["sight_pose"][np.minimum(sc["sight_ptr"][:-1], len(sc["sight_pose"]) - 1)]
+        tri = oracle.triangulate(sc["sight_uv"][np.minimum(sc["sight_ptr"][:-1], len(sc["sight_uv"]) - 1)], sc["track_uv"],
+                                 sc["poses"], sc["K"], idx1=first, idx2=np.full(n, sc["kf_pose"]),
+                                 min_parallax_cosine=1.0, max_reproj=4.0)
+        n_checked = 0
+        for t in range(n):
+            s0, s1 = sc["sight_ptr"][t], sc["sight_ptr"][t + 1]
+            if s1 <= s0 or sc["skip"][t] or not tri["keep"][t]:
+                assert d["status"][t] == 0
+                continue
+            X = d["xyz"][t].astype(np.float64)
+            errs = []
+            for s in range(s0, s1):
+                T = P[sc["sight_pose"][s]]
+                pc = T[:3, :3] @ X + T[:3, 3]
+                uv = np.array([fx * pc[0] / pc[2] + cx, fy * pc[1] / pc[2] + cy]) if pc[2] >= 0 else np.array([-1.0, -1.0])
+                errs.append(np.linalg.norm(uv - sc["sight_uv"][s]))
+            errs = np.array(errs)
+            if np.any(np.abs(errs - 4.0) < 1e-3):
+                continue                                     # too close to the 4 px threshold for a float64 referee
+            assert d["status"][t] == (2 if np.any(errs > 4.0) else 1)
+            if d["status"][t] != 1:
+                continue
+            Tf = P[sc["sight_pose"][s0]]
+            cf = -Tf[:3, :3].T @ Tf[:3, 3]
+            a, b = cf - X, ck - X
+            cosv = a @ b / np.linalg.norm(a) / np.linalg.norm(b)
+            turned = np.arccos(np.clip((np.trace(Tk[:3, :3] @ Tf[:3, :3].T) - 1.0) / 2.0, -1.0, 1.0))
+            assert abs(d["parallax_cos"][t] - cosv) < 2e-6
+            # (trace - 1) / 2 is evaluated in float in the reference: acos amplifies its rounding near 1
+            assert abs(d["required_cos"][t] - min(np.float32(0.999848), np.cos(0.2 * turned))) < 2e-6
+            n_checked += 1
+        assert n_checked > 100
+        cand = np.flatnonzero(d["status"] == 1)
+        ok = d["parallax_cos"][cand] <= d["required_cos"][cand]
+        acc, rej = cand[ok], cand[~ok]
+        top = 0
+        if len(acc) < quota and len(rej):
+            order = np.lexsort((rej, d["parallax_cos"][rej]))
+            top = min(quota - len(acc), len(rej))
+            acc = np.concatenate([acc, rej[order[:top]]])
+        assert np.array_equal(d["accepted"], acc) and d["n_topped_up"] == top
+        assert np.array_equal(d["inconsistent"], np.flatnonzero(d["status"] == 2))
+    assert top > 0        # the second scene exercises the quota
+    # empty input and all-skipped input
+    e = oracle.triangulate_tracks(np.zeros((0, 2), np.float32), np.zeros(1, np.int32), np.zeros(0, np.int32),
+                                  np.zeros((0, 2), np.float32), sc["poses"], 0, sc["K"])
+    assert len(e["accepted"]) == 0 and len(e["inconsistent"]) == 0
+    z = oracle.triangulate_tracks(sc["track_uv"], sc["sight_ptr"], sc["sight_pose"], sc["sight_uv"], sc["poses"],
+                                  sc["kf_pose"], sc["K"], skip=np.ones(len(sc["track_uv"]), np.uint8))
+    assert not z["status"].any() and len(z["accepted"]) == 0
+
+
 def test_pack_unpack_pose_roundtrip(oracle, rs, synth):
     rng = np.random.default_rng(6)
     for i in range(200):
