@@ -233,6 +233,36 @@ def main():
                            note="front end (match, reproj match, triangulate) on a second context/stream, BA on the first")
         ctx2.close()
 
+    # ---------------- widened row, measured beside the metric, not part of `value`:
+    # the body of Mapper::triangulate_tracks for one key frame (2000 tracks, <= 10 sightings each)
+    tracks_stage = None
+    if world == 1:
+        tk = synth.make_tracks(n_tracks=2000)
+        targs = (ctx.dev(tk["track_uv"]), ctx.dev(tk["sight_ptr"]), ctx.dev(tk["sight_pose"]), ctx.dev(tk["sight_uv"]),
+                 ctx.dev(tk["poses"]), tk["kf_pose"], tk["K"])
+        d_skip = ctx.dev(tk["skip"])
+        tout = ctx.triangulate_tracks(*targs, d_skip=d_skip)
+        torch.cuda.synchronize()
+        ctx.prof_begin()
+        t0 = time.perf_counter()
+        for _ in range(max(args.steps, 1)):
+            ctx.triangulate_tracks(*targs, d_skip=d_skip, out=tout)
+        torch.cuda.synchronize()
+        wall = (time.perf_counter() - t0) / max(args.steps, 1)
+        tprof = ctx.prof_end()
+        tracks_stage = dict(n_tracks=2000, n_sightings=int(len(tk["sight_pose"])), calls_per_s=1.0 / wall,
+                            us_per_call=1e6 * wall,
+                            per_kernel_us={k: round(1e3 * v[1] / max(v[0], 1), 2) for k, v in tprof.items()},
+                            accepted=int(tout["counts"].cpu()[0]))
+        if not args.no_cpu_baseline:
+            import pyoracle as O
+            O.build()
+            t0 = time.perf_counter()
+            for _ in range(5):
+                O.triangulate_tracks(tk["track_uv"], tk["sight_ptr"], tk["sight_pose"], tk["sight_uv"], tk["poses"],
+                                     tk["kf_pose"], tk["K"], skip=tk["skip"])
+            tracks_stage["cpu_us_per_call"] = 1e6 * (time.perf_counter() - t0) / 5
+
     # every hot kernel against its roof (same event timings)
     roofline_all = {}
     pmc_all = pmc_traffic()
@@ -290,6 +320,7 @@ def main():
             "ba_summary": last.get("ba"),
             "roofline_all": roofline_all,
             "two_streams": two_streams,
+            "tracks_stage": tracks_stage,
             "speedup_vs_cpu_baseline": (value / cpu["value"]) if cpu else None,
         }
         print(json.dumps(out))
