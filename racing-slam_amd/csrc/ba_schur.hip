@@ -272,7 +272,13 @@ __device__ __forceinline__ void syrk_scatter(const double* yt, int nchunks, int 
 
 // ---------------------------------------------------------------------- K5
 // One workgroup = one item of IT_L = 64 sorted landmarks (16 per wave).
-__global__ __launch_bounds__(64 * SCH_WAVES) void ba_schur_mfma(BaDims d, BaBufs b, BaOpt opt, BaGroup g, int it)
+// PREP_LDS: the per-camera blocks (rotation, left Jacobian, centre) of ALL cameras are staged in LDS (windows of
+// up to SCH_MAXC_LDS cameras); larger windows read them from global memory (L2-resident).  The U / gc partial
+// sums of a workgroup live in LDS indexed by the camera's RANK in the item's union (<= 21 cameras), so the
+// footprint does not grow with the window.
+#define SCH_UCAP 21
+template <bool PREP_LDS>
+static __device__ __forceinline__ void ba_schur_body(const BaDims& d, const BaBufs& b, const BaOpt& opt, const BaGroup& g, int it)
 {
     extern __shared__ __attribute__((aligned(16))) double lds[];
     BA_STAMP_DECL;
@@ -280,10 +286,10 @@ __global__ __launch_bounds__(64 * SCH_WAVES) void ba_schur_mfma(BaDims d, BaBufs
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     double* yt = lds;                                            // WG tile
-    double* ulds = lds + YT_DOUBLES;                             // [Cf][42]
-    double* cprep = ulds + (size_t)d.Cf * 42;                    // [C][BA_PREP] camera block staged in LDS (C <= 64)
-    int* gslot = (int*)(cprep + (size_t)d.C * BA_PREP);   // [24]
-    const int nlds = d.Cf * 42;
+    double* ulds = lds + YT_DOUBLES;                             // [SCH_UCAP][42], by rank in the item's camera union
+    double* cprep = ulds + SCH_UCAP * 42;                        // [C][BA_PREP] camera blocks (PREP_LDS only)
+    int* gslot = (int*)(cprep + (PREP_LDS ? (size_t)d.C * BA_PREP : 0));   // [24]
+    const int nlds = SCH_UCAP * 42;
     // ---- everything that does not depend on the LM state goes out before the state barrier: the item's
     // camera mask, this lane's landmark record {landmark, first observation, count} (one 16-byte load
     // instead of the chain sorted -> obs_ptr), LDS zeroing
@@ -300,8 +306,9 @@ __global__ __launch_bounds__(64 * SCH_WAVES) void ba_schur_mfma(BaDims d, BaBufs
     if (st.done) return;
     // ---- one more round trip: camera blocks -> LDS, the landmark, the first observation of every lane
     const double* gprep = b.prep + (size_t)st.cur * d.C * BA_PREP;
-    for (int i = threadIdx.x; i < d.C * BA_PREP; i += blockDim.x) cprep[i] = gprep[i];
-    const double* prep = cprep;       // pure LDS pointer: ds_read, not flat_load
+    if (PREP_LDS)
+        for (int i = threadIdx.x; i < d.C * BA_PREP; i += blockDim.x) cprep[i] = gprep[i];
+    const double* prep = PREP_LDS ? (const double*)cprep : gprep;       // pure LDS or pure global pointer per instantiation
     const double* Xp = b.Xp + (size_t)st.cur * d.P * 3;
     double X[3] = {0, 0, 0};
     if (p >= 0) { X[0] = Xp[3 * (size_t)p]; X[1] = Xp[3 * (size_t)p + 1]; X[2] = Xp[3 * (size_t)p + 2]; }
@@ -343,12 +350,21 @@ __global__ __launch_bounds__(64 * SCH_WAVES) void ba_schur_mfma(BaDims d, BaBufs
         for (int k = 0; k < 3; k++) gv[k] += w * (o.jp[k] * o.r0 + o.jp[3 + k] * o.r1);
         const int s = (cs >> 16) - 1;
         if (s >= 0) {
-            double* u = ulds + s * 42;
+            if (ns <= SCH_UCAP) {
+                double* u = ulds + rank_in_mask(um0, um1, s) * 42;
 #pragma unroll
-            for (int a = 0; a < 6; a++) {
+                for (int a = 0; a < 6; a++) {
 #pragma unroll
-                for (int e = a; e < 6; e++) atomicAdd(&u[a * 6 + e], w * (o.jc[a] * o.jc[e] + o.jc[6 + a] * o.jc[6 + e]));
-                atomicAdd(&u[36 + a], w * (o.jc[a] * o.r0 + o.jc[6 + a] * o.r1));
+                    for (int e = a; e < 6; e++) atomicAdd(&u[a * 6 + e], w * (o.jc[a] * o.jc[e] + o.jc[6 + a] * o.jc[6 + e]));
+                    atomicAdd(&u[36 + a], w * (o.jc[a] * o.r0 + o.jc[6 + a] * o.r1));
+                }
+            } else {        // union too large for the LDS table (generic covisibility): straight to the replicas
+#pragma unroll
+                for (int a = 0; a < 6; a++) {
+#pragma unroll
+                    for (int e = a; e < 6; e++) atomicAdd(&b.U[rep_off + s * 36 + a * 6 + e], w * (o.jc[a] * o.jc[e] + o.jc[6 + a] * o.jc[6 + e]));
+                    atomicAdd(&b.gc[rep_off + 6 * s + a], w * (o.jc[a] * o.r0 + o.jc[6 + a] * o.r1));
+                }
             }
         }
     }
@@ -504,8 +520,8 @@ __global__ __launch_bounds__(64 * SCH_WAVES) void ba_schur_mfma(BaDims d, BaBufs
         if (f > 0.0) atomicAdd(&b.scal[slot + 1], f);
         if (gm > 0.0) atomic_max_nonneg(&b.gmax[slot], gm);
     }
-    for (int i = threadIdx.x; i < nlds; i += blockDim.x) {
-        const int s = i / 42, k = i % 42;
+    for (int i = threadIdx.x; i < min(ns, SCH_UCAP) * 42; i += blockDim.x) {
+        const int s = gslot[i / 42], k = i % 42;          // rank in the union -> free-camera slot
         const double v = ulds[i];
         if (v != 0.0) {
             if (k < 36) atomicAdd(&b.U[rep_off + s * 36 + k], v);
@@ -514,6 +530,17 @@ __global__ __launch_bounds__(64 * SCH_WAVES) void ba_schur_mfma(BaDims d, BaBufs
     }
     BA_STAMP(b, 6);
     BA_STAMP_FLUSH(b, 8);
+}
+
+__global__ __launch_bounds__(64 * SCH_WAVES) void ba_schur_mfma(BaDims d, BaBufs b, BaOpt opt, BaGroup g, int it)
+{
+    ba_schur_body<true>(d, b, opt, g, it);
+}
+
+// windows of more than SCH_MAXC_LDS cameras (cfg 5: 100 key frames): camera blocks from global memory
+__global__ __launch_bounds__(64 * SCH_WAVES) void ba_schur_mfma_big(BaDims d, BaBufs b, BaOpt opt, BaGroup g, int it)
+{
+    ba_schur_body<false>(d, b, opt, g, it);
 }
 
 // ------------------------------------------------------------------ host glue
@@ -648,17 +675,21 @@ int ba_launch_grouping(rs_context* ctx, const BaDims& d, const BaBufs& b, const 
 
 size_t ba_schur_lds_bytes(int C, int Cf)
 {
-    const size_t prep = (size_t)C * BA_PREP;
-    return sizeof(double) * ((size_t)YT_DOUBLES + (size_t)Cf * 42 + prep) + sizeof(int) * 32;
+    (void)Cf;
+    const size_t prep = C <= SCH_MAXC_LDS ? (size_t)C * BA_PREP : 0;
+    return sizeof(double) * ((size_t)YT_DOUBLES + (size_t)SCH_UCAP * 42 + prep) + sizeof(int) * 32;
 }
 
 int ba_prepare_schur(int C, int Cf)
 {
-    return (int)hipFuncSetAttribute((const void*)ba_schur_mfma, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    (int)ba_schur_lds_bytes(C, Cf));
+    const void* fn = C <= SCH_MAXC_LDS ? (const void*)ba_schur_mfma : (const void*)ba_schur_mfma_big;
+    return (int)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ba_schur_lds_bytes(C, Cf));
 }
 
 void ba_launch_schur(hipStream_t s, const BaDims& d, const BaBufs& b, const BaOpt& opt, const BaGroup& g, int it)
 {
-    hipLaunchKernelGGL(ba_schur_mfma, dim3(g.n_items), dim3(8 * g.it_l), ba_schur_lds_bytes(d.C, d.Cf), s, d, b, opt, g, it);
+    if (d.C <= SCH_MAXC_LDS)
+        hipLaunchKernelGGL(ba_schur_mfma, dim3(g.n_items), dim3(8 * g.it_l), ba_schur_lds_bytes(d.C, d.Cf), s, d, b, opt, g, it);
+    else
+        hipLaunchKernelGGL(ba_schur_mfma_big, dim3(g.n_items), dim3(8 * g.it_l), ba_schur_lds_bytes(d.C, d.Cf), s, d, b, opt, g, it);
 }
