@@ -24,6 +24,7 @@ SOURCES = [
     ("tracks.hip", ["-ffp-contract=off"]),
     ("ba.hip", ["-munsafe-fp-atomics"]),
     ("ba_solve.hip", ["-munsafe-fp-atomics"]),
+    ("ba_solve_big.hip", ["-munsafe-fp-atomics"]),
     ("ba_schur.hip", ["-munsafe-fp-atomics"]),
     ("ba_update.hip", ["-munsafe-fp-atomics"]),
     ("host.cpp", ["-ffp-contract=off"]),

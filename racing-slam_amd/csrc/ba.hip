@@ -539,6 +539,8 @@ extern "C" int rs_bundle_adjust(rs_context* ctx, int n_cameras, int n_points, in
     const bool use_mfma = d.Cf >= 1 && d.Cf <= 128 && ba_schur_lds_bytes(d.C, d.Cf) <= 160 * 1024;
     const bool k8_lds = ba_backsub_lds_bytes(d.C, d.n) <= 64 * 1024;
     const size_t o_grp = carve(use_mfma ? ba_group_bytes(d.P, d.Cf, d.M) : 16);
+    const bool solve_big = d.n > BA_MAX_LDS_N;
+    const size_t o_big = carve(solve_big ? ba_big_bytes(d.n) : 16);
     void* wsv = nullptr;
     int rc = rs_workspace(ctx, off, &wsv);
     if (rc) return rc;
@@ -628,6 +630,10 @@ extern "C" int rs_bundle_adjust(rs_context* ctx, int n_cameras, int n_points, in
         if (solve_lds) {
             rs_prof_scope ps(ctx, "K7_ba_reduced_solve");
             ba_launch_reduced_solve_lds(s, d, b, opt);
+        } else if (solve_big) {
+            rs_prof_scope ps(ctx, "K7_ba_reduced_solve_blocked");
+            rc = ba_launch_reduced_solve_big(ctx, d, b, opt, ws + o_big);
+            if (rc) return rc;
         } else {
             rs_prof_scope ps(ctx, "K7_ba_reduced_solve_global");
             hipLaunchKernelGGL(ba_reduced_solve, dim3(1), dim3(256), 0, s, d, b, opt, 0);

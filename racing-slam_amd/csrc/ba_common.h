@@ -318,6 +318,10 @@ int ba_launch_grouping(rs_context* ctx, const BaDims& d, const BaBufs& b, const 
 size_t ba_schur_lds_bytes(int C, int Cf);
 int ba_prepare_schur(int C, int Cf);
 void ba_launch_schur(hipStream_t s, const BaDims& d, const BaBufs& b, const BaOpt& opt, const BaGroup& g, int it);
+// ---- blocked reduced solve for n > BA_MAX_LDS_N (ba_solve_big.hip)
+struct rs_context;
+size_t ba_big_bytes(int n);
+int ba_launch_reduced_solve_big(rs_context* ctx, const BaDims& d, const BaBufs& b, const BaOpt& opt, char* ws);
 // ---- LDS-resident reduced solve (ba_solve.hip), n = 6*Cf <= BA_MAX_LDS_N
 size_t ba_reduced_solve_lds_bytes(int n);
 int ba_prepare_reduced_solve_lds(int n);
