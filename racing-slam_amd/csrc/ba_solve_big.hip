@@ -99,17 +99,21 @@ __global__ __launch_bounds__(1024) void ba_big_prologue(BaDims d, BaBufs b, BaOp
         b.dc[i] = yy;                           // y
     }
     __syncthreads();
+}
+
+// The lower triangle (incl. the diagonal) of the damped reduced matrix, in place: S is accumulated in its upper
+// triangle; lower(i, j) = upper(j, i) + U (same camera) + lambda (diagonal).  The strict upper triangle is left
+// as it is (nothing below reads it meaningfully), so there is no read/write overlap between threads.
+__global__ __launch_bounds__(256) void ba_big_assemble(BaDims d, BaBufs b)
+{
+    if (b.st->done) return;
+    const int n = d.n;
     const double* lam = b.rhs;
-    for (int idx = tid; idx < n * n; idx += nt) {
-        const int i = idx / n, j = idx % n;
-        if (i > j) b.S[idx] = b.S[(size_t)j * n + i];
-    }
-    __syncthreads();
-    for (int idx = tid; idx < n * n; idx += nt) {
-        const int i = idx / n, j = idx % n;
-        if (i / 6 != j / 6) continue;
-        const int a = i % 6, e = j % 6;
-        double v = b.S[idx] + ((a <= e) ? b.U[(i / 6) * 36 + a * 6 + e] : b.U[(i / 6) * 36 + e * 6 + a]);
+    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < (size_t)n * n; idx += (size_t)gridDim.x * blockDim.x) {
+        const int i = (int)(idx / n), j = (int)(idx % n);
+        if (i < j) continue;
+        double v = b.S[(size_t)j * n + i];
+        if (i / 6 == j / 6) v += b.U[(i / 6) * 36 + (j % 6) * 6 + (i % 6)];     // U is stored upper: (row j%6, col i%6), j <= i
         if (i == j) v += lam[i];
         b.S[idx] = v;
     }
@@ -119,84 +123,98 @@ __global__ __launch_bounds__(1024) void ba_big_prologue(BaDims d, BaBufs b, BaOp
 __global__ __launch_bounds__(64) void ba_big_diag(BaDims d, BaBufs b, BigBufs g, int J)
 {
     if (b.st->done) return;
+    // One wave, lane = row; the block (rows 0..w-1, plus the right-hand side's entries as row w) lives in LDS.
+    // (A register-resident row with fully unrolled columns spilled to scratch and was 10x slower.)
+    __shared__ double Lm[(BB + 1) * BBS], Mm[BB * BBS];
     const int n = d.n, lane = threadIdx.x;
     const int c0 = BB * J, w = min(BB, n - c0);
-    // lane < w: row c0 + lane of the block; lanes w..47: identity padding; lane 63: the right-hand side's entries
-    // of this block (a row below all others)
-    double a[BB], m[BB];
-#pragma unroll
-    for (int k = 0; k < BB; k++) {
-        a[k] = 0.0;
-        if (k < w) {
-            if (lane < w) a[k] = b.S[(size_t)(c0 + lane) * n + c0 + k];
-            else if (lane == 63) a[k] = b.dc[c0 + k];
-        }
-        if (k >= w && lane == k) a[k] = 1.0;      // pad: identity rows keep the pivots of unused columns at 1, everything finite
-    }
+    const bool row = lane < w, rhs = lane == w;            // w <= 48 < 64
+    if (row || rhs)
+        for (int k = 0; k < w; k++) Lm[lane * BBS + k] = row ? b.S[(size_t)(c0 + lane) * n + c0 + k] : b.dc[c0 + k];
+    __syncthreads();
     bool bad = false;
-    double dpiv[BB];
-#pragma unroll
-    for (int c = 0; c < BB; c++) {
-        const double piv = rl64(a[c], c);
-        dpiv[c] = piv;
-        if (c < w && (!(piv > 0.0) || !isfinite(piv))) bad = true;
+    for (int c = 0; c < w; c++) {
+        const double piv = Lm[c * BBS + c];
+        if (!(piv > 0.0) || !isfinite(piv)) bad = true;
         const double rd = 1.0 / piv;
-        const double lc = a[c] * rd;                       // rows below c; the others compute unused values
+        const bool below = (row || rhs) && lane > c;
+        double lc = 0.0;
+        if (below) {
+            lc = Lm[lane * BBS + c] * rd;
+            // 12 columns at a time with explicit register batches: the compiler cannot tell that the store to
+            // this row does not alias the next pivot-column read and would serialise one LDS round trip per k
+            for (int k0 = c + 1; k0 < w; k0 += 12) {
+                double rk[12], ck[12];
 #pragma unroll
-        for (int k = c + 1; k < BB; k++) {
-            const double akc = rl64(a[c], k);              // row k, column c, still l_kc * d_c
-            a[k] -= lc * akc;
+                for (int u = 0; u < 12; u++) {
+                    const int k = min(k0 + u, w - 1);
+                    rk[u] = Lm[lane * BBS + k];
+                    ck[u] = Lm[k * BBS + c];                  // row k, column c: still l_kc * d_c
+                }
+#pragma unroll
+                for (int u = 0; u < 12; u++)
+                    if (k0 + u < w) Lm[lane * BBS + k0 + u] = rk[u] - lc * ck[u];
+            }
         }
-        if (lane > c) a[c] = lc;
+        __syncthreads();
+        if (below) Lm[lane * BBS + c] = lc;
+        if (lane == 0) g.dv[c0 + c] = piv;
+        __syncthreads();
     }
-    // M = L^-1 (unit lower), row `lane`: M L = I  =>  m[j] = -sum_{k > j} m[k] L[k][j]
-#pragma unroll
-    for (int j = 0; j < BB; j++) m[j] = (j == lane) ? 1.0 : 0.0;
-#pragma unroll
-    for (int j = BB - 2; j >= 0; j--) {
-        double sacc = m[j];
-#pragma unroll
-        for (int k = j + 1; k < BB; k++) sacc -= m[k] * rl64(a[j], k);      // L[k][j] lives in row k's a[j]
-        m[j] = lane > j ? sacc : m[j];
-    }
-    if (lane < w) {
-#pragma unroll
-        for (int k = 0; k < BB; k++) {
-            if (k < w) g.Ls[(size_t)(c0 + lane) * n + c0 + k] = k < lane ? a[k] : (k == lane ? 1.0 : 0.0);
-            g.M[lane * BB + k] = m[k];
-        }
-    } else if (lane < BB) {
-#pragma unroll
-        for (int k = 0; k < BB; k++) g.M[lane * BB + k] = (k == lane) ? 1.0 : 0.0;
-    }
-    if (lane == 63) {
-#pragma unroll
-        for (int k = 0; k < BB; k++) if (k < w) g.yf[c0 + k] = a[k];       // D^-1 L^-1 g of this block
-    }
-    if (lane == 0) {
-#pragma unroll
-        for (int k = 0; k < BB; k++) if (k < w) g.dv[c0 + k] = dpiv[k];
-    }
+    if (row)
+        for (int k = 0; k < w; k++) g.Ls[(size_t)(c0 + lane) * n + c0 + k] = k < lane ? Lm[lane * BBS + k] : (k == lane ? 1.0 : 0.0);
+    if (rhs)
+        for (int k = 0; k < w; k++) g.yf[c0 + k] = Lm[lane * BBS + k];      // D^-1 L^-1 g of this block
     if (__any(bad) && lane == 0) *g.fail = 1;
+    // M = L^-1 (unit lower), row `lane`: M L = I  =>  m[j] = -sum_{j < k <= lane} m[k] L[k][j]; rows / columns >= w
+    // are the identity (zero-padded operands of the trailing update)
+    if (lane < BB)
+        for (int k = 0; k < BB; k++) Mm[lane * BBS + k] = (k == lane) ? 1.0 : 0.0;
+    __syncthreads();
+    if (row) {
+        for (int j = lane - 1; j >= 0; j--) {
+            double sacc = 0.0;
+            for (int k0 = j + 1; k0 <= lane; k0 += 8) {
+                double mk[8], lk[8];
+#pragma unroll
+                for (int u = 0; u < 8; u++) {
+                    const int k = min(k0 + u, lane);
+                    mk[u] = Mm[lane * BBS + k];
+                    lk[u] = Lm[k * BBS + j];
+                }
+#pragma unroll
+                for (int u = 0; u < 8; u++) sacc -= (k0 + u <= lane) ? mk[u] * lk[u] : 0.0;
+            }
+            Mm[lane * BBS + j] = sacc;
+        }
+    }
+    __syncthreads();
+    for (int idx = lane; idx < BB * BB; idx += 64) g.M[idx] = Mm[(idx / BB) * BBS + idx % BB];
 }
 
 // ------------------------------------------------------------------ trailing update
-// X Z^T for 48x48 operands held [row][k] in LDS: thread (ty, tx) owns outputs (ty + 16 a, tx + 16 b)
-__device__ __forceinline__ void gemm_nt_48(const double* X, const double* Z, int w, double out[3][3])
+typedef __attribute__((ext_vector_type(4))) double d4;
+
+// out = X Z^T for 48 x K operands held [row][k] (row stride BBS) in LDS, K = 4 * nchunk, on the matrix cores:
+// v_mfma_f64_16x16x4_f64 takes A[lane&15][lane>>4] and B[lane&15][lane>>4] of a 16x4 slice, and returns
+// C[row = (lane>>4) + 4 reg][col = lane & 15].  The 9 output tiles are dealt round-robin to the 4 waves;
+// `store(R, C, v)` is called for every element this lane owns.
+template <typename F>
+__device__ __forceinline__ void gemm_nt_48(const double* X, const double* Z, int nchunk, F store)
 {
-    const int ty = threadIdx.x >> 4, tx = threadIdx.x & 15;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lr = lane & 15, lk = lane >> 4;
 #pragma unroll
-    for (int a = 0; a < 3; a++)
+    for (int ti = 0; ti < 3; ti++) {
+        const int t = wave + 4 * ti;                 // wave 0 owns three tiles, the others two
+        if (t >= 9) break;
+        const int tr = t / 3, tc = t % 3;
+        d4 acc = {0.0, 0.0, 0.0, 0.0};
+        const double* xa = X + (16 * tr + lr) * BBS + lk;
+        const double* zb = Z + (16 * tc + lr) * BBS + lk;
+        for (int kc = 0; kc < nchunk; kc++) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(xa[4 * kc], zb[4 * kc], acc, 0, 0, 0);
 #pragma unroll
-        for (int c = 0; c < 3; c++) out[a][c] = 0.0;
-    for (int k = 0; k < w; k++) {
-        double x[3], z[3];
-#pragma unroll
-        for (int a = 0; a < 3; a++) { x[a] = X[(ty + 16 * a) * BBS + k]; z[a] = Z[(tx + 16 * a) * BBS + k]; }
-#pragma unroll
-        for (int a = 0; a < 3; a++)
-#pragma unroll
-            for (int c = 0; c < 3; c++) out[a][c] += x[a] * z[c];
+        for (int reg = 0; reg < 4; reg++) store(16 * tr + lk + 4 * reg, 16 * tc + lr, acc[reg]);
     }
 }
 
@@ -215,7 +233,8 @@ __global__ __launch_bounds__(256) void ba_big_update(BaDims d, BaBufs b, BigBufs
     const bool rhs = bi == NBLK;
     const int ri0 = BB * bi, hi = rhs ? 1 : min(BB, n - ri0);
     const int rk0 = BB * bk, hk = min(BB, n - rk0);
-    for (int idx = tid; idx < BB * BB; idx += 256) {
+#pragma unroll
+    for (int idx = tid; idx < BB * BB; idx += 256) {       // 9 rounds, fully unrolled: 27 loads in flight
         const int r = idx / BB, k = idx % BB;
         Mm[r * BBS + k] = g.M[idx];
         double vi = 0.0, vk = 0.0;
@@ -228,22 +247,13 @@ __global__ __launch_bounds__(256) void ba_big_update(BaDims d, BaBufs b, BigBufs
     }
     if (tid < BB) dvl[tid] = tid < w ? g.dv[c0 + tid] : 1.0;
     __syncthreads();
-    const int ty = tid >> 4, tx = tid & 15;
-    double acc[3][3];
+    const int nchunk = (w + 3) / 4;            // operands are zero beyond w
     // P_k = A_kJ M^T D^-1  (and P_i likewise; the right-hand side's panel is yf, already final)
-    gemm_nt_48(Ak, Mm, w, acc);
-#pragma unroll
-    for (int a = 0; a < 3; a++)
-#pragma unroll
-        for (int c = 0; c < 3; c++) Pk[(ty + 16 * a) * BBS + tx + 16 * c] = acc[a][c] / dvl[tx + 16 * c];
+    gemm_nt_48(Ak, Mm, nchunk, [&](int R, int C, double v) { Pk[R * BBS + C] = v / dvl[C]; });
     if (rhs) {
         if (tid < BB) Pi[tid] = tid < w ? g.yf[c0 + tid] : 0.0;             // row 0 of Pi
     } else if (bi != bk) {
-        gemm_nt_48(Ai, Mm, w, acc);
-#pragma unroll
-        for (int a = 0; a < 3; a++)
-#pragma unroll
-            for (int c = 0; c < 3; c++) Pi[(ty + 16 * a) * BBS + tx + 16 * c] = acc[a][c] / dvl[tx + 16 * c];
+        gemm_nt_48(Ai, Mm, nchunk, [&](int R, int C, double v) { Pi[R * BBS + C] = v / dvl[C]; });
     }
     __syncthreads();
     const double* PI = (bi == bk) ? Pk : Pi;
@@ -261,16 +271,30 @@ __global__ __launch_bounds__(256) void ba_big_update(BaDims d, BaBufs b, BigBufs
         PD[r * BBS + k] = (rhs && r > 0) ? 0.0 : PI[r * BBS + k] * dvl[k];
     }
     __syncthreads();
-    gemm_nt_48(PD, Pk, w, acc);
+    // results first into registers, then ALL global loads, then the stores (a load-modify-store per element
+    // inside the tile loop would be a dozen dependent L2 round trips)
+    double upd[12];
+    int ur[12], uq[12];
+    int cnt = 0;
 #pragma unroll
-    for (int a = 0; a < 3; a++)
+    for (int u = 0; u < 12; u++) { upd[u] = 0.0; ur[u] = -1; uq[u] = 0; }
+    gemm_nt_48(PD, Pk, nchunk, [&](int r, int q, double v) {
+        const bool ok = q < hk && (rhs ? r == 0 : r < hi);
+        upd[cnt] = v; ur[cnt] = ok ? r : -1; uq[cnt] = q;
+        cnt++;
+    });
+    double old[12];
 #pragma unroll
-        for (int c = 0; c < 3; c++) {
-            const int r = ty + 16 * a, q = tx + 16 * c;
-            if (q >= hk) continue;
-            if (rhs) { if (r == 0) b.dc[rk0 + q] -= acc[a][c]; }
-            else if (r < hi) b.S[(size_t)(ri0 + r) * n + rk0 + q] -= acc[a][c];
-        }
+    for (int u = 0; u < 12; u++) {
+        const int r = max(ur[u], 0), q = min(uq[u], hk - 1);
+        old[u] = rhs ? b.dc[rk0 + q] : b.S[(size_t)(ri0 + min(r, hi - 1)) * n + rk0 + q];
+    }
+#pragma unroll
+    for (int u = 0; u < 12; u++) {
+        if (ur[u] < 0) continue;
+        if (rhs) b.dc[rk0 + uq[u]] = old[u] - upd[u];
+        else b.S[(size_t)(ri0 + ur[u]) * n + rk0 + uq[u]] = old[u] - upd[u];
+    }
 }
 
 // ------------------------------------------------------------------ finish
@@ -309,7 +333,13 @@ __global__ __launch_bounds__(1024) void ba_big_finish(BaDims d, BaBufs b, BaOpt 
         // y[0 : c0] -= L[block J rows, 0 : c0]^T x_J
         for (int k = tid; k < c0; k += nt) {
             double acc = 0.0;
-            for (int r = 0; r < w; r++) acc += g.Ls[(size_t)(c0 + r) * n + k] * y[c0 + r];
+            for (int r0 = 0; r0 < w; r0 += 12) {            // w is a multiple of 6; loads go out 12 at a time
+                double l[12];
+#pragma unroll
+                for (int u = 0; u < 12; u++) l[u] = g.Ls[(size_t)(c0 + min(r0 + u, w - 1)) * n + k];
+#pragma unroll
+                for (int u = 0; u < 12; u++) acc += (r0 + u < w) ? l[u] * y[c0 + r0 + u] : 0.0;
+            }
             y[k] -= acc;
         }
         __syncthreads();
@@ -379,6 +409,7 @@ int ba_launch_reduced_solve_big(rs_context* ctx, const BaDims& d, const BaBufs& 
     const size_t lds_upd = sizeof(double) * (5 * BB * BBS + BB);
     RS_HIP(ctx, hipFuncSetAttribute((const void*)ba_big_update, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_upd));
     hipLaunchKernelGGL(ba_big_prologue, dim3(1), dim3(1024), 0, s, d, b, opt, g);
+    hipLaunchKernelGGL(ba_big_assemble, dim3(256), dim3(256), 0, s, d, b);
     for (int J = 0; J < NBLK; J++) {
         hipLaunchKernelGGL(ba_big_diag, dim3(1), dim3(64), 0, s, d, b, g, J);
         const int nb = NBLK - J - 1;                       // trailing column blocks
