@@ -389,6 +389,27 @@ def test_bundle_adjust_arbitrary_covisibility(ctx, oracle, synth):
     assert np.allclose(p, rp, rtol=1e-6, atol=1e-7)
 
 
+def test_bundle_adjust_cfg5_full_size_properties(ctx, synth):
+    """cfg 5 at full size (100 key frames, 80 k landmarks, ~480 k observations, n = 588): the window-size-independent
+    MFMA Schur kernel and the blocked reduced solve.  The oracle needs minutes here, so the checks are the
+    size-independent ones: usable solve, large cost decrease, fixed cameras untouched, finite result, and a second
+    solve started from the result finds (almost) nothing left.  Small 100-KF windows are compared with the oracle
+    value by value in test_bundle_adjust_code_paths."""
+    w = synth.make_ba_window(n_kf=100, n_points=80000, config_id=5)
+    dc, dp = ctx.dev(w["cams"]), ctx.dev(w["points"])
+    args = (ctx.dev(w["obs_ptr"]), ctx.dev(w["obs_cam"]), ctx.dev(w["obs_uv"]))
+    s1 = ctx.bundle_adjust(dc, w["cam_free"], dp, *args, w["K"])
+    assert s1["usable"] == 1 and s1["iterations"] >= 5
+    assert s1["final_cost"] < 0.15 * s1["initial_cost"]
+    c1, p1 = to_np(dc), to_np(dp)
+    fixed = ~np.asarray(w["cam_free"]).astype(bool)
+    assert fixed.sum() == 2 and np.array_equal(c1[fixed], w["cams"][fixed])
+    assert np.isfinite(c1).all() and np.isfinite(p1).all()
+    s2 = ctx.bundle_adjust(dc, w["cam_free"], dp, *args, w["K"])
+    assert s2["initial_cost"] == pytest.approx(s1["final_cost"], rel=1e-9)
+    assert s2["final_cost"] <= s2["initial_cost"] and s2["final_cost"] > 0.5 * s2["initial_cost"]
+
+
 def test_match_descriptors_cfg4_batch_properties(ctx, synth):
     """BASELINE.json configs[3]: 64 pairs x 2k keypoints.  Size-independent properties: the batched
     launch equals 64 single launches bit for bit, and matching a set against itself is the identity."""
