@@ -120,17 +120,21 @@ __global__ __launch_bounds__(256) void ba_big_assemble(BaDims d, BaBufs b)
 }
 
 // ------------------------------------------------------------------ diagonal block
-__global__ __launch_bounds__(64) void ba_big_diag(BaDims d, BaBufs b, BigBufs g, int J)
+__global__ __launch_bounds__(256) void ba_big_diag(BaDims d, BaBufs b, BigBufs g, int J)
 {
     if (b.st->done) return;
-    // One wave, lane = row; the block (rows 0..w-1, plus the right-hand side's entries as row w) lives in LDS.
-    // (A register-resident row with fully unrolled columns spilled to scratch and was 10x slower.)
-    __shared__ double Lm[(BB + 1) * BBS], Mm[BB * BBS];
-    const int n = d.n, lane = threadIdx.x;
+    // The block (rows 0..w-1, plus the right-hand side's entries as row w) lives in LDS; lane = row, and the four
+    // waves split the trailing columns of a row (column k belongs to wave (k - c - 1) & 3), so that one batch of
+    // <= 12 LDS loads per wave covers a whole column step.  (A register-resident row with fully unrolled columns
+    // spilled to scratch and was 10x slower.)
+    __shared__ double Lm[(BB + 1) * BBS];
+    const int n = d.n, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int c0 = BB * J, w = min(BB, n - c0);
     const bool row = lane < w, rhs = lane == w;            // w <= 48 < 64
-    if (row || rhs)
-        for (int k = 0; k < w; k++) Lm[lane * BBS + k] = row ? b.S[(size_t)(c0 + lane) * n + c0 + k] : b.dc[c0 + k];
+    for (int idx = tid; idx < (w + 1) * w; idx += 256) {
+        const int r = idx / w, k = idx % w;
+        Lm[r * BBS + k] = r < w ? b.S[(size_t)(c0 + r) * n + c0 + k] : b.dc[c0 + k];
+    }
     __syncthreads();
     bool bad = false;
     for (int c = 0; c < w; c++) {
@@ -141,55 +145,55 @@ __global__ __launch_bounds__(64) void ba_big_diag(BaDims d, BaBufs b, BigBufs g,
         double lc = 0.0;
         if (below) {
             lc = Lm[lane * BBS + c] * rd;
-            // 12 columns at a time with explicit register batches: the compiler cannot tell that the store to
-            // this row does not alias the next pivot-column read and would serialise one LDS round trip per k
-            for (int k0 = c + 1; k0 < w; k0 += 12) {
-                double rk[12], ck[12];
+            double rk[12], ck[12];
 #pragma unroll
-                for (int u = 0; u < 12; u++) {
-                    const int k = min(k0 + u, w - 1);
-                    rk[u] = Lm[lane * BBS + k];
-                    ck[u] = Lm[k * BBS + c];                  // row k, column c: still l_kc * d_c
-                }
+            for (int u = 0; u < 12; u++) {
+                const int k = min(c + 1 + wave + 4 * u, w - 1);
+                rk[u] = Lm[lane * BBS + k];
+                ck[u] = Lm[k * BBS + c];                      // row k, column c: still l_kc * d_c
+            }
 #pragma unroll
-                for (int u = 0; u < 12; u++)
-                    if (k0 + u < w) Lm[lane * BBS + k0 + u] = rk[u] - lc * ck[u];
+            for (int u = 0; u < 12; u++) {
+                const int k = c + 1 + wave + 4 * u;
+                if (k < w) Lm[lane * BBS + k] = rk[u] - lc * ck[u];
             }
         }
         __syncthreads();
-        if (below) Lm[lane * BBS + c] = lc;
-        if (lane == 0) g.dv[c0 + c] = piv;
+        if (below && wave == 0) Lm[lane * BBS + c] = lc;
+        if (tid == 0) g.dv[c0 + c] = piv;
         __syncthreads();
     }
-    if (row)
-        for (int k = 0; k < w; k++) g.Ls[(size_t)(c0 + lane) * n + c0 + k] = k < lane ? Lm[lane * BBS + k] : (k == lane ? 1.0 : 0.0);
-    if (rhs)
-        for (int k = 0; k < w; k++) g.yf[c0 + k] = Lm[lane * BBS + k];      // D^-1 L^-1 g of this block
+    for (int idx = tid; idx < w * w; idx += 256) {
+        const int r = idx / w, k = idx % w;
+        g.Ls[(size_t)(c0 + r) * n + c0 + k] = k < r ? Lm[r * BBS + k] : (k == r ? 1.0 : 0.0);
+    }
+    if (tid < w) g.yf[c0 + tid] = Lm[w * BBS + tid];        // D^-1 L^-1 g of this block
     if (__any(bad) && lane == 0) *g.fail = 1;
-    // M = L^-1 (unit lower), row `lane`: M L = I  =>  m[j] = -sum_{j < k <= lane} m[k] L[k][j]; rows / columns >= w
-    // are the identity (zero-padded operands of the trailing update)
-    if (lane < BB)
-        for (int k = 0; k < BB; k++) Mm[lane * BBS + k] = (k == lane) ? 1.0 : 0.0;
+    // M = L^-1 (unit lower), row r by thread r of wave 0: M L = I  =>  m[j] = -sum_{j < k <= r} m[k] L[k][j], in LDS
+    // with explicit 8-wide batches of loads (a register-resident row with unrolled columns spills to scratch).
+    // Rows / columns >= w are the identity (zero-padded operands of the trailing update).
+    __shared__ double Mm[BB * BBS];
+    for (int idx = tid; idx < BB * BB; idx += 256) Mm[(idx / BB) * BBS + idx % BB] = (idx / BB == idx % BB) ? 1.0 : 0.0;
     __syncthreads();
-    if (row) {
-        for (int j = lane - 1; j >= 0; j--) {
+    if (tid < w) {
+        for (int j = tid - 1; j >= 0; j--) {
             double sacc = 0.0;
-            for (int k0 = j + 1; k0 <= lane; k0 += 8) {
+            for (int k0 = j + 1; k0 <= tid; k0 += 8) {
                 double mk[8], lk[8];
 #pragma unroll
                 for (int u = 0; u < 8; u++) {
-                    const int k = min(k0 + u, lane);
-                    mk[u] = Mm[lane * BBS + k];
+                    const int k = min(k0 + u, tid);
+                    mk[u] = Mm[tid * BBS + k];
                     lk[u] = Lm[k * BBS + j];
                 }
 #pragma unroll
-                for (int u = 0; u < 8; u++) sacc -= (k0 + u <= lane) ? mk[u] * lk[u] : 0.0;
+                for (int u = 0; u < 8; u++) sacc -= (k0 + u <= tid) ? mk[u] * lk[u] : 0.0;
             }
-            Mm[lane * BBS + j] = sacc;
+            Mm[tid * BBS + j] = sacc;
         }
     }
     __syncthreads();
-    for (int idx = lane; idx < BB * BB; idx += 64) g.M[idx] = Mm[(idx / BB) * BBS + idx % BB];
+    for (int idx = tid; idx < BB * BB; idx += 256) g.M[idx] = Mm[(idx / BB) * BBS + idx % BB];
 }
 
 // ------------------------------------------------------------------ trailing update
@@ -411,7 +415,7 @@ int ba_launch_reduced_solve_big(rs_context* ctx, const BaDims& d, const BaBufs& 
     hipLaunchKernelGGL(ba_big_prologue, dim3(1), dim3(1024), 0, s, d, b, opt, g);
     hipLaunchKernelGGL(ba_big_assemble, dim3(256), dim3(256), 0, s, d, b);
     for (int J = 0; J < NBLK; J++) {
-        hipLaunchKernelGGL(ba_big_diag, dim3(1), dim3(64), 0, s, d, b, g, J);
+        hipLaunchKernelGGL(ba_big_diag, dim3(1), dim3(256), 0, s, d, b, g, J);
         const int nb = NBLK - J - 1;                       // trailing column blocks
         const int pairs = nb * (nb + 1) / 2 + nb;          // (bi >= bk) pairs + one right-hand-side pair per bk
         if (pairs > 0) hipLaunchKernelGGL(ba_big_update, dim3(pairs), dim3(256), lds_upd, s, d, b, g, J);
