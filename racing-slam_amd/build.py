@@ -30,7 +30,7 @@ SOURCES = [
     ("host.cpp", ["-ffp-contract=off"]),
 ]
 STAMPS = ["-DRS_STAMPS=1"] if os.environ.get("RS_STAMPS") else []
-COMMON = STAMPS + ["-O3", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function", f"--offload-arch={ARCH}"]
+COMMON = STAMPS + ["-O3", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function", "-Wno-pass-failed", f"--offload-arch={ARCH}"]
 
 
 def hipcc():

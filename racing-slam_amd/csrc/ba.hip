@@ -516,7 +516,6 @@ extern "C" int rs_bundle_adjust(rs_context* ctx, int n_cameras, int n_points, in
     opt.min_rel = options->min_relative_decrease; opt.dmin = options->min_lm_diagonal;
     opt.dmax = options->max_lm_diagonal; opt.ftol = options->function_tolerance;
     opt.gtol = options->gradient_tolerance; opt.ptol = options->parameter_tolerance;
-    opt.dbg = 0;
     if (opt.max_iter < 0 || opt.max_iter > 1000) return rs_fail(ctx, RS_ERR_INVALID, "max_num_iterations out of range");
     if (d.Cf * 42 * sizeof(double) > 60 * 1024) return rs_fail(ctx, RS_ERR_UNSUPPORTED, "more than 182 free cameras");
 
@@ -871,7 +870,6 @@ extern "C" int rs_refine_pose(rs_context* ctx, double h_camera[6], const double*
     opt.min_rel = options->min_relative_decrease; opt.dmin = options->min_lm_diagonal;
     opt.dmax = options->max_lm_diagonal; opt.ftol = options->function_tolerance;
     opt.gtol = options->gradient_tolerance; opt.ptol = options->parameter_tolerance;
-    opt.dbg = 0;
     void* wsv = nullptr;
     int rc = rs_workspace(ctx, 1024, &wsv);
     if (rc) return rc;

@@ -59,7 +59,6 @@ struct BaBufs {
 
 struct BaOpt {
     int max_iter, max_invalid, jacobi;
-    int dbg;      // ablation mask for timing experiments (RS_K7_DEBUG env var; 0 in production)
     double r0, rmax, rmin, min_rel, dmin, dmax, ftol, gtol, ptol;
 };
 

@@ -94,36 +94,6 @@ __global__ __launch_bounds__(256) void ba_group_count(BaDims d, BaBufs b, BaGrou
     }
 }
 
-__global__ __launch_bounds__(1024) void ba_group_scan(BaGroup g)
-{
-    // exclusive scan over (bucket-major, replica-minor) of hist[rep][bucket] into cursor[rep][bucket]
-    __shared__ int wsum[16];
-    __shared__ int carry;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int nb = g.n_buckets + 1, total = nb * GRP_REP;
-    if (threadIdx.x == 0) carry = 0;
-    __syncthreads();
-    for (int base = 0; base < total; base += 1024) {
-        const int i = base + threadIdx.x;
-        const int bk = i / GRP_REP, rep = i % GRP_REP;
-        const int v = i < total ? g.hist[(size_t)rep * nb + bk] : 0;
-        int x = v;
-#pragma unroll
-        for (int off = 1; off < 64; off <<= 1) {
-            const int t = __shfl_up(x, off, 64);
-            if (lane >= off) x += t;
-        }
-        if (lane == 63) wsum[wave] = x;
-        __syncthreads();
-        int pre = carry;
-        for (int w = 0; w < wave; w++) pre += wsum[w];
-        if (i < total) g.cursor[(size_t)rep * nb + bk] = pre + x - v;
-        __syncthreads();
-        if (threadIdx.x == 1023) carry = pre + x;
-        __syncthreads();
-    }
-}
-
 __global__ __launch_bounds__(256) void ba_group_scatter(BaDims d, BaBufs b, BaGroup g)
 {
     const int p = blockIdx.x * blockDim.x + threadIdx.x;

@@ -9,37 +9,27 @@
 // Layout.  The lower triangle — plus the right-hand side as an extra ROW n, so
 // that the forward substitution falls out of the factorisation — lives in
 // REGISTERS in the accumulator layout of v_mfma_f64_16x16x4_f64: the
-// (n+1) x (n+1) matrix is cut into 16x16 tiles, the lower-triangle tiles are
-// dealt round-robin to the 4 waves (<= 9 tiles per wave, 4 doubles per lane per
-// tile).  LDS only carries the current 6-column panel.
-// Right-looking block Cholesky, one camera (6 columns) per step, 2 barriers:
-//   publish  owners copy block column J from their accumulators to LDS
-//   (a)      EVERY wave factors the 6x6 diagonal block redundantly in registers
-//            (no cross-lane traffic, no barrier before the panel solve) and
-//            inverts it; 1/sqrt from v_rsq_f64 + 2 Newton steps
-//   (b)      one thread per row: panel row <- row * L_JJ^-T (6x6 mat-vec with
-//            the inverse block held in registers)
-//   (c)      rank-6 update of the trailing matrix ON THE MATRIX CORES: per owned
-//            tile two MFMAs (K = 6 padded to 8), operands read straight from
-//            the LDS panel, accumulating into the resident tiles
-// then a block backward substitution with the stored inverse diagonal blocks.
-// Phase timings (s_memtime stamps) are in DESIGN.md.
+// (n+1) x (n+1) matrix is cut into 16x16 tiles, the 36 lower-triangle tiles
+// are dealt to six TILE waves.  LDS carries the published block columns, the
+// factor panels and the k-major MFMA operand panels.
+//
+// f64 MFMA and f64 VALU share one datapath per SIMD (tools/microbench/overlap.hip),
+// and waves w, w+4 of a workgroup share a SIMD, so the work is split by ROLE:
+//   chain waves (0, 4)   right-looking block L D L^T, one camera (6 columns) per step:
+//                        6x6 diagonal block per lane (v_rcp_f64 + Newton, no sqrt),
+//                        panel row by forward substitution, rank-6 fix-up of the next
+//                        block column on the VALU — never waits for the matrix cores
+//   tile waves (others)  rank-6 trailing update, 2 MFMAs per live tile (K = 6 padded
+//                        to 8), publish of the next block column
+// two barriers per step; the roles run different loops with equal barrier counts.
+// Then a backward substitution in one wave with y in registers, and the camera
+// step / candidate cameras / step scalars.  Measurements: DESIGN.md 4.2.
 #include "ba_common.h"
 
 #define K7_THREADS 512
 #define K7_TPW 6       // tiles per tile wave: 6 tile waves x 6 = the 36 lower-triangle tiles of a 128 x 128 matrix
 
 typedef __attribute__((ext_vector_type(4))) double d4;
-
-// 1/sqrt(x) from v_rsq_f64 + two Newton steps (quadratic convergence from ~2^-27)
-__device__ __forceinline__ double fast_rsqrt(double x)
-{
-    double y = __builtin_amdgcn_rsq(x);
-    const double h = 0.5 * x;
-    y = y * (1.5 - h * y * y);
-    y = y * (1.5 - h * y * y);
-    return y;
-}
 
 // broadcast one lane's double to the wave (lane is wave-uniform)
 __device__ __forceinline__ double readlane_f64(double v, int lane)

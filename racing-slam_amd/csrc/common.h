@@ -113,8 +113,3 @@ __device__ __forceinline__ int rs_block_exclusive_scan(int v, int* total)
 // comm.hip: sum / max all-reduce of f64 on the context stream (no-op when n_ranks == 1)
 int rs_allreduce_f64(rs_context* ctx, double* d_buf, size_t count, bool is_max);
 
-// ordered stream compaction used by matching and triangulation (compact.hip):
-// out_idx[0..count) = ascending i with flag[i] != 0, for `batch` independent
-// segments of length n each (segment b at offset b*n).
-void rs_launch_compact(rs_context* ctx, const uint8_t* d_flag, int n, int batch, int32_t* d_out_idx,
-                       int32_t* d_out_count);
