@@ -242,6 +242,22 @@ int rs_triangulate_tracks(rs_context* ctx, int n_tracks, const float* d_track_uv
                           float* d_xyz, float* d_parallax_cos, float* d_required_cos,
                           int32_t* d_accepted, int32_t* d_inconsistent, int32_t* d_counts /*[3]*/);
 
+/* §8(f) rank 3 — the arithmetic of Mapper::cull_points (reference src/Mapper.cpp:396-431) and of
+ * Slam::reprojection_error (src/Slam.cpp:302-317): for every point p with observations CSR
+ * d_obs_ptr[p] .. d_obs_ptr[p+1] (pose index into d_poses, pixel) the mean over its observations of
+ * |Camera::project(pose, X_p) - pixel| in f32, summed in CSR order (the reference iterates an
+ * unordered_map); d_cull[p] = 1 when the point has observations and the mean exceeds max_mean_error
+ * (MAX_POINT_REPROJECTION_ERROR = 3.0, src/Mapper.cpp:39); d_cull_idx[0 .. *d_cull_count) lists the culled
+ * points in ascending order; d_sums = {sum of all per-observation errors (f64 sum of the f32 values),
+ * number of observations}: reprojection_error() = sums[0] / sums[1].  The caller selects the local points
+ * (:398-408) and removes them from the map (:426-429). */
+int rs_point_errors(rs_context* ctx, int n_points, const float* d_positions /*[P][3]*/,
+                    const int32_t* d_obs_ptr /*[P+1]*/, const int32_t* d_obs_pose /*[M]*/,
+                    const float* d_obs_uv /*[M][2]*/, const float* d_poses /*[n_poses][16]*/, int n_poses,
+                    const float h_intrinsics[4], float max_mean_error, float* d_mean_err /*[P]*/,
+                    uint8_t* d_cull /*[P]*/, int32_t* d_cull_idx /*[P]*/, int32_t* d_cull_count /*[1]*/,
+                    double* d_sums /*[2]*/);
+
 /* ----------------------------------------------------- a9-a13: optimisation */
 
 typedef enum rs_ba_termination {

@@ -237,6 +237,31 @@ def triangulate_tracks(track_uv, sight_ptr, sight_pose, sight_uv, poses, kf_pose
                 accepted=acc[:int(cnt[0])].copy(), n_topped_up=int(cnt[1]), inconsistent=inc[:int(cnt[2])].copy())
 
 
+def point_errors(positions, obs_ptr, obs_pose, obs_uv, poses, K, max_mean_error=3.0):
+    positions = np.ascontiguousarray(positions, np.float32).reshape(-1, 3)
+    obs_ptr = np.ascontiguousarray(obs_ptr, np.int32)
+    obs_pose = np.ascontiguousarray(obs_pose, np.int32)
+    obs_uv = np.ascontiguousarray(obs_uv, np.float32).reshape(-1, 2)
+    poses = np.ascontiguousarray(poses, np.float32).reshape(-1, 16)
+    n = len(positions)
+    m = max(n, 1)
+    Kc = (C.c_float * 4)(*[float(v) for v in K])
+    mean = np.zeros(m, np.float32)
+    cull = np.zeros(m, np.uint8)
+    idx = np.zeros(m, np.int32)
+    cnt = np.zeros(1, np.int32)
+    sums = np.zeros(2, np.float64)
+    L = lib()
+    L.orc_point_errors.argtypes = [C.c_int, f32p, i32p, i32p, f32p, f32p, C.c_int, C.c_float * 4, C.c_float, f32p, u8p,
+                                   i32p, i32p, C.POINTER(C.c_double)]
+    rc = L.orc_point_errors(n, _p(positions, f32p), _p(obs_ptr, i32p), _p(obs_pose, i32p), _p(obs_uv, f32p),
+                            _p(poses, f32p), len(poses), Kc, float(max_mean_error), _p(mean, f32p), _p(cull, u8p),
+                            _p(idx, i32p), _p(cnt, i32p), sums.ctypes.data_as(C.POINTER(C.c_double)))
+    assert rc == 0
+    return dict(mean_err=mean[:n], cull=cull[:n], cull_idx=idx[:int(cnt[0])].copy(), err_sum=float(sums[0]),
+                n_obs=int(sums[1]))
+
+
 def null_vector4(A):
     A = np.ascontiguousarray(A, np.float64).reshape(16)
     v = np.zeros(4)

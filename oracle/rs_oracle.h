@@ -86,6 +86,10 @@ int orc_triangulate_tracks(int n_tracks, const float* track_uv, const uint8_t* s
                            float rotation_parallax_factor, int min_new_points, uint8_t* status, float* xyz,
                            float* parallax_cos, float* required_cos, int32_t* accepted, int32_t* n_accepted,
                            int32_t* n_topped_up, int32_t* inconsistent, int32_t* n_inconsistent);
+int orc_point_errors(int n_points, const float* positions, const int32_t* obs_ptr, const int32_t* obs_pose,
+                     const float* obs_uv, const float* poses, int n_poses, const float intrinsics[4],
+                     float max_mean_error, float* mean_err, uint8_t* cull, int32_t* cull_idx, int32_t* cull_count,
+                     double sums[2]);
 /* 4x4 f64 one-sided Jacobi SVD null vector (exposed for tests): v = right
  * singular vector of the smallest singular value of row-major A. */
 void orc_null_vector4(const double A[16], double v[4], double sigma[4]);

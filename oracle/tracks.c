@@ -165,3 +165,35 @@ done:
     free(uv1); free(idx1); free(idx2); free(keep); free(oi); free(ox);
     return rc;
 }
+
+/* Mapper::cull_points arithmetic (src/Mapper.cpp:410-419) and the sums of Slam::reprojection_error
+ * (src/Slam.cpp:302-317).  Observations of a point are visited in CSR order (the reference iterates an
+ * unordered_map: order unspecified upstream); f32 accumulation per point, f64 for the global sum. */
+int orc_point_errors(int n_points, const float* positions, const int32_t* obs_ptr, const int32_t* obs_pose,
+                     const float* obs_uv, const float* poses, int n_poses, const float K[4], float max_mean_error,
+                     float* mean_err, uint8_t* cull, int32_t* cull_idx, int32_t* cull_count, double sums[2])
+{
+    (void)n_poses;
+    int nc = 0;
+    sums[0] = 0.0; sums[1] = 0.0;
+    for (int p = 0; p < n_points; p++) {
+        const float* X = positions + 3 * (size_t)p;
+        float error = 0.0f;
+        int num = 0;
+        for (int o = obs_ptr[p]; o < obs_ptr[p + 1]; o++) {
+            float pr[2];
+            project(K, poses + 16 * (size_t)obs_pose[o], X, pr);
+            const float dx = pr[0] - obs_uv[2 * (size_t)o], dy = pr[1] - obs_uv[2 * (size_t)o + 1];
+            const float e = sqrtf(dx * dx + dy * dy);
+            error += e;                                                 /* :413 */
+            sums[0] += (double)e;
+            num++;
+        }
+        sums[1] += (double)num;
+        mean_err[p] = num > 0 ? error / (float)num : 0.0f;
+        cull[p] = (num > 0 && error / (float)num > max_mean_error) ? 1 : 0;   /* :416 */
+        if (cull[p]) cull_idx[nc++] = p;
+    }
+    *cull_count = nc;
+    return 0;
+}

@@ -19,40 +19,6 @@ struct TrackParams {
     int kf_pose;
 };
 
-__device__ __forceinline__ void load_pose(const float* __restrict__ poses, int idx, float* T)
-{
-    const float4* a = (const float4*)(poses + 16 * (size_t)idx);
-#pragma unroll
-    for (int r = 0; r < 4; r++) {
-        const float4 v = a[r];
-        T[4 * r] = v.x; T[4 * r + 1] = v.y; T[4 * r + 2] = v.z; T[4 * r + 3] = v.w;
-    }
-}
-
-// Camera::project, src/Camera.cpp:25-32: K * pose.block<3,4> first, then * homogeneous
-__device__ __forceinline__ float2 project_f32(const TriParams& k, const float* T, const float* X)
-{
-    float KP[12];
-    projection_rows(k, T, KP);
-    float uvw[3];
-#pragma unroll
-    for (int i = 0; i < 3; i++)
-        uvw[i] = (KP[4 * i] * X[0] + KP[4 * i + 1] * X[1]) + (KP[4 * i + 2] * X[2] + KP[4 * i + 3] * 1.0f);
-    if (uvw[2] < 0.0f) return make_float2(-1.0f, -1.0f);
-    return make_float2(uvw[0] / uvw[2], uvw[1] / uvw[2]);
-}
-
-// -R^T t, src/MotionModel.cpp:8-11, src/Frame.cpp:39-42
-__device__ __forceinline__ void camera_center_f32(const float* T, float* c)
-{
-    const float t[3] = {T[3], T[7], T[11]};
-#pragma unroll
-    for (int i = 0; i < 3; i++) {
-        const float a[3] = {-T[0 * 4 + i], -T[1 * 4 + i], -T[2 * 4 + i]};
-        c[i] = dot3f(a, t);
-    }
-}
-
 __global__ __launch_bounds__(64) void k6_tracks(const float2* __restrict__ track_uv, const uint8_t* __restrict__ skip,
                                                const int32_t* __restrict__ sight_ptr,
                                                const int32_t* __restrict__ sight_pose,
@@ -203,6 +169,99 @@ extern "C" int rs_triangulate_tracks(rs_context* ctx, int n_tracks, const float*
         rs_prof_scope ps(ctx, "K6b_select");
         hipLaunchKernelGGL(k6_select, dim3(1), dim3(1024), 0, ctx->stream, d_status, d_parallax_cos, d_required_cos,
                            n_tracks, min_new_points, d_accepted, d_inconsistent, (int32_t*)ws, d_counts);
+    }
+    RS_HIP(ctx, hipGetLastError());
+    return RS_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// K12: per-point mean reprojection error and the culling rule of Mapper::cull_points (reference
+// src/Mapper.cpp:396-431), plus the sums Slam::reprojection_error needs
+// (src/Slam.cpp:302-317).  One lane per point, observations in CSR order; the per-point error is the f32 sum
+// of (project(pose, X) - pixel).norm() in that order (the reference iterates an unordered_map: order
+// unspecified upstream), divided by the count; cull when mean > max_mean_error and the point has observations.
+__global__ __launch_bounds__(256) void k12_point_errors(const float* __restrict__ pos, const int32_t* __restrict__ obs_ptr,
+                                                        const int32_t* __restrict__ obs_pose,
+                                                        const float2* __restrict__ obs_uv, const float* __restrict__ poses,
+                                                        int n_points, TriParams k, float max_mean_error,
+                                                        float* __restrict__ mean_err, uint8_t* __restrict__ cull,
+                                                        double* __restrict__ sums)
+{
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    double esum = 0.0, ecnt = 0.0;
+    if (p < n_points) {
+        const float X[3] = {pos[3 * (size_t)p], pos[3 * (size_t)p + 1], pos[3 * (size_t)p + 2]};
+        const int o0 = obs_ptr[p], o1 = obs_ptr[p + 1];
+        float err = 0.0f;
+        for (int o = o0; o < o1; o++) {
+            float T[16];
+            load_pose(poses, obs_pose[o], T);
+            const float2 pr = project_f32(k, T, X);
+            const float2 px = obs_uv[o];
+            const float dx = pr.x - px.x, dy = pr.y - px.y;
+            const float e = sqrtf(dx * dx + dy * dy);
+            err += e;                                                    // :413
+            esum += (double)e;
+        }
+        const int cnt = o1 - o0;
+        ecnt = (double)cnt;
+        const float mean = cnt > 0 ? err / (float)cnt : 0.0f;
+        mean_err[p] = mean;
+        cull[p] = (cnt > 0 && mean > max_mean_error) ? 1 : 0;            // :416
+    }
+    // Slam::reprojection_error: sum and count over all observations (f64 sum of the f32 errors)
+    esum = wave_sum_f64(esum);
+    ecnt = wave_sum_f64(ecnt);
+    if ((threadIdx.x & 63) == 0 && ecnt > 0.0) { atomicAdd(&sums[0], esum); atomicAdd(&sums[1], ecnt); }
+}
+
+// ordered list of the culled points (one workgroup)
+__global__ __launch_bounds__(1024) void k12_cull_list(const uint8_t* __restrict__ cull, int n, int32_t* __restrict__ out_idx,
+                                                      int32_t* __restrict__ out_count)
+{
+    const int T = blockDim.x, chunk = (n + T - 1) / T;
+    const int lo = min((int)threadIdx.x * chunk, n), hi = min(lo + chunk, n);
+    int cnt = 0;
+    for (int i0 = lo; i0 < hi; i0 += 16) {
+        uint8_t k[16];
+#pragma unroll
+        for (int u = 0; u < 16; u++) k[u] = cull[min(i0 + u, hi - 1)];
+#pragma unroll
+        for (int u = 0; u < 16; u++) cnt += (i0 + u < hi && k[u] != 0) ? 1 : 0;
+    }
+    int total;
+    int off = rs_block_exclusive_scan(cnt, &total);
+    for (int i = lo; i < hi; i++)
+        if (cull[i]) out_idx[off++] = i;
+    if (threadIdx.x == 0) *out_count = total;
+}
+
+extern "C" int rs_point_errors(rs_context* ctx, int n_points, const float* d_positions, const int32_t* d_obs_ptr,
+                               const int32_t* d_obs_pose, const float* d_obs_uv, const float* d_poses, int n_poses,
+                               const float h_intrinsics[4], float max_mean_error, float* d_mean_err, uint8_t* d_cull,
+                               int32_t* d_cull_idx, int32_t* d_cull_count, double* d_sums)
+{
+    if (!ctx) return RS_ERR_INVALID;
+    if (n_points < 0 || n_poses < 0) return rs_fail(ctx, RS_ERR_INVALID, "negative size");
+    if (!d_cull_count || !d_sums) return rs_fail(ctx, RS_ERR_INVALID, "null output");
+    RS_HIP(ctx, hipSetDevice(ctx->device));
+    RS_HIP(ctx, hipMemsetAsync(d_sums, 0, 2 * sizeof(double), ctx->stream));
+    if (n_points == 0) {
+        RS_HIP(ctx, hipMemsetAsync(d_cull_count, 0, sizeof(int32_t), ctx->stream));
+        return RS_OK;
+    }
+    if (!d_positions || !d_obs_ptr || !d_obs_pose || !d_obs_uv || !d_poses || !h_intrinsics || !d_mean_err || !d_cull || !d_cull_idx)
+        return rs_fail(ctx, RS_ERR_INVALID, "null pointer");
+    if ((uintptr_t)d_poses & 15) return rs_fail(ctx, RS_ERR_INVALID, "poses must be 16-byte aligned");
+    const TriParams k = {h_intrinsics[0], h_intrinsics[1], h_intrinsics[2], h_intrinsics[3], 0.f, 0.f};
+    {
+        rs_prof_scope ps(ctx, "K12_point_errors");
+        hipLaunchKernelGGL(k12_point_errors, dim3((n_points + 255) / 256), dim3(256), 0, ctx->stream, d_positions, d_obs_ptr,
+                           d_obs_pose, (const float2*)d_obs_uv, d_poses, n_points, k, max_mean_error, d_mean_err, d_cull, d_sums);
+    }
+    {
+        rs_prof_scope ps(ctx, "K12b_cull_list");
+        hipLaunchKernelGGL(k12_cull_list, dim3(1), dim3(1024), 0, ctx->stream, d_cull, n_points, d_cull_idx, d_cull_count);
     }
     RS_HIP(ctx, hipGetLastError());
     return RS_OK;

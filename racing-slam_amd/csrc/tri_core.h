@@ -91,6 +91,47 @@ __device__ __forceinline__ void projection_rows(const TriParams& k, const float*
         }                                                                                      \
     }
 
+__device__ __forceinline__ void load_pose(const float* __restrict__ poses, int idx, float* T)
+{
+    const float4* a = (const float4*)(poses + 16 * (size_t)idx);
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+        const float4 v = a[r];
+        T[4 * r] = v.x; T[4 * r + 1] = v.y; T[4 * r + 2] = v.z; T[4 * r + 3] = v.w;
+    }
+}
+
+// Camera::project, src/Camera.cpp:25-32: K * pose.block<3,4> first, then * homogeneous
+__device__ __forceinline__ float2 project_f32(const TriParams& k, const float* T, const float* X)
+{
+    float KP[12];
+    projection_rows(k, T, KP);
+    float uvw[3];
+#pragma unroll
+    for (int i = 0; i < 3; i++)
+        uvw[i] = (KP[4 * i] * X[0] + KP[4 * i + 1] * X[1]) + (KP[4 * i + 2] * X[2] + KP[4 * i + 3] * 1.0f);
+    if (uvw[2] < 0.0f) return make_float2(-1.0f, -1.0f);
+    return make_float2(uvw[0] / uvw[2], uvw[1] / uvw[2]);
+}
+
+// -R^T t, src/MotionModel.cpp:8-11, src/Frame.cpp:39-42
+__device__ __forceinline__ void camera_center_f32(const float* T, float* c)
+{
+    const float t[3] = {T[3], T[7], T[11]};
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+        const float a[3] = {-T[0 * 4 + i], -T[1 * 4 + i], -T[2 * 4 + i]};
+        c[i] = dot3f(a, t);
+    }
+}
+
+__device__ __forceinline__ double wave_sum_f64(double v)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+
 // One correspondence: pixels p1 / p2 seen under world->camera poses T1 / T2 (row-major 4x4).
 // Returns the keep flag; Xout = the f32 point (written even when the gates reject it).
 __device__ __forceinline__ bool dlt_one(const float2 p1, const float2 p2, const float* T1, const float* T2,

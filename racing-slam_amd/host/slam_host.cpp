@@ -370,6 +370,48 @@ Selection select_track_points(const KeyFrame& key_frame, const std::vector<Track
     return out;
 }
 
+// src/Mapper.cpp:410-419 (+ src/Slam.cpp:302-317) -> rs_point_errors
+CullResult point_errors(const std::vector<MapPoint*>& points, const Camera& camera, float max_mean_error)
+{
+    CullResult out;
+    const size_t P = points.size();
+    if (P == 0) return out;
+    rs_context* ctx = Session::get().ctx();
+    std::vector<float> pos(3 * P), uv, poses;
+    std::vector<int32_t> obs_ptr(P + 1, 0), obs_pose;
+    std::vector<const KeyFrame*> frames;                      // pose table: one entry per observing key frame
+    for (size_t p = 0; p < P; p++) {
+        const Vec3f& X = points[p]->position();
+        pos[3 * p] = X.x; pos[3 * p + 1] = X.y; pos[3 * p + 2] = X.z;
+        for (const auto& ob : points[p]->observations()) {
+            size_t f = 0;
+            while (f < frames.size() && frames[f] != ob.first) f++;
+            if (f == frames.size()) { frames.push_back(ob.first); poses.insert(poses.end(), ob.first->pose().begin(), ob.first->pose().end()); }
+            obs_pose.push_back((int32_t)f);
+            const Vec2f px = ob.first->keypoint(ob.second).pt;
+            uv.push_back(px.x); uv.push_back(px.y);
+        }
+        obs_ptr[p + 1] = (int32_t)obs_pose.size();
+    }
+    if (obs_pose.empty()) { out.mean_error.assign(P, 0.0f); return out; }
+    DevBuf<float> d_pos(pos), d_uv(uv), d_poses(poses), d_mean(P);
+    DevBuf<int32_t> d_ptr(obs_ptr), d_op(obs_pose), d_idx(P), d_cnt(1);
+    DevBuf<uint8_t> d_cull(P);
+    DevBuf<double> d_sums(2);
+    const float K[4] = {camera.fx(), camera.fy(), camera.cx(), camera.cy()};
+    if (!rs_ok(rs_point_errors(ctx, (int)P, d_pos.get(), d_ptr.get(), d_op.get(), d_uv.get(), d_poses.get(), (int)frames.size(), K,
+                               max_mean_error, d_mean.get(), d_cull.get(), d_idx.get(), d_cnt.get(), d_sums.get()), "rs_point_errors"))
+        return out;
+    rs_context_synchronize(ctx);
+    out.mean_error = d_mean.download(P);
+    const int n = d_cnt.download(1)[0];
+    for (int32_t i : d_idx.download((size_t)n)) out.to_remove.push_back((size_t)i);
+    const auto sums = d_sums.download(2);
+    out.error_sum = sums[0];
+    out.observations = (size_t)sums[1];
+    return out;
+}
+
 }  // namespace tracks
 
 // ---------------------------------------------------------------------- optimisation

@@ -183,6 +183,19 @@ static const size_t MIN_NEW_POINTS_PER_KEY_FRAME = 100;
 Selection select_track_points(const KeyFrame& key_frame, const std::vector<Track>& tracks,
                               const std::vector<Mat4f>& trajectory_poses, const Camera& camera,
                               size_t min_new_points = MIN_NEW_POINTS_PER_KEY_FRAME);
+
+// The arithmetic of Mapper::cull_points (src/Mapper.cpp:410-419): mean reprojection error of every given point
+// over its observations, and which of them exceed the limit.  The Mapper selects the local points (:398-408)
+// and removes the returned ones from the map (:426-429).
+static const float MAX_POINT_REPROJECTION_ERROR = 3.0f;
+struct CullResult {
+    std::vector<float> mean_error;            // per input point
+    std::vector<size_t> to_remove;            // indices into the input vector, ascending
+    double error_sum = 0.0;                   // Slam::reprojection_error() = error_sum / observations (src/Slam.cpp:302-317)
+    size_t observations = 0;
+};
+CullResult point_errors(const std::vector<MapPoint*>& points, const Camera& camera,
+                        float max_mean_error = MAX_POINT_REPROJECTION_ERROR);
 }  // namespace tracks
 
 namespace optimization {

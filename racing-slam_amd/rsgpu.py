@@ -15,7 +15,7 @@ LIB_PATH = os.path.join(_HERE, "librsgpu.so")
 EXPORTS = [
     "rs_abi_version", "rs_context_create", "rs_context_destroy", "rs_context_set_stream",
     "rs_context_synchronize", "rs_last_error", "rs_hamming_knn2", "rs_match_descriptors",
-    "rs_kdtree_build", "rs_reproj_match", "rs_triangulate", "rs_triangulate_matches", "rs_triangulate_tracks", "rs_ba_default_options",
+    "rs_kdtree_build", "rs_reproj_match", "rs_triangulate", "rs_triangulate_matches", "rs_triangulate_tracks", "rs_point_errors", "rs_ba_default_options",
     "rs_bundle_adjust", "rs_refine_pose", "rs_pack_pose", "rs_unpack_pose", "rs_build_local_window",
     "rs_comm_get_unique_id", "rs_comm_init_rank", "rs_comm_destroy", "rs_prof_begin", "rs_prof_end", "rs_prof_counters",
 ]
@@ -289,6 +289,22 @@ class Context:
             int(min_new_points), _dp(out["status"]), _dp(out["xyz"]), _dp(out["parallax_cos"]),
             _dp(out["required_cos"]), _dp(out["accepted"]), _dp(out["inconsistent"]), _dp(out["counts"])),
             "rs_triangulate_tracks")
+        return out
+
+    # -- §8(f) rank 3: Mapper::cull_points / Slam::reprojection_error arithmetic
+    def point_errors(self, d_positions, d_obs_ptr, d_obs_pose, d_obs_uv, d_poses, K, max_mean_error=3.0, out=None):
+        t = self.torch
+        n = int(d_positions.shape[0])
+        m = max(n, 1)
+        if out is None:
+            out = dict(mean_err=self.empty((m,), t.float32), cull=self.empty((m,), t.uint8),
+                       cull_idx=self.empty((m,), t.int32), cull_count=self.empty((1,), t.int32),
+                       sums=self.empty((2,), t.float64))
+        Kc = (C.c_float * 4)(*[float(v) for v in K])
+        self._check(self.lib.rs_point_errors(self.h, n, _dp(d_positions), _dp(d_obs_ptr), _dp(d_obs_pose), _dp(d_obs_uv),
+                                             _dp(d_poses), int(d_poses.shape[0]), Kc, C.c_float(max_mean_error),
+                                             _dp(out["mean_err"]), _dp(out["cull"]), _dp(out["cull_idx"]),
+                                             _dp(out["cull_count"]), _dp(out["sums"])), "rs_point_errors")
         return out
 
     # -- a9-a13

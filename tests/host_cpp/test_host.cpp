@@ -256,6 +256,44 @@ int main()
         std::printf("select_track_points: %d tracks, %d accepted (%zu topped up), %d inconsistent\n", T, na, sel.topped_up, ninc);
     }
 
+    // ---- §8(f)3: Mapper::cull_points arithmetic vs oracle (before BA, on the perturbed map)
+    {
+        std::vector<MapPoint*> pts;
+        for (size_t i = 0; i < map.size(); i++) pts.push_back(&map[i]);
+        auto res = tracks::point_errors(pts, camera, 1.0f);
+        // oracle on the same marshalling: pose table in first-seen order
+        std::vector<float> pos, uv, ps;
+        std::vector<int32_t> optr{0}, opose;
+        std::vector<const KeyFrame*> frames;
+        for (auto* pt : pts) {
+            pos.insert(pos.end(), {pt->position().x, pt->position().y, pt->position().z});
+            for (auto& ob : pt->observations()) {
+                size_t f = 0;
+                while (f < frames.size() && frames[f] != ob.first) f++;
+                if (f == frames.size()) { frames.push_back(ob.first); ps.insert(ps.end(), ob.first->pose().begin(), ob.first->pose().end()); }
+                opose.push_back((int32_t)f);
+                uv.push_back(ob.first->keypoint(ob.second).pt.x); uv.push_back(ob.first->keypoint(ob.second).pt.y);
+            }
+            optr.push_back((int32_t)opose.size());
+        }
+        const int P = (int)pts.size();
+        std::vector<float> mean(P);
+        std::vector<uint8_t> cull(P);
+        std::vector<int32_t> idx(P);
+        int32_t cnt = 0;
+        double sums[2];
+        const float K[4] = {500.f, 500.f, 320.f, 240.f};
+        orc_point_errors(P, pos.data(), optr.data(), opose.data(), uv.data(), ps.data(), (int)frames.size(), K, 1.0f, mean.data(),
+                         cull.data(), idx.data(), &cnt, sums);
+        CHECK((int)res.to_remove.size() == cnt);
+        CHECK(cnt > 0 && cnt < P);
+        for (int i = 0; i < P; i++) CHECK(res.mean_error[(size_t)i] == mean[(size_t)i]);
+        for (int i = 0; i < cnt && i < (int)res.to_remove.size(); i++) CHECK((int)res.to_remove[(size_t)i] == idx[(size_t)i]);
+        CHECK(res.observations == (size_t)sums[1]);
+        CHECK(std::fabs(res.error_sum - sums[0]) < 1e-9 * sums[0]);
+        std::printf("point_errors: %d of %d points above 1 px, mean reprojection %.3f px\n", cnt, P, res.error_sum / (double)res.observations);
+    }
+
     // ---- a8 + a12: build_local_window + bundle_adjust
     {
         auto window = optimization::build_local_window(kfs, new_frame, 20);

@@ -195,6 +195,28 @@ def test_triangulate_tracks_body_edge_cases(ctx, synth):
                                ctx.dev(sc["sight_uv"]), ctx.dev(sc["poses"]), 99, sc["K"])
 
 
+@pytest.mark.parametrize("n_kf,n_points", [(8, 600), (20, 10000)])
+def test_point_errors_and_culling(ctx, oracle, synth, n_kf, n_points):
+    """K12 (Mapper::cull_points / Slam::reprojection_error arithmetic) vs the oracle: per-point means and cull
+    flags bit for bit (same f32 operations in CSR order), the culled list identical, the global f64 sum to 1e-12."""
+    from test_oracle_cpu import _cull_scene
+    sc = _cull_scene(synth, n_kf=n_kf, n_points=n_points)
+    ref = oracle.point_errors(sc["positions"], sc["obs_ptr"], sc["obs_pose"], sc["obs_uv"], sc["poses"], sc["K"])
+    d = ctx.point_errors(ctx.dev(sc["positions"]), ctx.dev(sc["obs_ptr"]), ctx.dev(sc["obs_pose"]), ctx.dev(sc["obs_uv"]),
+                         ctx.dev(sc["poses"]), sc["K"])
+    n = len(sc["positions"])
+    assert np.array_equal(to_np(d["mean_err"])[:n].view(np.uint32), ref["mean_err"].view(np.uint32))
+    assert np.array_equal(to_np(d["cull"])[:n], ref["cull"])
+    cnt = int(to_np(d["cull_count"])[0])
+    assert cnt == len(ref["cull_idx"]) > 0 and np.array_equal(to_np(d["cull_idx"])[:cnt], ref["cull_idx"])
+    sums = to_np(d["sums"])
+    assert sums[1] == ref["n_obs"] and sums[0] == pytest.approx(ref["err_sum"], rel=1e-12)
+    # empty map
+    e = ctx.point_errors(ctx.dev(np.zeros((0, 3), np.float32)), ctx.dev(np.zeros(1, np.int32)), ctx.dev(np.zeros(1, np.int32)),
+                         ctx.dev(np.zeros((1, 2), np.float32)), ctx.dev(sc["poses"]), sc["K"])
+    assert int(to_np(e["cull_count"])[0]) == 0 and to_np(e["sums"]).tolist() == [0.0, 0.0]
+
+
 def test_triangulate_empty_and_degenerate(ctx, oracle, synth):
     pr = synth.make_pair(1)
     d = ctx.triangulate(ctx.dev(pr["kp1"]), ctx.dev(pr["kp2"]), 0, ctx.dev(pr["poses"]), 2, pr["K"])

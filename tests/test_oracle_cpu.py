@@ -276,6 +276,42 @@ def test_triangulate_tracks_vs_numpy(oracle, synth):
     assert not z["status"].any() and len(z["accepted"]) == 0
 
 
+def _cull_scene(synth, n_kf=8, n_points=600, seed=3):
+    """A BA window re-expressed as what Mapper::cull_points sees: f32 poses, f32 positions, observation CSR."""
+    w = synth.make_ba_window(n_kf=n_kf, n_points=n_points, run_max=min(6, n_kf))
+    poses = np.stack([synth.make_pose(synth.rodrigues(w["cams"][c, :3]).T, w["cams"][c, 3:]) for c in range(n_kf)])
+    rng = np.random.default_rng(seed)
+    pos = w["points"].astype(np.float32)
+    bad = rng.random(n_points) < 0.1
+    pos[bad] += rng.normal(0, 0.4, (int(bad.sum()), 3)).astype(np.float32)      # some points worth culling
+    return dict(positions=pos, obs_ptr=w["obs_ptr"], obs_pose=w["obs_cam"], obs_uv=w["obs_uv"],
+                poses=poses.reshape(n_kf, 16).astype(np.float32), K=w["K"])
+
+
+def test_point_errors_vs_numpy(oracle, synth):
+    sc = _cull_scene(synth)
+    d = oracle.point_errors(sc["positions"], sc["obs_ptr"], sc["obs_pose"], sc["obs_uv"], sc["poses"], sc["K"])
+    fx, fy, cx, cy = [float(v) for v in sc["K"]]
+    P = sc["poses"].reshape(-1, 4, 4).astype(np.float64)
+    means = np.zeros(len(sc["positions"]))
+    tot = 0.0
+    for p in range(len(means)):
+        es = []
+        for o in range(sc["obs_ptr"][p], sc["obs_ptr"][p + 1]):
+            T = P[sc["obs_pose"][o]]
+            pc = T[:3, :3] @ sc["positions"][p].astype(np.float64) + T[:3, 3]
+            uv = np.array([fx * pc[0] / pc[2] + cx, fy * pc[1] / pc[2] + cy]) if pc[2] >= 0 else np.array([-1.0, -1.0])
+            es.append(np.linalg.norm(uv - sc["obs_uv"][o]))
+        means[p] = np.mean(es) if es else 0.0
+        tot += np.sum(es)
+    assert np.allclose(d["mean_err"], means, rtol=2e-5, atol=2e-4)
+    safe = np.abs(means - 3.0) > 1e-3
+    assert np.array_equal(d["cull"][safe], (means > 3.0)[safe].astype(np.uint8))
+    assert np.array_equal(d["cull_idx"], np.flatnonzero(d["cull"]))
+    assert 0 < d["cull"].sum() < len(means)
+    assert d["n_obs"] == sc["obs_ptr"][-1] and d["err_sum"] == pytest.approx(tot, rel=1e-5)
+
+
 def test_pack_unpack_pose_roundtrip(oracle, rs, synth):
     rng = np.random.default_rng(6)
     for i in range(200):
