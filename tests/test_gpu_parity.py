@@ -310,6 +310,20 @@ def test_bundle_adjust_cfg3_window(ctx, oracle, synth):
     assert s["final_cost"] < 0.2 * s["initial_cost"]
 
 
+@pytest.mark.parametrize("n_kf,n_points,run_max", [(20, 12000, 10), (70, 6000, 12), (30, 11000, 24)])
+def test_bundle_adjust_item_sizes_and_camera_staging(ctx, oracle, synth, n_kf, n_points, run_max):
+    """Value-by-value against the oracle for the K5 variants the other tests do not reach: 64-landmark items
+    (more than 10240 landmarks), camera blocks read from global memory (more than 64 cameras) with the blocked
+    reduced solve (n = 408), and camera unions beyond 10 per item (8x8-tile SYRK in two half batches) on big items."""
+    w = synth.make_ba_window(n_kf=n_kf, n_points=n_points, run_min=2, run_max=run_max, config_id=12)
+    c, p, s, rc, rp, rs_ = _ba_case(ctx, oracle, w)
+    assert s["usable"] == 1 and rs_["usable"] == 1
+    assert (s["iterations"], s["successful_steps"]) == (rs_["iterations"], rs_["successful_steps"])
+    assert np.isclose(s["final_cost"], rs_["final_cost"], rtol=1e-7)
+    assert np.allclose(c, rc, rtol=1e-6, atol=1e-8)
+    assert np.allclose(p, rp, rtol=1e-6, atol=1e-7)
+
+
 def test_bundle_adjust_rejected_keeps_input(ctx, synth):
     """solve()'s accept rule (src/Optimization.cpp:136-141): an unusable result leaves inputs untouched."""
     w = synth.make_ba_window(n_kf=5, n_points=80, run_max=4)
