@@ -235,7 +235,7 @@ __global__ __launch_bounds__(256) void ba_reduced_solve(BaDims d, BaBufs b, BaOp
         if ((tid & 63) == 0) red[tid >> 6] = gm;
         __syncthreads();
         double gslots = 0.0;
-        if (tid < 64) gslots = slot_max_bits(b.gmax);
+        if (tid < 64) gslots = slot_max_all(b);
         if (tid == 0) {
             double g = gslots;
             for (int w = 0; w < (nt + 63) / 64; w++) g = fmax(g, red[w]);
@@ -529,9 +529,10 @@ extern "C" int rs_bundle_adjust(rs_context* ctx, int n_cameras, int n_points, in
     const size_t o_Vinv = carve(sizeof(double) * P * 6), o_gp = carve(sizeof(double) * P * 3);
     const size_t o_lamp = carve(sizeof(double) * P * 3);
     const size_t cam_stride = (size_t)d.Cf * 36 + 2 * n;
-    const size_t acc_count = n * n + (size_t)BA_UREP * cam_stride + (size_t)BA_NSLOT * BA_SLOT_STRIDE;
+    const size_t n_ranks = ctx->comm ? (size_t)ctx->n_ranks : 1;
+    const size_t acc_count = n * n + (size_t)BA_UREP * cam_stride + (1 + n_ranks) * (size_t)BA_NSLOT * BA_SLOT_STRIDE;
     const size_t o_acc = carve(sizeof(double) * acc_count);
-    const size_t o_gmax = carve(sizeof(double) * BA_NSLOT * BA_SLOT_STRIDE), o_pts = carve(sizeof(double) * 2 * BA_NSLOT * BA_SLOT_STRIDE), o_dc = carve(sizeof(double) * (n + 1));
+    const size_t o_pts = carve(sizeof(double) * 2 * BA_NSLOT * BA_SLOT_STRIDE), o_dc = carve(sizeof(double) * (n + 1));
     const size_t o_st = carve(sizeof(BaState) * 2);
     const size_t o_dbg = carve(sizeof(unsigned long long) * 64);
     const size_t o_free = carve(C);
@@ -552,7 +553,9 @@ extern "C" int rs_bundle_adjust(rs_context* ctx, int n_cameras, int n_points, in
     b.acc = (double*)(ws + o_acc); b.acc_count = acc_count;
     b.S = b.acc; b.rhs = b.S + n * n; b.U = b.rhs + n; b.gc = b.U + (size_t)d.Cf * 36;
     b.cam_stride = cam_stride; b.scal = b.rhs + (size_t)BA_UREP * cam_stride;
-    b.gmax = (double*)(ws + o_gmax); b.pt_scal = (double*)(ws + o_pts); b.dc = (double*)(ws + o_dc);
+    b.gmax_all = b.scal + (size_t)BA_NSLOT * BA_SLOT_STRIDE; b.gmax_blocks = (int)n_ranks;
+    b.gmax = b.gmax_all + (size_t)(ctx->comm ? ctx->rank : 0) * BA_NSLOT * BA_SLOT_STRIDE;
+    b.pt_scal = (double*)(ws + o_pts); b.dc = (double*)(ws + o_dc);
     b.st = (BaState*)(ws + o_st);
     b.st_prev = b.st;
     b.pt_prev = b.pt_scal;
@@ -621,9 +624,8 @@ extern "C" int rs_bundle_adjust(rs_context* ctx, int n_cameras, int n_points, in
         }
         if (ctx->comm) {
             rs_prof_scope ps(ctx, "C1_allreduce_system");
+            // one SUM all-reduce: S | 8 x {rhs, U, gc} | cost / failure slots | every rank's gradient-max block
             rc = rs_allreduce_f64(ctx, b.acc, b.acc_count, false);
-            if (rc) return rc;
-            rc = rs_allreduce_f64(ctx, b.gmax, BA_NSLOT * BA_SLOT_STRIDE, true);
             if (rc) return rc;
         }
         if (solve_lds) {

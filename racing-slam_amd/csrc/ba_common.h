@@ -48,7 +48,9 @@ struct BaBufs {
     double* S; double* rhs; double* U; double* gc;   // rhs/U/gc: replica 0; replica r at + r * cam_stride
     size_t cam_stride;       // doubles per replica = Cf*36 + 2n
     double* scal;    // [BA_NSLOT][8] per slot: cost_x, fail_count (summed by K7)
-    double* gmax;    // [BA_NSLOT][8] per slot: bits of a non-negative double (max; K7 folds)
+    double* gmax;    // [BA_NSLOT][8] per slot: bits of a non-negative double (max; K7 folds); THIS rank's block of gmax_all
+    double* gmax_all;   // [gmax_blocks][BA_NSLOT][8], inside the all-reduced accumulator block: rank r only writes block r,
+    int gmax_blocks;    //   so that the SUM all-reduce of the accumulators also delivers every rank's maximum (no max collective)
     double* pt_scal; // [BA_NSLOT][8] per slot, K8 of THIS iteration: cand_cost, mcc_p, step_sq_p, x_sq_p
     const double* pt_prev;   // the same block of the PREVIOUS iteration (read by the next linearisation's decision)
     double* dc;      // [n]
@@ -235,6 +237,14 @@ __device__ __forceinline__ double slot_sum(const double* base, int field)
     double v = base[(size_t)(threadIdx.x & 63) * BA_SLOT_STRIDE + field];
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+__device__ __forceinline__ double slot_max_bits(const double* base);
+// maximum over the slot lines of every rank's block (called by the first wave)
+__device__ __forceinline__ double slot_max_all(const BaBufs& b)
+{
+    double v = 0.0;
+    for (int r = 0; r < b.gmax_blocks; r++) v = fmax(v, slot_max_bits(b.gmax_all + (size_t)r * BA_NSLOT * BA_SLOT_STRIDE));
     return v;
 }
 __device__ __forceinline__ double slot_max_bits(const double* base)

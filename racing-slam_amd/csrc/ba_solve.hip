@@ -101,7 +101,8 @@ __global__ __launch_bounds__(K7_THREADS) void ba_reduced_solve_lds(BaDims d, BaB
     if (tid < 64) {
         pre_cost = b.scal[(size_t)tid * BA_SLOT_STRIDE + 0];
         pre_fail = b.scal[(size_t)tid * BA_SLOT_STRIDE + 1];
-        pre_gm = __longlong_as_double((long long)((const unsigned long long*)b.gmax)[(size_t)tid * BA_SLOT_STRIDE]);
+        for (int r = 0; r < b.gmax_blocks; r++)      // every rank's block (they arrive through the SUM all-reduce)
+            pre_gm = fmax(pre_gm, b.gmax_all[((size_t)r * BA_NSLOT + tid) * BA_SLOT_STRIDE]);
     }
     const double pre_sc = tid < n ? b.sc[tid] : 1.0;                   // n <= 126: one entry per thread
     double fold[2] = {0.0, 0.0};                                       // cam_stride = 8 n <= 1008: two entries per thread

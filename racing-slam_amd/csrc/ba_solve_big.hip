@@ -75,7 +75,7 @@ __global__ __launch_bounds__(1024) void ba_big_prologue(BaDims d, BaBufs b, BaOp
         if ((tid & 63) == 0) red[tid >> 6] = gm;
         __syncthreads();
         double gslots = 0.0;
-        if (tid < 64) gslots = slot_max_bits(b.gmax);
+        if (tid < 64) gslots = slot_max_all(b);
         if (tid == 0) {
             double gg = gslots;
             for (int w = 0; w < (nt + 63) / 64; w++) gg = fmax(gg, red[w]);
