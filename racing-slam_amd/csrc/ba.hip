@@ -528,6 +528,7 @@ extern "C" int rs_bundle_adjust(rs_context* ctx, int n_cameras, int n_points, in
     const size_t o_sc = carve(sizeof(double) * (n + 1)), o_sp = carve(sizeof(double) * P * 3);
     const size_t o_Vinv = carve(sizeof(double) * P * 6), o_gp = carve(sizeof(double) * P * 3);
     const size_t o_lamp = carve(sizeof(double) * P * 3);
+    const size_t o_Vc = carve(sizeof(double) * P * 6), o_Ukeep = carve(sizeof(double) * ((size_t)d.Cf * 36 + n + 1));
     const size_t cam_stride = (size_t)d.Cf * 36 + 2 * n;
     const size_t n_ranks = ctx->comm ? (size_t)ctx->n_ranks : 1;
     const size_t acc_count = n * n + (size_t)BA_UREP * cam_stride + (1 + n_ranks) * (size_t)BA_NSLOT * BA_SLOT_STRIDE;
@@ -550,6 +551,7 @@ extern "C" int rs_bundle_adjust(rs_context* ctx, int n_cameras, int n_points, in
     b.Xc = (double*)(ws + o_Xc); b.Xp = (double*)(ws + o_Xp); b.prep = (double*)(ws + o_prep);
     b.slot = (int32_t*)(ws + o_slot); b.sc = (double*)(ws + o_sc); b.sp = (double*)(ws + o_sp);
     b.Vinv = (double*)(ws + o_Vinv); b.gp = (double*)(ws + o_gp); b.lamp = (double*)(ws + o_lamp);
+    b.Vc = (double*)(ws + o_Vc); b.Ukeep = (double*)(ws + o_Ukeep);
     b.acc = (double*)(ws + o_acc); b.acc_count = acc_count;
     b.S = b.acc; b.rhs = b.S + n * n; b.U = b.rhs + n; b.gc = b.U + (size_t)d.Cf * 36;
     b.cam_stride = cam_stride; b.scal = b.rhs + (size_t)BA_UREP * cam_stride;

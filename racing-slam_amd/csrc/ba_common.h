@@ -48,6 +48,8 @@ struct BaBufs {
     double* S; double* rhs; double* U; double* gc;   // rhs/U/gc: replica 0; replica r at + r * cam_stride
     size_t cam_stride;       // doubles per replica = Cf*36 + 2n
     double* scal;    // [BA_NSLOT][8] per slot: cost_x, fail_count (summed by K7)
+    double* Vc;      // [P][6] undamped point blocks of the last FRESH linearisation (a rejected step only changes the damping)
+    double* Ukeep;   // [Cf*36 + n] folded U | gc of the last fresh linearisation
     double* gmax;    // [BA_NSLOT][8] per slot: bits of a non-negative double (max; K7 folds); THIS rank's block of gmax_all
     double* gmax_all;   // [gmax_blocks][BA_NSLOT][8], inside the all-reduced accumulator block: rank r only writes block r,
     int gmax_blocks;    //   so that the SUM all-reduce of the accumulators also delivers every rank's maximum (no max collective)

@@ -298,6 +298,10 @@ static __device__ __forceinline__ void ba_schur_body(const BaDims& d, const BaBu
     // ---- pass 1: V, g, cost, U/gc
     double V[6] = {0, 0, 0, 0, 0, 0}, gv[3] = {0, 0, 0};
     ObsLin o;
+    // A rejected step leaves x where it was: V, g, U, gc and the cost are those of the last fresh linearisation
+    // (only the damping changes), so this pass runs on fresh iterations only; V comes back from b.Vc, g from b.gp,
+    // and K7 takes U / gc from its own copy.
+    if (st.fresh)
     for (int j = sub; j < nobs; j += SCH_SUBS) {
         int cs = cs0;
         float2 uvv = uv0;
@@ -344,6 +348,19 @@ static __device__ __forceinline__ void ba_schur_body(const BaDims& d, const BaBu
     for (int k = 0; k < 6; k++) { V[k] += __shfl_xor(V[k], 8, 64); V[k] += __shfl_xor(V[k], 16, 64); V[k] += __shfl_xor(V[k], 32, 64); }
 #pragma unroll
     for (int k = 0; k < 3; k++) { gv[k] += __shfl_xor(gv[k], 8, 64); gv[k] += __shfl_xor(gv[k], 16, 64); gv[k] += __shfl_xor(gv[k], 32, 64); }
+    if (p >= 0) {
+        if (st.fresh) {
+            if (sub == 0) {
+#pragma unroll
+                for (int k = 0; k < 6; k++) b.Vc[6 * (size_t)p + k] = V[k];
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < 6; k++) V[k] = b.Vc[6 * (size_t)p + k];
+#pragma unroll
+            for (int k = 0; k < 3; k++) gv[k] = b.gp[3 * (size_t)p + k];
+        }
+    }
 
     double Li[6] = {0, 0, 0, 0, 0, 0}, I[6] = {0, 0, 0, 0, 0, 0};
     bool ok = false;

@@ -105,13 +105,14 @@ __global__ __launch_bounds__(K7_THREADS) void ba_reduced_solve_lds(BaDims d, BaB
             pre_gm = fmax(pre_gm, b.gmax_all[((size_t)r * BA_NSLOT + tid) * BA_SLOT_STRIDE]);
     }
     const double pre_sc = tid < n ? b.sc[tid] : 1.0;                   // n <= 126: one entry per thread
-    double fold[2] = {0.0, 0.0};                                       // cam_stride = 8 n <= 1008: two entries per thread
+    double fold[2] = {0.0, 0.0}, keep[2] = {0.0, 0.0};                 // cam_stride = 8 n <= 1008: two entries per thread
 #pragma unroll
     for (int h = 0; h < 2; h++) {
         const int i = tid + h * nt;
         if (i < (int)b.cam_stride) {
 #pragma unroll
             for (int r = 0; r < BA_UREP; r++) fold[h] += b.rhs[(size_t)r * b.cam_stride + i];
+            if (i >= n) keep[h] = b.Ukeep[i - n];                      // U | gc of the last fresh linearisation
         }
     }
     double sv[K7_TPW][4];                                              // tile waves: their entries of S
@@ -137,9 +138,12 @@ __global__ __launch_bounds__(K7_THREADS) void ba_reduced_solve_lds(BaDims d, BaB
     for (int h = 0; h < 2; h++) {
         const int i = tid + h * nt;
         if (i < (int)b.cam_stride) {
-            if (i < n) grs[i] = fold[h];                   // rhs part
-            else if (i < n + 6 * n) Us[i - n] = fold[h];
-            else gcs[i - 7 * n] = fold[h];
+            // U and gc are only accumulated on fresh iterations (K5 skips its first pass after a rejected step)
+            const double v = (i < n || st.fresh) ? fold[h] : keep[h];
+            if (i >= n && st.fresh) b.Ukeep[i - n] = v;
+            if (i < n) grs[i] = v;                         // rhs part
+            else if (i < n + 6 * n) Us[i - n] = v;
+            else gcs[i - 7 * n] = v;
         }
     }
     __syncthreads();

@@ -51,6 +51,8 @@ __global__ __launch_bounds__(1024) void ba_big_prologue(BaDims d, BaBufs b, BaOp
     for (size_t i = tid; i < b.cam_stride; i += nt) {
         double v = 0.0;
         for (int r = 0; r < BA_UREP; r++) v += b.rhs[(size_t)r * b.cam_stride + i];
+        // U | gc are only accumulated on fresh iterations (K5 skips its first pass after a rejected step)
+        if ((int)i >= n) { if (st.fresh) b.Ukeep[i - n] = v; else v = b.Ukeep[i - n]; }
         b.rhs[i] = v;
     }
     __syncthreads();
