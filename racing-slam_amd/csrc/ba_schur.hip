@@ -48,7 +48,7 @@ typedef __attribute__((ext_vector_type(4))) double d4;
 #define GRP_REP 8
 #define GRP_LDS_BINS 4096
 
-__global__ __launch_bounds__(256) void ba_group_count(BaDims d, BaBufs b, BaGroup g, int* ticket)
+__global__ __launch_bounds__(256) void ba_group_count(BaDims d, BaBufs b, BaGroup g)
 {
     __shared__ int lh[GRP_LDS_BINS];
     const int nb = g.n_buckets + 1;
@@ -78,21 +78,38 @@ __global__ __launch_bounds__(256) void ba_group_count(BaDims d, BaBufs b, BaGrou
     __syncthreads();
     if (use_lds)
         for (int i = threadIdx.x; i < nb; i += blockDim.x) { const int v = lh[i]; if (v) atomicAdd(&hist[i], v); }
-    // the last workgroup scans: exclusive prefix over (bucket-major, replica-minor) of hist into cursor
-    if (rs_last_workgroup(ticket)) {
-        const int total = nb * GRP_REP, T = blockDim.x, chunk = (total + T - 1) / T;
-        const int lo = min((int)threadIdx.x * chunk, total), hi = min(lo + chunk, total);
-        int sum = 0;
-        for (int i = lo; i < hi; i++) sum += __builtin_nontemporal_load(&g.hist[(size_t)(i % GRP_REP) * nb + i / GRP_REP]);
-        int tot;
-        int off = rs_block_exclusive_scan(sum, &tot);
-        for (int i = lo; i < hi; i++) {
-            const size_t a = (size_t)(i % GRP_REP) * nb + i / GRP_REP;
-            g.cursor[a] = off;
-            off += __builtin_nontemporal_load(&g.hist[a]);
+}
+
+__global__ __launch_bounds__(1024) void ba_group_scan(BaGroup g)
+{
+    // exclusive scan over (bucket-major, replica-minor) of hist[rep][bucket] into cursor[rep][bucket]
+    __shared__ int wsum[16];
+    __shared__ int carry;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int nb = g.n_buckets + 1, total = nb * GRP_REP;
+    if (threadIdx.x == 0) carry = 0;
+    __syncthreads();
+    for (int base = 0; base < total; base += 1024) {
+        const int i = base + threadIdx.x;
+        const int bk = i / GRP_REP, rep = i % GRP_REP;
+        const int v = i < total ? g.hist[(size_t)rep * nb + bk] : 0;
+        int x = v;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const int t = __shfl_up(x, off, 64);
+            if (lane >= off) x += t;
         }
+        if (lane == 63) wsum[wave] = x;
+        __syncthreads();
+        int pre = carry;
+        for (int w = 0; w < wave; w++) pre += wsum[w];
+        if (i < total) g.cursor[(size_t)rep * nb + bk] = pre + x - v;
+        __syncthreads();
+        if (threadIdx.x == 1023) carry = pre + x;
+        __syncthreads();
     }
 }
+
 
 __global__ __launch_bounds__(256) void ba_group_scatter(BaDims d, BaBufs b, BaGroup g)
 {
@@ -654,7 +671,8 @@ int ba_launch_grouping(rs_context* ctx, const BaDims& d, const BaBufs& b, const 
     }
     // g.hist was zeroed by ba_init (ba_group_zero_range)
     const int pb = (d.P + 255) / 256;
-    hipLaunchKernelGGL(ba_group_count, dim3(pb), dim3(256), 0, s, d, b, g, ctx->tickets + RS_TICKET_GROUP);
+    hipLaunchKernelGGL(ba_group_count, dim3(pb), dim3(256), 0, s, d, b, g);
+    hipLaunchKernelGGL(ba_group_scan, dim3(1), dim3(1024), 0, s, g);
     hipLaunchKernelGGL(ba_group_scatter, dim3(pb), dim3(256), 0, s, d, b, g);
     hipLaunchKernelGGL(ba_group_items, dim3((g.n_items + 3) / 4), dim3(256), 0, s, d, g);
     return RS_OK;

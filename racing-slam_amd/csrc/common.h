@@ -38,31 +38,10 @@ struct rs_context {
     int rank = 0;
     // cached BA graph / buffers live in ba.hip
     void* ba_cache = nullptr;
-    // "last workgroup runs the tail" tickets (one int per fused kernel pair; always left at 0)
-    int* tickets = nullptr;
     // proposal table of rs_reproj_match: persistent, always left at all-ones by the accept tail
     unsigned long long* prop = nullptr;
     size_t prop_cap = 0;
 };
-enum { RS_TICKET_K2 = 0, RS_TICKET_K4 = 1, RS_TICKET_K1 = 2, RS_TICKET_K5 = 3, RS_TICKET_GROUP = 4, RS_TICKETS = 16 };
-
-// Grid-wide "am I the last workgroup to get here": every thread's global writes are released first;
-// the last workgroup acquires (L1 invalidate) and resets the ticket for the next launch on the stream.
-__device__ __forceinline__ bool rs_last_workgroup(int* ticket)
-{
-    __shared__ int rs_is_last;
-    __threadfence();
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        const int t = atomicAdd(ticket, 1);
-        rs_is_last = (t == (int)gridDim.x - 1);
-        if (rs_is_last) *ticket = 0;
-    }
-    __syncthreads();
-    const bool last = rs_is_last != 0;
-    if (last) __threadfence();
-    return last;
-}
 
 int rs_fail(rs_context* ctx, int code, const char* fmt, ...);
 

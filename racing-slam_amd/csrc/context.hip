@@ -39,11 +39,6 @@ extern "C" int rs_context_create(int device_id, rs_context** out)
     }
     rs_context* c = new rs_context();
     c->device = device_id;
-    if (hipMalloc(&c->tickets, sizeof(int) * RS_TICKETS) != hipSuccess ||
-        hipMemset(c->tickets, 0, sizeof(int) * RS_TICKETS) != hipSuccess) {
-        delete c;
-        return RS_ERR_NOMEM;
-    }
     *out = c;
     return RS_OK;
 }
@@ -57,7 +52,6 @@ extern "C" int rs_context_destroy(rs_context* ctx)
     rs_comm_destroy(ctx);
     rs_ba_cache_free(ctx);
     if (ctx->ws) (void)hipFree(ctx->ws);
-    if (ctx->tickets) (void)hipFree(ctx->tickets);
     if (ctx->prop) (void)hipFree(ctx->prop);
     if (ctx->pinned) (void)hipHostFree(ctx->pinned);
     for (auto& s : ctx->prof)

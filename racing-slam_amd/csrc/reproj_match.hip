@@ -119,12 +119,7 @@ __device__ __forceinline__ void k3_accept_body(unsigned long long* __restrict__ 
 __global__ __launch_bounds__(K2_THREADS) void k2_reproj_match(K2Frame f, K2Map m, int replace, int max_distance, int tree_in_lds,
                                                              int32_t* __restrict__ point_kp,
                                                              int32_t* __restrict__ point_dist,
-                                                             unsigned long long* __restrict__ prop, int* ticket,
-                                                             int32_t* __restrict__ prop_point,
-                                                             int32_t* __restrict__ prop_dist,
-                                                             int32_t* __restrict__ match_kp,
-                                                             int32_t* __restrict__ match_point,
-                                                             int32_t* __restrict__ match_count)
+                                                             unsigned long long* __restrict__ prop)
 {
     // dynamic LDS: [K2_STACK][K2_THREADS] traversal stacks, then the packed tree
     // {x, y, left, right} per node (one ds_read_b128 per visited node instead of three
@@ -287,12 +282,10 @@ __global__ __launch_bounds__(K2_THREADS) void k2_reproj_match(K2Frame f, K2Map m
         point_kp[p] = out_kp;
         point_dist[p] = out_d;
     }
-    // K3 fused: the last workgroup to finish accepts the proposals (a separate launch costs ~4 us)
-    if (rs_last_workgroup(ticket))
-        k3_accept_body(prop, f.n_keypoints, max_distance, prop_point, prop_dist, match_kp, match_point, match_count);
 }
 
-// stand-alone acceptance (no map points: nothing was proposed)
+// K3: one workgroup decodes the proposal table, compacts the accepted matches in order and resets the table
+// (tried as a tail of K2's last workgroup: no cheaper than this launch)
 __global__ __launch_bounds__(1024) void k3_accept(unsigned long long* __restrict__ prop, int n,
                                                   int max_distance, int32_t* __restrict__ prop_point,
                                                   int32_t* __restrict__ prop_dist, int32_t* __restrict__ match_kp,
@@ -350,10 +343,9 @@ extern "C" int rs_reproj_match(rs_context* ctx, const rs_frame_view* fr, const r
             RS_HIP(ctx, hipFuncSetAttribute((const void*)k2_reproj_match, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         rs_prof_scope ps(ctx, "K2_reproj_match");
         hipLaunchKernelGGL(k2_reproj_match, dim3((P + K2_THREADS - 1) / K2_THREADS), dim3(K2_THREADS), lds,
-                           ctx->stream, f, m, replace, max_distance, tree_in_lds, d_point_kp, d_point_dist, prop,
-                           ctx->tickets + RS_TICKET_K2, d_prop_point, d_prop_dist, d_match_kp, d_match_point,
-                           d_match_count);
-    } else {
+                           ctx->stream, f, m, replace, max_distance, tree_in_lds, d_point_kp, d_point_dist, prop);
+    }
+    {
         rs_prof_scope ps(ctx, "K3_accept");
         hipLaunchKernelGGL(k3_accept, dim3(1), dim3(1024), 0, ctx->stream, prop, N, max_distance, d_prop_point,
                            d_prop_dist, d_match_kp, d_match_point, d_match_count);

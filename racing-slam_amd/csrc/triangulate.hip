@@ -87,17 +87,24 @@ __device__ __forceinline__ void k4_compact_body(const uint8_t* __restrict__ keep
     if (threadIdx.x == 0) *out_count = total;
 }
 
-// K4 + K4b: every workgroup triangulates 64 correspondences; the last one to finish compacts
-// (a separate single-workgroup launch costs ~4 us).
+// K4: every workgroup triangulates 64 correspondences.  (Running the compaction in the last workgroup to finish
+// instead of a second launch was measured: release fence + ticket + acquire + a 64-thread tail cost more GPU time
+// than the ~4 us launch they saved.)
 __global__ __launch_bounds__(64) void k4_triangulate(
     const float2* __restrict__ uv1, const float2* __restrict__ uv2, int n,
     const float* __restrict__ poses, const int32_t* __restrict__ idx1, const int32_t* __restrict__ idx2,
     const int32_t* __restrict__ gather1, const int32_t* __restrict__ gather2, const int32_t* __restrict__ d_n,
-    TriParams prm, float* __restrict__ xyz, uint8_t* __restrict__ keep, int* ticket,
-    int32_t* __restrict__ out_index, float* __restrict__ out_xyz, int32_t* __restrict__ out_count)
+    TriParams prm, float* __restrict__ xyz, uint8_t* __restrict__ keep)
 {
     k4_triangulate_body(uv1, uv2, n, poses, idx1, idx2, gather1, gather2, d_n, prm, xyz, keep);
-    if (rs_last_workgroup(ticket)) k4_compact_body(keep, xyz, n, d_n, out_index, out_xyz, out_count);
+}
+
+// K4b: one workgroup, ordered compaction of the kept correspondences (:102)
+__global__ __launch_bounds__(1024) void k4_compact(const uint8_t* __restrict__ keep, const float* __restrict__ xyz, int n,
+                                                   const int32_t* __restrict__ d_n, int32_t* __restrict__ out_index,
+                                                   float* __restrict__ out_xyz, int32_t* __restrict__ out_count)
+{
+    k4_compact_body(keep, xyz, n, d_n, out_index, out_xyz, out_count);
 }
 
 static int tri_launch(rs_context* ctx, const float* d_uv1, const float* d_uv2, int n, const float* d_poses,
@@ -123,8 +130,12 @@ static int tri_launch(rs_context* ctx, const float* d_uv1, const float* d_uv2, i
     {
         rs_prof_scope ps(ctx, "K4_triangulate_dlt");
         hipLaunchKernelGGL(k4_triangulate, dim3((n + 63) / 64), dim3(64), 0, ctx->stream, (const float2*)d_uv1,
-                           (const float2*)d_uv2, n, d_poses, d_pose_idx1, d_pose_idx2, g1, g2, d_n, prm, d_xyz, d_keep,
-                           ctx->tickets + RS_TICKET_K4, d_out_index, d_out_xyz, d_out_count);
+                           (const float2*)d_uv2, n, d_poses, d_pose_idx1, d_pose_idx2, g1, g2, d_n, prm, d_xyz, d_keep);
+    }
+    {
+        rs_prof_scope ps(ctx, "K4b_compact");
+        hipLaunchKernelGGL(k4_compact, dim3(1), dim3(1024), 0, ctx->stream, d_keep, d_xyz, n, d_n, d_out_index,
+                           d_out_xyz, d_out_count);
     }
     RS_HIP(ctx, hipGetLastError());
     return RS_OK;
