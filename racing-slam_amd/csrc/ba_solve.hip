@@ -305,6 +305,13 @@ __global__ __launch_bounds__(K7_THREADS) void ba_reduced_solve_lds(BaDims d, BaB
             opA[s][0] = opA[s][1] = opB[s][0] = opB[s][1] = 0.0;
             if (!tv[s]) continue;                       // wave-uniform
             const int k = 16 * tc[s] + lr;
+            if (tr[s] >= tc[s] + 2 && 16 * tr[s] + 15 < n) {
+                // a tile at least two tile rows below the diagonal and above the rhs row: |i - k| >= 17, so no
+                // camera block and no diagonal entry falls into it — it is S alone (wave-uniform shortcut)
+#pragma unroll
+                for (int q = 0; q < 4; q++) acc[s][q] = (k < n) ? sv[s][q] : 0.0;
+                continue;
+            }
             const int kc = min(k, n - 1), kb = kc / 6;
             const double gv = grs[kc];
 #pragma unroll
