@@ -73,11 +73,16 @@ __device__ __forceinline__ void cam_prepare(const double* cam, double* out)
     const double th2 = ax * ax + ay * ay + az * az;
     double A, B, Cc, small;
     if (th2 > 2.220446049250313e-16) {
+        // one sincos of the half angle instead of two sines (this sits on K7's serial epilogue):
+        // sin(th) = 2 sin(th/2) cos(th/2), 1 - cos(th) = 2 sin^2(th/2); reciprocals instead of three divides
         const double th = sqrt(th2);
-        const double sh = sin(0.5 * th);
-        A = sin(th) / th;
-        B = 2.0 * sh * sh / th2;
-        Cc = (th - sin(th)) / (th2 * th);
+        double sh, ch;
+        sincos(0.5 * th, &sh, &ch);
+        const double sth = 2.0 * sh * ch;
+        const double ith = 1.0 / th, ith2 = ith * ith;
+        A = sth * ith;
+        B = 2.0 * sh * sh * ith2;
+        Cc = (th - sth) * ith2 * ith;
         small = 0.0;
     } else {   // ceres::AngleAxisRotatePoint's first-order branch: R = I + [w]x, d/dw = -[q]x
         A = 1.0; B = 0.0; Cc = 0.0; small = 1.0;
