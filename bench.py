@@ -300,6 +300,30 @@ def main():
                    sample="%d full passes of the same workload (oracle/liboracle.so, gcc -O2, 1 thread; "
                           "faithful restatement, not the reference binary)" % passes)
 
+    # all-cores variant of the same CPU baseline (OpenMP build of the oracle); informational
+    cpu_all = None
+    if cpu is not None:
+        import pyoracle as O
+        ncore = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+        os.environ.setdefault("OMP_NUM_THREADS", str(ncore))
+        os.environ.setdefault("OMP_PROC_BIND", "spread")
+        try:
+            O.use_all_cores(True)
+            passes = max(1, args.cpu_passes)
+            t0 = time.perf_counter()
+            for _ in range(passes):
+                mq, mt = O.match_descriptors(pair["desc2"], pair["desc1"])
+                O.reproj_match(frame, mp)
+                O.triangulate(pair["kp1"][mt], pair["kp2"][mq], pair["poses"], pair["K"])
+                O.bundle_adjust(window["cams"], window["cam_free"], window["points"], window["obs_ptr"],
+                                window["obs_cam"], window["obs_uv"], window["K"])
+            dt = time.perf_counter() - t0
+            cpu_all = dict(value=passes / dt, unit="passes/s", cores=int(os.environ["OMP_NUM_THREADS"]), kind="port",
+                           sample="%d full passes, OpenMP build of the oracle (queries, observations and landmark blocks "
+                                  "in parallel; reproj match and triangulation serial)" % passes)
+        finally:
+            O.use_all_cores(False)
+
     if rank == 0:
         out = {
             "metric": "match+triangulate+local-BA passes/sec @ 2k kpts/frame, 20-KF x 10k-pt window",
@@ -315,6 +339,7 @@ def main():
                        "parallelism": "landmark-sharded BA, RCCL all-reduce of the reduced camera system" if world > 1 else "single GPU"},
             "roofline": roofline,
             "cpu_baseline": cpu,
+            "cpu_baseline_all_cores": cpu_all,
             "per_kernel_us": {k: round(v["avg_us"], 2) for k, v in sorted(per_kernel.items())},
             "per_kernel_launches_per_pass": {k: v["launches"] / max(args.steps, 1) for k, v in sorted(per_kernel.items())},
             "ba_summary": last.get("ba"),

@@ -196,6 +196,9 @@ typedef struct {
 static double eval_cost(const problem* pr, const double* cams, const double* pts)
 {
     double cost = 0.0;
+#ifdef ORC_OMP      /* all-cores baseline build only (liboracle_omp.so); the summation order then differs */
+#pragma omp parallel for schedule(static) reduction(+ : cost)
+#endif
     for (int p = 0; p < pr->P; p++) {
         for (int o = pr->obs_ptr[p]; o < pr->obs_ptr[p + 1]; o++) {
             double r[2], rho[3];
@@ -214,11 +217,27 @@ static double eval_jacobian(const problem* pr, const double* cams, const double*
     double cost = 0.0;
     double* gc = (double*)calloc((size_t)pr->C * 6 + 1, sizeof(double));
     double gmax = 0.0;
+#ifdef ORC_OMP      /* the autodiff of every observation in parallel first; the (cheap) gradient sums stay serial below */
+#pragma omp parallel for schedule(static) reduction(+ : cost)
+    for (int p = 0; p < pr->P; p++)
+        for (int o = pr->obs_ptr[p]; o < pr->obs_ptr[p + 1]; o++) {
+            double* r = R + 2 * o; double* jc = JC + 12 * o; double* jp = JP + 6 * o;
+            orc_reprojection(cams + 6 * pr->obs_cam[o], pts + 3 * p, pr->obs_uv + 2 * o, pr->K, r, jc, jp);
+            double rho[3];
+            huber(pr->huber_a, r[0] * r[0] + r[1] * r[1], rho);
+            cost += 0.5 * rho[0];
+            const double sr = sqrt(rho[1]);
+            for (int k = 0; k < 12; k++) jc[k] *= sr;
+            for (int k = 0; k < 6; k++) jp[k] *= sr;
+            r[0] *= sr; r[1] *= sr;
+        }
+#endif
     for (int p = 0; p < pr->P; p++) {
         double gp[3] = {0, 0, 0};
         for (int o = pr->obs_ptr[p]; o < pr->obs_ptr[p + 1]; o++) {
             double* r = R + 2 * o; double* jc = JC + 12 * o; double* jp = JP + 6 * o;
             const int c = pr->obs_cam[o];
+#ifndef ORC_OMP
             orc_reprojection(cams + 6 * c, pts + 3 * p, pr->obs_uv + 2 * o, pr->K, r, jc, jp);
             double rho[3];
             huber(pr->huber_a, r[0] * r[0] + r[1] * r[1], rho);
@@ -227,6 +246,7 @@ static double eval_jacobian(const problem* pr, const double* cams, const double*
             for (int k = 0; k < 12; k++) jc[k] *= sr;
             for (int k = 0; k < 6; k++) jp[k] *= sr;
             r[0] *= sr; r[1] *= sr;
+#endif
             for (int k = 0; k < 6; k++) gc[6 * c + k] += jc[k] * r[0] + jc[6 + k] * r[1];
             for (int k = 0; k < 3; k++) gp[k] += jp[k] * r[0] + jp[3 + k] * r[1];
         }
@@ -338,7 +358,12 @@ static int lm_solve(problem* pr, double* cams, double* pts, const orc_ba_options
             }
         }
         int solver_failed = 0;
+#ifdef ORC_OMP      /* landmark blocks in parallel, per-thread copies of S and rhs summed at the end */
+#pragma omp parallel for schedule(static) reduction(+ : S[: n6 * n6], rhs[: n6]) reduction(| : solver_failed)
+        for (int p = 0; p < NP; p++) {
+#else
         for (int p = 0; p < NP && !solver_failed; p++) {
+#endif
             double ete[9] = {0}, eb[3] = {0};
             const int o0 = pr->obs_ptr[p], o1 = pr->obs_ptr[p + 1];
             for (int o = o0; o < o1; o++) {
@@ -349,7 +374,11 @@ static int lm_solve(problem* pr, double* cams, double* pts, const orc_ba_options
                 }
             }
             for (int a = 0; a < 3; a++) ete[a * 3 + a] += diag_p[3 * p + a];
+#ifdef ORC_OMP
+            if (inv3_psd(ete, Vinv + 9 * p)) { solver_failed = 1; continue; }
+#else
             if (inv3_psd(ete, Vinv + 9 * p)) { solver_failed = 1; break; }
+#endif
             memcpy(etb + 3 * p, eb, sizeof eb);
             const double* vi = Vinv + 9 * p;
             for (int oi = o0; oi < o1; oi++) {
@@ -380,6 +409,9 @@ static int lm_solve(problem* pr, double* cams, double* pts, const orc_ba_options
         }
         if (!solver_failed) {
             /* back substitution */
+#ifdef ORC_OMP
+#pragma omp parallel for schedule(static)
+#endif
             for (int p = 0; p < NP; p++) {
                 double t[3] = {etb[3 * p], etb[3 * p + 1], etb[3 * p + 2]};
                 for (int o = pr->obs_ptr[p]; o < pr->obs_ptr[p + 1]; o++) {
@@ -398,6 +430,9 @@ static int lm_solve(problem* pr, double* cams, double* pts, const orc_ba_options
         }
         double model_cost_change = 0.0;
         if (!solver_failed) {
+#ifdef ORC_OMP
+#pragma omp parallel for schedule(static) reduction(+ : model_cost_change)
+#endif
             for (int o = 0; o < M; o++) {
                 const int s = pr->cam_slot[pr->obs_cam[o]];
                 double m0 = 0, m1 = 0;

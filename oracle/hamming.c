@@ -12,6 +12,8 @@
  *   distances the LOWER train index ranks first.  Distance = sum of popcounts
  *   of the XOR of the 32 bytes.
  */
+#include <stdlib.h>
+
 #include "rs_oracle.h"
 
 static int hamming256(const uint8_t* a, const uint8_t* b)
@@ -28,6 +30,9 @@ int orc_hamming_knn2(const uint8_t* query, int nq, const uint8_t* train, int nt,
 {
     if (nq < 0 || nt < 0) return 1;
     if (nt == 0) return 0;
+#ifdef ORC_OMP      /* all-cores baseline build only (liboracle_omp.so): queries are independent */
+#pragma omp parallel for schedule(static) if (nq > 64)
+#endif
     for (int q = 0; q < nq; q++) {
         int bi0 = -1, bd0 = 1 << 30, bi1 = -1, bd1 = 1 << 30;
         const uint8_t* qd = query + (size_t)q * 32;
@@ -56,10 +61,20 @@ int orc_match_descriptors(const uint8_t* query, int nq, const uint8_t* train, in
     if (nq <= 0 || nt <= 0) return 0;   /* src/MapMatcher.cpp:139-141 */
     const int k = nt >= 2 ? 2 : 1;      /* :145 */
     int count = 0;
+#ifdef ORC_OMP
+    /* all-cores baseline build: the 2-NN of every query in parallel first, the ordered filter after */
+    int32_t* a0 = (int32_t*)malloc(sizeof(int32_t) * 4 * (size_t)nq);
+    int32_t *ad0 = a0 + nq, *a1 = a0 + 2 * (size_t)nq, *ad1 = a0 + 3 * (size_t)nq;
+    orc_hamming_knn2(query, nq, train, nt, a0, ad0, a1, ad1);
+#endif
     for (int q = 0; q < nq; q++) {
         int32_t i0, d0, i1 = 0, d1;
         (void)i1;
+#ifdef ORC_OMP
+        i0 = a0[q]; d0 = ad0[q]; d1 = ad1[q];
+#else
         orc_hamming_knn2(query + (size_t)q * 32, 1, train, nt, &i0, &d0, &i1, &d1);
+#endif
         if (d0 > max_distance) continue;                 /* :152 */
         /* :156  d0 > 0.75f*d1 in f32; both are integers <= 256 so 0.75f*d1 is
          * exact and the test equals 4*d0 > 3*d1 */
@@ -68,6 +83,9 @@ int orc_match_descriptors(const uint8_t* query, int nq, const uint8_t* train, in
         match_train[count] = i0;
         count++;
     }
+#ifdef ORC_OMP
+    free(a0);
+#endif
     *match_count = count;
     return 0;
 }

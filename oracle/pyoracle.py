@@ -37,6 +37,20 @@ def lib():
     return _LIB
 
 
+def use_all_cores(on=True):
+    """bench.py only: switch to / from the OpenMP build (liboracle_omp.so), for the all-cores CPU baseline."""
+    global _LIB
+    so = os.path.join(_HERE, "liboracle_omp.so" if on else "liboracle.so")
+    if on:
+        srcs = [os.path.join(_HERE, f) for f in os.listdir(_HERE) if f.endswith((".c", ".h"))]
+        if not os.path.exists(so) or any(os.path.getmtime(x) > os.path.getmtime(so) for x in srcs):
+            subprocess.check_call(["make", "-C", _HERE, "-B", "liboracle_omp.so"], stdout=subprocess.DEVNULL)
+    elif not os.path.exists(so):
+        build()
+    _LIB = C.CDLL(so)
+    return _LIB
+
+
 def _p(a, t):
     return None if a is None else a.ctypes.data_as(t)
 
