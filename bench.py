@@ -305,6 +305,7 @@ def main():
     if cpu is not None:
         import pyoracle as O
         ncore = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+        ncore = min(ncore, 16)          # a one-GPU box's CPU share is 16 cores, whatever the affinity mask says
         os.environ.setdefault("OMP_NUM_THREADS", str(ncore))
         os.environ.setdefault("OMP_PROC_BIND", "spread")
         try:
