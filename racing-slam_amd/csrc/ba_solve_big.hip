@@ -171,14 +171,16 @@ __global__ __launch_bounds__(256) void ba_big_diag(BaDims d, BaBufs b, BigBufs g
     }
     if (tid < w) g.yf[c0 + tid] = Lm[w * BBS + tid];        // D^-1 L^-1 g of this block
     if (__any(bad) && lane == 0) *g.fail = 1;
-    // M = L^-1 (unit lower), row r by thread r of wave 0: M L = I  =>  m[j] = -sum_{j < k <= r} m[k] L[k][j], in LDS
-    // with explicit 8-wide batches of loads (a register-resident row with unrolled columns spills to scratch).
-    // Rows / columns >= w are the identity (zero-padded operands of the trailing update).
+    // Inverses of the three 16x16 diagonal sub-blocks of L (unit lower), row r by thread r:
+    // m[j] = -sum_{j < k <= r} m[k] L[k][j] with j, k inside r's sub-block (chains of <= 15 instead of 47).  The
+    // trailing-update kernel does the rest of the triangular solve as a block forward substitution on the matrix
+    // cores.  Everything outside the sub-blocks, and rows / columns >= w, is the identity / zero.
     __shared__ double Mm[BB * BBS];
     for (int idx = tid; idx < BB * BB; idx += 256) Mm[(idx / BB) * BBS + idx % BB] = (idx / BB == idx % BB) ? 1.0 : 0.0;
     __syncthreads();
     if (tid < w) {
-        for (int j = tid - 1; j >= 0; j--) {
+        const int sb = tid & ~15;
+        for (int j = tid - 1; j >= sb; j--) {
             double sacc = 0.0;
             for (int k0 = j + 1; k0 <= tid; k0 += 8) {
                 double mk[8], lk[8];
@@ -228,7 +230,8 @@ __global__ __launch_bounds__(256) void ba_big_update(BaDims d, BaBufs b, BigBufs
 {
     if (b.st->done) return;
     extern __shared__ __attribute__((aligned(16))) double ulds[];
-    double *Ai = ulds, *Ak = Ai + BB * BBS, *Mm = Ak + BB * BBS, *Pi = Mm + BB * BBS, *Pk = Pi + BB * BBS, *dvl = Pk + BB * BBS;
+    double *Ai = ulds, *Ak = Ai + BB * BBS, *Mm = Ak + BB * BBS, *Pi = Mm + BB * BBS, *Pk = Pi + BB * BBS, *Lj = Pk + BB * BBS,
+           *Rt = Lj + BB * BBS, *dvl = Rt + 2 * BB * 17;
     const int n = d.n, tid = threadIdx.x;
     const int NBLK = (n + BB - 1) / BB;
     const int c0 = BB * J, w = min(BB, n - c0);
@@ -243,6 +246,7 @@ __global__ __launch_bounds__(256) void ba_big_update(BaDims d, BaBufs b, BigBufs
     for (int idx = tid; idx < BB * BB; idx += 256) {       // 9 rounds, fully unrolled: 27 loads in flight
         const int r = idx / BB, k = idx % BB;
         Mm[r * BBS + k] = g.M[idx];
+        Lj[r * BBS + k] = (r < w && k < w) ? g.Ls[(size_t)(c0 + r) * n + c0 + k] : (r == k ? 1.0 : 0.0);
         double vi = 0.0, vk = 0.0;
         if (k < w) {
             if (!rhs && r < hi) vi = b.S[(size_t)(ri0 + r) * n + c0 + k];
@@ -254,12 +258,58 @@ __global__ __launch_bounds__(256) void ba_big_update(BaDims d, BaBufs b, BigBufs
     if (tid < BB) dvl[tid] = tid < w ? g.dv[c0 + tid] : 1.0;
     __syncthreads();
     const int nchunk = (w + 3) / 4;            // operands are zero beyond w
-    // P_k = A_kJ M^T D^-1  (and P_i likewise; the right-hand side's panel is yf, already final)
-    gemm_nt_48(Ak, Mm, nchunk, [&](int R, int C, double v) { Pk[R * BBS + C] = v / dvl[C]; });
-    if (rhs) {
-        if (tid < BB) Pi[tid] = tid < w ? g.yf[c0 + tid] : 0.0;             // row 0 of Pi
-    } else if (bi != bk) {
-        gemm_nt_48(Ai, Mm, nchunk, [&](int R, int C, double v) { Pi[R * BBS + C] = v / dvl[C]; });
+    // Panels P = A L_JJ^-T D^-1 by block forward substitution over the three 16-column sub-blocks (M holds the
+    // inverses of L's 16x16 diagonal sub-blocks):   R_c = A_c - sum_{e<c} T_e L_ce^T,   T_c = R_c M_cc^T,   P_c = T_c / d.
+    // Both panels (rows of block bi and of block bk) go through the stages together: 6 row tiles over 4 waves.
+    // The right-hand side's panel is yf, already final.
+    {
+        const int lane = tid & 63, wave = tid >> 6, lr = lane & 15, lk = lane >> 4;
+        const bool two = !rhs && bi != bk;
+        for (int c = 0; c < 3; c++) {
+            if (16 * c >= w) break;                                        // wave-uniform: nothing but padding left
+#pragma unroll
+            for (int ti = 0; ti < 2; ti++) {
+                const int t = wave + 4 * ti;
+                if (t >= 6 || (t >= 3 && !two)) break;
+                double* X = t < 3 ? Ak : Ai;
+                double* R = Rt + (t < 3 ? 0 : BB * 17);
+                const int tr = t % 3;
+                d4 acc = {0.0, 0.0, 0.0, 0.0};
+                for (int kc = 0; kc < 4 * c; kc++)
+                    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(X[(16 * tr + lr) * BBS + 4 * kc + lk], Lj[(16 * c + lr) * BBS + 4 * kc + lk], acc, 0, 0, 0);
+#pragma unroll
+                for (int reg = 0; reg < 4; reg++) {
+                    const int rr = 16 * tr + lk + 4 * reg;
+                    R[rr * 17 + lr] = X[rr * BBS + 16 * c + lr] - acc[reg];
+                }
+            }
+            __syncthreads();
+#pragma unroll
+            for (int ti = 0; ti < 2; ti++) {
+                const int t = wave + 4 * ti;
+                if (t >= 6 || (t >= 3 && !two)) break;
+                double* X = t < 3 ? Ak : Ai;
+                double* P = t < 3 ? Pk : Pi;
+                const double* R = Rt + (t < 3 ? 0 : BB * 17);
+                const int tr = t % 3;
+                d4 acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                for (int kc = 0; kc < 4; kc++)
+                    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(R[(16 * tr + lr) * 17 + 4 * kc + lk], Mm[(16 * c + lr) * BBS + 16 * c + 4 * kc + lk], acc, 0, 0, 0);
+#pragma unroll
+                for (int reg = 0; reg < 4; reg++) {
+                    const int rr = 16 * tr + lk + 4 * reg;
+                    X[rr * BBS + 16 * c + lr] = acc[reg];                  // T_c, read by the later sub-blocks
+                    P[rr * BBS + 16 * c + lr] = acc[reg] / dvl[16 * c + lr];
+                }
+            }
+            __syncthreads();
+        }
+        for (int idx = tid; idx < BB * BB; idx += 256) {                   // sub-blocks that are pure padding
+            const int r = idx / BB, k = idx % BB;
+            if (k >= 16 * ((w + 15) / 16)) { Pk[r * BBS + k] = 0.0; Pi[r * BBS + k] = 0.0; }
+        }
+        if (rhs && tid < BB) Pi[tid] = tid < w ? g.yf[c0 + tid] : 0.0;     // row 0 of Pi
     }
     __syncthreads();
     const double* PI = (bi == bk) ? Pk : Pi;
@@ -412,7 +462,7 @@ int ba_launch_reduced_solve_big(rs_context* ctx, const BaDims& d, const BaBufs& 
     const size_t lds_fin = sizeof(double) * (n + BB * BBS);
     if (lds_fin > 48 * 1024)
         RS_HIP(ctx, hipFuncSetAttribute((const void*)ba_big_finish, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_fin));
-    const size_t lds_upd = sizeof(double) * (5 * BB * BBS + BB);
+    const size_t lds_upd = sizeof(double) * (6 * BB * BBS + 2 * BB * 17 + BB);
     RS_HIP(ctx, hipFuncSetAttribute((const void*)ba_big_update, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_upd));
     hipLaunchKernelGGL(ba_big_prologue, dim3(1), dim3(1024), 0, s, d, b, opt, g);
     hipLaunchKernelGGL(ba_big_assemble, dim3(256), dim3(256), 0, s, d, b);
