@@ -389,12 +389,12 @@ __global__ __launch_bounds__(1024) void ba_big_finish(BaDims d, BaBufs b, BaOpt 
         // y[0 : c0] -= L[block J rows, 0 : c0]^T x_J
         for (int k = tid; k < c0; k += nt) {
             double acc = 0.0;
-            for (int r0 = 0; r0 < w; r0 += 12) {            // w is a multiple of 6; loads go out 12 at a time
-                double l[12];
+            {                                               // all (<= 48) loads of the column go out together
+                double l[BB];
 #pragma unroll
-                for (int u = 0; u < 12; u++) l[u] = g.Ls[(size_t)(c0 + min(r0 + u, w - 1)) * n + k];
+                for (int u = 0; u < BB; u++) l[u] = g.Ls[(size_t)(c0 + min(u, w - 1)) * n + k];
 #pragma unroll
-                for (int u = 0; u < 12; u++) acc += (r0 + u < w) ? l[u] * y[c0 + r0 + u] : 0.0;
+                for (int u = 0; u < BB; u++) acc += (u < w) ? l[u] * y[c0 + u] : 0.0;
             }
             y[k] -= acc;
         }
