@@ -415,7 +415,7 @@ __global__ __launch_bounds__(BA_THREADS) void ba_backsub_cost(BaDims d, BaBufs b
 
 // -------------------------------------------------------------------- finalize
 __global__ void ba_finalize(BaDims d, BaBufs b, BaOpt opt, int it, double* __restrict__ cams_out,
-                            const uint8_t* __restrict__ cam_free, double* __restrict__ pts_out)
+                            const uint8_t* __restrict__ cam_free, double* __restrict__ pts_out, BaState* host_st)
 {
     __shared__ int usable, cur;
     __shared__ BaState st_fin;
@@ -437,7 +437,11 @@ __global__ void ba_finalize(BaDims d, BaBufs b, BaOpt opt, int it, double* __res
         usable = ok ? 1 : 0;
         cur = st.cur;
         st.usable = usable;
-        if (blockIdx.x == 0) *b.st = st;
+        if (blockIdx.x == 0) {
+            *b.st = st;
+            *host_st = st;            // the summary goes straight into pinned host memory: no copy launch after the solve
+            __threadfence_system();
+        }
     }
     __syncthreads();
     if (!usable) return;
@@ -660,10 +664,9 @@ extern "C" int rs_bundle_adjust(rs_context* ctx, int n_cameras, int n_points, in
         const int itf = opt.max_iter;
         b.st = st_base + (itf & 1); b.st_prev = st_base + ((itf + 1) & 1);
         b.pt_prev = pts_base + (size_t)((itf + 1) & 1) * BA_NSLOT * BA_SLOT_STRIDE;
-        hipLaunchKernelGGL(ba_finalize, dim3(32), dim3(256), 0, s, d, b, opt, itf, d_cameras, (const uint8_t*)d_cam_free, d_points);
+        hipLaunchKernelGGL(ba_finalize, dim3(32), dim3(256), 0, s, d, b, opt, itf, d_cameras, (const uint8_t*)d_cam_free, d_points, h_st);
     }
-    RS_HIP(ctx, hipMemcpyAsync(h_st, b.st, sizeof(BaState), hipMemcpyDeviceToHost, s));
-    RS_HIP(ctx, hipStreamSynchronize(s));
+    RS_HIP(ctx, hipStreamSynchronize(s));        // ba_finalize wrote the state block into the pinned h_st
     RS_HIP(ctx, hipGetLastError());
     h_summary->termination = h_st->termination;
     h_summary->iterations = h_st->iter;
