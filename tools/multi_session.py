@@ -4,7 +4,7 @@ chain that leaves most CUs idle), so the aggregate throughput grows without any 
     1 session 1335 BA/s, 2 -> 2541, 4 -> 2547, 8 -> 4385 (MI355X, cfg-3 window).
 Run from the repo root on a GPU box:  python tools/multi_session.py"""
 import sys, importlib, time, threading, numpy as np
-sys.path[:0]=['.', 'oracle']
+sys.path[:0] = ['.']
 import torch
 pkg = importlib.import_module("racing-slam_amd"); rs, synth = pkg.rsgpu, pkg.synth
 w = synth.make_ba_window()
