@@ -493,3 +493,34 @@ def test_bundle_adjust_through_rccl_single_rank(ctx, rs, synth):
     assert prof["C1_allreduce_system"][0] == 10 and prof["C2_allreduce_cost"][0] == 10
     assert (s0["iterations"], s0["successful_steps"], s0["termination"]) == (s1["iterations"], s1["successful_steps"], s1["termination"])
     assert np.allclose(c0, c1, rtol=1e-9, atol=1e-12) and np.allclose(p0, p1, rtol=1e-9, atol=1e-11)
+
+
+def test_repeatability_of_a_pass(ctx, synth):
+    """Twenty repetitions of the benchmark pass on the same inputs: integer outputs identical every time, the BA (f64
+    atomics and matrix-core sums in varying order) reproducible to 1e-9 relative with the same LM schedule — a cheap
+    race detector for the kernels that hand data to each other through global memory."""
+    pr = synth.make_pair(2)
+    w = synth.make_ba_window()
+    d_q, d_t = ctx.dev(pr["desc2"]), ctx.dev(pr["desc1"])
+    cams0, pts0 = ctx.dev(w["cams"]), ctx.dev(w["points"])
+    args = (ctx.dev(w["obs_ptr"]), ctx.dev(w["obs_cam"]), ctx.dev(w["obs_uv"]))
+    tk = synth.make_tracks(n_tracks=2000)
+    targs = (ctx.dev(tk["track_uv"]), ctx.dev(tk["sight_ptr"]), ctx.dev(tk["sight_pose"]), ctx.dev(tk["sight_uv"]),
+             ctx.dev(tk["poses"]), tk["kf_pose"], tk["K"])
+    ref = None
+    for rep in range(20):
+        m = ctx.match_descriptors(d_q, d_t, 2000, 2000)
+        cnt = int(to_np(m["cnt"])[0])
+        mq = to_np(m["mq"])[0, :cnt].copy()
+        t = ctx.triangulate_tracks(*targs, d_skip=ctx.dev(tk["skip"]))
+        acc = to_np(t["accepted"])[:int(to_np(t["counts"])[0])].copy()
+        dc, dp = cams0.clone(), pts0.clone()
+        s = ctx.bundle_adjust(dc, w["cam_free"], dp, *args, w["K"])
+        cur = (mq, acc, s["final_cost"], s["iterations"], s["successful_steps"], to_np(dc).copy())
+        if ref is None:
+            ref = cur
+            continue
+        assert np.array_equal(cur[0], ref[0]) and np.array_equal(cur[1], ref[1])
+        assert cur[3:5] == ref[3:5]
+        assert cur[2] == pytest.approx(ref[2], rel=1e-9)
+        assert np.allclose(cur[5], ref[5], rtol=1e-9, atol=1e-12)
