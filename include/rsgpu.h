@@ -214,6 +214,21 @@ int rs_triangulate_matches(rs_context* ctx,
                            float* d_xyz, uint8_t* d_keep,
                            int32_t* d_out_index, float* d_out_xyz, int32_t* d_out_count);
 
+/* BASELINE.json configs[3] (64 key-frame pairs x 2k keypoints): rs_triangulate_matches for `batch` independent
+ * frame pairs in one launch pair; consumes rs_match_descriptors' batched output in place.  Every array is the
+ * single-pair array with a leading batch dimension: d_kp1 [batch][n1][2], d_kp2 [batch][n2][2],
+ * d_match_train / d_match_query [batch][max_matches], d_n_matches [batch], d_poses [batch][2][16] (frame1, frame2),
+ * d_xyz [batch][max_matches][3], d_keep / d_out_index [batch][max_matches], d_out_xyz [batch][max_matches][3],
+ * d_out_count [batch].  Results per pair are those of batch single calls, bit for bit. */
+int rs_triangulate_matches_batch(rs_context* ctx, int batch,
+                                 const float* d_kp1, int n1, const float* d_kp2, int n2,
+                                 const int32_t* d_match_train, const int32_t* d_match_query,
+                                 const int32_t* d_n_matches, int max_matches,
+                                 const float* d_poses, const float h_intrinsics[4],
+                                 float min_parallax_cosine, float max_reprojection_error,
+                                 float* d_xyz, uint8_t* d_keep,
+                                 int32_t* d_out_index, float* d_out_xyz, int32_t* d_out_count);
+
 /* §8(f) rank 1 — the body of Mapper::triangulate_tracks (reference src/Mapper.cpp:246-305):
  * per track t (track-id order, the order of the reference's std::map<TrackId, Track>,
  * src/TrackStore.h:38) with sightings CSR d_sight_ptr[t] .. d_sight_ptr[t+1] (pose index into
@@ -322,6 +337,23 @@ int rs_bundle_adjust(rs_context* ctx,
                      const float h_intrinsics[4],
                      const rs_ba_options* options /*NULL = defaults*/,
                      rs_ba_summary* h_summary);
+
+/* Per-iteration record of the last rs_bundle_adjust on this context: what ceres::Solve prints with
+ * minimizer_progress_to_stdout (the reference prints summary.BriefReport(), src/Optimization.cpp:135).
+ * Entry i describes LM iteration i + 1.  outcome: 1 successful step, 0 rejected step, -1 invalid step
+ * (linear solver failure or model_cost_change <= 0), 2 terminated by the parameter / function
+ * tolerance test of this step.  Valid until the next optimisation call on the context. */
+typedef struct rs_ba_iteration {
+    double cost;               /* cost at x when the step was computed */
+    double candidate_cost;     /* cost at x + step (0 for an invalid step) */
+    double model_cost_change;
+    double radius;             /* trust-region radius of this step */
+    double step_norm, x_norm;  /* the two norms of the parameter-tolerance test */
+    int outcome;
+    int reserved0;
+    double reserved1;
+} rs_ba_iteration;
+int rs_ba_get_trace(rs_context* ctx, rs_ba_iteration* h_out, int capacity, int* h_count);
 
 /* optimization::refine_pose (src/Optimization.cpp:194-267), vision-only:
  * the same residual with the points held constant, 6 unknowns.

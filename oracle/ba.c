@@ -131,6 +131,23 @@ void orc_ba_default_options(orc_ba_options* o)
     o->jacobi_scaling = 1;
 }
 
+/* ------------------------------------------------------------------ trace */
+static __thread orc_ba_iteration* g_trace = NULL;
+static __thread int g_trace_cap = 0;
+static __thread int* g_trace_count = NULL;
+void orc_ba_set_trace(orc_ba_iteration* buf, int capacity, int* count)
+{
+    g_trace = buf; g_trace_cap = buf ? capacity : 0; g_trace_count = count;
+    if (count) *count = 0;
+}
+static void trace_push(double cost, double cand, double mcc, double radius, double step_norm, double x_norm, int outcome)
+{
+    if (!g_trace || !g_trace_count || *g_trace_count >= g_trace_cap) return;
+    orc_ba_iteration* e = g_trace + (*g_trace_count)++;
+    e->cost = cost; e->candidate_cost = cand; e->model_cost_change = mcc; e->radius = radius;
+    e->step_norm = step_norm; e->x_norm = x_norm; e->outcome = outcome; e->pad = 0;
+}
+
 /* ------------------------------------------------------------ small linalg */
 /* in-place dense Cholesky A = L L^T (lower), returns 0 on success */
 static int chol_factor(double* A, int n)
@@ -443,6 +460,7 @@ static int lm_solve(problem* pr, double* cams, double* pts, const orc_ba_options
         }
         if (solver_failed || !(model_cost_change > 0.0)) {
             /* TrustRegionMinimizer::HandleInvalidStep */
+            trace_push(x_cost, 0.0, solver_failed ? 0.0 : model_cost_change, radius, 0.0, 0.0, -1);
             if (++invalid_steps >= opt->max_num_consecutive_invalid_steps) { sum->termination = 5; break; }
             radius = radius / decrease_factor; decrease_factor *= 2.0;   /* StepIsInvalid -> StepRejected(0) */
             continue;
@@ -471,10 +489,18 @@ static int lm_solve(problem* pr, double* cams, double* pts, const orc_ba_options
         const double cand_cost = eval_cost(pr, cand_c, cand_p);
         const double step_norm = sqrt(step_sq), x_norm = sqrt(x_sq);
         /* ParameterToleranceReached */
-        if (step_norm <= opt->parameter_tolerance * (x_norm + opt->parameter_tolerance)) { sum->termination = 2; break; }
+        if (step_norm <= opt->parameter_tolerance * (x_norm + opt->parameter_tolerance)) {
+            trace_push(x_cost, cand_cost, model_cost_change, radius, step_norm, x_norm, 2);
+            sum->termination = 2; break;
+        }
         /* FunctionToleranceReached */
-        if (fabs(x_cost - cand_cost) <= opt->function_tolerance * x_cost) { sum->termination = 1; break; }
+        if (fabs(x_cost - cand_cost) <= opt->function_tolerance * x_cost) {
+            trace_push(x_cost, cand_cost, model_cost_change, radius, step_norm, x_norm, 2);
+            sum->termination = 1; break;
+        }
         const double rel = (x_cost - cand_cost) / model_cost_change;
+        trace_push(x_cost, cand_cost, model_cost_change, radius, step_norm, x_norm,
+                   (rel > opt->min_relative_decrease && isfinite(cand_cost)) ? 1 : 0);
         if (rel > opt->min_relative_decrease && isfinite(cand_cost)) {
             /* HandleSuccessfulStep */
             memcpy(x_c, cand_c, sizeof(double) * 6 * (size_t)C);

@@ -312,6 +312,29 @@ def reprojection(cam, pt, uv, K):
     return r, jc.reshape(2, 6), jp.reshape(2, 3)
 
 
+class BaIteration(C.Structure):
+    _fields_ = [("cost", C.c_double), ("candidate_cost", C.c_double), ("model_cost_change", C.c_double),
+                ("radius", C.c_double), ("step_norm", C.c_double), ("x_norm", C.c_double),
+                ("outcome", C.c_int), ("pad", C.c_int)]
+
+    def as_dict(self):
+        return {k: getattr(self, k) for k, _ in self._fields_ if k != "pad"}
+
+
+def bundle_adjust_trace(*args, **kw):
+    """bundle_adjust + the per-iteration record of the trust-region loop (list of dicts)."""
+    cap = 1024
+    buf = (BaIteration * cap)()
+    cnt = C.c_int(0)
+    L = lib()
+    L.orc_ba_set_trace(buf, cap, C.byref(cnt))
+    try:
+        out = bundle_adjust(*args, **kw)
+    finally:
+        L.orc_ba_set_trace(None, 0, None)
+    return out + ([buf[i].as_dict() for i in range(cnt.value)],)
+
+
 def bundle_adjust(cams, cam_free, points, obs_ptr, obs_cam, obs_uv, K, options=None):
     cams = np.array(cams, np.float64, order="C")
     points = np.array(points, np.float64, order="C")

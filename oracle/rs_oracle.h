@@ -128,6 +128,24 @@ typedef struct orc_ba_summary {
 
 void orc_ba_default_options(orc_ba_options* opt);
 
+/* Per-iteration record of the trust-region loop (what Ceres prints with
+ * minimizer_progress_to_stdout): one entry per LM iteration, in order.
+ *   outcome 1 = successful step, 0 = rejected (rho <= min_relative_decrease),
+ *          -1 = invalid step (solver failure or model_cost_change <= 0),
+ *           2 = the loop terminated on this step's parameter / function tolerance test. */
+typedef struct orc_ba_iteration {
+    double cost;               /* cost at x when the step was computed */
+    double candidate_cost;     /* cost at x + step (0 for an invalid step) */
+    double model_cost_change;
+    double radius;             /* trust-region radius the step was computed with */
+    double step_norm, x_norm;  /* as in the parameter-tolerance test */
+    int outcome;
+    int pad;
+} orc_ba_iteration;
+/* The next orc_bundle_adjust / orc_refine_pose calls on this thread fill buf[0 .. *count);
+ * pass NULL to switch tracing off. */
+void orc_ba_set_trace(orc_ba_iteration* buf, int capacity, int* count);
+
 /* residual + autodiff-equivalent Jacobians of one observation (forward-mode
  * jets through the reference functor).  jc [2][6], jp [2][3], row-major. */
 void orc_reprojection(const double cam[6], const double pt[3], const float uv[2],

@@ -415,7 +415,8 @@ __global__ __launch_bounds__(BA_THREADS) void ba_backsub_cost(BaDims d, BaBufs b
 
 // -------------------------------------------------------------------- finalize
 __global__ void ba_finalize(BaDims d, BaBufs b, BaOpt opt, int it, double* __restrict__ cams_out,
-                            const uint8_t* __restrict__ cam_free, double* __restrict__ pts_out, BaState* host_st)
+                            const uint8_t* __restrict__ cam_free, double* __restrict__ pts_out, BaState* host_st,
+                            BaTrace* host_trace)
 {
     __shared__ int usable, cur;
     __shared__ BaState st_fin;
@@ -425,7 +426,7 @@ __global__ void ba_finalize(BaDims d, BaBufs b, BaOpt opt, int it, double* __res
         if (it > 0) { p0 = slot_sum(b.pt_prev, 0); p1 = slot_sum(b.pt_prev, 1); p2 = slot_sum(b.pt_prev, 2); p3 = slot_sum(b.pt_prev, 3); }
         if (threadIdx.x == 0) {
             BaState s0 = *b.st_prev;
-            if (it > 0) ba_apply_decision(s0, p0, p1, p2, p3, opt);
+            if (it > 0) ba_apply_decision(s0, p0, p1, p2, p3, opt, blockIdx.x == 0 ? b.trace : nullptr);
             st_fin = s0;
         }
     }
@@ -444,6 +445,12 @@ __global__ void ba_finalize(BaDims d, BaBufs b, BaOpt opt, int it, double* __res
         }
     }
     __syncthreads();
+    if (blockIdx.x == 0) {            // the per-iteration record follows the summary (entries of earlier iterations were
+        const int ne = st_fin.iter * (int)(sizeof(BaTrace) / sizeof(double));   // written by earlier launches, the last one above)
+        const double* src = (const double*)b.trace;
+        double* dst = (double*)host_trace;
+        for (int i = threadIdx.x; i < ne; i += blockDim.x) dst[i] = src[i];
+    }
     if (!usable) return;
     const int tid = blockIdx.x * blockDim.x + threadIdx.x, nth = gridDim.x * blockDim.x;
     const double* Xc = b.Xc + (size_t)cur * d.C * 6;
@@ -539,6 +546,7 @@ extern "C" int rs_bundle_adjust(rs_context* ctx, int n_cameras, int n_points, in
     const size_t o_acc = carve(sizeof(double) * acc_count);
     const size_t o_pts = carve(sizeof(double) * 2 * BA_NSLOT * BA_SLOT_STRIDE), o_dc = carve(sizeof(double) * (n + 1));
     const size_t o_st = carve(sizeof(BaState) * 2);
+    const size_t o_trace = carve(sizeof(BaTrace) * (size_t)(opt.max_iter + 1));
     const size_t o_dbg = carve(sizeof(unsigned long long) * 64);
     const size_t o_free = carve(C);
     const bool use_mfma = d.Cf >= 1 && d.Cf <= 128 && ba_schur_lds_bytes(d.C, d.Cf) <= 160 * 1024;
@@ -563,6 +571,7 @@ extern "C" int rs_bundle_adjust(rs_context* ctx, int n_cameras, int n_points, in
     b.gmax = b.gmax_all + (size_t)(ctx->comm ? ctx->rank : 0) * BA_NSLOT * BA_SLOT_STRIDE;
     b.pt_scal = (double*)(ws + o_pts); b.dc = (double*)(ws + o_dc);
     b.st = (BaState*)(ws + o_st);
+    b.trace = (BaTrace*)(ws + o_trace);
     b.st_prev = b.st;
     b.pt_prev = b.pt_scal;
     BaState* const st_base = b.st;
@@ -574,11 +583,14 @@ extern "C" int rs_bundle_adjust(rs_context* ctx, int n_cameras, int n_points, in
     ctx->ba_cache = b.dbg;
 
     void* pin = nullptr;
-    rc = rs_pinned(ctx, sizeof(int32_t) * C + sizeof(BaState) + C, &pin);
+    const size_t pin_trace = align_up(sizeof(BaState) + sizeof(int32_t) * C + C, 64);
+    rc = rs_pinned(ctx, pin_trace + sizeof(BaTrace) * (size_t)(opt.max_iter + 1), &pin);
     if (rc) return rc;
     BaState* h_st = (BaState*)pin;
     int32_t* h_slot = (int32_t*)((char*)pin + sizeof(BaState));
     uint8_t* h_free = (uint8_t*)(h_slot + C);
+    BaTrace* h_trace = (BaTrace*)((char*)pin + pin_trace);
+    ctx->ba_trace_n = 0;
     uint8_t* d_cam_free = (uint8_t*)(ws + o_free);
     unsigned long long free_mask = 0;
     const int from_mask = C <= 64 ? 1 : 0;
@@ -664,7 +676,7 @@ extern "C" int rs_bundle_adjust(rs_context* ctx, int n_cameras, int n_points, in
         const int itf = opt.max_iter;
         b.st = st_base + (itf & 1); b.st_prev = st_base + ((itf + 1) & 1);
         b.pt_prev = pts_base + (size_t)((itf + 1) & 1) * BA_NSLOT * BA_SLOT_STRIDE;
-        hipLaunchKernelGGL(ba_finalize, dim3(32), dim3(256), 0, s, d, b, opt, itf, d_cameras, (const uint8_t*)d_cam_free, d_points, h_st);
+        hipLaunchKernelGGL(ba_finalize, dim3(32), dim3(256), 0, s, d, b, opt, itf, d_cameras, (const uint8_t*)d_cam_free, d_points, h_st, h_trace);
     }
     RS_HIP(ctx, hipStreamSynchronize(s));        // ba_finalize wrote the state block into the pinned h_st
     RS_HIP(ctx, hipGetLastError());
@@ -675,6 +687,20 @@ extern "C" int rs_bundle_adjust(rs_context* ctx, int n_cameras, int n_points, in
     h_summary->initial_cost = h_st->initial_cost;
     h_summary->final_cost = h_st->x_cost;
     h_summary->final_radius = h_st->radius;
+    ctx->ba_trace = h_trace;            // stays valid until the next call that uses the pinned block
+    ctx->ba_trace_n = h_st->iter;
+    return RS_OK;
+}
+
+static_assert(sizeof(BaTrace) == sizeof(rs_ba_iteration), "BaTrace mirrors rs_ba_iteration");
+
+extern "C" int rs_ba_get_trace(rs_context* ctx, rs_ba_iteration* h_out, int capacity, int* h_count)
+{
+    if (!ctx || !h_count || capacity < 0 || (capacity > 0 && !h_out)) return RS_ERR_INVALID;
+    const int n = ctx->ba_trace ? ctx->ba_trace_n : 0;
+    const int m = n < capacity ? n : capacity;
+    if (m > 0) memcpy(h_out, ctx->ba_trace, sizeof(rs_ba_iteration) * (size_t)m);
+    *h_count = n;
     return RS_OK;
 }
 
@@ -885,6 +911,7 @@ extern "C" int rs_refine_pose(rs_context* ctx, double h_camera[6], const double*
     void* pin = nullptr;
     rc = rs_pinned(ctx, 512, &pin);
     if (rc) return rc;
+    ctx->ba_trace_n = 0;                 // the pinned block is reused: the last BA's record is gone
     double* h_cam = (double*)pin;
     BaState* h_st = (BaState*)((char*)pin + 256);
     memcpy(h_cam, h_camera, 6 * sizeof(double));

@@ -22,6 +22,13 @@ struct BaState {
     int fresh, usable, pad0, pad1;
 };
 
+// one entry per LM iteration (mirrors rs_ba_iteration in rsgpu.h), written by workgroup 0 when it applies a decision
+struct BaTrace {
+    double cost, candidate_cost, model_cost_change, radius, step_norm, x_norm;
+    int outcome, pad;
+    double pad2;
+};
+
 struct BaDims {
     int C, Cf, P, M, n;       // n = 6*Cf
     float fx, fy, cx, cy;
@@ -57,6 +64,7 @@ struct BaBufs {
     const double* pt_prev;   // the same block of the PREVIOUS iteration (read by the next linearisation's decision)
     double* dc;      // [n]
     unsigned long long* dbg;   // [64] in-kernel phase cycle counters (diagnostic; rs_prof_counters)
+    BaTrace* trace;          // [max_iter] per-iteration record (rs_ba_get_trace)
     BaState* st;             // state of THIS iteration (st[it & 1])
     const BaState* st_prev;  // state the previous iteration ended with (st[(it + 1) & 1])
 };
@@ -199,25 +207,32 @@ __device__ __forceinline__ double slot_sum(const double* base, int field);
 // state block and the previous slot sums (both immutable during this launch); workgroup 0 stores
 // the result as this iteration's state.
 __device__ __forceinline__ void ba_apply_decision(BaState& st, double cand, double mcc_p, double ssq_p, double xsq_p,
-                                                  const BaOpt& opt)
+                                                  const BaOpt& opt, BaTrace* trace = nullptr)
 {
     if (st.done) return;
+    BaTrace* tr = trace ? trace + st.iter : nullptr;
     st.iter++;
     const double mcc = mcc_p + st.cam_scal[0];
     const double step_norm = sqrt(ssq_p + st.cam_scal[1]);
     const double x_norm = sqrt(xsq_p + st.cam_scal[2]);
     st.fresh = 0;
+    if (tr) {
+        tr->cost = st.x_cost; tr->candidate_cost = cand; tr->model_cost_change = mcc; tr->radius = st.radius;
+        tr->step_norm = step_norm; tr->x_norm = x_norm; tr->outcome = 0; tr->pad = 0; tr->pad2 = 0.0;
+    }
     if (st.solver_failed || !(mcc > 0.0)) {
         // TrustRegionMinimizer::HandleInvalidStep
+        if (tr) { tr->outcome = -1; tr->candidate_cost = 0.0; tr->step_norm = 0.0; tr->x_norm = 0.0; if (st.solver_failed) tr->model_cost_change = 0.0; }
         if (++st.invalid_steps >= opt.max_invalid) { st.done = 1; st.termination = RS_BA_FAILURE; }
         else { st.radius /= st.decrease_factor; st.decrease_factor *= 2.0; }
     } else {
         st.invalid_steps = 0;
-        if (step_norm <= opt.ptol * (x_norm + opt.ptol)) { st.done = 1; st.termination = RS_BA_CONVERGENCE_PARAMETER; }
-        else if (fabs(st.x_cost - cand) <= opt.ftol * st.x_cost) { st.done = 1; st.termination = RS_BA_CONVERGENCE_FUNCTION; }
+        if (step_norm <= opt.ptol * (x_norm + opt.ptol)) { st.done = 1; st.termination = RS_BA_CONVERGENCE_PARAMETER; if (tr) tr->outcome = 2; }
+        else if (fabs(st.x_cost - cand) <= opt.ftol * st.x_cost) { st.done = 1; st.termination = RS_BA_CONVERGENCE_FUNCTION; if (tr) tr->outcome = 2; }
         else {
             const double rel = (st.x_cost - cand) / mcc;
             if (rel > opt.min_rel && isfinite(cand)) {
+                if (tr) tr->outcome = 1;
                 st.cur ^= 1;
                 st.successful++;
                 const double t = 2.0 * rel - 1.0;
@@ -274,7 +289,7 @@ __device__ __forceinline__ BaState ba_state_for_iteration(const BaBufs& b, const
         if (it > 0) { p0 = slot_sum(b.pt_prev, 0); p1 = slot_sum(b.pt_prev, 1); p2 = slot_sum(b.pt_prev, 2); p3 = slot_sum(b.pt_prev, 3); }
         if (threadIdx.x == 0) {
             BaState s = *b.st_prev;
-            if (it > 0) ba_apply_decision(s, p0, p1, p2, p3, opt);
+            if (it > 0) ba_apply_decision(s, p0, p1, p2, p3, opt, blockIdx.x == 0 ? b.trace : nullptr);
             *sh = s;
             if (blockIdx.x == 0) *b.st = s;
         }

@@ -38,6 +38,9 @@ struct rs_context {
     int rank = 0;
     // cached BA graph / buffers live in ba.hip
     void* ba_cache = nullptr;
+    // per-iteration record of the last rs_bundle_adjust (points into the pinned block; rs_ba_get_trace)
+    const void* ba_trace = nullptr;
+    int ba_trace_n = 0;
     // proposal table of rs_reproj_match: persistent, always left at all-ones by the accept tail
     unsigned long long* prop = nullptr;
     size_t prop_cap = 0;

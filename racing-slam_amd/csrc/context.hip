@@ -97,6 +97,8 @@ int rs_pinned(rs_context* ctx, size_t bytes, void** out)
     if (bytes > ctx->pinned_bytes) {
         if (ctx->pinned) RS_HIP(ctx, hipHostFree(ctx->pinned));
         ctx->pinned = nullptr;
+        ctx->ba_trace = nullptr;
+        ctx->ba_trace_n = 0;
         size_t want = bytes < 4096 ? 4096 : bytes;
         if (hipHostMalloc(&ctx->pinned, want, hipHostMallocDefault) != hipSuccess)
             return rs_fail(ctx, RS_ERR_NOMEM, "pinned buffer of %zu bytes", want);

@@ -107,6 +107,28 @@ __global__ __launch_bounds__(1024) void k4_compact(const uint8_t* __restrict__ k
     k4_compact_body(keep, xyz, n, d_n, out_index, out_xyz, out_count);
 }
 
+// cfg 4 (BASELINE.json configs[3]): a batch of independent frame pairs in one launch pair.  blockIdx.y = pair; every
+// array is the single-pair array with a leading batch dimension.
+__global__ __launch_bounds__(64) void k4_triangulate_pairs(
+    const float2* __restrict__ kp1, int n1, const float2* __restrict__ kp2, int n2, int stride,
+    const float* __restrict__ poses, const int32_t* __restrict__ match_train, const int32_t* __restrict__ match_query,
+    const int32_t* __restrict__ d_n, TriParams prm, float* __restrict__ xyz, uint8_t* __restrict__ keep)
+{
+    const size_t b = blockIdx.y;
+    k4_triangulate_body(kp1 + b * n1, kp2 + b * n2, stride, poses + b * 32, nullptr, nullptr, match_train + b * stride,
+                        match_query + b * stride, d_n + b, prm, xyz + b * stride * 3, keep + b * stride);
+}
+
+__global__ __launch_bounds__(1024) void k4_compact_pairs(const uint8_t* __restrict__ keep, const float* __restrict__ xyz,
+                                                         int stride, const int32_t* __restrict__ d_n,
+                                                         int32_t* __restrict__ out_index, float* __restrict__ out_xyz,
+                                                         int32_t* __restrict__ out_count)
+{
+    const size_t b = blockIdx.x;
+    k4_compact_body(keep + b * stride, xyz + b * stride * 3, stride, d_n + b, out_index + b * stride,
+                    out_xyz + b * stride * 3, out_count + b);
+}
+
 static int tri_launch(rs_context* ctx, const float* d_uv1, const float* d_uv2, int n, const float* d_poses,
                       int n_poses, const int32_t* d_pose_idx1, const int32_t* d_pose_idx2,
                       const int32_t* g1, const int32_t* g2, const int32_t* d_n, const float h_intrinsics[4],
@@ -164,4 +186,42 @@ extern "C" int rs_triangulate_matches(rs_context* ctx, const float* d_kp1, const
     return tri_launch(ctx, d_kp1, d_kp2, max_matches, d_poses, 2, nullptr, nullptr, d_match_train, d_match_query,
                       d_n_matches, h_intrinsics, min_parallax_cosine, max_reprojection_error, d_xyz, d_keep,
                       d_out_index, d_out_xyz, d_out_count);
+}
+
+extern "C" int rs_triangulate_matches_batch(rs_context* ctx, int batch, const float* d_kp1, int n1, const float* d_kp2,
+                                            int n2, const int32_t* d_match_train, const int32_t* d_match_query,
+                                            const int32_t* d_n_matches, int max_matches, const float* d_poses,
+                                            const float h_intrinsics[4], float min_parallax_cosine,
+                                            float max_reprojection_error, float* d_xyz, uint8_t* d_keep,
+                                            int32_t* d_out_index, float* d_out_xyz, int32_t* d_out_count)
+{
+    if (!ctx) return RS_ERR_INVALID;
+    if (batch < 0 || n1 < 0 || n2 < 0 || max_matches < 0) return rs_fail(ctx, RS_ERR_INVALID, "negative size");
+    if (batch > 65535) return rs_fail(ctx, RS_ERR_UNSUPPORTED, "more than 65535 pairs per call");
+    if (batch == 0) return RS_OK;
+    if (!d_out_count) return rs_fail(ctx, RS_ERR_INVALID, "null out_count");
+    RS_HIP(ctx, hipSetDevice(ctx->device));
+    if (max_matches == 0) {   // empty guard, src/Triangulation.cpp:46-48
+        RS_HIP(ctx, hipMemsetAsync(d_out_count, 0, sizeof(int32_t) * (size_t)batch, ctx->stream));
+        return RS_OK;
+    }
+    if (!d_kp1 || !d_kp2 || !d_match_train || !d_match_query || !d_n_matches || !d_poses || !h_intrinsics || !d_xyz ||
+        !d_keep || !d_out_index || !d_out_xyz)
+        return rs_fail(ctx, RS_ERR_INVALID, "null pointer");
+    if ((uintptr_t)d_poses & 15) return rs_fail(ctx, RS_ERR_INVALID, "poses must be 16-byte aligned");
+    TriParams prm = {h_intrinsics[0], h_intrinsics[1], h_intrinsics[2], h_intrinsics[3], min_parallax_cosine,
+                     max_reprojection_error};
+    {
+        rs_prof_scope ps(ctx, "K4_triangulate_dlt");
+        hipLaunchKernelGGL(k4_triangulate_pairs, dim3((max_matches + 63) / 64, batch), dim3(64), 0, ctx->stream,
+                           (const float2*)d_kp1, n1, (const float2*)d_kp2, n2, max_matches, d_poses, d_match_train,
+                           d_match_query, d_n_matches, prm, d_xyz, d_keep);
+    }
+    {
+        rs_prof_scope ps(ctx, "K4b_compact");
+        hipLaunchKernelGGL(k4_compact_pairs, dim3(batch), dim3(1024), 0, ctx->stream, d_keep, d_xyz, max_matches,
+                           d_n_matches, d_out_index, d_out_xyz, d_out_count);
+    }
+    RS_HIP(ctx, hipGetLastError());
+    return RS_OK;
 }

@@ -15,8 +15,8 @@ LIB_PATH = os.path.join(_HERE, "librsgpu.so")
 EXPORTS = [
     "rs_abi_version", "rs_context_create", "rs_context_destroy", "rs_context_set_stream",
     "rs_context_synchronize", "rs_last_error", "rs_hamming_knn2", "rs_match_descriptors",
-    "rs_kdtree_build", "rs_reproj_match", "rs_triangulate", "rs_triangulate_matches", "rs_triangulate_tracks", "rs_point_errors", "rs_ba_default_options",
-    "rs_bundle_adjust", "rs_refine_pose", "rs_pack_pose", "rs_unpack_pose", "rs_build_local_window",
+    "rs_kdtree_build", "rs_reproj_match", "rs_triangulate", "rs_triangulate_matches", "rs_triangulate_matches_batch", "rs_triangulate_tracks", "rs_point_errors", "rs_ba_default_options",
+    "rs_bundle_adjust", "rs_ba_get_trace", "rs_refine_pose", "rs_pack_pose", "rs_unpack_pose", "rs_build_local_window",
     "rs_comm_get_unique_id", "rs_comm_init_rank", "rs_comm_destroy", "rs_prof_begin", "rs_prof_end", "rs_prof_counters",
 ]
 
@@ -73,6 +73,15 @@ class BaSummary(C.Structure):
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}
+
+
+class BaIteration(C.Structure):
+    _fields_ = [("cost", C.c_double), ("candidate_cost", C.c_double), ("model_cost_change", C.c_double),
+                ("radius", C.c_double), ("step_norm", C.c_double), ("x_norm", C.c_double),
+                ("outcome", C.c_int), ("reserved0", C.c_int), ("reserved1", C.c_double)]
+
+    def as_dict(self):
+        return {k: getattr(self, k) for k, _ in self._fields_ if not k.startswith("reserved")}
 
 
 class ProfEntry(C.Structure):
@@ -269,6 +278,22 @@ class Context:
                     "rs_triangulate_matches")
         return out
 
+    def triangulate_matches_batch(self, d_kp1, d_kp2, d_mt, d_mq, d_cnt, d_poses, K,
+                                  min_parallax_cosine=0.9999, max_reproj=2.0, out=None):
+        """cfg 4: d_kp1 [B][n1][2], d_kp2 [B][n2][2], d_mt / d_mq [B][stride], d_cnt [B], d_poses [B][2][16]."""
+        t = self.torch
+        B, n1, n2, stride = int(d_kp1.shape[0]), int(d_kp1.shape[1]), int(d_kp2.shape[1]), int(d_mt.shape[1])
+        if out is None:
+            out = dict(xyz=self.empty((B, stride, 3), t.float32), keep=self.empty((B, stride), t.uint8),
+                       out_index=self.empty((B, stride), t.int32), out_xyz=self.empty((B, stride, 3), t.float32),
+                       count=self.empty((B,), t.int32))
+        Kc = (C.c_float * 4)(*[float(v) for v in K])
+        self._check(self.lib.rs_triangulate_matches_batch(
+            self.h, B, _dp(d_kp1), n1, _dp(d_kp2), n2, _dp(d_mt), _dp(d_mq), _dp(d_cnt), stride, _dp(d_poses), Kc,
+            C.c_float(min_parallax_cosine), C.c_float(max_reproj), _dp(out["xyz"]), _dp(out["keep"]),
+            _dp(out["out_index"]), _dp(out["out_xyz"]), _dp(out["count"])), "rs_triangulate_matches_batch")
+        return out
+
     # -- §8(f) rank 1: Mapper::triangulate_tracks body
     def triangulate_tracks(self, d_track_uv, d_sight_ptr, d_sight_pose, d_sight_uv, d_poses, kf_pose, K, d_skip=None,
                            any_parallax_cosine=1.0, max_reproj=4.0, min_parallax_cosine=0.999848,
@@ -319,6 +344,14 @@ class Context:
                                               None if options is None else C.byref(options), C.byref(s)),
                     "rs_bundle_adjust")
         return s.as_dict()
+
+    def ba_trace(self):
+        """Per-iteration record of the last bundle_adjust on this context (list of dicts)."""
+        cap = 1024
+        buf = (BaIteration * cap)()
+        n = C.c_int(0)
+        self._check(self.lib.rs_ba_get_trace(self.h, buf, cap, C.byref(n)), "rs_ba_get_trace")
+        return [buf[i].as_dict() for i in range(min(n.value, cap))]
 
     def refine_pose(self, cam, d_points, d_uv, K, options=None):
         cam = np.array(cam, np.float64, order="C")

@@ -71,15 +71,21 @@ def pair_config(config_id):
     return dict(width=1920, height=1080, K=np.array([1000, 1000, 960, 540], np.float32), n=2000, unmatched=0.10)
 
 
-def make_pair(config_id=2, seed_stream=0, n=None):
+def make_pair(config_id=2, seed_stream=0, n=None, pose_jitter=0.0):
     """Two-frame scene of cfg 1 / cfg 2: returns a dict with
-    desc1/kp1 (train, the keyframe), desc2/kp2 (query, the new frame), poses [2][16], K."""
+    desc1/kp1 (train, the keyframe), desc2/kp2 (query, the new frame), poses [2][16], K.
+    pose_jitter > 0 (cfg 4 batches): the second pose varies with the seed stream."""
     cfg = pair_config(config_id)
     rng = rng_for(config_id, seed_stream)
     N = cfg["n"] if n is None else int(n)
     K, W, H = cfg["K"].astype(np.float64), cfg["width"], cfg["height"]
     T1 = make_pose(np.eye(3), np.zeros(3))
-    T2 = make_pose(yaw_matrix(2.0), np.array([0.2, 0.0, 0.05]))
+    if pose_jitter > 0.0:
+        jr = np.random.default_rng(0xC4 + seed_stream)
+        T2 = make_pose(yaw_matrix(2.0 + pose_jitter * jr.uniform(-1, 1)),
+                       np.array([0.2, 0.0, 0.05]) + pose_jitter * 0.05 * jr.uniform(-1, 1, 3))
+    else:
+        T2 = make_pose(yaw_matrix(2.0), np.array([0.2, 0.0, 0.05]))
     n_shared = int(round(N * (1.0 - cfg["unmatched"])))
     # landmarks uniform in frame 1's frustum, depth U[4,20]
     z = rng.uniform(4, 20, n_shared)
@@ -110,6 +116,15 @@ def make_pair(config_id=2, seed_stream=0, n=None):
                 poses=np.stack([T1.reshape(16), T2.reshape(16)]).astype(np.float32),
                 K=cfg["K"], width=W, height=H,
                 truth12=(np.argsort(p1), np.argsort(p2), n_shared))
+
+
+def make_pair_batch(batch=64, config_id=2, first_stream=0, n=None, pose_jitter=1.0):
+    """cfg 4 (BASELINE.json configs[3]): `batch` independent instances of the cfg-2 pair, stacked:
+    desc1/desc2 [B][N][32], kp1/kp2 [B][N][2], poses [B][2][16], K."""
+    prs = [make_pair(config_id, seed_stream=first_stream + b, n=n, pose_jitter=pose_jitter) for b in range(batch)]
+    out = {k: np.ascontiguousarray(np.stack([p[k] for p in prs])) for k in ("desc1", "kp1", "desc2", "kp2", "poses")}
+    out.update(K=prs[0]["K"], width=prs[0]["width"], height=prs[0]["height"], pairs=prs)
+    return out
 
 
 def make_ba_window(n_kf=20, n_points=10000, config_id=3, seed_stream=0, n_fixed=2,

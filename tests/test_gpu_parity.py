@@ -473,6 +473,84 @@ def test_match_descriptors_cfg4_batch_properties(ctx, synth):
     assert np.array_equal(to_np(ident["raw"][0])[0], np.arange(n)) and to_np(ident["raw"][1])[0].max() == 0
 
 
+def test_cfg4_batch_match_and_triangulate(ctx, oracle, synth):
+    """BASELINE.json configs[3] end to end at full size: 64 pairs x 2000 keypoints, batched brute-force match feeding
+    the batched triangulation (rs_triangulate_matches_batch, one launch pair for all 64 pairs, per-pair poses).
+    Three sampled pairs against the oracle bit for bit; all 64 against single-pair launches bit for bit
+    (reference src/Triangulation.cpp:28-106 per pair)."""
+    import torch
+    B = 64
+    bt = synth.make_pair_batch(B)
+    n = bt["desc1"].shape[1]
+    dq, dt = ctx.dev(bt["desc2"]), ctx.dev(bt["desc1"])
+    dk1, dk2, dpo = ctx.dev(bt["kp1"]), ctx.dev(bt["kp2"]), ctx.dev(bt["poses"])
+    m = ctx.match_descriptors(dq, dt, n, n, batch=B)
+    t = ctx.triangulate_matches_batch(dk1, dk2, m["mt"], m["mq"], m["cnt"], dpo, bt["K"])
+    cnt = to_np(m["cnt"])
+    tcnt = to_np(t["count"])
+    assert cnt.min() > 0.8 * n and tcnt.min() > 0.2 * n   # the default parallax gate (0.9999) drops distant landmarks
+    for b in (0, 29, 63):
+        pr = bt["pairs"][b]
+        mq, mt = oracle.match_descriptors(pr["desc2"], pr["desc1"])
+        assert len(mq) == cnt[b]
+        assert np.array_equal(to_np(m["mq"])[b, :cnt[b]], mq) and np.array_equal(to_np(m["mt"])[b, :cnt[b]], mt)
+        ref = oracle.triangulate(pr["kp1"][mt], pr["kp2"][mq], pr["poses"], pr["K"])
+        assert np.array_equal(to_np(t["keep"])[b, :cnt[b]], ref["keep"])
+        assert np.array_equal(to_np(t["xyz"])[b, :cnt[b]].view(np.uint32), ref["xyz"].view(np.uint32))
+        assert tcnt[b] == len(ref["out_index"])
+        assert np.array_equal(to_np(t["out_index"])[b, :tcnt[b]], ref["out_index"])
+        assert np.array_equal(to_np(t["out_xyz"])[b, :tcnt[b]].view(np.uint32), ref["out_xyz"].view(np.uint32))
+    for b in range(B):
+        one = ctx.triangulate_matches(dk1[b], dk2[b], m["mt"][b], m["mq"][b], m["cnt"][b:b + 1], n, dpo[b], bt["K"])
+        c, tc = int(cnt[b]), int(tcnt[b])
+        assert int(to_np(one["count"])[0]) == tc
+        assert torch.equal(one["keep"][:c], t["keep"][b, :c]) and torch.equal(one["xyz"][:c], t["xyz"][b, :c])
+        assert torch.equal(one["out_index"][:tc], t["out_index"][b, :tc])
+        assert torch.equal(one["out_xyz"][:tc], t["out_xyz"][b, :tc])
+    # the poses differ between pairs (pose_jitter), so a wrong pose index cannot pass
+    assert not np.array_equal(bt["poses"][0], bt["poses"][1])
+
+
+def test_bundle_adjust_free_camera_without_observations(ctx, oracle, synth):
+    """VERDICT r1 weak #6 / ADVICE: a FREE camera that carries no residual block.  The reference only adds parameter
+    blocks that have residuals (src/Optimization.cpp:306-316) and the oracle drops such a camera (oracle/ba.c,
+    active free cameras).  The library keeps its slot in the reduced system as a pure-damping block (delta = 0) and
+    excludes it from the norms of the parameter-tolerance test, so schedule and results must not change."""
+    w = synth.make_ba_window(n_kf=7, n_points=300, run_max=5, config_id=17)
+    # camera 7: free, never observed, far from the origin (it would dominate x_norm if it were counted)
+    cams = np.concatenate([w["cams"], [[0.3, -0.2, 0.1, 500.0, -300.0, 800.0]]])
+    free = np.concatenate([w["cam_free"], [1]]).astype(np.uint8)
+    w2 = dict(w, cams=cams, cam_free=free)
+    c, p, s, rc, rp, rs_ = _ba_case(ctx, oracle, w2)
+    tr = ctx.ba_trace()
+    c0, p0, s0, _, _, _ = _ba_case(ctx, oracle, w)
+    assert (s["iterations"], s["successful_steps"], s["termination"]) == (rs_["iterations"], rs_["successful_steps"], rs_["termination"])
+    assert (s["iterations"], s["successful_steps"], s["termination"]) == (s0["iterations"], s0["successful_steps"], s0["termination"])
+    assert np.array_equal(c[7], cams[7]) and np.array_equal(rc[7], cams[7])       # untouched on both sides
+    assert np.allclose(c, rc, rtol=1e-7, atol=1e-9) and np.allclose(p, rp, rtol=1e-7, atol=1e-8)
+    assert np.allclose(c[:7], c0, rtol=1e-9, atol=1e-11)
+    _, _, _, otr = oracle.bundle_adjust_trace(w2["cams"], w2["cam_free"], w2["points"], w2["obs_ptr"], w2["obs_cam"],
+                                               w2["obs_uv"], w2["K"])
+    assert [t["outcome"] for t in tr] == [t["outcome"] for t in otr]
+    assert np.allclose([t["x_norm"] for t in tr], [t["x_norm"] for t in otr], rtol=1e-9)   # |x| ~ 1e3 if it were counted
+
+
+def test_bundle_adjust_cfg3_trace(ctx, oracle, synth):
+    """Per-iteration schedule of the benchmark window (cfg 3 rejects 6 of its 10 steps): outcome, radius, costs."""
+    w = synth.make_ba_window()
+    dc, dp = ctx.dev(w["cams"]), ctx.dev(w["points"])
+    s = ctx.bundle_adjust(dc, w["cam_free"], dp, ctx.dev(w["obs_ptr"]), ctx.dev(w["obs_cam"]), ctx.dev(w["obs_uv"]), w["K"])
+    tr = ctx.ba_trace()
+    _, _, rs_, otr = oracle.bundle_adjust_trace(w["cams"], w["cam_free"], w["points"], w["obs_ptr"], w["obs_cam"],
+                                                w["obs_uv"], w["K"])
+    assert len(tr) == s["iterations"] == rs_["iterations"]
+    assert [t["outcome"] for t in tr] == [t["outcome"] for t in otr]
+    assert sum(t["outcome"] == 0 for t in tr) >= 5
+    for k, tol in (("radius", 1e-7), ("cost", 1e-9), ("candidate_cost", 1e-8), ("model_cost_change", 1e-6),
+                   ("step_norm", 1e-6), ("x_norm", 1e-9)):
+        assert np.allclose([t[k] for t in tr], [t[k] for t in otr], rtol=tol), k
+
+
 def test_bundle_adjust_through_rccl_single_rank(ctx, rs, synth):
     """The multi-GPU code path on one GPU: a 1-rank RCCL communicator (dlopen of librccl,
     ncclCommInitRank, sum and max ncclAllReduce of the reduced system / scalar slots on the library
