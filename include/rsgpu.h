@@ -67,6 +67,10 @@ int rs_context_destroy(rs_context* ctx);
 /* `hip_stream` is a hipStream_t (NULL = the legacy default stream). */
 int rs_context_set_stream(rs_context* ctx, void* hip_stream);
 int rs_context_synchronize(rs_context* ctx);
+/* Tuning knobs (integers by name).  "ba_speculative_sets": 1 .. 3 trust-region radii evaluated per round of
+ * rs_bundle_adjust on the local-window path (0 = library default); the LM schedule, iteration count and
+ * results do not depend on it (tests/test_gpu_parity.py), only the number of launches does. */
+int rs_context_set_int(rs_context* ctx, const char* name, int value);
 const char* rs_last_error(const rs_context* ctx);
 
 /* --------------------------------------------------- a4: match_descriptors */

@@ -44,11 +44,14 @@ __global__ void ba_init(BaDims d, BaBufs b, BaOpt opt, const double* __restrict_
         b.slot[tid] = fr ? __popcll(free_mask & ((1ull << tid) - 1ull)) : -1;
         cam_free[tid] = (uint8_t)fr;
     }
-    for (int i = tid; i < d.C * 6; i += nth) { b.Xc[i] = cams_in[i]; b.Xc[d.C * 6 + i] = cams_in[i]; }
+    for (int i = tid; i < d.C * 6; i += nth) {
+        const double v = cams_in[i];
+        for (int q = 0; q <= b.ns; q++) b.Xc[(size_t)q * d.C * 6 + i] = v;
+    }
     for (int i = tid; i < d.P * 3; i += nth) b.Xp[i] = pts_in[i];
     for (int c = tid; c < d.C; c += nth) cam_prepare(cams_in + 6 * c, b.prep + (size_t)c * BA_PREP);
     for (size_t i = tid; i < b.acc_count; i += nth) b.acc[i] = 0.0;
-    for (int i = tid; i < 2 * BA_NSLOT * BA_SLOT_STRIDE; i += nth) b.pt_scal[i] = 0.0;
+    for (int i = tid; i < 2 * b.ns * BA_NSLOT * BA_SLOT_STRIDE; i += nth) b.pt_scal[i] = 0.0;
     for (int i = tid; i < BA_NSLOT * BA_SLOT_STRIDE; i += nth) b.gmax[i] = 0.0;
     for (int i = tid; i < zero_n; i += nth) zero_i32[i] = 0;      // histogram of the landmark grouping
     if (tid == 0) {
@@ -57,7 +60,7 @@ __global__ void ba_init(BaDims d, BaBufs b, BaOpt opt, const double* __restrict_
         s.cam_scal[0] = s.cam_scal[1] = s.cam_scal[2] = s.cam_scal[3] = 0.0;
         s.iter = 0; s.successful = 0; s.invalid_steps = 0; s.done = 0;
         s.termination = 0; s.cur = 0; s.have_scale = 0; s.solver_failed = 0;
-        s.fresh = 1; s.usable = 0; s.pad0 = 0; s.pad1 = 0;
+        s.fresh = 1; s.usable = 0; s.consec_accepts = 0; s.nact = 1;
         b.st[1] = s;      // the state iteration 0 starts from (st[(0 + 1) & 1])
     }
 }
@@ -420,16 +423,8 @@ __global__ void ba_finalize(BaDims d, BaBufs b, BaOpt opt, int it, double* __res
 {
     __shared__ int usable, cur;
     __shared__ BaState st_fin;
-    // the decision of the last iteration (every workgroup recomputes it; b.st_prev / b.pt_prev are immutable here)
-    if (threadIdx.x < 64) {
-        double p0 = 0.0, p1 = 0.0, p2 = 0.0, p3 = 0.0;
-        if (it > 0) { p0 = slot_sum(b.pt_prev, 0); p1 = slot_sum(b.pt_prev, 1); p2 = slot_sum(b.pt_prev, 2); p3 = slot_sum(b.pt_prev, 3); }
-        if (threadIdx.x == 0) {
-            BaState s0 = *b.st_prev;
-            if (it > 0) ba_apply_decision(s0, p0, p1, p2, p3, opt, blockIdx.x == 0 ? b.trace : nullptr);
-            st_fin = s0;
-        }
-    }
+    // the decisions of the last round (every workgroup recomputes them; b.st_prev / b.pt_prev are immutable here)
+    if (threadIdx.x < 64) ba_decide(b, opt, it, blockIdx.x == 0 ? b.trace : nullptr, &st_fin);
     __syncthreads();
     if (threadIdx.x == 0) {
         BaState st = st_fin;
@@ -530,42 +525,55 @@ extern "C" int rs_bundle_adjust(rs_context* ctx, int n_cameras, int n_points, in
     if (opt.max_iter < 0 || opt.max_iter > 1000) return rs_fail(ctx, RS_ERR_INVALID, "max_num_iterations out of range");
     if (d.Cf * 42 * sizeof(double) > 60 * 1024) return rs_fail(ctx, RS_ERR_UNSUPPORTED, "more than 182 free cameras");
 
+    // which kernels: the MFMA Schur path + LDS reduced solve + LDS back-substitution form the fast path of a local
+    // window; only that path evaluates speculative radii (ns > 1)
+    const bool use_mfma = d.Cf >= 1 && d.Cf <= 128 && ba_schur_lds_bytes(d.C, d.Cf) <= 160 * 1024;
+    const bool k8_lds = ba_backsub_lds_bytes(d.C, d.n) <= 64 * 1024;
+    const bool solve_lds = d.n >= 6 && d.n <= BA_MAX_LDS_N;
+    const bool solve_big = d.n > BA_MAX_LDS_N;
+    int ns = 1;
+    if (use_mfma && k8_lds && solve_lds) {
+        ns = ctx->ba_sets > 0 ? ctx->ba_sets : BA_DEFAULT_SETS;
+        if (ns > BA_MAXSETS) ns = BA_MAXSETS;
+        if (ns > opt.max_iter) ns = opt.max_iter > 0 ? opt.max_iter : 1;
+    }
     // workspace carve (all offsets multiples of 256 B)
     const size_t n = (size_t)d.n, C = (size_t)d.C, P = (size_t)d.P;
+    const size_t nb = (size_t)ns + 1;
     size_t off = 0;
     auto carve = [&](size_t bytes) { size_t o = off; off += align_up(bytes, 256); return o; };
-    const size_t o_Xc = carve(sizeof(double) * 2 * C * 6), o_Xp = carve(sizeof(double) * 2 * P * 3);
-    const size_t o_prep = carve(sizeof(double) * 2 * C * BA_PREP), o_slot = carve(sizeof(int32_t) * C);
+    const size_t o_Xc = carve(sizeof(double) * nb * C * 6), o_Xp = carve(sizeof(double) * nb * P * 3);
+    const size_t o_prep = carve(sizeof(double) * nb * C * BA_PREP), o_slot = carve(sizeof(int32_t) * C);
     const size_t o_sc = carve(sizeof(double) * (n + 1)), o_sp = carve(sizeof(double) * P * 3);
-    const size_t o_Vinv = carve(sizeof(double) * P * 6), o_gp = carve(sizeof(double) * P * 3);
-    const size_t o_lamp = carve(sizeof(double) * P * 3);
+    const size_t o_Vinv = carve(sizeof(double) * ns * P * 6), o_gp = carve(sizeof(double) * P * 3);
+    const size_t o_lamp = carve(sizeof(double) * ns * P * 3);
     const size_t o_Vc = carve(sizeof(double) * P * 6), o_Ukeep = carve(sizeof(double) * ((size_t)d.Cf * 36 + n + 1));
-    const size_t cam_stride = (size_t)d.Cf * 36 + 2 * n;
+    const size_t cam_stride = (size_t)ns * n + (size_t)d.Cf * 36 + n;
     const size_t n_ranks = ctx->comm ? (size_t)ctx->n_ranks : 1;
-    const size_t acc_count = n * n + (size_t)BA_UREP * cam_stride + (1 + n_ranks) * (size_t)BA_NSLOT * BA_SLOT_STRIDE;
+    const size_t acc_count = (size_t)ns * n * n + (size_t)BA_UREP * cam_stride + (1 + n_ranks) * (size_t)BA_NSLOT * BA_SLOT_STRIDE;
     const size_t o_acc = carve(sizeof(double) * acc_count);
-    const size_t o_pts = carve(sizeof(double) * 2 * BA_NSLOT * BA_SLOT_STRIDE), o_dc = carve(sizeof(double) * (n + 1));
+    const size_t pts_block = (size_t)ns * BA_NSLOT * BA_SLOT_STRIDE;
+    const size_t o_pts = carve(sizeof(double) * 2 * pts_block), o_dc = carve(sizeof(double) * ns * (n + 2));
     const size_t o_st = carve(sizeof(BaState) * 2);
+    const size_t o_set = carve(sizeof(BaSetOut) * 2 * BA_MAXSETS);
     const size_t o_trace = carve(sizeof(BaTrace) * (size_t)(opt.max_iter + 1));
     const size_t o_dbg = carve(sizeof(unsigned long long) * 64);
     const size_t o_free = carve(C);
-    const bool use_mfma = d.Cf >= 1 && d.Cf <= 128 && ba_schur_lds_bytes(d.C, d.Cf) <= 160 * 1024;
-    const bool k8_lds = ba_backsub_lds_bytes(d.C, d.n) <= 64 * 1024;
     const size_t o_grp = carve(use_mfma ? ba_group_bytes(d.P, d.Cf, d.M) : 16);
-    const bool solve_big = d.n > BA_MAX_LDS_N;
     const size_t o_big = carve(solve_big ? ba_big_bytes(d.n) : 16);
     void* wsv = nullptr;
     int rc = rs_workspace(ctx, off, &wsv);
     if (rc) return rc;
     char* ws = (char*)wsv;
     BaBufs b;
+    b.ns = ns;
     b.obs_ptr = d_obs_ptr; b.obs_cam = d_obs_cam; b.obs_uv = (const float2*)d_obs_uv;
     b.Xc = (double*)(ws + o_Xc); b.Xp = (double*)(ws + o_Xp); b.prep = (double*)(ws + o_prep);
     b.slot = (int32_t*)(ws + o_slot); b.sc = (double*)(ws + o_sc); b.sp = (double*)(ws + o_sp);
     b.Vinv = (double*)(ws + o_Vinv); b.gp = (double*)(ws + o_gp); b.lamp = (double*)(ws + o_lamp);
     b.Vc = (double*)(ws + o_Vc); b.Ukeep = (double*)(ws + o_Ukeep);
     b.acc = (double*)(ws + o_acc); b.acc_count = acc_count;
-    b.S = b.acc; b.rhs = b.S + n * n; b.U = b.rhs + n; b.gc = b.U + (size_t)d.Cf * 36;
+    b.S = b.acc; b.rhs = b.S + (size_t)ns * n * n; b.U = b.rhs + (size_t)ns * n; b.gc = b.U + (size_t)d.Cf * 36;
     b.cam_stride = cam_stride; b.scal = b.rhs + (size_t)BA_UREP * cam_stride;
     b.gmax_all = b.scal + (size_t)BA_NSLOT * BA_SLOT_STRIDE; b.gmax_blocks = (int)n_ranks;
     b.gmax = b.gmax_all + (size_t)(ctx->comm ? ctx->rank : 0) * BA_NSLOT * BA_SLOT_STRIDE;
@@ -574,8 +582,10 @@ extern "C" int rs_bundle_adjust(rs_context* ctx, int n_cameras, int n_points, in
     b.trace = (BaTrace*)(ws + o_trace);
     b.st_prev = b.st;
     b.pt_prev = b.pt_scal;
+    b.set_out = (BaSetOut*)(ws + o_set); b.set_prev = b.set_out;
     BaState* const st_base = b.st;
     double* const pts_base = b.pt_scal;
+    BaSetOut* const set_base = b.set_out;
     b.dbg = (unsigned long long*)(ws + o_dbg);
 #if RS_STAMPS
     RS_HIP(ctx, hipMemsetAsync(b.dbg, 0, sizeof(unsigned long long) * 64, ctx->stream));
@@ -583,9 +593,13 @@ extern "C" int rs_bundle_adjust(rs_context* ctx, int n_cameras, int n_points, in
     ctx->ba_cache = b.dbg;
 
     void* pin = nullptr;
-    const size_t pin_trace = align_up(sizeof(BaState) + sizeof(int32_t) * C + C, 64);
+    const size_t pin_prog = align_up(sizeof(BaState) + sizeof(int32_t) * C + C, 64);
+    const size_t pin_trace = pin_prog + 64;
     rc = rs_pinned(ctx, pin_trace + sizeof(BaTrace) * (size_t)(opt.max_iter + 1), &pin);
     if (rc) return rc;
+    BaProgress* h_prog = (BaProgress*)((char*)pin + pin_prog);
+    h_prog->round = 0; h_prog->done = 0; h_prog->iter = 0;
+    b.prog = ns > 1 ? h_prog : nullptr;
     BaState* h_st = (BaState*)pin;
     int32_t* h_slot = (int32_t*)((char*)pin + sizeof(BaState));
     uint8_t* h_free = (uint8_t*)(h_slot + C);
@@ -603,7 +617,6 @@ extern "C" int rs_bundle_adjust(rs_context* ctx, int n_cameras, int n_points, in
         RS_HIP(ctx, hipMemcpyAsync(d_cam_free, h_free, C, hipMemcpyHostToDevice, ctx->stream));
     }
 
-    const bool solve_lds = d.n >= 6 && d.n <= BA_MAX_LDS_N;
     if (solve_lds && ba_prepare_reduced_solve_lds(d.n) != 0) return rs_fail(ctx, RS_ERR_HIP, "LDS attribute (K7)");
     const size_t k5_lds = sizeof(double) * (size_t)d.Cf * 42;
     if (!use_mfma && k5_lds > 48 * 1024)
@@ -628,11 +641,17 @@ extern "C" int rs_bundle_adjust(rs_context* ctx, int n_cameras, int n_points, in
         rc = ba_launch_grouping(ctx, d, b, grp);
         if (rc) return rc;
     }
-    for (int it = 0; it < opt.max_iter; it++) {
-        // double-buffered state / step-scalar blocks: iteration `it` works on [it & 1] and reads [(it + 1) & 1]
+    // One ROUND = K5 + K7 + K8 and evaluates the next `ns` LM iterations of the sequential loop (all of them only if
+    // the first ns - 1 are rejected).  At least ceil(max_iter / ns) rounds are needed and at most max_iter; beyond the
+    // minimum the host follows the state machine through the progress word the first kernel of every round publishes
+    // in pinned memory: when round r starts with `iter` iterations done, at most max_iter - iter rounds (r included)
+    // can still do work.  The host stays one round ahead of the GPU, so the stream never drains.
+    auto enqueue_round = [&](int it) -> int {
+        // double-buffered state / step-scalar blocks: round `it` works on [it & 1] and reads [(it + 1) & 1]
         b.st = st_base + (it & 1); b.st_prev = st_base + ((it + 1) & 1);
-        b.pt_scal = pts_base + (size_t)(it & 1) * BA_NSLOT * BA_SLOT_STRIDE;
-        b.pt_prev = pts_base + (size_t)((it + 1) & 1) * BA_NSLOT * BA_SLOT_STRIDE;
+        b.pt_scal = pts_base + (size_t)(it & 1) * pts_block;
+        b.pt_prev = pts_base + (size_t)((it + 1) & 1) * pts_block;
+        b.set_out = set_base + (size_t)(it & 1) * BA_MAXSETS; b.set_prev = set_base + (size_t)((it + 1) & 1) * BA_MAXSETS;
         if (use_mfma) {
             rs_prof_scope ps(ctx, "K5_ba_schur_mfma");
             ba_launch_schur(s, d, b, opt, grp, it);
@@ -643,16 +662,16 @@ extern "C" int rs_bundle_adjust(rs_context* ctx, int n_cameras, int n_points, in
         if (ctx->comm) {
             rs_prof_scope ps(ctx, "C1_allreduce_system");
             // one SUM all-reduce: S | 8 x {rhs, U, gc} | cost / failure slots | every rank's gradient-max block
-            rc = rs_allreduce_f64(ctx, b.acc, b.acc_count, false);
-            if (rc) return rc;
+            int rc2 = rs_allreduce_f64(ctx, b.acc, b.acc_count, false);
+            if (rc2) return rc2;
         }
         if (solve_lds) {
             rs_prof_scope ps(ctx, "K7_ba_reduced_solve");
             ba_launch_reduced_solve_lds(s, d, b, opt);
         } else if (solve_big) {
             rs_prof_scope ps(ctx, "K7_ba_reduced_solve_blocked");
-            rc = ba_launch_reduced_solve_big(ctx, d, b, opt, ws + o_big);
-            if (rc) return rc;
+            int rc2 = ba_launch_reduced_solve_big(ctx, d, b, opt, ws + o_big);
+            if (rc2) return rc2;
         } else {
             rs_prof_scope ps(ctx, "K7_ba_reduced_solve_global");
             hipLaunchKernelGGL(ba_reduced_solve, dim3(1), dim3(256), 0, s, d, b, opt, 0);
@@ -666,16 +685,38 @@ extern "C" int rs_bundle_adjust(rs_context* ctx, int n_cameras, int n_points, in
         }
         if (ctx->comm) {
             rs_prof_scope ps(ctx, "C2_allreduce_cost");
-            rc = rs_allreduce_f64(ctx, b.pt_scal, BA_NSLOT * BA_SLOT_STRIDE, false);
-            if (rc) return rc;
+            int rc2 = rs_allreduce_f64(ctx, b.pt_scal, pts_block, false);
+            if (rc2) return rc2;
         }
+        return RS_OK;
+    };
+    int rounds = 0;
+    const int min_rounds = (opt.max_iter + ns - 1) / ns;
+    for (; rounds < min_rounds; rounds++) {
+        rc = enqueue_round(rounds);
+        if (rc) return rc;
+    }
+    while (ns > 1 && rounds < opt.max_iter) {
+        // wait until the GPU has started the last enqueued round (it then has a whole round of work in front of it)
+        long spins = 0;
+        while (h_prog->round < rounds) {
+            if ((++spins & 0xFFFFF) == 0 && hipStreamQuery(s) != hipErrorNotReady) break;   // stream drained or failed
+        }
+        if (h_prog->round < rounds) break;                 // nothing left in flight: finalize reports the state
+        const int it_seen = h_prog->iter, done_seen = h_prog->done;
+        if (done_seen || opt.max_iter - it_seen <= 1) break;          // the round in flight is the last that can matter
+        rc = enqueue_round(rounds);
+        if (rc) return rc;
+        rounds++;
     }
     {
         rs_prof_scope ps(ctx, "K10_ba_finalize");
-        // the last decision: iteration index max_iter reads the blocks of iteration max_iter - 1
-        const int itf = opt.max_iter;
+        // the last decisions: round index `rounds` reads the blocks of round rounds - 1
+        const int itf = rounds;
         b.st = st_base + (itf & 1); b.st_prev = st_base + ((itf + 1) & 1);
-        b.pt_prev = pts_base + (size_t)((itf + 1) & 1) * BA_NSLOT * BA_SLOT_STRIDE;
+        b.pt_prev = pts_base + (size_t)((itf + 1) & 1) * pts_block;
+        b.set_prev = set_base + (size_t)((itf + 1) & 1) * BA_MAXSETS;
+        b.prog = nullptr;
         hipLaunchKernelGGL(ba_finalize, dim3(32), dim3(256), 0, s, d, b, opt, itf, d_cameras, (const uint8_t*)d_cam_free, d_points, h_st, h_trace);
     }
     RS_HIP(ctx, hipStreamSynchronize(s));        // ba_finalize wrote the state block into the pinned h_st
@@ -741,7 +782,7 @@ __global__ __launch_bounds__(RP_THREADS) void ba_refine_pose(BaDims d, BaOpt opt
         cam_prepare(x, prep);
         st.radius = opt.r0; st.decrease_factor = 2.0; st.x_cost = 0.0; st.initial_cost = 0.0;
         st.iter = 0; st.successful = 0; st.invalid_steps = 0; st.done = 0; st.termination = 0; st.cur = 0;
-        st.have_scale = 0; st.solver_failed = 0; st.fresh = 1; st.usable = 0;
+        st.have_scale = 0; st.solver_failed = 0; st.fresh = 1; st.usable = 0; st.consec_accepts = 0; st.nact = 1;
     }
     __syncthreads();
     double acc[28];

@@ -13,13 +13,37 @@
 #define BA_UREP 8             // replicas of the camera-side accumulators (U, gc, rhs): workgroup w adds
                               // into replica w % 8, K7 folds them; cuts same-line atomic traffic 8x
 #define BA_MAX_LDS_N 126      // largest reduced system kept in LDS by K7
+#define BA_DEFAULT_SETS 3      // default number of speculative radii per round on the local-window path
+#define BA_MAXSETS 3          // speculative trust-region radii evaluated per round (see "Speculative radii" below)
 
 struct BaState {
     double radius, decrease_factor, x_cost, initial_cost;
-    double cam_scal[4];       // K7: mcc_c, step_sq_c, x_sq_c, unused
+    double cam_scal[4];       // K7 (set 0): mcc_c, step_sq_c, x_sq_c, unused
     int iter, successful, invalid_steps, done;
     int termination, cur, have_scale, solver_failed;
-    int fresh, usable, pad0, pad1;
+    int fresh, usable;
+    int consec_accepts;       // successful steps in a row (drives how many radii the next round speculates on)
+    int nact;                 // sets evaluated by THIS round (1 .. ns)
+};
+
+// Speculative radii.  After a REJECTED step Ceres does not relinearise: x stays, the radius becomes
+// radius / decrease_factor and the factor doubles (oracle/ba.c, TrustRegionMinimizer).  The radii of the next
+// rejections are therefore known in advance, and one round (K5 + K7 + K8) evaluates the LM step for `ns` of them
+// at once: set 0 with the state's radius r, set 1 with r / f, set 2 with r / (f * 2f).  The decision at the start
+// of the next round walks the sets in order — exactly the iterations the sequential loop would have run — and
+// stops at the first accepted step or termination.  Sets >= 1 cost K5 a second / third damped-inverse + SYRK
+// phase; K7 and K8 run the sets side by side in extra workgroups.  What a set needs of its own:
+//   S, the Schur part of the rhs, damped V^-1, point damping, delta_c, candidate state, step scalars.
+// The undamped linearisation (U, gc, V, gp, cost at x) is shared.
+struct BaSetOut {             // written by K7's workgroup of set s >= 1 (set 0 writes BaState)
+    double cam_scal[4];
+    int solver_failed, pad[7];
+};
+
+// progress word in pinned host memory: the first kernel of every round publishes where the state machine is, so
+// that the host only enqueues the rounds that can still be needed (see rs_bundle_adjust)
+struct BaProgress {
+    volatile int round, done, iter, pad;
 };
 
 // one entry per LM iteration (mirrors rs_ba_iteration in rsgpu.h), written by workgroup 0 when it applies a decision
@@ -40,29 +64,35 @@ struct BaBufs {
     const int32_t* obs_cam;   // [M]
     const float2* obs_uv;     // [M]
     const int32_t* obs_cs;    // [M] cam | (slot + 1) << 16, built by the landmark grouping (null on the generic path)
-    double* Xc;      // [2][C][6]
-    double* Xp;      // [2][P][3]
-    double* prep;    // [2][C][BA_PREP]
+    int ns;          // speculative sets (1 .. BA_MAXSETS); state buffers rotate over ns + 1 slots:
+                     // x lives in slot st.cur, the candidate of set s in slot (st.cur + 1 + s) % (ns + 1)
+    double* Xc;      // [ns+1][C][6]
+    double* Xp;      // [ns+1][P][3]
+    double* prep;    // [ns+1][C][BA_PREP]
     int32_t* slot;   // [C]  reduced-system slot of a free camera or -1
     double* sc;      // [n]
     double* sp;      // [P][3]
-    double* Vinv;    // [P][6]  (xx xy xz yy yz zz)
+    double* Vinv;    // [ns][P][6]  (xx xy xz yy yz zz)
     double* gp;      // [P][3]
-    double* lamp;    // [P][3]
-    // accumulators, contiguous for one all-reduce: S[n*n] rhs[n] U[Cf*36] gc[n] scal[2]
+    double* lamp;    // [ns][P][3]
+    // accumulators, contiguous for one all-reduce: S[ns][n*n] | BA_UREP x { rhs[ns][n] U[Cf*36] gc[n] } | scal | gmax
     double* acc;
     size_t acc_count;
-    double* S; double* rhs; double* U; double* gc;   // rhs/U/gc: replica 0; replica r at + r * cam_stride
-    size_t cam_stride;       // doubles per replica = Cf*36 + 2n
-    double* scal;    // [BA_NSLOT][8] per slot: cost_x, fail_count (summed by K7)
+    double* S; double* rhs; double* U; double* gc;   // S: set 0, set s at + s*n*n; rhs/U/gc: replica 0 (rhs of set s at
+                                                     // + s*n); replica r at + r * cam_stride
+    size_t cam_stride;       // doubles per replica = ns*n + Cf*36 + n
+    double* scal;    // [BA_NSLOT][8] per slot: cost_x, fail_count of set 0, 1, 2 (summed by K7)
     double* Vc;      // [P][6] undamped point blocks of the last FRESH linearisation (a rejected step only changes the damping)
     double* Ukeep;   // [Cf*36 + n] folded U | gc of the last fresh linearisation
     double* gmax;    // [BA_NSLOT][8] per slot: bits of a non-negative double (max; K7 folds); THIS rank's block of gmax_all
     double* gmax_all;   // [gmax_blocks][BA_NSLOT][8], inside the all-reduced accumulator block: rank r only writes block r,
     int gmax_blocks;    //   so that the SUM all-reduce of the accumulators also delivers every rank's maximum (no max collective)
-    double* pt_scal; // [BA_NSLOT][8] per slot, K8 of THIS iteration: cand_cost, mcc_p, step_sq_p, x_sq_p
-    const double* pt_prev;   // the same block of the PREVIOUS iteration (read by the next linearisation's decision)
-    double* dc;      // [n]
+    double* pt_scal; // [ns][BA_NSLOT][8] per slot, K8 of THIS round: cand_cost, mcc_p, step_sq_p, x_sq_p
+    const double* pt_prev;   // the same block of the PREVIOUS round (read by the next linearisation's decision)
+    double* dc;      // [ns][n+2]
+    BaSetOut* set_out;            // [ns] K7 results of sets >= 1, THIS round
+    const BaSetOut* set_prev;     // the previous round's
+    BaProgress* prog;             // pinned host memory (null when the caller does not poll)
     unsigned long long* dbg;   // [64] in-kernel phase cycle counters (diagnostic; rs_prof_counters)
     BaTrace* trace;          // [max_iter] per-iteration record (rs_ba_get_trace)
     BaState* st;             // state of THIS iteration (st[it & 1])
@@ -216,6 +246,8 @@ __device__ __forceinline__ void ba_apply_decision(BaState& st, double cand, doub
     const double step_norm = sqrt(ssq_p + st.cam_scal[1]);
     const double x_norm = sqrt(xsq_p + st.cam_scal[2]);
     st.fresh = 0;
+    const int consec_before = st.consec_accepts;
+    st.consec_accepts = 0;
     if (tr) {
         tr->cost = st.x_cost; tr->candidate_cost = cand; tr->model_cost_change = mcc; tr->radius = st.radius;
         tr->step_norm = step_norm; tr->x_norm = x_norm; tr->outcome = 0; tr->pad = 0; tr->pad2 = 0.0;
@@ -233,8 +265,8 @@ __device__ __forceinline__ void ba_apply_decision(BaState& st, double cand, doub
             const double rel = (st.x_cost - cand) / mcc;
             if (rel > opt.min_rel && isfinite(cand)) {
                 if (tr) tr->outcome = 1;
-                st.cur ^= 1;
-                st.successful++;
+                st.successful++;                // the caller moves st.cur to the accepted set's buffer
+                st.consec_accepts = consec_before + 1;
                 const double t = 2.0 * rel - 1.0;
                 st.radius = st.radius / fmax(1.0 / 3.0, 1.0 - t * t * t);
                 st.radius = fmin(opt.rmax, st.radius);
@@ -278,24 +310,73 @@ __device__ __forceinline__ double slot_max_bits(const double* base)
 }
 
 
-// phase stamps: thread 0 of block 0 accumulates s_memtime deltas per phase in REGISTERS
-// (static slot indices) and flushes them once at kernel end, so the stamps do not add
-// global-memory round trips to the phases they measure.
-// state of iteration `it` (called by all threads of the first kernel of the iteration; one barrier)
+// The decisions of the previous round, applied by the first wave of a workgroup (threadIdx.x < 64): the sets are
+// walked in order — set k is LM iteration (iter + k) of the sequential loop — until a step is accepted or the
+// loop terminates.  Lane 0 leaves the resulting state in *out.
+__device__ __forceinline__ void ba_decide(const BaBufs& b, const BaOpt& opt, int it, BaTrace* trace, BaState* out)
+{
+    double ps[BA_MAXSETS][4];
+#pragma unroll
+    for (int k = 0; k < BA_MAXSETS; k++) {
+#pragma unroll
+        for (int f = 0; f < 4; f++) ps[k][f] = 0.0;
+        if (it > 0 && k < b.ns) {
+            const double* base = b.pt_prev + (size_t)k * BA_NSLOT * BA_SLOT_STRIDE;
+#pragma unroll
+            for (int f = 0; f < 4; f++) ps[k][f] = slot_sum(base, f);
+        }
+    }
+    if (threadIdx.x == 0) {
+        BaState s = *b.st_prev;
+        if (it > 0) {
+            const int nb = b.ns + 1;
+            const int nact_prev = s.nact;
+#pragma unroll
+            for (int k = 0; k < BA_MAXSETS; k++) {
+                if (k >= nact_prev || s.done) break;
+                if (k > 0) {
+                    const BaSetOut so = b.set_prev[k];
+#pragma unroll
+                    for (int q = 0; q < 4; q++) s.cam_scal[q] = so.cam_scal[q];
+                    s.solver_failed = so.solver_failed;
+                }
+                ba_apply_decision(s, ps[k][0], ps[k][1], ps[k][2], ps[k][3], opt, trace);
+                if (s.fresh) { s.cur = (s.cur + 1 + k) % nb; break; }
+            }
+        }
+        // How many radii this round speculates on: the first step (initial radius 1e4: practically Gauss-Newton)
+        // and a step after two successful ones in a row are most likely accepted — extra sets would be wasted
+        // work in K5 — so those rounds evaluate one radius only.
+        s.nact = (it == 0 || s.consec_accepts >= 2) ? 1 : b.ns;
+        *out = s;
+    }
+}
+
+// state of round `it` (called by all threads of the first kernel of the round; one barrier)
 __device__ __forceinline__ BaState ba_state_for_iteration(const BaBufs& b, const BaOpt& opt, int it, BaState* sh)
 {
     if (threadIdx.x < 64) {
-        double p0 = 0.0, p1 = 0.0, p2 = 0.0, p3 = 0.0;
-        if (it > 0) { p0 = slot_sum(b.pt_prev, 0); p1 = slot_sum(b.pt_prev, 1); p2 = slot_sum(b.pt_prev, 2); p3 = slot_sum(b.pt_prev, 3); }
-        if (threadIdx.x == 0) {
-            BaState s = *b.st_prev;
-            if (it > 0) ba_apply_decision(s, p0, p1, p2, p3, opt, blockIdx.x == 0 ? b.trace : nullptr);
-            *sh = s;
-            if (blockIdx.x == 0) *b.st = s;
+        ba_decide(b, opt, it, blockIdx.x == 0 ? b.trace : nullptr, sh);
+        if (threadIdx.x == 0 && blockIdx.x == 0) {
+            *b.st = *sh;
+            if (b.prog) {            // tell the host where the state machine is (pinned memory)
+                b.prog->iter = sh->iter;
+                b.prog->done = sh->done;
+                __threadfence_system();
+                b.prog->round = it + 1;
+            }
         }
     }
     __syncthreads();
     return *sh;
+}
+
+// radius and decrease factor of speculative set k, given the state's (set 0)
+__device__ __forceinline__ double ba_set_radius(const BaState& st, int k)
+{
+    double r = st.radius, f = st.decrease_factor;
+    for (int q = 0; q < k; q++) { r /= f; f *= 2.0; }
+    return r;
 }
 
 #ifndef RS_STAMPS

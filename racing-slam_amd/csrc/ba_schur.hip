@@ -311,7 +311,10 @@ static __device__ __forceinline__ void ba_schur_body(const BaDims& d, const BaBu
     BA_STAMP(b, 0);
     const size_t rep_off = (size_t)(blockIdx.x & (BA_UREP - 1)) * b.cam_stride;
     double* rhs_rep = b.rhs + rep_off;
-    double cost = 0.0, gmax = 0.0, fail = 0.0;
+    double cost = 0.0, gmax = 0.0;
+    double fail[BA_MAXSETS];
+#pragma unroll
+    for (int k = 0; k < BA_MAXSETS; k++) fail[k] = 0.0;
     // ---- pass 1: V, g, cost, U/gc
     double V[6] = {0, 0, 0, 0, 0, 0}, gv[3] = {0, 0, 0};
     ObsLin o;
@@ -379,35 +382,55 @@ static __device__ __forceinline__ void ba_schur_body(const BaDims& d, const BaBu
         }
     }
 
-    double Li[6] = {0, 0, 0, 0, 0, 0}, I[6] = {0, 0, 0, 0, 0, 0};
-    bool ok = false;
+    // Jacobi scale of the point block (fixed at the first linearisation) and the gradient norm: once, for all sets
+    double sp[3] = {1.0, 1.0, 1.0};
+    const double Vd[3] = {V[0], V[3], V[5]};
     if (p >= 0) {
         if (sub == 0) gmax = fmax(fabs(gv[0]), fmax(fabs(gv[1]), fabs(gv[2])));
-        double sp[3], lam[3];
-        const double Vd[3] = {V[0], V[3], V[5]};
 #pragma unroll
         for (int k = 0; k < 3; k++) {
             if (!st.have_scale) sp[k] = opt.jacobi ? 1.0 / (1.0 + sqrt(Vd[k])) : 1.0;
             else sp[k] = b.sp[3 * (size_t)p + k];
+        }
+        if (sub == 0) {
+#pragma unroll
+            for (int k = 0; k < 3; k++) {
+                if (!st.have_scale) b.sp[3 * (size_t)p + k] = sp[k];
+                b.gp[3 * (size_t)p + k] = gv[k];
+            }
+        }
+    }
+    // ---- per speculative radius (set): damped V^-1, Y, SYRK into the set's own S / rhs (ba_common.h "Speculative radii")
+    for (int set = 0; set < st.nact; set++) {
+    const double radius = ba_set_radius(st, set);
+    double* const S_set = b.S + (size_t)set * d.n * d.n;
+    double* const rhs_set = rhs_rep + (size_t)set * d.n;
+    double Li[6] = {0, 0, 0, 0, 0, 0}, I[6] = {0, 0, 0, 0, 0, 0};
+    bool ok = false;
+    if (p >= 0) {
+        double lam[3];
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
             const double s2 = sp[k] * sp[k];
-            lam[k] = clampd(s2 * Vd[k], opt.dmin, opt.dmax) / (st.radius * s2);
+            lam[k] = clampd(s2 * Vd[k], opt.dmin, opt.dmax) / (radius * s2);
         }
         const double Vdm[6] = {V[0] + lam[0], V[1], V[2], V[3] + lam[1], V[4], V[5] + lam[2]};
         ok = chol3_inv(Vdm, Li, I);
         if (!ok) {
 #pragma unroll
             for (int k = 0; k < 6; k++) { I[k] = 0.0; Li[k] = 0.0; }
-            if (sub == 0) fail = 1.0;
+            if (sub == 0) {
+#pragma unroll
+                for (int k = 0; k < BA_MAXSETS; k++) fail[k] = (k == set) ? 1.0 : fail[k];
+            }
         }
         if (sub == 0) {
+            double* lamp_set = b.lamp + ((size_t)set * d.P + p) * 3;
+            double* vinv_set = b.Vinv + ((size_t)set * d.P + p) * 6;
 #pragma unroll
-            for (int k = 0; k < 3; k++) {
-                if (!st.have_scale) b.sp[3 * (size_t)p + k] = sp[k];
-                b.lamp[3 * (size_t)p + k] = lam[k];
-                b.gp[3 * (size_t)p + k] = gv[k];
-            }
+            for (int k = 0; k < 3; k++) lamp_set[k] = lam[k];
 #pragma unroll
-            for (int k = 0; k < 6; k++) b.Vinv[6 * (size_t)p + k] = I[k];
+            for (int k = 0; k < 6; k++) vinv_set[k] = I[k];
         }
     }
     // t = L^-1 g : the rhs row
@@ -421,7 +444,7 @@ static __device__ __forceinline__ void ba_schur_body(const BaDims& d, const BaBu
         const int stride = big ? YT_STRIDE8 : YT_STRIDE4;
         for (int bt = 0; bt < nbatch; bt++) {
             const int ncol = 3 * lb_n;
-            if (bt > 0) {                                      // the first batch's tile was zeroed at kernel start
+            if (bt > 0 || set > 0) {                           // the very first tile was zeroed at kernel start
                 __syncthreads();                               // previous batch fully consumed
                 for (int i = threadIdx.x; i < ncol * stride; i += blockDim.x) yt[i] = 0.0;
                 __syncthreads();
@@ -463,10 +486,10 @@ static __device__ __forceinline__ void ba_schur_body(const BaDims& d, const BaBu
             BA_STAMP(b, 4);
             const int nw = (int)(blockDim.x >> 6);            // 8 (64 landmarks) or 5 (40 landmarks)
             if (big) {
-                if (nw >= 8) syrk_scatter<8, 5, YT_STRIDE8>(yt, ncol / 4, ns, gslot, d.n, wave, nw, b.S, rhs_rep);
-                else syrk_scatter<8, 8, YT_STRIDE8>(yt, ncol / 4, ns, gslot, d.n, wave, nw, b.S, rhs_rep);
+                if (nw >= 8) syrk_scatter<8, 5, YT_STRIDE8>(yt, ncol / 4, ns, gslot, d.n, wave, nw, S_set, rhs_set);
+                else syrk_scatter<8, 8, YT_STRIDE8>(yt, ncol / 4, ns, gslot, d.n, wave, nw, S_set, rhs_set);
             } else {
-                syrk_scatter<4, 2, YT_STRIDE4>(yt, ncol / 4, ns, gslot, d.n, wave, nw, b.S, rhs_rep);
+                syrk_scatter<4, 2, YT_STRIDE4>(yt, ncol / 4, ns, gslot, d.n, wave, nw, S_set, rhs_set);
             }
         }
     } else if (ns > 21) {
@@ -485,14 +508,14 @@ static __device__ __forceinline__ void ba_schur_body(const BaDims& d, const BaBu
                     Y[a * 3 + 0] = w0 * I[0] + w1 * I[1] + w2 * I[2];
                     Y[a * 3 + 1] = w0 * I[1] + w1 * I[3] + w2 * I[4];
                     Y[a * 3 + 2] = w0 * I[2] + w1 * I[4] + w2 * I[5];
-                    atomicAdd(&rhs_rep[6 * si + a], -(Y[a * 3] * gv[0] + Y[a * 3 + 1] * gv[1] + Y[a * 3 + 2] * gv[2]));
+                    atomicAdd(&rhs_set[6 * si + a], -(Y[a * 3] * gv[0] + Y[a * 3 + 1] * gv[1] + Y[a * 3 + 2] * gv[2]));
                 }
                 ObsLin oj;
                 for (int ojx = o0; ojx < o0 + nobs; ojx++) {
                     const int sj = b.slot[b.obs_cam[ojx]];
                     if (sj < si) continue;      // upper block triangle only
                     obs_eval<true>(prep + (size_t)b.obs_cam[ojx] * BA_PREP, X, b.obs_uv[ojx], d, oj);
-                    double* Sblk = b.S + (size_t)(6 * si) * d.n + 6 * sj;
+                    double* Sblk = S_set + (size_t)(6 * si) * d.n + 6 * sj;
 #pragma unroll
                     for (int e = 0; e < 6; e++) {
                         const double w0 = oj.w * (oj.jc[e] * oj.jp[0] + oj.jc[6 + e] * oj.jp[3]);
@@ -507,21 +530,35 @@ static __device__ __forceinline__ void ba_schur_body(const BaDims& d, const BaBu
             }
         }
     }
+    }   // sets
     BA_STAMP(b, 5);
     cost = wave_sum(cost);
-    fail = wave_sum(fail);
+#pragma unroll
+    for (int k = 0; k < BA_MAXSETS; k++) fail[k] = wave_sum(fail[k]);
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) gmax = fmax(gmax, __shfl_down(gmax, off, 64));
-    __shared__ double redw[SCH_WAVES][3];
+    __shared__ double redw[SCH_WAVES][2 + BA_MAXSETS];
     const int nwaves = (int)(blockDim.x >> 6);
-    if (lane == 0) { redw[wave][0] = cost; redw[wave][1] = fail; redw[wave][2] = gmax; }
+    if (lane == 0) {
+        redw[wave][0] = cost; redw[wave][1] = gmax;
+#pragma unroll
+        for (int k = 0; k < BA_MAXSETS; k++) redw[wave][2 + k] = fail[k];
+    }
     __syncthreads();
     if (threadIdx.x == 0) {      // one atomic per workgroup, spread over BA_NSLOT lines
-        double c = 0.0, f = 0.0, gm = 0.0;
-        for (int w = 0; w < nwaves; w++) { c += redw[w][0]; f += redw[w][1]; gm = fmax(gm, redw[w][2]); }
+        double c = 0.0, gm = 0.0, f[BA_MAXSETS];
+#pragma unroll
+        for (int k = 0; k < BA_MAXSETS; k++) f[k] = 0.0;
+        for (int w = 0; w < nwaves; w++) {
+            c += redw[w][0]; gm = fmax(gm, redw[w][1]);
+#pragma unroll
+            for (int k = 0; k < BA_MAXSETS; k++) f[k] += redw[w][2 + k];
+        }
         const size_t slot = (size_t)(blockIdx.x & (BA_NSLOT - 1)) * BA_SLOT_STRIDE;
         if (c != 0.0) atomicAdd(&b.scal[slot], c);
-        if (f > 0.0) atomicAdd(&b.scal[slot + 1], f);
+#pragma unroll
+        for (int k = 0; k < BA_MAXSETS; k++)
+            if (f[k] > 0.0) atomicAdd(&b.scal[slot + 1 + k], f[k]);      // slot field 1 + set
         if (gm > 0.0) atomic_max_nonneg(&b.gmax[slot], gm);
     }
     for (int i = threadIdx.x; i < min(ns, SCH_UCAP) * 42; i += blockDim.x) {

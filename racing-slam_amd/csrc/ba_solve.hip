@@ -52,6 +52,7 @@ __global__ __launch_bounds__(K7_THREADS) void ba_reduced_solve_lds(BaDims d, BaB
 {
     extern __shared__ __attribute__((aligned(16))) double sm[];
     const int n = d.n, tid = threadIdx.x, nt = K7_THREADS;
+    const int set = blockIdx.x;                    // speculative radius evaluated by this workgroup (ba_common.h)
     const int LD = n + 1 + ((n & 1) ? 1 : 0);     // odd row stride (n is a multiple of 6)
     double* A = sm;                                // (n+1) x LD: published panels + rhs row n
     double* lam = A + (size_t)(n + 1) * LD;        // [n] camera damping
@@ -100,18 +101,20 @@ __global__ __launch_bounds__(K7_THREADS) void ba_reduced_solve_lds(BaDims d, BaB
     double pre_cost = 0.0, pre_fail = 0.0, pre_gm = 0.0;
     if (tid < 64) {
         pre_cost = b.scal[(size_t)tid * BA_SLOT_STRIDE + 0];
-        pre_fail = b.scal[(size_t)tid * BA_SLOT_STRIDE + 1];
+        pre_fail = b.scal[(size_t)tid * BA_SLOT_STRIDE + 1 + set];
         for (int r = 0; r < b.gmax_blocks; r++)      // every rank's block (they arrive through the SUM all-reduce)
             pre_gm = fmax(pre_gm, b.gmax_all[((size_t)r * BA_NSLOT + tid) * BA_SLOT_STRIDE]);
     }
     const double pre_sc = tid < n ? b.sc[tid] : 1.0;                   // n <= 126: one entry per thread
-    double fold[2] = {0.0, 0.0}, keep[2] = {0.0, 0.0};                 // cam_stride = 8 n <= 1008: two entries per thread
+    double fold[2] = {0.0, 0.0}, keep[2] = {0.0, 0.0};                 // 8 n <= 1008 entries: two per thread
+    // replica layout: rhs[ns][n] U[Cf*36] gc[n]; this set's view of it is entry i < n -> its rhs, i >= n -> U | gc
 #pragma unroll
     for (int h = 0; h < 2; h++) {
         const int i = tid + h * nt;
-        if (i < (int)b.cam_stride) {
+        if (i < 8 * n) {
+            const size_t addr = i < n ? (size_t)set * n + i : (size_t)(b.ns - 1) * n + i;
 #pragma unroll
-            for (int r = 0; r < BA_UREP; r++) fold[h] += b.rhs[(size_t)r * b.cam_stride + i];
+            for (int r = 0; r < BA_UREP; r++) fold[h] += b.rhs[(size_t)r * b.cam_stride + addr];
             if (i >= n) keep[h] = b.Ukeep[i - n];                      // U | gc of the last fresh linearisation
         }
     }
@@ -125,22 +128,23 @@ __global__ __launch_bounds__(K7_THREADS) void ba_reduced_solve_lds(BaDims d, BaB
 #pragma unroll
         for (int q = 0; q < 4; q++) {
             const int ic = min(16 * tr[s] + lq + 4 * q, n - 1);
-            sv[s][q] = b.S[(size_t)kc * n + ic];                       // only k <= i is used: (k, i) is S's upper triangle
+            sv[s][q] = b.S[((size_t)set * n + kc) * n + ic];           // only k <= i is used: (k, i) is S's upper triangle
         }
     }
     __syncthreads();
-    if (st.done) return;
+    if (st.done || set >= st.nact) return;
     BA_STAMP(b, 2);
-    for (int i = tid; i < BA_NSLOT * BA_SLOT_STRIDE; i += nt) b.pt_scal[i] = 0.0;     // K8 of this iteration accumulates here
+    for (int i = tid; i < BA_NSLOT * BA_SLOT_STRIDE; i += nt)                         // K8 of this round accumulates here
+        b.pt_scal[(size_t)set * BA_NSLOT * BA_SLOT_STRIDE + i] = 0.0;
     for (int i = tid; i < 2 * 8 * 128; i += nt) Pd[i] = 0.0;
     // fold the replicas of the camera-side accumulators (replica layout: rhs[n] U[Cf*36] gc[n])
 #pragma unroll
     for (int h = 0; h < 2; h++) {
         const int i = tid + h * nt;
-        if (i < (int)b.cam_stride) {
+        if (i < 8 * n) {
             // U and gc are only accumulated on fresh iterations (K5 skips its first pass after a rejected step)
             const double v = (i < n || st.fresh) ? fold[h] : keep[h];
-            if (i >= n && st.fresh) b.Ukeep[i - n] = v;
+            if (i >= n && st.fresh && set == 0) b.Ukeep[i - n] = v;
             if (i < n) grs[i] = v;                         // rhs part
             else if (i < n + 6 * n) Us[i - n] = v;
             else gcs[i - 7 * n] = v;
@@ -154,10 +158,10 @@ __global__ __launch_bounds__(K7_THREADS) void ba_reduced_solve_lds(BaDims d, BaB
         double sc = pre_sc;
         if (!st.have_scale) {
             sc = opt.jacobi ? 1.0 / (1.0 + sqrt(h)) : 1.0;
-            b.sc[tid] = sc;
+            if (set == 0) b.sc[tid] = sc;
         }
         const double s2 = sc * sc;
-        lam[tid] = clampd(s2 * h, opt.dmin, opt.dmax) / (st.radius * s2);
+        lam[tid] = clampd(s2 * h, opt.dmin, opt.dmax) / (ba_set_radius(st, set) * s2);
     }
     BA_STAMP(b, 3);
 
@@ -183,7 +187,7 @@ __global__ __launch_bounds__(K7_THREADS) void ba_reduced_solve_lds(BaDims d, BaB
             else if (g <= opt.gtol) { st.done = 1; st.termination = RS_BA_CONVERGENCE_GRADIENT; }
         }
         __syncthreads();
-        if (st.done) { if (tid == 0) *b.st = st; return; }
+        if (st.done) { if (tid == 0 && set == 0) *b.st = st; return; }      // every set reaches the same verdict
     } else {
         __syncthreads();
     }
@@ -404,7 +408,10 @@ __global__ __launch_bounds__(K7_THREADS) void ba_reduced_solve_lds(BaDims d, BaB
     }
     __syncthreads();
     if (s_fail) {
-        if (tid == 0) { st.solver_failed = 1; *b.st = st; }
+        if (tid == 0) {
+            if (set == 0) { st.solver_failed = 1; *b.st = st; }
+            else b.set_out[set].solver_failed = 1;
+        }
         return;
     }
     // (4) backward substitution L^T x = y in ONE wave without block barriers: y (row n of the panels)
@@ -460,7 +467,9 @@ __global__ __launch_bounds__(K7_THREADS) void ba_reduced_solve_lds(BaDims d, BaB
     double mcc = 0.0, ssq = 0.0, xsq = 0.0;
     bool bad = false;
     const double* Xc = b.Xc + (size_t)st.cur * d.C * 6;
-    double* Xn = b.Xc + (size_t)(st.cur ^ 1) * d.C * 6;
+    const int cand = (st.cur + 1 + set) % (b.ns + 1);       // this set's candidate buffer
+    double* Xn = b.Xc + (size_t)cand * d.C * 6;
+    double* dc_set = b.dc + (size_t)set * (n + 2);
     for (int c = tid; c < d.C; c += nt) {
         const int s = b.slot[c];
         bool active = false;
@@ -475,12 +484,12 @@ __global__ __launch_bounds__(K7_THREADS) void ba_reduced_solve_lds(BaDims d, BaB
                 const double xn = x + dlt;
                 if (active) { ssq += (x - xn) * (x - xn); xsq += x * x; }
                 Xn[6 * c + k] = xn;
-                b.dc[6 * s + k] = dlt;
+                dc_set[6 * s + k] = dlt;
             } else {
                 Xn[6 * c + k] = x;
             }
         }
-        cam_prepare(Xn + 6 * c, b.prep + ((size_t)(st.cur ^ 1) * d.C + c) * BA_PREP);
+        cam_prepare(Xn + 6 * c, b.prep + ((size_t)cand * d.C + c) * BA_PREP);
     }
     mcc = wave_sum(mcc); ssq = wave_sum(ssq); xsq = wave_sum(xsq);
     if (__any(bad) && (tid & 63) == 0) s_fail = 1;
@@ -489,9 +498,18 @@ __global__ __launch_bounds__(K7_THREADS) void ba_reduced_solve_lds(BaDims d, BaB
     if (tid == 0) {
         double a0 = 0, a1 = 0, a2 = 0;
         for (int w = 0; w < nt / 64; w++) { a0 += red3[w][0]; a1 += red3[w][1]; a2 += red3[w][2]; }
-        st.cam_scal[0] = a0; st.cam_scal[1] = a1; st.cam_scal[2] = a2;
-        st.solver_failed = s_fail;
-        *b.st = st;
+        if (set == 0) {
+            st.cam_scal[0] = a0; st.cam_scal[1] = a1; st.cam_scal[2] = a2;
+            st.solver_failed = s_fail;
+            *b.st = st;
+        } else {
+            BaSetOut so;
+            so.cam_scal[0] = a0; so.cam_scal[1] = a1; so.cam_scal[2] = a2; so.cam_scal[3] = 0.0;
+            so.solver_failed = s_fail;
+#pragma unroll
+            for (int q = 0; q < 7; q++) so.pad[q] = 0;
+            b.set_out[set] = so;
+        }
     }
     BA_STAMP(b, 7);
     BA_STAMP_FLUSH(b, 0);
@@ -506,7 +524,7 @@ size_t ba_reduced_solve_lds_bytes(int n)
 void ba_launch_reduced_solve_lds(hipStream_t s, const BaDims& d, const BaBufs& b, const BaOpt& opt)
 {
     const size_t lds = ba_reduced_solve_lds_bytes(d.n);
-    hipLaunchKernelGGL(ba_reduced_solve_lds, dim3(1), dim3(K7_THREADS), lds, s, d, b, opt);
+    hipLaunchKernelGGL(ba_reduced_solve_lds, dim3(b.ns), dim3(K7_THREADS), lds, s, d, b, opt);
 }
 
 int ba_prepare_reduced_solve_lds(int n)

@@ -20,32 +20,44 @@ __global__ __launch_bounds__(K8_THREADS) void ba_backsub_cost4(BaDims d, BaBufs 
     const int lane = threadIdx.x & 63, l = lane & 15, sub = lane >> 4;
     const int p = blockIdx.x * 64 + (threadIdx.x >> 6) * 16 + l;
     const bool valid = p < d.P;
+    const int set = blockIdx.y;             // speculative radius evaluated by this workgroup (ba_common.h)
     int o0 = 0, nobs = 0;
-    double g[3] = {0, 0, 0}, I[6] = {0, 0, 0, 0, 0, 0}, lamp[3] = {0, 0, 0}, Xa[3] = {0, 0, 0}, Xb[3] = {0, 0, 0};
+    double g[3] = {0, 0, 0}, I[6] = {0, 0, 0, 0, 0, 0}, lamp[3] = {0, 0, 0}, Xq[BA_MAXSETS + 1][3];
+#pragma unroll
+    for (int q = 0; q <= BA_MAXSETS; q++) Xq[q][0] = Xq[q][1] = Xq[q][2] = 0.0;
     if (valid) {
         o0 = b.obs_ptr[p];
         nobs = b.obs_ptr[p + 1] - o0;
 #pragma unroll
         for (int k = 0; k < 3; k++) {
             g[k] = b.gp[3 * (size_t)p + k];
-            lamp[k] = b.lamp[3 * (size_t)p + k];
-            Xa[k] = b.Xp[3 * (size_t)p + k];
-            Xb[k] = b.Xp[(size_t)d.P * 3 + 3 * (size_t)p + k];
+            lamp[k] = b.lamp[((size_t)set * d.P + p) * 3 + k];
         }
+        // x may live in any of the ns + 1 state buffers: all of them are fetched before the state block is known
 #pragma unroll
-        for (int k = 0; k < 6; k++) I[k] = b.Vinv[6 * (size_t)p + k];
+        for (int q = 0; q <= BA_MAXSETS; q++)
+            if (q <= b.ns) {
+#pragma unroll
+                for (int k = 0; k < 3; k++) Xq[q][k] = b.Xp[((size_t)q * d.P + p) * 3 + k];
+            }
+#pragma unroll
+        for (int k = 0; k < 6; k++) I[k] = b.Vinv[((size_t)set * d.P + p) * 6 + k];
     }
     const BaState st = *b.st;
     if (st.done) return;
+    const int set_failed = set == 0 ? st.solver_failed : b.set_out[set].solver_failed;
     // K7 has consumed the accumulators: clear them for the next linearisation (no separate launch)
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < b.acc_count; i += (size_t)gridDim.x * blockDim.x) b.acc[i] = 0.0;
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < BA_NSLOT * BA_SLOT_STRIDE; i += gridDim.x * blockDim.x) b.gmax[i] = 0.0;
-    if (st.solver_failed) return;
+    const size_t gtid = ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * blockDim.x + threadIdx.x;
+    const size_t gnth = (size_t)gridDim.y * gridDim.x * blockDim.x;
+    for (size_t i = gtid; i < b.acc_count; i += gnth) b.acc[i] = 0.0;
+    for (size_t i = gtid; i < BA_NSLOT * BA_SLOT_STRIDE; i += gnth) b.gmax[i] = 0.0;
+    if (set_failed || set >= st.nact) return;
     double* cprep = lds;                                    // [C][BA_PREP] current
     double* cprepn = lds + (size_t)d.C * BA_PREP;           // [C][BA_PREP] candidate
     double* dcl = cprepn + (size_t)d.C * BA_PREP;           // [n] delta_c
     const double* gprep = b.prep + (size_t)st.cur * d.C * BA_PREP;
-    double* gprepn = b.prep + (size_t)(st.cur ^ 1) * d.C * BA_PREP;
+    const int cand = (st.cur + 1 + set) % (b.ns + 1);        // this set's candidate buffer (written by K7)
+    double* gprepn = b.prep + (size_t)cand * d.C * BA_PREP;
     // second round trip: K7's candidate camera blocks (prep[cur^1]) and the current ones -> LDS, and the
     // first two observations of every lane (later rounds load on demand)
     int cs_pre[2] = {0, 0};
@@ -61,15 +73,20 @@ __global__ __launch_bounds__(K8_THREADS) void ba_backsub_cost4(BaDims d, BaBufs 
         }
     }
     for (int i = threadIdx.x; i < d.C * BA_PREP; i += blockDim.x) { cprep[i] = gprep[i]; cprepn[i] = gprepn[i]; }
-    for (int i = threadIdx.x; i < d.n; i += blockDim.x) dcl[i] = b.dc[i];
+    for (int i = threadIdx.x; i < d.n; i += blockDim.x) dcl[i] = b.dc[(size_t)set * (d.n + 2) + i];
     __syncthreads();
     const double* prep = cprep;
 
-    double* Xn = b.Xp + (size_t)(st.cur ^ 1) * d.P * 3;
+    double* Xn = b.Xp + (size_t)cand * d.P * 3;
     double cost = 0.0, mcc = 0.0, ssq = 0.0, xsq = 0.0;
     double X[3];
 #pragma unroll
-    for (int k = 0; k < 3; k++) X[k] = st.cur ? Xb[k] : Xa[k];
+    for (int k = 0; k < 3; k++) {
+        double v = Xq[0][k];
+#pragma unroll
+        for (int q = 1; q <= BA_MAXSETS; q++) v = (st.cur == q) ? Xq[q][k] : v;
+        X[k] = v;
+    }
     double t[3] = {0, 0, 0};
     ObsLin o;
     for (int j = sub, r = 0; j < nobs; j += 4, r++) {
@@ -125,7 +142,7 @@ __global__ __launch_bounds__(K8_THREADS) void ba_backsub_cost4(BaDims d, BaBufs 
     if (threadIdx.x < 4) {       // one atomic per workgroup and scalar, spread over BA_NSLOT lines
         double v = 0.0;
         for (int w = 0; w < K8_THREADS / 64; w++) v += redw[w][threadIdx.x];
-        atomicAdd(&b.pt_scal[(size_t)(blockIdx.x & (BA_NSLOT - 1)) * BA_SLOT_STRIDE + threadIdx.x], v);
+        atomicAdd(&b.pt_scal[((size_t)set * BA_NSLOT + (blockIdx.x & (BA_NSLOT - 1))) * BA_SLOT_STRIDE + threadIdx.x], v);
     }
 }
 
@@ -136,5 +153,5 @@ size_t ba_backsub_lds_bytes(int C, int n)
 
 void ba_launch_backsub(hipStream_t s, const BaDims& d, const BaBufs& b)
 {
-    hipLaunchKernelGGL(ba_backsub_cost4, dim3((d.P + 63) / 64), dim3(K8_THREADS), ba_backsub_lds_bytes(d.C, d.n), s, d, b);
+    hipLaunchKernelGGL(ba_backsub_cost4, dim3((d.P + 63) / 64, b.ns), dim3(K8_THREADS), ba_backsub_lds_bytes(d.C, d.n), s, d, b);
 }

@@ -41,6 +41,8 @@ struct rs_context {
     // per-iteration record of the last rs_bundle_adjust (points into the pinned block; rs_ba_get_trace)
     const void* ba_trace = nullptr;
     int ba_trace_n = 0;
+    // speculative trust-region radii per BA round (0 = library default; rs_context_set_int "ba_speculative_sets")
+    int ba_sets = 0;
     // proposal table of rs_reproj_match: persistent, always left at all-ones by the accept tail
     unsigned long long* prop = nullptr;
     size_t prop_cap = 0;

@@ -2,6 +2,7 @@
 // communicator of librsgpu.so.
 #include <dlfcn.h>
 #include <stdarg.h>
+#include <stdlib.h>
 
 #include "common.h"
 
@@ -39,6 +40,7 @@ extern "C" int rs_context_create(int device_id, rs_context** out)
     }
     rs_context* c = new rs_context();
     c->device = device_id;
+    if (const char* e = getenv("RS_BA_SETS")) { const int v = atoi(e); if (v >= 1 && v <= 3) c->ba_sets = v; }
     *out = c;
     return RS_OK;
 }
@@ -65,6 +67,17 @@ extern "C" int rs_context_set_stream(rs_context* ctx, void* s)
     if (!ctx) return RS_ERR_INVALID;
     ctx->stream = (hipStream_t)s;
     return RS_OK;
+}
+
+extern "C" int rs_context_set_int(rs_context* ctx, const char* name, int value)
+{
+    if (!ctx || !name) return RS_ERR_INVALID;
+    if (strcmp(name, "ba_speculative_sets") == 0) {
+        if (value < 0 || value > 3) return rs_fail(ctx, RS_ERR_INVALID, "ba_speculative_sets must be 0 (default) .. 3");
+        ctx->ba_sets = value;
+        return RS_OK;
+    }
+    return rs_fail(ctx, RS_ERR_INVALID, "unknown option %s", name);
 }
 
 extern "C" int rs_context_synchronize(rs_context* ctx)

@@ -14,7 +14,7 @@ LIB_PATH = os.path.join(_HERE, "librsgpu.so")
 
 EXPORTS = [
     "rs_abi_version", "rs_context_create", "rs_context_destroy", "rs_context_set_stream",
-    "rs_context_synchronize", "rs_last_error", "rs_hamming_knn2", "rs_match_descriptors",
+    "rs_context_synchronize", "rs_context_set_int", "rs_last_error", "rs_hamming_knn2", "rs_match_descriptors",
     "rs_kdtree_build", "rs_reproj_match", "rs_triangulate", "rs_triangulate_matches", "rs_triangulate_matches_batch", "rs_triangulate_tracks", "rs_point_errors", "rs_ba_default_options",
     "rs_bundle_adjust", "rs_ba_get_trace", "rs_refine_pose", "rs_pack_pose", "rs_unpack_pose", "rs_build_local_window",
     "rs_comm_get_unique_id", "rs_comm_init_rank", "rs_comm_destroy", "rs_prof_begin", "rs_prof_end", "rs_prof_counters",
@@ -164,6 +164,9 @@ class Context:
 
     def use_stream(self, stream):
         self._check(self.lib.rs_context_set_stream(self.h, C.c_void_p(stream.cuda_stream)), "set_stream")
+
+    def set_int(self, name, value):
+        self._check(self.lib.rs_context_set_int(self.h, name.encode(), int(value)), "rs_context_set_int")
 
     def close(self):
         if self.h:

@@ -532,7 +532,7 @@ def test_bundle_adjust_free_camera_without_observations(ctx, oracle, synth):
     _, _, _, otr = oracle.bundle_adjust_trace(w2["cams"], w2["cam_free"], w2["points"], w2["obs_ptr"], w2["obs_cam"],
                                                w2["obs_uv"], w2["K"])
     assert [t["outcome"] for t in tr] == [t["outcome"] for t in otr]
-    assert np.allclose([t["x_norm"] for t in tr], [t["x_norm"] for t in otr], rtol=1e-9)   # |x| ~ 1e3 if it were counted
+    assert np.allclose([t["x_norm"] for t in tr], [t["x_norm"] for t in otr], rtol=1e-6)   # would be >= 1e3 from the first iteration if it were counted
 
 
 def test_bundle_adjust_cfg3_trace(ctx, oracle, synth):
@@ -549,6 +549,39 @@ def test_bundle_adjust_cfg3_trace(ctx, oracle, synth):
     for k, tol in (("radius", 1e-7), ("cost", 1e-9), ("candidate_cost", 1e-8), ("model_cost_change", 1e-6),
                    ("step_norm", 1e-6), ("x_norm", 1e-9)):
         assert np.allclose([t[k] for t in tr], [t[k] for t in otr], rtol=tol), k
+
+
+@pytest.mark.parametrize("kw", [dict(), dict(n_kf=8, n_points=150, run_max=5, config_id=36, outlier_frac=0.1, rot_noise_deg=2.0),
+                                dict(n_kf=5, n_points=100, run_max=5, config_id=48, outlier_frac=0.15, rot_noise_deg=1.0),
+                                dict(n_kf=12, n_points=3000, run_max=8, config_id=19, outlier_frac=0.06)])
+def test_bundle_adjust_speculative_radii_do_not_change_the_schedule(ctx, rs, oracle, synth, kw):
+    """Speculative radii (1, 2 or 3 trust-region radii evaluated per round) only change how many
+    launches a solve takes: per-iteration outcomes, radii, costs and the result are those of the sequential loop
+    (ns = 1) and of the oracle, whatever the accept / reject pattern (cfg 3: A R R R R A R R A A)."""
+    w = synth.make_ba_window(**kw)
+    args = (w["cam_free"],)
+    runs = {}
+    try:
+        for ns in (1, 2, 3):
+            ctx.set_int("ba_speculative_sets", ns)
+            dc, dp = ctx.dev(w["cams"]), ctx.dev(w["points"])
+            s = ctx.bundle_adjust(dc, w["cam_free"], dp, ctx.dev(w["obs_ptr"]), ctx.dev(w["obs_cam"]), ctx.dev(w["obs_uv"]), w["K"])
+            runs[ns] = (s, ctx.ba_trace(), to_np(dc), to_np(dp))
+    finally:
+        ctx.set_int("ba_speculative_sets", 0)
+    _, _, os_, otr = oracle.bundle_adjust_trace(w["cams"], w["cam_free"], w["points"], w["obs_ptr"], w["obs_cam"], w["obs_uv"], w["K"])
+    s1, t1, c1, p1 = runs[1]
+    for ns in (1, 2, 3):
+        s, tr, c, p = runs[ns]
+        assert (s["iterations"], s["successful_steps"], s["termination"], s["usable"]) == \
+               (os_["iterations"], os_["successful_steps"], os_["termination"], os_["usable"]), ns
+        assert [t["outcome"] for t in tr] == [t["outcome"] for t in otr], ns
+        assert np.allclose([t["radius"] for t in tr], [t["radius"] for t in otr], rtol=1e-7), ns
+        # (costs of far-off REJECTED candidates amplify the 1e-12 differences of the step: 2e-8 observed)
+        assert np.allclose([t["candidate_cost"] for t in tr], [t["candidate_cost"] for t in otr], rtol=1e-6), ns
+        assert np.isclose(s["final_cost"], s1["final_cost"], rtol=1e-10), ns
+        assert np.allclose(c, c1, rtol=1e-9, atol=1e-11) and np.allclose(p, p1, rtol=1e-9, atol=1e-10), ns
+    del args
 
 
 def test_bundle_adjust_through_rccl_single_rank(ctx, rs, synth):
