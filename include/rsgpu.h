@@ -277,6 +277,16 @@ int rs_point_errors(rs_context* ctx, int n_points, const float* d_positions /*[P
                     uint8_t* d_cull /*[P]*/, int32_t* d_cull_idx /*[P]*/, int32_t* d_cull_count /*[1]*/,
                     double* d_sums /*[2]*/);
 
+/* The tail of Mapper::bundle_adjust (reference src/Mapper.cpp:366-393): single-observation points are excluded from
+ * the optimisation (MIN_OBSERVATIONS_TO_OPTIMIZE, src/Optimization.cpp:98) and afterwards moved rigidly with the
+ * free frame that observes them:  X' = R_after^T ((R_before X + t_before) - t_after), in f32.
+ * Entry i moves point d_point_idx[i] (NULL = point i) of d_positions [.][3] with frame d_frame_idx[i];
+ * d_poses_before / d_poses_after [n_frames][16] are Frame::pose() before and after rs_bundle_adjust.  A point must
+ * be listed at most once (it has one observation). */
+int rs_reanchor_points(rs_context* ctx, int n, const int32_t* d_point_idx, const int32_t* d_frame_idx,
+                       const float* d_poses_before, const float* d_poses_after, int n_frames,
+                       float* d_positions);
+
 /* ----------------------------------------------------- a9-a13: optimisation */
 
 typedef enum rs_ba_termination {
@@ -358,6 +368,15 @@ typedef struct rs_ba_iteration {
     double reserved1;
 } rs_ba_iteration;
 int rs_ba_get_trace(rs_context* ctx, rs_ba_iteration* h_out, int capacity, int* h_count);
+/* The cameras as rs_bundle_adjust left them in d_cameras, from a pinned-memory mirror the last kernel of the solve
+ * wrote: no device read-back, no synchronisation.  The reference keeps poses in host objects (Frame::set_pose after
+ * unpack_pose, src/Optimization.cpp:363-368); the shim calls this, then rs_unpack_poses.  n_cameras must be the
+ * solve's.  Valid until the next optimisation call on the context. */
+int rs_ba_get_cameras(rs_context* ctx, double* h_cameras /*[n_cameras][6]*/, int n_cameras);
+/* Launch accounting of the last rs_bundle_adjust: h_out[0] = rounds that did work (one K5 + K7 + K8 each),
+ * [1] = rounds that relinearised (the others only re-damped after a rejected step), [2] = speculative sets
+ * evaluated in total (= LM steps solved for, >= iterations), [3] = rounds enqueued by the host. */
+int rs_ba_get_stats(rs_context* ctx, int h_out[4]);
 
 /* optimization::refine_pose (src/Optimization.cpp:194-267), vision-only:
  * the same residual with the points held constant, 6 unknowns.
@@ -373,6 +392,9 @@ int rs_refine_pose(rs_context* ctx, double h_camera[6],
  * centre = -R^T t (src/Frame.cpp:39-42), widened to f64; and back. */
 void rs_pack_pose(const float h_pose[16], double h_camera[6]);
 void rs_unpack_pose(const double h_camera[6], float h_pose[16]);
+/* the loops around them (src/Optimization.cpp:273-282, 363-368); h_mask (NULL = all) selects the frames written */
+void rs_pack_poses(const float* h_poses /*[n][16]*/, int n, double* h_cameras /*[n][6]*/);
+void rs_unpack_poses(const double* h_cameras /*[n][6]*/, int n, const uint8_t* h_mask /*[n] or NULL*/, float* h_poses /*[n][16]*/);
 
 /* ------------------------------------------------------- a8: local window */
 
@@ -401,6 +423,12 @@ int rs_build_local_window(int n_key_frames, int new_frame, int window_size, int 
 int rs_comm_get_unique_id(uint8_t h_id[RS_COMM_ID_BYTES]);
 int rs_comm_init_rank(rs_context* ctx, const uint8_t h_id[RS_COMM_ID_BYTES], int n_ranks, int rank);
 int rs_comm_destroy(rs_context* ctx);
+/* The same exchange step WITHOUT RCCL for n <= 8 contexts of one process (one host thread each, each with its own
+ * stream, on one device or on peer-accessible devices): context i becomes rank i of an in-process group whose
+ * all-reduce is a deterministic on-device sum in rank order.  Every member must then make the same sequence of
+ * rs_bundle_adjust calls, each from its own thread.  Used to run landmark shards side by side on one GPU and to
+ * test the N > 1 path on a one-GPU box.  rs_comm_destroy on every member releases the group. */
+int rs_comm_init_local(rs_context** ctxs, int n);
 
 /* ------------------------------------------------------------- profiling */
 

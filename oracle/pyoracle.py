@@ -51,6 +51,41 @@ def use_all_cores(on=True):
     return _LIB
 
 
+def cpu_model():
+    """(model name, logical CPUs, a short tag that names baseline builds after the host CPU)."""
+    import hashlib
+    model, flags = "unknown", ""
+    try:
+        with open("/proc/cpuinfo") as fh:
+            for line in fh:
+                if line.startswith("model name") and model == "unknown":
+                    model = line.split(":", 1)[1].strip()
+                elif line.startswith("flags") and not flags:
+                    flags = line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    tag = hashlib.sha1((model + flags).encode()).hexdigest()[:10]
+    return model, os.cpu_count() or 1, tag
+
+
+def use_baseline(kind):
+    """bench.py only: switch the binding to a CPU-BASELINE build of the same sources (never used by tests):
+    "fast"  = gcc -O3 -march=native, serial;  "fast_omp" = the same + OpenMP over queries / points / landmark
+    blocks; None = back to the checker (liboracle.so, -O2, portable).  -march=native code is built on the
+    machine that runs it: the file name carries a hash of the host CPU's model and flags."""
+    global _LIB
+    if kind is None:
+        _LIB = None
+        return lib()
+    assert kind in ("fast", "fast_omp")
+    so = os.path.join(_HERE, f"liboracle_{kind}_{cpu_model()[2]}.so")
+    srcs = [os.path.join(_HERE, f) for f in os.listdir(_HERE) if f.endswith((".c", ".h"))]
+    if not os.path.exists(so) or any(os.path.getmtime(x) > os.path.getmtime(so) for x in srcs):
+        subprocess.check_call(["make", "-C", _HERE, "-B", kind, "FAST_OUT=" + os.path.basename(so)], stdout=subprocess.DEVNULL)
+    _LIB = C.CDLL(so)
+    return _LIB
+
+
 def _p(a, t):
     return None if a is None else a.ctypes.data_as(t)
 
@@ -274,6 +309,16 @@ def point_errors(positions, obs_ptr, obs_pose, obs_uv, poses, K, max_mean_error=
     assert rc == 0
     return dict(mean_err=mean[:n], cull=cull[:n], cull_idx=idx[:int(cnt[0])].copy(), err_sum=float(sums[0]),
                 n_obs=int(sums[1]))
+
+
+def reanchor_points(point_idx, frame_idx, before, after, positions):
+    pos = np.array(positions, np.float32, order="C")
+    fi = np.ascontiguousarray(frame_idx, np.int32)
+    pi = None if point_idx is None else np.ascontiguousarray(point_idx, np.int32)
+    rc = lib().orc_reanchor_points(len(fi), _p(pi, i32p), _p(fi, i32p), _p(np.ascontiguousarray(before, np.float32), f32p),
+                                   _p(np.ascontiguousarray(after, np.float32), f32p), _p(pos, f32p))
+    assert rc == 0
+    return pos
 
 
 def null_vector4(A):

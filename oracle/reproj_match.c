@@ -16,6 +16,8 @@
 #include <math.h>
 #include <stdlib.h>
 
+#include <string.h>
+
 #include "rs_oracle.h"
 
 #define SEARCH_RADIUS 20.0f            /* src/MapMatcher.cpp:12 */
@@ -36,9 +38,11 @@ static void normalize3(float* v)
 
 static int hamming256(const uint8_t* a, const uint8_t* b)
 {
-    int d = 0;
-    for (int i = 0; i < 32; i++) d += __builtin_popcount((unsigned)(a[i] ^ b[i]));
-    return d;
+    uint64_t x[4], y[4];
+    memcpy(x, a, 32);
+    memcpy(y, b, 32);
+    return __builtin_popcountll(x[0] ^ y[0]) + __builtin_popcountll(x[1] ^ y[1]) +
+           __builtin_popcountll(x[2] ^ y[2]) + __builtin_popcountll(x[3] ^ y[3]);
 }
 
 int orc_reproj_match(const orc_frame_view* f, const orc_map_view* m, int replace,
@@ -66,10 +70,22 @@ int orc_reproj_match(const orc_frame_view* f, const orc_map_view* m, int replace
         KP[2 * 4 + j] = (0.0f * T[0 * 4 + j] + 0.0f * T[1 * 4 + j]) + 1.0f * T[2 * 4 + j];
     }
 
+    /* Per-point work first (independent: the all-cores baseline build runs it in parallel), then the per-keypoint
+     * proposal table in MAP ORDER (:95-97), which is what makes the result order dependent. */
+    int32_t* raw_kp = (int32_t*)malloc(sizeof(int32_t) * 2 * (size_t)(P > 0 ? P : 1));
+    int32_t* raw_d = raw_kp + (P > 0 ? P : 1);
+#ifdef ORC_OMP
+#pragma omp parallel
+#endif
+    {
     int32_t* cand = (int32_t*)malloc(sizeof(int32_t) * (size_t)(N > 0 ? N : 1));
+#ifdef ORC_OMP
+#pragma omp for schedule(static, 64)
+#endif
     for (int p = 0; p < P; p++) {
         point_kp[p] = -1;
         point_dist[p] = max_distance;
+        raw_kp[p] = -1;
         if (!m->eligible[p]) continue;            /* :53, :169, :121-123 folded by the caller */
         const float* X = m->positions + 3 * (size_t)p;
         /* Camera::project, src/Camera.cpp:25-32 */
@@ -119,12 +135,18 @@ int orc_reproj_match(const orc_frame_view* f, const orc_map_view* m, int replace
             }
         }
         if (best_d < max_distance) { point_kp[p] = best_kp; point_dist[p] = best_d; }
-        if (best_d < prop_dist[best_kp]) {                                  /* :95-97 */
-            prop_point[best_kp] = p;
-            prop_dist[best_kp] = best_d;
-        }
+        raw_kp[p] = best_kp; raw_d[p] = best_d;
     }
     free(cand);
+    }
+    for (int p = 0; p < P; p++) {
+        if (raw_kp[p] < 0) continue;
+        if (raw_d[p] < prop_dist[raw_kp[p]]) {                              /* :95-97 */
+            prop_point[raw_kp[p]] = p;
+            prop_dist[raw_kp[p]] = raw_d[p];
+        }
+    }
+    free(raw_kp);
     /* accepted_matches, :34-43 */
     int count = 0;
     for (int i = 0; i < N; i++) {

@@ -90,6 +90,8 @@ int orc_point_errors(int n_points, const float* positions, const int32_t* obs_pt
                      const float* obs_uv, const float* poses, int n_poses, const float intrinsics[4],
                      float max_mean_error, float* mean_err, uint8_t* cull, int32_t* cull_idx, int32_t* cull_count,
                      double sums[2]);
+int orc_reanchor_points(int n, const int32_t* point_idx, const int32_t* frame_idx, const float* before,
+                        const float* after, float* positions);
 /* 4x4 f64 one-sided Jacobi SVD null vector (exposed for tests): v = right
  * singular vector of the smallest singular value of row-major A. */
 void orc_null_vector4(const double A[16], double v[4], double sigma[4]);

@@ -197,3 +197,23 @@ int orc_point_errors(int n_points, const float* positions, const int32_t* obs_pt
     *cull_count = nc;
     return 0;
 }
+
+/* The tail of Mapper::bundle_adjust, reference src/Mapper.cpp:380-393: a single-observation point keeps its place
+ * relative to the frame that observes it.  f32; 3-term dot products as (a0 b0 + a1 b1) + a2 b2. */
+int orc_reanchor_points(int n, const int32_t* point_idx, const int32_t* frame_idx, const float* before,
+                        const float* after, float* positions)
+{
+    for (int i = 0; i < n; i++) {
+        const int p = point_idx ? point_idx[i] : i;
+        const float* B = before + 16 * (size_t)frame_idx[i];
+        const float* A = after + 16 * (size_t)frame_idx[i];
+        float* X = positions + 3 * (size_t)p;
+        float c[3], d[3];
+        for (int r = 0; r < 3; r++) {
+            c[r] = ((B[4 * r] * X[0] + B[4 * r + 1] * X[1]) + B[4 * r + 2] * X[2]) + B[4 * r + 3];   /* :389 */
+            d[r] = c[r] - A[4 * r + 3];
+        }
+        for (int r = 0; r < 3; r++) X[r] = (A[r] * d[0] + A[4 + r] * d[1]) + A[8 + r] * d[2];        /* :390 */
+    }
+    return 0;
+}

@@ -143,7 +143,10 @@ int orc_triangulate(const float* uv1, const float* uv2, int n, const float* pose
     *out_count = 0;
     if (n <= 0) return 0;                                   /* src/Triangulation.cpp:46-48 */
     if (n_poses < 2 && !(pose_idx1 && pose_idx2)) return 1;
-    int count = 0;
+    /* per-correspondence work (independent; parallel in the all-cores baseline build), ordered compaction after */
+#ifdef ORC_OMP
+#pragma omp parallel for schedule(static, 64)
+#endif
     for (int i = 0; i < n; i++) {
         const float* T1 = poses + 16 * (size_t)(pose_idx1 ? pose_idx1[i] : 0);
         const float* T2 = poses + 16 * (size_t)(pose_idx2 ? pose_idx2[i] : 1);
@@ -198,8 +201,12 @@ int orc_triangulate(const float* uv1, const float* uv2, int n, const float* pose
         if (err1 > max_reprojection_error || err2 > max_reprojection_error) continue;  /* :97-100 */
 
         keep[i] = 1;
+    }
+    int count = 0;
+    for (int i = 0; i < n; i++) {
+        if (!keep[i]) continue;
         out_index[count] = i;                                                /* :102 */
-        out_xyz[3 * count + 0] = X[0]; out_xyz[3 * count + 1] = X[1]; out_xyz[3 * count + 2] = X[2];
+        out_xyz[3 * count + 0] = xyz[3 * i + 0]; out_xyz[3 * count + 1] = xyz[3 * i + 1]; out_xyz[3 * count + 2] = xyz[3 * i + 2];
         count++;
     }
     *out_count = count;

@@ -61,6 +61,7 @@ __global__ void ba_init(BaDims d, BaBufs b, BaOpt opt, const double* __restrict_
         s.iter = 0; s.successful = 0; s.invalid_steps = 0; s.done = 0;
         s.termination = 0; s.cur = 0; s.have_scale = 0; s.solver_failed = 0;
         s.fresh = 1; s.usable = 0; s.consec_accepts = 0; s.nact = 1;
+        s.n_rounds = 0; s.n_fresh = 0; s.n_sets = 0; s.pad = 0;
         b.st[1] = s;      // the state iteration 0 starts from (st[(0 + 1) & 1])
     }
 }
@@ -419,12 +420,12 @@ __global__ __launch_bounds__(BA_THREADS) void ba_backsub_cost(BaDims d, BaBufs b
 // -------------------------------------------------------------------- finalize
 __global__ void ba_finalize(BaDims d, BaBufs b, BaOpt opt, int it, double* __restrict__ cams_out,
                             const uint8_t* __restrict__ cam_free, double* __restrict__ pts_out, BaState* host_st,
-                            BaTrace* host_trace)
+                            BaTrace* host_trace, double* __restrict__ host_cams)
 {
     __shared__ int usable, cur;
     __shared__ BaState st_fin;
     // the decisions of the last round (every workgroup recomputes them; b.st_prev / b.pt_prev are immutable here)
-    if (threadIdx.x < 64) ba_decide(b, opt, it, blockIdx.x == 0 ? b.trace : nullptr, &st_fin);
+    if (threadIdx.x < 64) ba_decide(b, opt, it, blockIdx.x == 0 ? b.trace : nullptr, &st_fin, false);
     __syncthreads();
     if (threadIdx.x == 0) {
         BaState st = st_fin;
@@ -446,10 +447,13 @@ __global__ void ba_finalize(BaDims d, BaBufs b, BaOpt opt, int it, double* __res
         double* dst = (double*)host_trace;
         for (int i = threadIdx.x; i < ne; i += blockDim.x) dst[i] = src[i];
     }
-    if (!usable) return;
     const int tid = blockIdx.x * blockDim.x + threadIdx.x, nth = gridDim.x * blockDim.x;
     const double* Xc = b.Xc + (size_t)cur * d.C * 6;
     const double* Xp = b.Xp + (size_t)cur * d.P * 3;
+    // the cameras as the caller will see them in d_cameras, mirrored into pinned host memory: poses are host-owned
+    // objects in the reference (Frame::set_pose, src/Optimization.cpp:363-368), so the shim needs them there anyway
+    for (int i = tid; i < d.C * 6; i += nth) host_cams[i] = (usable && cam_free[i / 6]) ? Xc[i] : cams_out[i];
+    if (!usable) return;
     for (int i = tid; i < d.C * 6; i += nth)
         if (cam_free[i / 6]) cams_out[i] = Xc[i];
     for (int i = tid; i < d.P * 3; i += nth) pts_out[i] = Xp[i];
@@ -549,7 +553,7 @@ extern "C" int rs_bundle_adjust(rs_context* ctx, int n_cameras, int n_points, in
     const size_t o_lamp = carve(sizeof(double) * ns * P * 3);
     const size_t o_Vc = carve(sizeof(double) * P * 6), o_Ukeep = carve(sizeof(double) * ((size_t)d.Cf * 36 + n + 1));
     const size_t cam_stride = (size_t)ns * n + (size_t)d.Cf * 36 + n;
-    const size_t n_ranks = ctx->comm ? (size_t)ctx->n_ranks : 1;
+    const size_t n_ranks = rs_comm_active(ctx) ? (size_t)ctx->n_ranks : 1;
     const size_t acc_count = (size_t)ns * n * n + (size_t)BA_UREP * cam_stride + (1 + n_ranks) * (size_t)BA_NSLOT * BA_SLOT_STRIDE;
     const size_t o_acc = carve(sizeof(double) * acc_count);
     const size_t pts_block = (size_t)ns * BA_NSLOT * BA_SLOT_STRIDE;
@@ -576,7 +580,7 @@ extern "C" int rs_bundle_adjust(rs_context* ctx, int n_cameras, int n_points, in
     b.S = b.acc; b.rhs = b.S + (size_t)ns * n * n; b.U = b.rhs + (size_t)ns * n; b.gc = b.U + (size_t)d.Cf * 36;
     b.cam_stride = cam_stride; b.scal = b.rhs + (size_t)BA_UREP * cam_stride;
     b.gmax_all = b.scal + (size_t)BA_NSLOT * BA_SLOT_STRIDE; b.gmax_blocks = (int)n_ranks;
-    b.gmax = b.gmax_all + (size_t)(ctx->comm ? ctx->rank : 0) * BA_NSLOT * BA_SLOT_STRIDE;
+    b.gmax = b.gmax_all + (size_t)(rs_comm_active(ctx) ? ctx->rank : 0) * BA_NSLOT * BA_SLOT_STRIDE;
     b.pt_scal = (double*)(ws + o_pts); b.dc = (double*)(ws + o_dc);
     b.st = (BaState*)(ws + o_st);
     b.trace = (BaTrace*)(ws + o_trace);
@@ -595,8 +599,11 @@ extern "C" int rs_bundle_adjust(rs_context* ctx, int n_cameras, int n_points, in
     void* pin = nullptr;
     const size_t pin_prog = align_up(sizeof(BaState) + sizeof(int32_t) * C + C, 64);
     const size_t pin_trace = pin_prog + 64;
-    rc = rs_pinned(ctx, pin_trace + sizeof(BaTrace) * (size_t)(opt.max_iter + 1), &pin);
+    const size_t pin_cams = pin_trace + sizeof(BaTrace) * (size_t)(opt.max_iter + 1);
+    rc = rs_pinned(ctx, pin_cams + sizeof(double) * 6 * C, &pin);
     if (rc) return rc;
+    ctx->ba_cams = nullptr;
+    ctx->ba_cams_n = 0;
     BaProgress* h_prog = (BaProgress*)((char*)pin + pin_prog);
     h_prog->round = 0; h_prog->done = 0; h_prog->iter = 0;
     b.prog = ns > 1 ? h_prog : nullptr;
@@ -659,7 +666,7 @@ extern "C" int rs_bundle_adjust(rs_context* ctx, int n_cameras, int n_points, in
             rs_prof_scope ps(ctx, "K5_ba_linearize_schur");
             hipLaunchKernelGGL(ba_linearize_schur, dim3(pblocks), dim3(BA_THREADS), k5_lds, s, d, b, opt, it);
         }
-        if (ctx->comm) {
+        if (rs_comm_active(ctx)) {
             rs_prof_scope ps(ctx, "C1_allreduce_system");
             // one SUM all-reduce: S | 8 x {rhs, U, gc} | cost / failure slots | every rank's gradient-max block
             int rc2 = rs_allreduce_f64(ctx, b.acc, b.acc_count, false);
@@ -683,7 +690,7 @@ extern "C" int rs_bundle_adjust(rs_context* ctx, int n_cameras, int n_points, in
             rs_prof_scope ps(ctx, "K8_ba_backsub_cost_global");
             hipLaunchKernelGGL(ba_backsub_cost, dim3(pblocks), dim3(BA_THREADS), 0, s, d, b);
         }
-        if (ctx->comm) {
+        if (rs_comm_active(ctx)) {
             rs_prof_scope ps(ctx, "C2_allreduce_cost");
             int rc2 = rs_allreduce_f64(ctx, b.pt_scal, pts_block, false);
             if (rc2) return rc2;
@@ -717,7 +724,8 @@ extern "C" int rs_bundle_adjust(rs_context* ctx, int n_cameras, int n_points, in
         b.pt_prev = pts_base + (size_t)((itf + 1) & 1) * pts_block;
         b.set_prev = set_base + (size_t)((itf + 1) & 1) * BA_MAXSETS;
         b.prog = nullptr;
-        hipLaunchKernelGGL(ba_finalize, dim3(32), dim3(256), 0, s, d, b, opt, itf, d_cameras, (const uint8_t*)d_cam_free, d_points, h_st, h_trace);
+        hipLaunchKernelGGL(ba_finalize, dim3(32), dim3(256), 0, s, d, b, opt, itf, d_cameras, (const uint8_t*)d_cam_free, d_points, h_st, h_trace,
+                           (double*)((char*)pin + pin_cams));
     }
     RS_HIP(ctx, hipStreamSynchronize(s));        // ba_finalize wrote the state block into the pinned h_st
     RS_HIP(ctx, hipGetLastError());
@@ -730,6 +738,10 @@ extern "C" int rs_bundle_adjust(rs_context* ctx, int n_cameras, int n_points, in
     h_summary->final_radius = h_st->radius;
     ctx->ba_trace = h_trace;            // stays valid until the next call that uses the pinned block
     ctx->ba_trace_n = h_st->iter;
+    ctx->ba_stats[0] = h_st->n_rounds; ctx->ba_stats[1] = h_st->n_fresh; ctx->ba_stats[2] = h_st->n_sets;
+    ctx->ba_stats[3] = rounds;
+    ctx->ba_cams = (const double*)((char*)pin + pin_cams);
+    ctx->ba_cams_n = n_cameras;
     return RS_OK;
 }
 
@@ -742,6 +754,21 @@ extern "C" int rs_ba_get_trace(rs_context* ctx, rs_ba_iteration* h_out, int capa
     const int m = n < capacity ? n : capacity;
     if (m > 0) memcpy(h_out, ctx->ba_trace, sizeof(rs_ba_iteration) * (size_t)m);
     *h_count = n;
+    return RS_OK;
+}
+
+extern "C" int rs_ba_get_cameras(rs_context* ctx, double* h_cameras, int n_cameras)
+{
+    if (!ctx || !h_cameras || n_cameras < 0) return RS_ERR_INVALID;
+    if (!ctx->ba_cams || n_cameras != ctx->ba_cams_n) return rs_fail(ctx, RS_ERR_INVALID, "no bundle adjustment result of %d cameras on this context", n_cameras);
+    memcpy(h_cameras, ctx->ba_cams, sizeof(double) * 6 * (size_t)n_cameras);
+    return RS_OK;
+}
+
+extern "C" int rs_ba_get_stats(rs_context* ctx, int h_out[4])
+{
+    if (!ctx || !h_out) return RS_ERR_INVALID;
+    for (int i = 0; i < 4; i++) h_out[i] = ctx->ba_stats[i];
     return RS_OK;
 }
 
@@ -783,6 +810,7 @@ __global__ __launch_bounds__(RP_THREADS) void ba_refine_pose(BaDims d, BaOpt opt
         st.radius = opt.r0; st.decrease_factor = 2.0; st.x_cost = 0.0; st.initial_cost = 0.0;
         st.iter = 0; st.successful = 0; st.invalid_steps = 0; st.done = 0; st.termination = 0; st.cur = 0;
         st.have_scale = 0; st.solver_failed = 0; st.fresh = 1; st.usable = 0; st.consec_accepts = 0; st.nact = 1;
+        st.n_rounds = 0; st.n_fresh = 0; st.n_sets = 0; st.pad = 0;
     }
     __syncthreads();
     double acc[28];
@@ -953,6 +981,8 @@ extern "C" int rs_refine_pose(rs_context* ctx, double h_camera[6], const double*
     rc = rs_pinned(ctx, 512, &pin);
     if (rc) return rc;
     ctx->ba_trace_n = 0;                 // the pinned block is reused: the last BA's record is gone
+    ctx->ba_cams = nullptr;
+    ctx->ba_cams_n = 0;
     double* h_cam = (double*)pin;
     BaState* h_st = (BaState*)((char*)pin + 256);
     memcpy(h_cam, h_camera, 6 * sizeof(double));

@@ -24,6 +24,7 @@ struct BaState {
     int fresh, usable;
     int consec_accepts;       // successful steps in a row (drives how many radii the next round speculates on)
     int nact;                 // sets evaluated by THIS round (1 .. ns)
+    int n_rounds, n_fresh, n_sets, pad;   // accounting: rounds that did work, of those relinearised, sets evaluated
 };
 
 // Speculative radii.  After a REJECTED step Ceres does not relinearise: x stays, the radius becomes
@@ -313,7 +314,8 @@ __device__ __forceinline__ double slot_max_bits(const double* base)
 // The decisions of the previous round, applied by the first wave of a workgroup (threadIdx.x < 64): the sets are
 // walked in order — set k is LM iteration (iter + k) of the sequential loop — until a step is accepted or the
 // loop terminates.  Lane 0 leaves the resulting state in *out.
-__device__ __forceinline__ void ba_decide(const BaBufs& b, const BaOpt& opt, int it, BaTrace* trace, BaState* out)
+__device__ __forceinline__ void ba_decide(const BaBufs& b, const BaOpt& opt, int it, BaTrace* trace, BaState* out,
+                                          bool count_round = true)
 {
     double ps[BA_MAXSETS][4];
 #pragma unroll
@@ -348,6 +350,7 @@ __device__ __forceinline__ void ba_decide(const BaBufs& b, const BaOpt& opt, int
         // and a step after two successful ones in a row are most likely accepted — extra sets would be wasted
         // work in K5 — so those rounds evaluate one radius only.
         s.nact = (it == 0 || s.consec_accepts >= 2) ? 1 : b.ns;
+        if (!s.done && count_round) { s.n_rounds++; s.n_fresh += s.fresh; s.n_sets += s.nact; }
         *out = s;
     }
 }

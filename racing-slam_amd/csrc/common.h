@@ -36,11 +36,16 @@ struct rs_context {
     void* comm = nullptr;
     int n_ranks = 1;
     int rank = 0;
+    // in-process group of contexts (rs_comm_init_local): the same exchange step without RCCL
+    struct rs_local_group* local = nullptr;
     // cached BA graph / buffers live in ba.hip
     void* ba_cache = nullptr;
     // per-iteration record of the last rs_bundle_adjust (points into the pinned block; rs_ba_get_trace)
     const void* ba_trace = nullptr;
     int ba_trace_n = 0;
+    int ba_stats[4] = {0, 0, 0, 0};     // rs_ba_get_stats
+    const double* ba_cams = nullptr;    // cameras after the last rs_bundle_adjust, mirrored in the pinned block
+    int ba_cams_n = 0;
     // speculative trust-region radii per BA round (0 = library default; rs_context_set_int "ba_speculative_sets")
     int ba_sets = 0;
     // proposal table of rs_reproj_match: persistent, always left at all-ones by the accept tail
@@ -94,6 +99,8 @@ __device__ __forceinline__ int rs_block_exclusive_scan(int v, int* total)
     return pre + x - v;
 }
 
-// comm.hip: sum / max all-reduce of f64 on the context stream (no-op when n_ranks == 1)
+// sum all-reduce of f64 on the context stream over the attached communicator (RCCL or the in-process group);
+// no-op without one
 int rs_allreduce_f64(rs_context* ctx, double* d_buf, size_t count, bool is_max);
+static inline bool rs_comm_active(const rs_context* ctx) { return ctx->comm != nullptr || ctx->local != nullptr; }
 

@@ -112,6 +112,8 @@ int rs_pinned(rs_context* ctx, size_t bytes, void** out)
         ctx->pinned = nullptr;
         ctx->ba_trace = nullptr;
         ctx->ba_trace_n = 0;
+        ctx->ba_cams = nullptr;
+        ctx->ba_cams_n = 0;
         size_t want = bytes < 4096 ? 4096 : bytes;
         if (hipHostMalloc(&ctx->pinned, want, hipHostMallocDefault) != hipSuccess)
             return rs_fail(ctx, RS_ERR_NOMEM, "pinned buffer of %zu bytes", want);
@@ -255,11 +257,111 @@ extern "C" int rs_comm_init_rank(rs_context* ctx, const uint8_t id[RS_COMM_ID_BY
     return RS_OK;
 }
 
+// ------------------------------------------------------- in-process group
+// Several contexts of ONE process (one host thread each, own stream, same or peer-accessible device) form a group
+// whose exchange step needs no RCCL: the landmark-sharded BA then runs, for instance, as two shards on one GPU.
+// The all-reduce is a deterministic sum in rank order (every member computes the identical result, as the
+// redundant reduced solves require):
+//   record "my buffer is ready" -> host barrier -> every stream waits for all ready events -> each member sums all
+//   buffers into its own scratch -> record "I have read" -> host barrier -> wait for all -> scratch -> buffer.
+#include <condition_variable>
+#include <mutex>
+#define RS_LOCAL_MAX 8
+struct rs_local_group {
+    int n = 0;
+    int refs = 0;
+    std::mutex m;
+    std::condition_variable cv;
+    int arrived = 0;
+    unsigned long generation = 0;
+    double* buf[RS_LOCAL_MAX] = {};
+    hipEvent_t ready[RS_LOCAL_MAX] = {}, read_done[RS_LOCAL_MAX] = {};
+    double* scratch[RS_LOCAL_MAX] = {};
+    size_t scratch_cap[RS_LOCAL_MAX] = {};
+};
+
+static void local_barrier(rs_local_group* g)
+{
+    std::unique_lock<std::mutex> lk(g->m);
+    const unsigned long gen = g->generation;
+    if (++g->arrived == g->n) { g->arrived = 0; g->generation++; g->cv.notify_all(); }
+    else g->cv.wait(lk, [&] { return g->generation != gen; });
+}
+
+struct LocalBufs { double* p[RS_LOCAL_MAX]; };
+__global__ void rs_local_sum(LocalBufs b, int n, size_t count, double* __restrict__ out)
+{
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (size_t)gridDim.x * blockDim.x) {
+        double v = 0.0;
+        for (int r = 0; r < n; r++) v += b.p[r][i];
+        out[i] = v;
+    }
+}
+
+static int local_allreduce(rs_context* ctx, double* d_buf, size_t count)
+{
+    rs_local_group* g = ctx->local;
+    const int r = ctx->rank;
+    if (count > g->scratch_cap[r]) {
+        if (g->scratch[r]) RS_HIP(ctx, hipFree(g->scratch[r]));
+        g->scratch[r] = nullptr;
+        RS_HIP(ctx, hipMalloc(&g->scratch[r], sizeof(double) * count));
+        g->scratch_cap[r] = count;
+    }
+    g->buf[r] = d_buf;
+    RS_HIP(ctx, hipEventRecord(g->ready[r], ctx->stream));
+    local_barrier(g);
+    LocalBufs lb;
+    for (int q = 0; q < RS_LOCAL_MAX; q++) lb.p[q] = q < g->n ? g->buf[q] : nullptr;
+    for (int q = 0; q < g->n; q++)
+        if (q != r) RS_HIP(ctx, hipStreamWaitEvent(ctx->stream, g->ready[q], 0));
+    const int blocks = (int)((count + 255) / 256 < 512 ? (count + 255) / 256 : 512);
+    hipLaunchKernelGGL(rs_local_sum, dim3(blocks), dim3(256), 0, ctx->stream, lb, g->n, count, g->scratch[r]);
+    RS_HIP(ctx, hipEventRecord(g->read_done[r], ctx->stream));
+    local_barrier(g);
+    for (int q = 0; q < g->n; q++)
+        if (q != r) RS_HIP(ctx, hipStreamWaitEvent(ctx->stream, g->read_done[q], 0));
+    RS_HIP(ctx, hipMemcpyAsync(d_buf, g->scratch[r], sizeof(double) * count, hipMemcpyDeviceToDevice, ctx->stream));
+    return RS_OK;
+}
+
+extern "C" int rs_comm_init_local(rs_context** ctxs, int n)
+{
+    if (!ctxs || n < 1 || n > RS_LOCAL_MAX) return RS_ERR_INVALID;
+    for (int i = 0; i < n; i++)
+        if (!ctxs[i] || rs_comm_active(ctxs[i])) return RS_ERR_INVALID;
+    rs_local_group* g = new rs_local_group();
+    g->n = n;
+    g->refs = n;
+    for (int i = 0; i < n; i++) {
+        RS_HIP(ctxs[i], hipSetDevice(ctxs[i]->device));
+        RS_HIP(ctxs[i], hipEventCreateWithFlags(&g->ready[i], hipEventDisableTiming));
+        RS_HIP(ctxs[i], hipEventCreateWithFlags(&g->read_done[i], hipEventDisableTiming));
+        ctxs[i]->local = g;
+        ctxs[i]->n_ranks = n;
+        ctxs[i]->rank = i;
+    }
+    return RS_OK;
+}
+
 extern "C" int rs_comm_destroy(rs_context* ctx)
 {
     if (!ctx) return RS_ERR_INVALID;
     if (ctx->comm && g_rccl.destroy) g_rccl.destroy(ctx->comm);
     ctx->comm = nullptr;
+    if (ctx->local) {
+        rs_local_group* g = ctx->local;
+        const int r = ctx->rank;
+        (void)hipSetDevice(ctx->device);
+        (void)hipStreamSynchronize(ctx->stream);
+        if (g->scratch[r]) (void)hipFree(g->scratch[r]);
+        (void)hipEventDestroy(g->ready[r]);
+        (void)hipEventDestroy(g->read_done[r]);
+        bool last;
+        { std::lock_guard<std::mutex> lk(g->m); last = --g->refs == 0; }
+        if (last) delete g;
+        ctx->local = nullptr;
+    }
     ctx->n_ranks = 1;
     ctx->rank = 0;
     return RS_OK;
@@ -267,6 +369,7 @@ extern "C" int rs_comm_destroy(rs_context* ctx)
 
 int rs_allreduce_f64(rs_context* ctx, double* d_buf, size_t count, bool is_max)
 {
+    if (ctx->local) return is_max ? rs_fail(ctx, RS_ERR_UNSUPPORTED, "max over the in-process group") : local_allreduce(ctx, d_buf, count);
     if (!ctx->comm) return RS_OK;     // a 1-rank communicator still goes through RCCL (exercised by the tests)
     // ncclFloat64 = 8, ncclSum = 0, ncclMax = 2
     int e = g_rccl.allreduce(d_buf, d_buf, count, 8, is_max ? 2 : 0, ctx->comm, ctx->stream);

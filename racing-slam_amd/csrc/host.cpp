@@ -72,6 +72,19 @@ extern "C" void rs_pack_pose(const float T[16], double cam[6])
     }
 }
 
+// The loops around pack_pose / unpack_pose in bundle_adjust (reference src/Optimization.cpp:273-282, 363-368):
+// `mask` (may be NULL) selects the frames, like FrameConfig::optimize on write-back.
+extern "C" void rs_unpack_pose(const double cam[6], float T[16]);
+extern "C" void rs_pack_poses(const float* h_poses, int n, double* h_cameras)
+{
+    for (int i = 0; i < n; i++) rs_pack_pose(h_poses + 16 * (size_t)i, h_cameras + 6 * (size_t)i);
+}
+extern "C" void rs_unpack_poses(const double* h_cameras, int n, const uint8_t* h_mask, float* h_poses)
+{
+    for (int i = 0; i < n; i++)
+        if (!h_mask || h_mask[i]) rs_unpack_pose(h_cameras + 6 * (size_t)i, h_poses + 16 * (size_t)i);
+}
+
 // unpack_pose, reference src/Optimization.cpp:151-159 (rodrigues_to_matrix :100-105)
 extern "C" void rs_unpack_pose(const double cam[6], float T[16])
 {
@@ -151,13 +164,25 @@ extern "C" int rs_build_local_window(int n_key_frames, int new_frame, int window
     std::vector<uint8_t> role((size_t)n + 1, kOutside);
     role[self] = kWindow;                                                          // :16
     for (int i = first_optimized; i < n; i++) role[i] = kWindow;                  // :17-19
-    for (int f = 0; f <= n; f++) {                                                 // :21-30
-        if (role[f] != kWindow) continue;
-        for (int a = frame_ptr[f]; a < frame_ptr[f + 1]; a++) {
-            const int p = frame_pt[a];
-            for (int o = pt_ptr[p]; o < pt_ptr[p + 1]; o++) {
-                uint8_t& r = role[pt_obs[o]];
-                if (r == kOutside) r = kAnchor;
+    // :21-30.  The reference walks (window frame, matched point, observer) triples; the result is a SET of observers,
+    // so every point needs to be visited once only, and the walk can stop when no key frame is left outside.
+    int outside = 0;
+    for (int i = 0; i < n; i++) outside += role[i] == kOutside ? 1 : 0;
+    if (outside > 0) {
+        int n_pts = 0;
+        for (int f = 0; f <= n; f++)
+            for (int a = frame_ptr[f]; a < frame_ptr[f + 1]; a++) n_pts = frame_pt[a] >= n_pts ? frame_pt[a] + 1 : n_pts;
+        std::vector<uint8_t> seen((size_t)n_pts, 0);
+        for (int f = 0; f <= n && outside > 0; f++) {
+            if (role[f] != kWindow) continue;
+            for (int a = frame_ptr[f]; a < frame_ptr[f + 1] && outside > 0; a++) {
+                const int p = frame_pt[a];
+                if (seen[p]) continue;
+                seen[p] = 1;
+                for (int o = pt_ptr[p]; o < pt_ptr[p + 1]; o++) {
+                    uint8_t& r = role[pt_obs[o]];
+                    if (r == kOutside) { r = kAnchor; outside--; }
+                }
             }
         }
     }

@@ -266,3 +266,51 @@ extern "C" int rs_point_errors(rs_context* ctx, int n_points, const float* d_pos
     RS_HIP(ctx, hipGetLastError());
     return RS_OK;
 }
+
+// ---------------------------------------------------------------------- K13
+// The tail of Mapper::bundle_adjust (reference src/Mapper.cpp:380-393): points with a single observation were not
+// optimised; they are carried along rigidly with the frame that observes them,
+//     in_camera = R_before X + t_before;   X' = R_after^T (in_camera - t_after)          (all f32)
+// One lane per listed point.  f32 operation order as everywhere in this library: a 3-term dot product is
+// (a0 b0 + a1 b1) + a2 b2 (Eigen's own order is unspecified upstream).
+__global__ __launch_bounds__(256) void k13_reanchor(int n, const int32_t* __restrict__ point_idx,
+                                                    const int32_t* __restrict__ frame_idx,
+                                                    const float* __restrict__ before, const float* __restrict__ after,
+                                                    float* __restrict__ pos)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int p = point_idx ? point_idx[i] : i;
+    float B[16], A[16];
+    load_pose(before, frame_idx[i], B);
+    load_pose(after, frame_idx[i], A);
+    const float X[3] = {pos[3 * (size_t)p], pos[3 * (size_t)p + 1], pos[3 * (size_t)p + 2]};
+    float c[3], d[3];
+#pragma unroll
+    for (int r = 0; r < 3; r++) {
+        c[r] = ((B[4 * r] * X[0] + B[4 * r + 1] * X[1]) + B[4 * r + 2] * X[2]) + B[4 * r + 3];     // :389
+        d[r] = c[r] - A[4 * r + 3];
+    }
+#pragma unroll
+    for (int r = 0; r < 3; r++)                                                                       // :390
+        pos[3 * (size_t)p + r] = (A[r] * d[0] + A[4 + r] * d[1]) + A[8 + r] * d[2];
+}
+
+extern "C" int rs_reanchor_points(rs_context* ctx, int n, const int32_t* d_point_idx, const int32_t* d_frame_idx,
+                                  const float* d_poses_before, const float* d_poses_after, int n_frames,
+                                  float* d_positions)
+{
+    if (!ctx) return RS_ERR_INVALID;
+    if (n < 0 || n_frames < 0) return rs_fail(ctx, RS_ERR_INVALID, "negative size");
+    if (n == 0) return RS_OK;
+    if (!d_frame_idx || !d_poses_before || !d_poses_after || !d_positions) return rs_fail(ctx, RS_ERR_INVALID, "null pointer");
+    if (((uintptr_t)d_poses_before | (uintptr_t)d_poses_after) & 15) return rs_fail(ctx, RS_ERR_INVALID, "poses must be 16-byte aligned");
+    RS_HIP(ctx, hipSetDevice(ctx->device));
+    {
+        rs_prof_scope ps(ctx, "K13_reanchor");
+        hipLaunchKernelGGL(k13_reanchor, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, n, d_point_idx, d_frame_idx,
+                           d_poses_before, d_poses_after, d_positions);
+    }
+    RS_HIP(ctx, hipGetLastError());
+    return RS_OK;
+}

@@ -16,8 +16,8 @@ EXPORTS = [
     "rs_abi_version", "rs_context_create", "rs_context_destroy", "rs_context_set_stream",
     "rs_context_synchronize", "rs_context_set_int", "rs_last_error", "rs_hamming_knn2", "rs_match_descriptors",
     "rs_kdtree_build", "rs_reproj_match", "rs_triangulate", "rs_triangulate_matches", "rs_triangulate_matches_batch", "rs_triangulate_tracks", "rs_point_errors", "rs_ba_default_options",
-    "rs_bundle_adjust", "rs_ba_get_trace", "rs_refine_pose", "rs_pack_pose", "rs_unpack_pose", "rs_build_local_window",
-    "rs_comm_get_unique_id", "rs_comm_init_rank", "rs_comm_destroy", "rs_prof_begin", "rs_prof_end", "rs_prof_counters",
+    "rs_bundle_adjust", "rs_ba_get_trace", "rs_ba_get_stats", "rs_ba_get_cameras", "rs_reanchor_points", "rs_refine_pose", "rs_pack_pose", "rs_unpack_pose", "rs_pack_poses", "rs_unpack_poses", "rs_build_local_window",
+    "rs_comm_get_unique_id", "rs_comm_init_rank", "rs_comm_destroy", "rs_comm_init_local", "rs_prof_begin", "rs_prof_end", "rs_prof_counters",
 ]
 
 _lib = None
@@ -115,6 +115,16 @@ def unpack_pose(cam):
     p = np.zeros(16, np.float32)
     load().rs_unpack_pose(c.ctypes.data_as(C.c_void_p), p.ctypes.data_as(C.c_void_p))
     return p.reshape(4, 4)
+
+
+def unpack_poses(cams, mask, out):
+    """In place: out [n][16] f32 rows of the frames selected by mask [n] u8 (None = all) are rewritten."""
+    c = np.ascontiguousarray(cams, np.float64)
+    assert out.dtype == np.float32 and out.flags.c_contiguous and out.size == 16 * len(c)
+    m = None if mask is None else np.ascontiguousarray(mask, np.uint8)
+    load().rs_unpack_poses(c.ctypes.data_as(C.c_void_p), len(c), None if m is None else m.ctypes.data_as(C.c_void_p),
+                           out.ctypes.data_as(C.c_void_p))
+    return out
 
 
 def kdtree_build(keypoints):
@@ -356,6 +366,24 @@ class Context:
         self._check(self.lib.rs_ba_get_trace(self.h, buf, cap, C.byref(n)), "rs_ba_get_trace")
         return [buf[i].as_dict() for i in range(min(n.value, cap))]
 
+    def ba_cameras(self, out):
+        """Cameras after the last bundle_adjust from the pinned mirror (no device read-back); out [C][6] f64."""
+        assert out.dtype == np.float64 and out.flags.c_contiguous
+        self._check(self.lib.rs_ba_get_cameras(self.h, out.ctypes.data_as(C.c_void_p), int(out.shape[0])), "rs_ba_get_cameras")
+        return out
+
+    def ba_stats(self):
+        buf = (C.c_int * 4)()
+        self._check(self.lib.rs_ba_get_stats(self.h, buf), "rs_ba_get_stats")
+        return dict(rounds=buf[0], fresh_rounds=buf[1], set_evaluations=buf[2], rounds_enqueued=buf[3])
+
+    def reanchor_points(self, d_point_idx, d_frame_idx, d_before, d_after, d_positions):
+        """Mapper::bundle_adjust's tail (src/Mapper.cpp:380-393); d_positions [P][3] f32 is updated in place."""
+        n = int(d_frame_idx.shape[0])
+        self._check(self.lib.rs_reanchor_points(self.h, n, None if d_point_idx is None else _dp(d_point_idx),
+                                                _dp(d_frame_idx), _dp(d_before), _dp(d_after), int(d_before.shape[0]),
+                                                _dp(d_positions)), "rs_reanchor_points")
+
     def refine_pose(self, cam, d_points, d_uv, K, options=None):
         cam = np.array(cam, np.float64, order="C")
         Kc = (C.c_float * 4)(*[float(v) for v in K])
@@ -378,6 +406,14 @@ class Context:
     def comm_init(self, uid, n_ranks, rank):
         buf = (C.c_uint8 * 128).from_buffer_copy(uid)
         self._check(self.lib.rs_comm_init_rank(self.h, buf, int(n_ranks), int(rank)), "rs_comm_init_rank")
+
+    @staticmethod
+    def comm_init_local(contexts):
+        """In-process group: contexts[i] becomes rank i (see rs_comm_init_local)."""
+        arr = (C.c_void_p * len(contexts))(*[c.h for c in contexts])
+        rc = load().rs_comm_init_local(arr, len(contexts))
+        if rc:
+            raise RsError(f"rs_comm_init_local -> {rc}")
 
     def comm_destroy(self):
         self._check(self.lib.rs_comm_destroy(self.h), "rs_comm_destroy")

@@ -498,3 +498,36 @@ def test_build_local_window(oracle, rs, n_kf, window, new_in, fix):
     assert list(zip(of.tolist(), oo.tolist())) == exp
     lf, lo = rs.build_local_window(n_kf, new_frame, window, fix, fptr, fpt, pptr, pobs)
     assert np.array_equal(lf, of) and np.array_equal(lo, oo)
+
+
+def test_reanchor_points_vs_numpy(oracle, rs, synth):
+    """The tail of Mapper::bundle_adjust (src/Mapper.cpp:380-393) against a float32 numpy restatement, and the
+    batched pose helpers of the library against the single-pose ones."""
+    rng = np.random.default_rng(5)
+    w = synth.make_ba_window(n_kf=6, n_points=50, run_max=4)
+    before = np.stack([rs.unpack_pose(c) for c in w["cams"]]).astype(np.float32)
+    after = np.stack([rs.unpack_pose(c) for c in w["cams_true"]]).astype(np.float32)
+    n = 300
+    fi = rng.integers(0, 6, n).astype(np.int32)
+    X = rng.normal(0, 5, (n, 3)).astype(np.float32)
+    out = oracle.reanchor_points(None, fi, before.reshape(-1, 16), after.reshape(-1, 16), X)
+    for i in range(n):
+        B, A = before[fi[i]], after[fi[i]]
+        c = (B[:3, :3].astype(np.float64) @ X[i].astype(np.float64) + B[:3, 3]).astype(np.float32)
+        ref = A[:3, :3].T.astype(np.float64) @ (c - A[:3, 3]).astype(np.float64)
+        assert np.allclose(out[i], ref, rtol=2e-6, atol=2e-6)
+    # identity when nothing moved
+    same = oracle.reanchor_points(None, fi, before.reshape(-1, 16), before.reshape(-1, 16), X)
+    assert np.allclose(same, X, atol=5e-6)
+    # index list form
+    idx = rng.permutation(n)[:100].astype(np.int32)
+    part = oracle.reanchor_points(idx, fi[idx], before.reshape(-1, 16), after.reshape(-1, 16), X)
+    assert np.array_equal(part[idx], out[idx])
+    rest = np.setdiff1d(np.arange(n), idx)
+    assert np.array_equal(part[rest], X[rest])
+    # rs_unpack_poses == rs_unpack_pose per frame, masked
+    mask = (np.arange(6) % 2).astype(np.uint8)
+    buf = np.zeros((6, 16), np.float32)
+    rs.unpack_poses(w["cams"], mask, buf)
+    for c in range(6):
+        assert np.array_equal(buf[c], rs.unpack_pose(w["cams"][c]).reshape(16) if mask[c] else np.zeros(16, np.float32))
