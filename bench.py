@@ -254,6 +254,27 @@ def finish(e, args, line):
         e.dist.destroy_process_group()
 
 
+def boundary_timings(reps=30):
+    """The CALLER's cost per interface call (host objects in -> host results out) through the C++ host mirror, i.e.
+    what the replaced translation units of INTEGRATION.md pay including flattening the pointer graph, the staging-pool
+    upload and the read-back.  `value` never includes this (inputs resident); it is reported beside it."""
+    import subprocess
+    exe = os.path.join(ROOT, "tests", "host_cpp", "bench_boundary.bin")
+    if not os.path.exists(exe):
+        return {"error": "tests/host_cpp/bench_boundary.bin not built (run __graft_entry__.build())"}
+    try:
+        r = subprocess.run([exe, str(reps)], capture_output=True, text=True, timeout=300)
+        lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+        if r.returncode != 0 or not lines:
+            return {"error": "bench_boundary.bin failed", "stderr": r.stderr[-400:], "stdout": r.stdout[-400:]}
+        out = json.loads(lines[-1])
+        out["what"] = ("end-to-end microseconds per call of the host mirror (racing-slam_amd/host/slam_host.cpp) on a 20-KF / "
+                       "2000-keypoint scene: marshal + upload (staging pool) + kernels + read-back; median / p10 / p90")
+        return out
+    except Exception as ex:      # noqa: BLE001
+        return {"error": repr(ex)}
+
+
 # =============================================================================================== pass
 def build_pass(e):
     """Inputs of one pass, resident in HBM, and the closures that run it on the GPU and on the CPU."""
@@ -396,6 +417,9 @@ def bench_pass(e, args):
         roofline = dict(roofline, timing="hip events per launch on the library stream, %d instrumented passes" % args.steps,
                         traffic_source=pmc_file, traffic_matches_kernel_sources=pmc_fresh)
 
+    boundary = None
+    if e.rank == 0 and e.world == 1 and args.boundary:
+        boundary = boundary_timings()
     cpu = None
     if e.rank == 0 and e.world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline(cpu_pass, 1.0, "passes/s", "full passes of the same workload (all stages incl. both "
@@ -420,6 +444,7 @@ def bench_pass(e, args):
         "per_kernel_launches_per_pass": {k: v["launches"] / max(args.steps, 1) for k, v in sorted(per_kernel.items())},
         "ba_summary": meta["last"].get("ba"), "ba_rounds": stats,
         "roofline_all": rl,
+        "boundary": boundary,
     }
     finish(e, args, line)
 
@@ -585,6 +610,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--config", default="pass", choices=["pass", "cfg2", "cfg3", "cfg4", "cfg5"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-boundary", dest="boundary", action="store_false",
+                    help="skip the end-to-end interface timings (tests/host_cpp/bench_boundary.bin) of --config pass")
     ap.add_argument("--cpu-seconds", type=float, default=25.0, help="time budget of the CPU baseline leg")
     args = ap.parse_args()
     e = setup(args)

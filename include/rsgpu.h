@@ -73,6 +73,24 @@ int rs_context_synchronize(rs_context* ctx);
 int rs_context_set_int(rs_context* ctx, const char* name, int value);
 const char* rs_last_error(const rs_context* ctx);
 
+/* ------------------------------------------------------------ staging pool */
+
+/* What a drop-in translation unit does around every entry point below: upload a few freshly flattened host arrays,
+ * get device scratch for the outputs, read some results back.  The pool is two grow-only bump allocators (device and
+ * pinned host memory) per context; copies are asynchronous on the context stream.  Typical shim body:
+ *     rs_stage_begin(ctx);                                    // recycles the pool (waits for copies still in flight)
+ *     rs_stage_upload(ctx, h_desc, bytes, (void**)&d_desc);   // host -> pinned -> device, async
+ *     rs_stage_alloc(ctx, out_bytes, (void**)&d_out);         // device scratch
+ *     rs_xxx(ctx, d_desc, ..., d_out);                        // kernels, same stream
+ *     rs_stage_download(ctx, d_out, out_bytes, h_out);        // device -> pinned, async
+ *     rs_stage_sync(ctx);                                     // one synchronisation; h_out is filled on return
+ * Device pointers obtained from the pool are valid until the next rs_stage_begin on the context. */
+int rs_stage_begin(rs_context* ctx);
+int rs_stage_alloc(rs_context* ctx, size_t bytes, void** d_out);
+int rs_stage_upload(rs_context* ctx, const void* h_src, size_t bytes, void** d_out);
+int rs_stage_download(rs_context* ctx, const void* d_src, size_t bytes, void* h_dst);
+int rs_stage_sync(rs_context* ctx);
+
 /* --------------------------------------------------- a4: match_descriptors */
 
 /* Brute-force 2-nearest-neighbour search under 256-bit Hamming distance.

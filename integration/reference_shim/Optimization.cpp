@@ -1,9 +1,13 @@
 // Drop-in replacement of the reference's src/Optimization.cpp (keeps src/Optimization.h).
-// NOT COMPILED IN THIS REPO; see rs_shim_common.h.  Vision-only: when InertialInput::usable() or an
-// InertialConstraint is set the IMU residual blocks (src/Optimization.cpp:237-258,317-346) are not
-// yet supported by the GPU solver — the shim then logs and returns false, and
-// pose_graph (a14) is left to the reference's own Ceres implementation (keep that function from the
-// original file).
+// Compiled only in the reference's tree; syntax-checked here, see rs_shim_common.h.
+//  * Vision-only: when InertialInput::usable() or an InertialConstraint is set, the IMU residual blocks
+//    (src/Optimization.cpp:237-258,317-346) are not yet supported by the GPU solver — the shim
+//    logs and returns false (nothing written), like a rejected solve.
+//  * pose_graph (a14, src/Optimization.cpp:376-639) is DEFINED here as the documented stub SURVEY.md §8 a14 allows:
+//    it logs and returns false.  The only caller (Slam::step, src/Slam.cpp:259-283) then records
+//    `loop_closed = false` and skips fuse_loop and the fix_oldest bundle adjustment: loop candidates are detected
+//    but not applied.  A project that needs loop closure keeps the reference's Ceres implementation of this one
+//    function (move it into a file of its own); it does not touch the accelerated path.
 #include "Optimization.h"
 
 #include <unordered_map>
@@ -19,11 +23,7 @@ namespace slam::optimization {
 namespace {
 constexpr size_t MIN_OBSERVATIONS_TO_OPTIMIZE = 2;
 
-void intrinsics(const Camera& camera, float K[4])
-{
-    const Eigen::Matrix3f& M = camera.get_intrinsic_matrix();
-    K[0] = M(0, 0); K[1] = M(1, 1); K[2] = M(0, 2); K[3] = M(1, 2);
-}
+void intrinsics(const Camera& camera, float K[4]) { rs_shim::intrinsics(camera.get_intrinsic_matrix(), K); }
 
 bool report(const char* what, const rs_ba_summary& s)
 {
@@ -54,6 +54,7 @@ bool refine_pose(Frame& frame, const Camera& camera, const InertialConstraint& i
     pose_to_row_major(frame.pose(), T);
     rs_pack_pose(T, cam);
     intrinsics(camera, K);
+    Stage stage;
     DevBuf<double> dp(pts);
     DevBuf<float> duv(uv);
     rs_ba_summary s{};
@@ -107,6 +108,7 @@ bool bundle_adjust(const std::vector<FrameConfig>& frames, const Camera& camera,
     if (P == 0 || obs_cam.empty()) return false;
     float K[4];
     intrinsics(camera, K);
+    Stage stage;
     DevBuf<double> dc(cams), dp(pts);
     DevBuf<int32_t> dptr(obs_ptr), dcam(obs_cam);
     DevBuf<float> duv(obs_uv);
@@ -115,8 +117,10 @@ bool bundle_adjust(const std::vector<FrameConfig>& frames, const Camera& camera,
                              nullptr, &s), "rs_bundle_adjust"))
         return false;
     if (!report("bundle_adjust", s)) return false;
-    const auto hc = dc.download(6 * C);
-    const auto hp = dp.download(3 * P);
+    std::vector<double> hc(6 * C);
+    if (!ok(rs_ba_get_cameras(context(), hc.data(), (int)C), "rs_ba_get_cameras")) return false;   // pinned mirror, no read-back
+    const auto hp = dp.fetch(3 * P);
+    stage.sync();
     for (size_t c = 0; c < C; c++)
         if (frames[c].optimize) {
             float T[16];
@@ -127,6 +131,14 @@ bool bundle_adjust(const std::vector<FrameConfig>& frames, const Camera& camera,
     return true;
 }
 
-// pose_graph(...): keep the reference's implementation (src/Optimization.cpp:376-639) in this file.
+// a14: documented stub (see the header of this file).  Returning false is the reference's own "rejected" outcome
+// (src/Optimization.cpp:612-615): nothing is moved, the caller carries on without the loop correction.
+bool pose_graph(const std::vector<std::shared_ptr<KeyFrame>>& key_frames, const std::vector<PoseGraphConstraint>& loops, Map&,
+                bool four_dof, const Eigen::Vector3d&)
+{
+    std::printf("Pose graph %s not run: not part of the GPU drop-in (%zu key frames, %zu loops); loop not applied\n",
+                four_dof ? "4-DOF" : "SE3", key_frames.size(), loops.size());
+    return false;
+}
 
 }  // namespace slam::optimization

@@ -1,5 +1,5 @@
 // Drop-in replacement of the reference's src/Triangulation.cpp (keeps src/Triangulation.h).
-// NOT COMPILED IN THIS REPO; see rs_shim_common.h.
+// Compiled only in the reference's tree; syntax-checked here, see rs_shim_common.h.
 #include "Triangulation.h"
 
 #include "Frame.h"
@@ -38,25 +38,26 @@ std::vector<TriangulatedPoint> triangulate_points(const std::vector<Eigen::Vecto
     for (size_t i = 0; i < n; i++) { uv1[2 * i] = points1[i].x(); uv1[2 * i + 1] = points1[i].y(); uv2[2 * i] = points2[i].x(); uv2[2 * i + 1] = points2[i].y(); }
     pose_to_row_major(pose1, poses.data());
     pose_to_row_major(pose2, poses.data() + 16);
-    const Eigen::Matrix3f& Km = camera.get_intrinsic_matrix();
-    const float K[4] = {Km(0, 0), Km(1, 1), Km(0, 2), Km(1, 2)};
+    float K[4];
+    intrinsics(camera.get_intrinsic_matrix(), K);
+    Stage stage;
     DevBuf<float> d1(uv1), d2(uv2), dp(poses), xyz(3 * n), oxyz(3 * n);
     DevBuf<uint8_t> keep(n);
     DevBuf<int32_t> oidx(n), cnt(1);
     if (!ok(rs_triangulate(context(), d1.p, d2.p, (int)n, dp.p, 2, nullptr, nullptr, K, min_parallax_cosine, max_reprojection_error,
                            xyz.p, keep.p, oidx.p, oxyz.p, cnt.p), "rs_triangulate"))
         return {};
-    rs_context_synchronize(context());
-    const int m = cnt.download(1)[0];
-    const auto hi = oidx.download(m);
-    const auto hx = oxyz.download(3 * (size_t)m);
+    const auto hm = cnt.fetch(1);
+    const auto hi = oidx.fetch(n);
+    const auto hx = oxyz.fetch(3 * n);
+    stage.sync();
     std::vector<TriangulatedPoint> out;
-    for (int i = 0; i < m; i++) out.push_back(TriangulatedPoint{Eigen::Vector3f(hx[3 * i], hx[3 * i + 1], hx[3 * i + 2]), hi[i]});
+    for (int i = 0; i < hm[0]; i++) out.push_back(TriangulatedPoint{Eigen::Vector3f(hx[3 * i], hx[3 * i + 1], hx[3 * i + 2]), hi[i]});
     return out;
 }
 
 }  // namespace slam::triangulation
-// Mapper::triangulate_tracks (src/Mapper.cpp:246-259) calls the function above once per track with
-// N = 1.  It keeps working unchanged; to get one launch per keyframe instead of <= 2000, gather the
-// tracks' (first sighting pixel, keyframe pixel, first pose) and call rs_triangulate once with
-// per-item pose indices (d_pose_idx1[i] = track's first pose, d_pose_idx2[i] = keyframe pose).
+// Mapper::triangulate_tracks (src/Mapper.cpp:246-259) calls the function above once per track with N = 1 (and
+// pose::recover_pose four times per frame).  That keeps working unchanged but costs one staging group + two launches +
+// one synchronisation per call (bench.py --config pass -> boundary.triangulate_points_n1); the one-launch-per-key-frame
+// form is Mapper_triangulate_tracks.inc in this directory.

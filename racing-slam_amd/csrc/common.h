@@ -19,6 +19,15 @@ struct rs_prof_slot {
     std::vector<hipEvent_t> ev;   // pairs (start, stop)
 };
 
+// grow-only bump arena (device or pinned host memory); slabs that became too small are retired and freed at the
+// next reset, after the stream has drained
+struct rs_arena {
+    char* base = nullptr;
+    size_t cap = 0, used = 0;
+    std::vector<void*> retired;
+};
+struct rs_pending_download { const void* pinned; void* user; size_t bytes; };
+
 struct rs_context {
     int device = 0;
     hipStream_t stream = nullptr;
@@ -29,6 +38,10 @@ struct rs_context {
     // pinned host scratch for small result read-back
     void* pinned = nullptr;
     size_t pinned_bytes = 0;
+    // staging pool of the boundary (rs_stage_*): inputs flattened by a shim travel host -> pinned -> device with
+    // asynchronous copies on the context stream; outputs come back the same way
+    rs_arena stage_dev, stage_pin;
+    std::vector<rs_pending_download> stage_down;
     // profiling
     bool prof_on = false;
     std::vector<rs_prof_slot> prof;

@@ -46,6 +46,7 @@ extern "C" int rs_context_create(int device_id, rs_context** out)
 }
 
 void rs_ba_cache_free(rs_context* ctx);
+static void arena_free(rs_arena& a, bool pinned);
 
 extern "C" int rs_context_destroy(rs_context* ctx)
 {
@@ -53,6 +54,8 @@ extern "C" int rs_context_destroy(rs_context* ctx)
     (void)hipSetDevice(ctx->device);
     rs_comm_destroy(ctx);
     rs_ba_cache_free(ctx);
+    arena_free(ctx->stage_dev, false);
+    arena_free(ctx->stage_pin, true);
     if (ctx->ws) (void)hipFree(ctx->ws);
     if (ctx->prop) (void)hipFree(ctx->prop);
     if (ctx->pinned) (void)hipHostFree(ctx->pinned);
@@ -120,6 +123,97 @@ int rs_pinned(rs_context* ctx, size_t bytes, void** out)
         ctx->pinned_bytes = want;
     }
     *out = ctx->pinned;
+    return RS_OK;
+}
+
+// ------------------------------------------------------------- staging pool
+// What a drop-in shim needs around every call: upload a handful of freshly flattened host arrays, get device scratch
+// for the outputs, read a few results back.  hipMalloc / hipFree per array (the first version of the shims) costs
+// tens of microseconds each and synchronises the device; here both sides are bump allocators over grow-only slabs
+// and every copy is asynchronous on the context stream.
+static int arena_take(rs_context* ctx, rs_arena& a, bool pinned, size_t bytes, void** out)
+{
+    const size_t need = (bytes + 255) & ~(size_t)255;
+    if (a.used + need > a.cap) {
+        size_t want = a.cap ? a.cap * 2 : (size_t)1 << 20;
+        while (want < a.used + need) want *= 2;
+        void* p = nullptr;
+        const hipError_t e = pinned ? hipHostMalloc(&p, want, hipHostMallocDefault) : hipMalloc(&p, want);
+        if (e != hipSuccess) return rs_fail(ctx, RS_ERR_NOMEM, "staging slab of %zu bytes", want);
+        if (a.base) a.retired.push_back(a.base);      // earlier takes of this group stay valid until the reset
+        a.base = (char*)p;
+        a.cap = want;
+        a.used = 0;
+    }
+    *out = a.base + a.used;
+    a.used += need;
+    return RS_OK;
+}
+
+static void arena_reset(rs_arena& a, bool pinned)
+{
+    for (void* p : a.retired) { if (pinned) (void)hipHostFree(p); else (void)hipFree(p); }
+    a.retired.clear();
+    a.used = 0;
+}
+
+static void arena_free(rs_arena& a, bool pinned)
+{
+    arena_reset(a, pinned);
+    if (a.base) { if (pinned) (void)hipHostFree(a.base); else (void)hipFree(a.base); }
+    a.base = nullptr;
+    a.cap = 0;
+}
+
+extern "C" int rs_stage_begin(rs_context* ctx)
+{
+    if (!ctx) return RS_ERR_INVALID;
+    RS_HIP(ctx, hipSetDevice(ctx->device));
+    if (ctx->stage_dev.used || ctx->stage_pin.used || !ctx->stage_down.empty())
+        RS_HIP(ctx, hipStreamSynchronize(ctx->stream));      // copies of the previous group may still be in flight
+    ctx->stage_down.clear();
+    arena_reset(ctx->stage_dev, false);
+    arena_reset(ctx->stage_pin, true);
+    return RS_OK;
+}
+
+extern "C" int rs_stage_alloc(rs_context* ctx, size_t bytes, void** d_out)
+{
+    if (!ctx || !d_out) return RS_ERR_INVALID;
+    return arena_take(ctx, ctx->stage_dev, false, bytes ? bytes : 1, d_out);
+}
+
+extern "C" int rs_stage_upload(rs_context* ctx, const void* h_src, size_t bytes, void** d_out)
+{
+    if (!ctx || !d_out || (bytes && !h_src)) return RS_ERR_INVALID;
+    int rc = arena_take(ctx, ctx->stage_dev, false, bytes ? bytes : 1, d_out);
+    if (rc || !bytes) return rc;
+    void* pin = nullptr;
+    rc = arena_take(ctx, ctx->stage_pin, true, bytes, &pin);
+    if (rc) return rc;
+    memcpy(pin, h_src, bytes);
+    RS_HIP(ctx, hipMemcpyAsync(*d_out, pin, bytes, hipMemcpyHostToDevice, ctx->stream));
+    return RS_OK;
+}
+
+extern "C" int rs_stage_download(rs_context* ctx, const void* d_src, size_t bytes, void* h_dst)
+{
+    if (!ctx || (bytes && (!d_src || !h_dst))) return RS_ERR_INVALID;
+    if (!bytes) return RS_OK;
+    void* pin = nullptr;
+    const int rc = arena_take(ctx, ctx->stage_pin, true, bytes, &pin);
+    if (rc) return rc;
+    RS_HIP(ctx, hipMemcpyAsync(pin, d_src, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    ctx->stage_down.push_back({pin, h_dst, bytes});
+    return RS_OK;
+}
+
+extern "C" int rs_stage_sync(rs_context* ctx)
+{
+    if (!ctx) return RS_ERR_INVALID;
+    RS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    for (const auto& d : ctx->stage_down) memcpy(d.user, d.pinned, d.bytes);
+    ctx->stage_down.clear();
     return RS_OK;
 }
 

@@ -20,33 +20,40 @@ void hip_ok(hipError_t e, const char* what)
     if (e != hipSuccess) throw std::runtime_error(std::string(what) + ": " + hipGetErrorString(e));
 }
 
+// Device arrays of one interface call, carved from the context's staging pool (rs_stage_*, include/rsgpu.h): no
+// hipMalloc / hipFree per call, uploads go host -> pinned -> device asynchronously on the context stream, results come
+// back with ONE synchronisation per call (fetch ... fetch, stage_sync).
+struct StageScope {
+    StageScope() { if (rs_stage_begin(Session::get().ctx()) != RS_OK) throw std::runtime_error("rs_stage_begin"); }
+};
+
 template <typename T>
 class DevBuf {
   public:
-    DevBuf() = default;
-    explicit DevBuf(size_t n) { resize(n); }
-    explicit DevBuf(const std::vector<T>& h) { upload(h); }
+    explicit DevBuf(size_t n) : m_n(n)
+    {
+        if (rs_stage_alloc(Session::get().ctx(), sizeof(T) * (n ? n : 1), (void**)&m_p) != RS_OK) throw std::runtime_error("rs_stage_alloc");
+    }
+    explicit DevBuf(const std::vector<T>& h) : m_n(h.size())
+    {
+        if (rs_stage_upload(Session::get().ctx(), h.data(), sizeof(T) * h.size(), (void**)&m_p) != RS_OK) throw std::runtime_error("rs_stage_upload");
+    }
     DevBuf(const DevBuf&) = delete;
     DevBuf& operator=(const DevBuf&) = delete;
-    ~DevBuf() { if (m_p) (void)hipFree(m_p); }
-    void resize(size_t n)
+    // registers an asynchronous read-back of the first n entries; the vector is filled by stage_sync()
+    std::vector<T> fetch(size_t n) const
     {
-        if (m_p) (void)hipFree(m_p);
-        m_p = nullptr;
-        m_n = n;
-        hip_ok(hipMalloc((void**)&m_p, sizeof(T) * (n ? n : 1)), "hipMalloc");
-    }
-    void upload(const std::vector<T>& h)
-    {
-        resize(h.size());
-        if (!h.empty()) hip_ok(hipMemcpy(m_p, h.data(), sizeof(T) * h.size(), hipMemcpyHostToDevice), "H2D");
+        std::vector<T> h(n);
+        if (n && rs_stage_download(Session::get().ctx(), m_p, sizeof(T) * n, h.data()) != RS_OK) throw std::runtime_error("rs_stage_download");
+        return h;           // moved out: the heap block registered above stays where it is
     }
     std::vector<T> download(size_t n) const
     {
-        std::vector<T> h(n);
-        if (n) hip_ok(hipMemcpy(h.data(), m_p, sizeof(T) * n, hipMemcpyDeviceToHost), "D2H");
+        std::vector<T> h = fetch(n);
+        stage_sync();
         return h;
     }
+    static void stage_sync() { if (rs_stage_sync(Session::get().ctx()) != RS_OK) throw std::runtime_error("rs_stage_sync"); }
     T* get() const { return m_p; }
     size_t size() const { return m_n; }
 
@@ -54,6 +61,7 @@ class DevBuf {
     T* m_p = nullptr;
     size_t m_n = 0;
 };
+inline void stage_sync() { DevBuf<int>::stage_sync(); }
 
 // The reference has no error codes: a failed C-ABI call is logged to stdout like the
 // reference logs, and the interface function returns "empty / false".  Nothing throws across it.
@@ -217,6 +225,7 @@ std::vector<MapPointMatch> MapMatcher::match(const Frame& frame, const std::vect
         }
         obs_ptr[p + 1] = (int32_t)obs_kf.size();
     }
+    StageScope stage;
     DevBuf<float> d_kp(kp), d_pos(pos), d_centers(centers);
     DevBuf<uint8_t> d_desc(frame.features().descriptors), d_matched(matched), d_elig(eligible), d_pool(pool);
     DevBuf<int32_t> d_nk(frame.kd_node_kp()), d_l(frame.kd_left()), d_r(frame.kd_right()), d_optr(obs_ptr), d_okf(obs_kf),
@@ -234,9 +243,10 @@ std::vector<MapPointMatch> MapMatcher::match(const Frame& frame, const std::vect
     if (!rs_ok(rs_reproj_match(ctx, &fv, &mv, replace ? 1 : 0, (int)m_max_descriptor_distance, pk.get(), pd.get(), pp.get(),
                                pdist.get(), mkp.get(), mpt.get(), cnt.get()), "rs_reproj_match"))
         return {};
-    rs_context_synchronize(ctx);
-    const int n = cnt.download(1)[0];
-    const auto hk = mkp.download((size_t)n), hp = mpt.download((size_t)n);
+    const auto hn = cnt.fetch(1);
+    const auto hk = mkp.fetch(N), hp = mpt.fetch(N);          // at most N matches: one read-back, one synchronisation
+    stage_sync();
+    const int n = hn[0];
     std::vector<MapPointMatch> out;
     for (int i = 0; i < n; i++) out.push_back(MapPointMatch{*points[(size_t)hp[i]], (size_t)hk[i]});
     return out;
@@ -254,14 +264,16 @@ std::vector<MapPointMatch> MapMatcher::match_descriptors(const Frame& frame, con
     }
     const int nq = (int)frame.features().keypoints.size(), nt = (int)km.size();
     if (nt == 0 || nq == 0) return {};                        // :139-141
+    StageScope stage;
     DevBuf<uint8_t> dq(frame.features().descriptors), dt(train);
     DevBuf<int32_t> mq((size_t)nq), mt((size_t)nq), cnt(1);
     if (!rs_ok(rs_match_descriptors(ctx, dq.get(), nq, dt.get(), nt, 1, (int)m_max_descriptor_distance, mq.get(), mt.get(),
                                     cnt.get(), nullptr, nullptr, nullptr, nullptr), "rs_match_descriptors"))
         return {};
-    rs_context_synchronize(ctx);
-    const int n = cnt.download(1)[0];
-    const auto hq = mq.download((size_t)n), ht = mt.download((size_t)n);
+    const auto hn = cnt.fetch(1);
+    const auto hq = mq.fetch((size_t)nq), ht = mt.fetch((size_t)nq);
+    stage_sync();
+    const int n = hn[0];
     std::vector<MapPointMatch> out;
     for (int i = 0; i < n; i++) out.push_back(MapPointMatch{km[(size_t)ht[i]].point, (size_t)hq[i]});   // :159-160
     return out;
@@ -292,6 +304,7 @@ std::vector<TriangulatedPoint> triangulate_points(const std::vector<Vec2f>& poin
     for (size_t i = 0; i < n; i++) { uv1[2 * i] = points1[i].x; uv1[2 * i + 1] = points1[i].y; uv2[2 * i] = points2[i].x; uv2[2 * i + 1] = points2[i].y; }
     std::memcpy(poses.data(), pose1.data(), 64);
     std::memcpy(poses.data() + 16, pose2.data(), 64);
+    StageScope stage;
     DevBuf<float> d1(uv1), d2(uv2), dp(poses), xyz(3 * n), oxyz(3 * n);
     DevBuf<uint8_t> keep(n);
     DevBuf<int32_t> oidx(n), cnt(1);
@@ -299,10 +312,11 @@ std::vector<TriangulatedPoint> triangulate_points(const std::vector<Vec2f>& poin
     if (!rs_ok(rs_triangulate(ctx, d1.get(), d2.get(), (int)n, dp.get(), 2, nullptr, nullptr, K, min_parallax_cosine,
                               max_reprojection_error, xyz.get(), keep.get(), oidx.get(), oxyz.get(), cnt.get()), "rs_triangulate"))
         return {};
-    rs_context_synchronize(ctx);
-    const int m = cnt.download(1)[0];
-    const auto hi = oidx.download((size_t)m);
-    const auto hx = oxyz.download(3 * (size_t)m);
+    const auto hm = cnt.fetch(1);
+    const auto hi = oidx.fetch(n);
+    const auto hx = oxyz.fetch(3 * n);
+    stage_sync();
+    const int m = hm[0];
     std::vector<TriangulatedPoint> out((size_t)m);
     for (int i = 0; i < m; i++) out[(size_t)i] = TriangulatedPoint{Vec3f{hx[3 * i], hx[3 * i + 1], hx[3 * i + 2]}, hi[(size_t)i]};
     return out;
@@ -346,6 +360,7 @@ Selection select_track_points(const KeyFrame& key_frame, const std::vector<Track
     const int kf_pose = (int)trajectory_poses.size();                                         // key_frame.pose(), :257
     std::memcpy(&poses[16 * (size_t)kf_pose], key_frame.pose().data(), 64);
     if (sight_pose.empty()) { sight_pose.push_back(0); sight_uv.resize(2); }
+    StageScope stage;
     DevBuf<float> d_tuv(track_uv), d_suv(sight_uv), d_poses(poses), d_xyz(3 * T), d_pc(T), d_rc(T);
     DevBuf<uint8_t> d_skip(skip), d_status(T);
     DevBuf<int32_t> d_sptr(sight_ptr), d_spose(sight_pose), d_acc(T), d_inc(T), d_cnt(3);
@@ -356,17 +371,19 @@ Selection select_track_points(const KeyFrame& key_frame, const std::vector<Track
                                      (int)min_new_points, d_status.get(), d_xyz.get(), d_pc.get(), d_rc.get(), d_acc.get(),
                                      d_inc.get(), d_cnt.get()), "rs_triangulate_tracks"))
         return out;
-    rs_context_synchronize(ctx);
-    const auto cnt = d_cnt.download(3);
-    const auto acc = d_acc.download((size_t)cnt[0]);
-    const auto inc = d_inc.download((size_t)cnt[2]);
-    const auto xyz = d_xyz.download(3 * T);
-    const auto pc = d_pc.download(T), rc = d_rc.download(T);
-    for (int32_t t : acc)
+    const auto cnt = d_cnt.fetch(3);
+    const auto acc = d_acc.fetch(T);
+    const auto inc = d_inc.fetch(T);
+    const auto xyz = d_xyz.fetch(3 * T);
+    const auto pc = d_pc.fetch(T), rc = d_rc.fetch(T);
+    stage_sync();
+    for (int i = 0; i < cnt[0]; i++) {
+        const int32_t t = acc[(size_t)i];
         out.accepted.push_back(Candidate{(size_t)t, Vec3f{xyz[3 * (size_t)t], xyz[3 * (size_t)t + 1], xyz[3 * (size_t)t + 2]},
                                          tracks[(size_t)t].keypoint_index, pc[(size_t)t], rc[(size_t)t]});
+    }
     out.topped_up = (size_t)cnt[1];
-    for (int32_t t : inc) out.inconsistent.push_back((size_t)t);
+    for (int i = 0; i < cnt[2]; i++) out.inconsistent.push_back((size_t)inc[(size_t)i]);
     return out;
 }
 
@@ -394,6 +411,7 @@ CullResult point_errors(const std::vector<MapPoint*>& points, const Camera& came
         obs_ptr[p + 1] = (int32_t)obs_pose.size();
     }
     if (obs_pose.empty()) { out.mean_error.assign(P, 0.0f); return out; }
+    StageScope stage;
     DevBuf<float> d_pos(pos), d_uv(uv), d_poses(poses), d_mean(P);
     DevBuf<int32_t> d_ptr(obs_ptr), d_op(obs_pose), d_idx(P), d_cnt(1);
     DevBuf<uint8_t> d_cull(P);
@@ -402,11 +420,12 @@ CullResult point_errors(const std::vector<MapPoint*>& points, const Camera& came
     if (!rs_ok(rs_point_errors(ctx, (int)P, d_pos.get(), d_ptr.get(), d_op.get(), d_uv.get(), d_poses.get(), (int)frames.size(), K,
                                max_mean_error, d_mean.get(), d_cull.get(), d_idx.get(), d_cnt.get(), d_sums.get()), "rs_point_errors"))
         return out;
-    rs_context_synchronize(ctx);
-    out.mean_error = d_mean.download(P);
-    const int n = d_cnt.download(1)[0];
-    for (int32_t i : d_idx.download((size_t)n)) out.to_remove.push_back((size_t)i);
-    const auto sums = d_sums.download(2);
+    out.mean_error = d_mean.fetch(P);
+    const auto hn = d_cnt.fetch(1);
+    const auto hidx = d_idx.fetch(P);
+    const auto sums = d_sums.fetch(2);
+    stage_sync();
+    for (int i = 0; i < hn[0]; i++) out.to_remove.push_back((size_t)hidx[(size_t)i]);
     out.error_sum = sums[0];
     out.observations = (size_t)sums[1];
     return out;
@@ -433,6 +452,7 @@ bool refine_pose(Frame& frame, const Camera& camera)
     if (uv.empty()) return false;                              // :227-229
     double cam[6];
     rs_pack_pose(frame.pose().data(), cam);
+    StageScope stage;
     DevBuf<double> dp(pts);
     DevBuf<float> duv(uv);
     const float K[4] = {camera.fx(), camera.fy(), camera.cx(), camera.cy()};
@@ -481,6 +501,7 @@ bool bundle_adjust(const std::vector<FrameConfig>& frames, const Camera& camera,
         obs_ptr[p + 1] = (int32_t)obs_cam.size();
     }
     if (P == 0 || obs_cam.empty()) return false;
+    StageScope stage;
     DevBuf<double> dc(cams), dp(pts);
     DevBuf<int32_t> dptr(obs_ptr), dcam(obs_cam);
     DevBuf<float> duv(obs_uv);
@@ -491,7 +512,8 @@ bool bundle_adjust(const std::vector<FrameConfig>& frames, const Camera& camera,
     std::printf("bundle_adjust: iterations %d, cost %.6e -> %.6e, termination %d\n", g_summary.iterations,
                 g_summary.initial_cost, g_summary.final_cost, g_summary.termination);
     if (!g_summary.usable) { std::printf("Optimization rejected, unusable or non-improving solution\n"); return false; }
-    const auto hc = dc.download(6 * C);
+    std::vector<double> hc(6 * C);
+    rs_ba_get_cameras(ctx, hc.data(), (int)C);                  // pinned mirror written by the solve's last kernel
     const auto hp = dp.download(3 * P);
     for (size_t c = 0; c < C; c++)
         if (frames[c].optimize) { Mat4f T; rs_unpack_pose(&hc[6 * c], T.data()); frames[c].frame->set_pose(T); }   // :363-368

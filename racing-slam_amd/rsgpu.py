@@ -14,7 +14,7 @@ LIB_PATH = os.path.join(_HERE, "librsgpu.so")
 
 EXPORTS = [
     "rs_abi_version", "rs_context_create", "rs_context_destroy", "rs_context_set_stream",
-    "rs_context_synchronize", "rs_context_set_int", "rs_last_error", "rs_hamming_knn2", "rs_match_descriptors",
+    "rs_context_synchronize", "rs_context_set_int", "rs_stage_begin", "rs_stage_alloc", "rs_stage_upload", "rs_stage_download", "rs_stage_sync", "rs_last_error", "rs_hamming_knn2", "rs_match_descriptors",
     "rs_kdtree_build", "rs_reproj_match", "rs_triangulate", "rs_triangulate_matches", "rs_triangulate_matches_batch", "rs_triangulate_tracks", "rs_point_errors", "rs_ba_default_options",
     "rs_bundle_adjust", "rs_ba_get_trace", "rs_ba_get_stats", "rs_ba_get_cameras", "rs_reanchor_points", "rs_refine_pose", "rs_pack_pose", "rs_unpack_pose", "rs_pack_poses", "rs_unpack_poses", "rs_build_local_window",
     "rs_comm_get_unique_id", "rs_comm_init_rank", "rs_comm_destroy", "rs_comm_init_local", "rs_prof_begin", "rs_prof_end", "rs_prof_counters",

@@ -1,0 +1,192 @@
+// bench_boundary.cpp — what a CALLER of the drop-in pays per interface call: host objects in, host results out,
+// through the host mirror (racing-slam_amd/host/slam_host.h) exactly as the replaced translation units of
+// INTEGRATION.md would run: flatten the pointer graph -> staging pool upload -> kernels -> read-back.
+// bench.py --boundary runs this binary and merges its JSON line.  Scene at the metric's scale: 20 key frames on a
+// forward track, 1080p camera, ~2000 keypoints per frame, ~10k map points with 2-10 observations.
+// Usage: bench_boundary.bin [reps]        (needs a GPU; no CPU fallback)
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <memory>
+#include <random>
+#include <string>
+#include <vector>
+
+#include "../../racing-slam_amd/host/slam_host.h"
+
+using namespace slam;
+using clk = std::chrono::steady_clock;
+
+static Mat4f make_pose(double yaw, double cx, double cy, double cz)
+{
+    const double c = std::cos(yaw), s = std::sin(yaw);
+    const double R[3][3] = {{c, 0, s}, {0, 1, 0}, {-s, 0, c}};
+    Mat4f T = identity4();
+    for (int i = 0; i < 3; i++)
+        for (int j = 0; j < 3; j++) T[4 * i + j] = (float)R[j][i];
+    const double ctr[3] = {cx, cy, cz};
+    for (int i = 0; i < 3; i++) {
+        double t = 0;
+        for (int j = 0; j < 3; j++) t -= R[j][i] * ctr[j];
+        T[4 * i + 3] = (float)t;
+    }
+    return T;
+}
+
+struct Stat { double median, p10, p90; };
+template <typename F>
+static Stat measure(int reps, F&& fn)
+{
+    fn();   // warm-up (first call grows the staging pool / workspace)
+    fn();
+    std::vector<double> t;
+    for (int r = 0; r < reps; r++) {
+        const auto t0 = clk::now();
+        fn();
+        t.push_back(std::chrono::duration<double, std::micro>(clk::now() - t0).count());
+    }
+    std::sort(t.begin(), t.end());
+    return Stat{t[t.size() / 2], t[t.size() / 10], t[(t.size() * 9) / 10]};
+}
+
+int main(int argc, char** argv)
+{
+    const int reps = argc > 1 ? std::atoi(argv[1]) : 30;
+    std::mt19937_64 rng(7);
+    std::normal_distribution<double> gauss(0.0, 1.0);
+    std::uniform_real_distribution<double> uni(0.0, 1.0);
+    const int W = 1920, H = 1080, NKF = 20, NPT = 30000, MAXKP = 2000;
+    const Camera camera(1000.f, 1000.f, 960.f, 540.f, W, H);
+    std::vector<Mat4f> poses;
+    for (int k = 0; k <= NKF; k++) poses.push_back(make_pose(0.026 * k, 0.02 * k, 0.0, 0.5 * k));
+    // landmarks in front of the track; each key frame keeps at most MAXKP of the visible ones
+    std::vector<std::array<double, 3>> X(NPT);
+    std::vector<std::array<uint8_t, 32>> base(NPT);
+    for (int p = 0; p < NPT; p++) {
+        const double z = 4 + 16 * uni(rng), u = W * uni(rng), v = H * uni(rng), along = 10.0 * uni(rng);
+        X[p] = {(u - 960) / 1000 * z, (v - 540) / 1000 * z, z + along};
+        for (auto& b : base[p]) b = (uint8_t)(rng() & 0xFF);
+    }
+    std::vector<std::vector<int>> kp_landmark(NKF + 1);
+    auto make_frame = [&](int k) {
+        ExtractedFeatures f;
+        std::vector<int> order(NPT);
+        for (int p = 0; p < NPT; p++) order[p] = p;
+        std::shuffle(order.begin(), order.end(), rng);
+        for (int p : order) {
+            if ((int)f.keypoints.size() >= MAXKP) break;
+            const Mat4f& T = poses[k];
+            double q[3];
+            for (int i = 0; i < 3; i++) q[i] = T[4 * i] * X[p][0] + T[4 * i + 1] * X[p][1] + T[4 * i + 2] * X[p][2] + T[4 * i + 3];
+            if (q[2] < 0.5) continue;
+            Vec2f uv{(float)(1000 * q[0] / q[2] + 960 + 0.5 * gauss(rng)), (float)(1000 * q[1] / q[2] + 540 + 0.5 * gauss(rng))};
+            if (uv.x < 0 || uv.x >= W || uv.y < 0 || uv.y >= H) continue;
+            f.keypoints.push_back(KeyPoint{uv});
+            f.descriptors.resize(f.descriptors.size() + 32);
+            uint8_t* d = f.descriptors.data() + f.descriptors.size() - 32;
+            for (int i = 0; i < 32; i++) {
+                uint8_t b = base[p][i];
+                for (int bit = 0; bit < 8; bit++)
+                    if (uni(rng) < 0.04) b ^= (uint8_t)(1u << bit);
+                d[i] = b;
+            }
+            kp_landmark[k].push_back(p);
+        }
+        return Frame(k, std::move(f));
+    };
+    std::vector<std::shared_ptr<KeyFrame>> kfs;
+    for (int k = 0; k < NKF; k++) {
+        kfs.push_back(std::make_shared<KeyFrame>(make_frame(k)));
+        kfs.back()->set_pose(poses[k]);
+    }
+    Frame new_frame = make_frame(NKF);
+    new_frame.set_pose(poses[NKF]);
+    Map map;
+    std::vector<int> point_of(NPT, -1), seen(NPT, 0);
+    for (int k = 0; k < NKF; k++)
+        for (int lm : kp_landmark[k]) seen[lm]++;
+    for (int p = 0; p < NPT; p++) {
+        if (seen[p] < 2) continue;
+        point_of[p] = (int)map.size();
+        map.create_point(Vec3f{(float)(X[p][0] + 0.02 * gauss(rng)), (float)(X[p][1] + 0.02 * gauss(rng)), (float)(X[p][2] + 0.05 * gauss(rng))});
+    }
+    size_t n_obs = 0;
+    for (int k = 0; k < NKF; k++)
+        for (size_t i = 0; i < kp_landmark[k].size(); i++)
+            if (point_of[kp_landmark[k][i]] >= 0) { map.associate(*kfs[k], map[(size_t)point_of[kp_landmark[k][i]]], i); n_obs++; }
+
+    MapMatcher matcher(camera, 64.f, NORM_HAMMING);
+    std::string js = "{";
+    auto add = [&](const char* name, const Stat& s, const std::string& extra) {
+        char buf[512];
+        std::snprintf(buf, sizeof buf, "%s\"%s\": {\"median_us\": %.1f, \"p10_us\": %.1f, \"p90_us\": %.1f%s%s}", js.size() > 1 ? ", " : "",
+                      name, s.median, s.p10, s.p90, extra.empty() ? "" : ", ", extra.c_str());
+        js += buf;
+    };
+    char ex[256];
+
+    size_t n_mm = 0;
+    const Stat s_map = measure(reps, [&] { n_mm = matcher.match_map(new_frame, map).size(); });
+    std::snprintf(ex, sizeof ex, "\"map_points\": %zu, \"observations\": %zu, \"keypoints\": %zu, \"matches\": %zu", map.size(), n_obs,
+                  new_frame.features().keypoints.size(), n_mm);
+    add("match_map", s_map, ex);
+    size_t n_mk = 0;
+    const Stat s_kf = measure(reps, [&] { n_mk = matcher.match_key_frame(new_frame, map, kfs[NKF - 1].get()).size(); });
+    std::snprintf(ex, sizeof ex, "\"matches\": %zu", n_mk);
+    add("match_key_frame", s_kf, ex);
+    size_t n_md = 0;
+    const Stat s_md = measure(reps, [&] { n_md = matcher.match_descriptors(new_frame, *kfs[NKF - 1]).size(); });
+    std::snprintf(ex, sizeof ex, "\"train_rows\": %zu, \"matches\": %zu", kfs[NKF - 1]->map_matches().size(), n_md);
+    add("match_descriptors", s_md, ex);
+
+    // triangulate_points with N = 1 (what Mapper::triangulate_tracks and pose::recover_pose call, src/Mapper.cpp:253)
+    // and N = 2000 (one call for a whole frame pair)
+    std::vector<Vec2f> p1, p2;
+    {
+        const auto& a = kp_landmark[NKF - 4];
+        const auto& b = kp_landmark[NKF - 1];
+        for (size_t i = 0; i < a.size() && p1.size() < 2000; i++)
+            for (size_t j = 0; j < b.size(); j++)
+                if (a[i] == b[j]) { p1.push_back(kfs[NKF - 4]->keypoint(i).pt); p2.push_back(kfs[NKF - 1]->keypoint(j).pt); break; }
+    }
+    const std::vector<Vec2f> o1(p1.begin(), p1.begin() + 1), o2(p2.begin(), p2.begin() + 1);
+    size_t kept = 0;
+    const Stat s_t1 = measure(reps * 4, [&] { kept = triangulation::triangulate_points(o1, o2, poses[NKF - 4], poses[NKF - 1], camera, 1.0f, 4.0f).size(); });
+    add("triangulate_points_n1", s_t1, "\"n\": 1");
+    const Stat s_tn = measure(reps, [&] { kept = triangulation::triangulate_points(p1, p2, poses[NKF - 4], poses[NKF - 1], camera, 1.0f, 4.0f).size(); });
+    std::snprintf(ex, sizeof ex, "\"n\": %zu, \"kept\": %zu", p1.size(), kept);
+    add("triangulate_points_frame_pair", s_tn, ex);
+
+    // refine_pose of the new frame (matches taken from match_map)
+    for (auto& m : matcher.match_map(new_frame, map)) new_frame.add_map_match(m);
+    const Mat4f pose0 = new_frame.pose();
+    const Stat s_rp = measure(reps, [&] { new_frame.set_pose(pose0); optimization::refine_pose(new_frame, camera); });
+    std::snprintf(ex, sizeof ex, "\"residual_pairs\": %zu, \"iterations\": %d", new_frame.num_map_matches(), optimization::last_summary().iterations);
+    add("refine_pose", s_rp, ex);
+
+    // build_local_window + bundle_adjust of the 20-key-frame window (state restored before every repetition)
+    std::vector<Mat4f> kf_pose0;
+    for (auto& k : kfs) kf_pose0.push_back(k->pose());
+    std::vector<Vec3f> pos0;
+    for (size_t i = 0; i < map.size(); i++) pos0.push_back(map[i].position());
+    std::vector<Mat4f> perturbed = kf_pose0;
+    for (int k = 2; k < NKF; k++) perturbed[(size_t)k] = make_pose(0.026 * k + 0.004 * gauss(rng), 0.02 * k + 0.01 * gauss(rng), 0.01 * gauss(rng), 0.5 * k + 0.01 * gauss(rng));
+    double t_window = 0;
+    const Stat s_ba = measure(std::max(reps / 3, 5), [&] {
+        for (int k = 0; k < NKF; k++) kfs[(size_t)k]->set_pose(perturbed[(size_t)k]);
+        for (size_t i = 0; i < map.size(); i++) map[i].set_position(pos0[i]);
+        const auto t0 = clk::now();
+        auto window = optimization::build_local_window(kfs, *kfs[NKF - 1], 20, false);
+        t_window = std::chrono::duration<double, std::micro>(clk::now() - t0).count();
+        optimization::bundle_adjust(window, camera, map);
+    });
+    const rs_ba_summary& su = optimization::last_summary();
+    std::snprintf(ex, sizeof ex, "\"key_frames\": %d, \"iterations\": %d, \"usable\": %d, \"build_local_window_us\": %.1f, "
+                  "\"note\": \"includes restoring 20 poses and the map positions on the host\"", NKF, su.iterations, su.usable, t_window);
+    add("bundle_adjust", s_ba, ex);
+    js += "}";
+    std::printf("%s\n", js.c_str());
+    return 0;
+}

@@ -26,8 +26,28 @@ def build_host_test(rs, oracle):
     return BIN
 
 
+BENCH_BIN = os.path.join(ROOT, "tests", "host_cpp", "bench_boundary.bin")
+
+
+def build_boundary_bench(rs):
+    """tests/host_cpp/bench_boundary.cpp: the caller's view of the drop-in (host objects in, host results out), timed.
+    No oracle in it: it is a measurement of the product path (bench.py --boundary runs it)."""
+    rs.load()
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    srcs = [os.path.join(ROOT, "tests", "host_cpp", "bench_boundary.cpp"), os.path.join(ROOT, "racing-slam_amd", "host", "slam_host.cpp")]
+    deps = srcs + [os.path.join(ROOT, "racing-slam_amd", "host", "slam_host.h"), os.path.join(ROOT, "include", "rsgpu.h"),
+                   os.path.join(ROOT, "racing-slam_amd", "librsgpu.so")]
+    if os.path.exists(BENCH_BIN) and all(os.path.getmtime(d) <= os.path.getmtime(BENCH_BIN) for d in deps):
+        return BENCH_BIN
+    cmd = [hipcc, "-O2", "-std=c++17", "-Wall", "-o", BENCH_BIN] + srcs + [
+        "-L" + os.path.join(ROOT, "racing-slam_amd"), "-lrsgpu", "-Wl,-rpath," + os.path.join(ROOT, "racing-slam_amd"), "-lm"]
+    subprocess.check_call(cmd)
+    return BENCH_BIN
+
+
 def test_host_mirror_compiles_and_links(rs, oracle):
     assert os.path.exists(build_host_test(rs, oracle))
+    assert os.path.exists(build_boundary_bench(rs))
 
 
 @pytest.mark.gpu
