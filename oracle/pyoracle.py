@@ -396,6 +396,118 @@ def bundle_adjust(cams, cam_free, points, obs_ptr, obs_cam, obs_uv, K, options=N
     return cams, points, s.as_dict()
 
 
+class ImuFactor(C.Structure):
+    """orc_imu_factor / rs_imu_factor (identical layout)."""
+    _fields_ = [("cam_i", C.c_int), ("cam_j", C.c_int), ("duration", C.c_double), ("rotation", C.c_double * 9),
+                ("velocity", C.c_double * 3), ("position", C.c_double * 3), ("covariance", C.c_double * 81),
+                ("bias_gyro", C.c_double * 3), ("bias_accel", C.c_double * 3), ("bias_jacobian", C.c_double * 54),
+                ("gyro_bias_sigma", C.c_double), ("accel_bias_sigma", C.c_double)]
+
+
+def imu_factor_array(imu, cls=ImuFactor):
+    """synth.make_imu(...) dict -> ctypes array of factor structs."""
+    n = len(imu["cam_i"])
+    arr = (cls * max(n, 1))()
+    for f in range(n):
+        a = arr[f]
+        a.cam_i, a.cam_j, a.duration = int(imu["cam_i"][f]), int(imu["cam_j"][f]), float(imu["duration"][f])
+        for name in ("rotation", "velocity", "position", "covariance", "bias_gyro", "bias_accel", "bias_jacobian"):
+            v = np.asarray(imu[name][f], np.float64).ravel()
+            getattr(a, name)[:] = list(v)
+        a.gyro_bias_sigma, a.accel_bias_sigma = float(imu["gyro_bias_sigma"]), float(imu["accel_bias_sigma"])
+    return arr, n
+
+
+def imu_preintegration(imu, f, pose_i, vel_i, bias_i, pose_j, vel_j):
+    arr, _ = imu_factor_array(imu)
+    r = np.zeros(9); J = np.zeros((9, 24))
+    g = np.ascontiguousarray(imu["gravity"], np.float64)
+    args = [np.ascontiguousarray(x, np.float64) for x in (pose_i, vel_i, bias_i, pose_j, vel_j)]
+    lib().orc_imu_preintegration(C.byref(arr[f]), _p(g, f64p), *[_p(x, f64p) for x in args], _p(r, f64p), _p(J, f64p))
+    return r, J
+
+
+def imu_bias_walk(imu, f, bias_i, bias_j):
+    arr, _ = imu_factor_array(imu)
+    r = np.zeros(6); J = np.zeros((6, 12))
+    lib().orc_imu_bias_walk(C.byref(arr[f]), _p(np.ascontiguousarray(bias_i, np.float64), f64p),
+                            _p(np.ascontiguousarray(bias_j, np.float64), f64p), _p(r, f64p), _p(J, f64p))
+    return r, J
+
+
+def rotation_prior(predicted, sigma, pose):
+    r = np.zeros(3); J = np.zeros((3, 6))
+    lib().orc_rotation_prior(_p(np.ascontiguousarray(predicted, np.float64), f64p), C.c_double(sigma),
+                             _p(np.ascontiguousarray(pose, np.float64), f64p), _p(r, f64p), _p(J, f64p))
+    return r, J
+
+
+def imu_whitener(cov):
+    W = np.zeros((9, 9))
+    lib().orc_imu_whitener(_p(np.ascontiguousarray(cov, np.float64), f64p), _p(W, f64p))
+    return W
+
+
+def bundle_adjust_inertial(cams, cam_free, points, obs_ptr, obs_cam, obs_uv, K, imu, options=None, trace=False):
+    """Returns cams, points, velocity, bias, summary (+ trace list when asked)."""
+    cams = np.array(cams, np.float64, order="C")
+    points = np.array(points, np.float64, order="C")
+    vel = np.array(imu["cam_velocity"], np.float64, order="C")
+    bias = np.array(imu["cam_bias"], np.float64, order="C")
+    cam_free = np.ascontiguousarray(cam_free, np.uint8)
+    obs_ptr = np.ascontiguousarray(obs_ptr, np.int32)
+    obs_cam = np.ascontiguousarray(obs_cam, np.int32)
+    obs_uv = np.ascontiguousarray(obs_uv, np.float32)
+    Kc = np.ascontiguousarray(K, np.float32)
+    g = np.ascontiguousarray(imu["gravity"], np.float64)
+    arr, nf = imu_factor_array(imu)
+    s = BaSummary()
+    L = lib()
+    cap = 1024
+    buf = (BaIteration * cap)()
+    cnt = C.c_int(0)
+    if trace:
+        L.orc_ba_set_trace(buf, cap, C.byref(cnt))
+    try:
+        rc = L.orc_bundle_adjust_inertial(len(cams), len(points), len(obs_cam), _p(cams, f64p), _p(cam_free, u8p), _p(points, f64p),
+                                          _p(obs_ptr, i32p), _p(obs_cam, i32p), _p(obs_uv, f32p), _p(Kc, f32p), _p(vel, f64p),
+                                          _p(bias, f64p), arr, nf, _p(g, f64p), None if options is None else C.byref(options),
+                                          C.byref(s))
+    finally:
+        if trace:
+            L.orc_ba_set_trace(None, 0, None)
+    assert rc == 0
+    out = (cams, points, vel, bias, s.as_dict())
+    return out + ([buf[i].as_dict() for i in range(cnt.value)],) if trace else out
+
+
+def refine_pose_inertial(cam, points, uv, K, prior=None, delta=None, options=None):
+    """prior = (predicted 3x3, sigma)  or  delta = dict(imu=<one-factor make_imu dict>, prev_pose, prev_velocity, prev_bias,
+    velocity).  Returns cam, velocity, summary."""
+    cam = np.array(cam, np.float64, order="C")
+    points = np.ascontiguousarray(points, np.float64)
+    uv = np.ascontiguousarray(uv, np.float32)
+    Kc = np.ascontiguousarray(K, np.float32)
+    s = BaSummary()
+    z3, z6, z9 = np.zeros(3), np.zeros(6), np.zeros(9)
+    vel = np.zeros(3)
+    kind, pred, sigma, pp, pv, pb, g, farr = 0, z9, 0.0, z6, z3, z6, z3, None
+    if prior is not None:
+        kind, pred, sigma = 1, np.ascontiguousarray(prior[0], np.float64), float(prior[1])
+    if delta is not None:
+        kind = 2
+        farr, _ = imu_factor_array(delta["imu"])
+        pp, pv, pb = [np.ascontiguousarray(delta[k], np.float64) for k in ("prev_pose", "prev_velocity", "prev_bias")]
+        g = np.ascontiguousarray(delta["imu"]["gravity"], np.float64)
+        vel = np.array(delta["velocity"], np.float64)
+    rc = lib().orc_refine_pose_inertial(_p(cam, f64p), _p(points, f64p), _p(uv, f32p), len(points), _p(Kc, f32p), kind,
+                                        _p(pred, f64p), C.c_double(sigma), _p(pp, f64p), _p(pv, f64p), _p(pb, f64p),
+                                        farr, _p(g, f64p), _p(vel, f64p), None if options is None else C.byref(options),
+                                        C.byref(s))
+    assert rc == 0
+    return cam, vel, s.as_dict()
+
+
 def ba_linearize(cams, points, obs_ptr, obs_cam, obs_uv, K, huber_delta=5.991 ** 0.5):
     cams = np.ascontiguousarray(cams, np.float64)
     points = np.ascontiguousarray(points, np.float64)

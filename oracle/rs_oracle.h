@@ -158,6 +158,35 @@ int orc_bundle_adjust(int n_cameras, int n_points, int n_obs, double* cameras,
                       const int32_t* obs_cam, const float* obs_uv, const float intrinsics[4],
                       const orc_ba_options* options, orc_ba_summary* summary);
 
+/* -- imu.c: the inertial residual blocks (src/ImuFactor.cpp:10-118, src/Optimization.cpp:74-95) ------------- */
+/* One IMU factor pair between two consecutive optimised frames: imu::Preintegrated (src/Imu.h:30-40) as
+ * imu::preintegrate left it (ROW-major matrices), plus the two bias random-walk densities of imu::NoiseDensity. */
+typedef struct orc_imu_factor {
+    int cam_i, cam_j;
+    double duration;
+    double rotation[9];
+    double velocity[3], position[3];
+    double covariance[81];
+    double bias_gyro[3], bias_accel[3];
+    double bias_jacobian[54];
+    double gyro_bias_sigma, accel_bias_sigma;
+} orc_imu_factor;
+void orc_imu_whitener(const double cov[81], double W[81]);
+void orc_imu_preintegration(const orc_imu_factor* f, const double gravity[3], const double pose_i[6], const double vel_i[3],
+                            const double bias_i[6], const double pose_j[6], const double vel_j[3], double r[9], double J[216]);
+void orc_imu_bias_walk(const orc_imu_factor* f, const double bias_i[6], const double bias_j[6], double r[6], double J[72]);
+void orc_rotation_prior(const double predicted[9], double sigma, const double pose[6], double r[3], double J[18]);
+int orc_bundle_adjust_inertial(int n_cameras, int n_points, int n_obs, double* cameras, const uint8_t* cam_free,
+                               double* points, const int32_t* obs_ptr, const int32_t* obs_cam, const float* obs_uv,
+                               const float intrinsics[4], double* velocity, double* bias, const orc_imu_factor* factors,
+                               int n_factors, const double gravity[3], const orc_ba_options* options,
+                               orc_ba_summary* summary);
+int orc_refine_pose_inertial(double camera[6], const double* points, const float* uv, int n, const float intrinsics[4],
+                             int kind, const double predicted[9], double sigma, const double prev_pose[6],
+                             const double prev_velocity[3], const double prev_bias[6], const orc_imu_factor* delta,
+                             const double gravity[3], double velocity[3], const orc_ba_options* options,
+                             orc_ba_summary* summary);
+
 /* One linearisation at the given state (no update), for tests and for the
  * multi-GPU sharding tests: fills the UNDAMPED normal equations
  *   U [C][6][6], gc [C][6], V [P][3][3], gp [P][3] and the robust cost. */

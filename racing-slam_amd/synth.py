@@ -194,6 +194,57 @@ def make_ba_window(n_kf=20, n_points=10000, config_id=3, seed_stream=0, n_fixed=
                 run_len=run_len.astype(np.int32))
 
 
+def make_imu(window, seed=11, duration=0.5, sigma_rot=2e-3, sigma_vel=2e-2, sigma_pos=1e-2, skip=()):
+    """Synthetic IMU factor pairs for a BA window (reference src/Optimization.cpp:317-346): one per pair of consecutive
+    FREE cameras (pairs listed in `skip` are left out, like a gap with fewer than two samples), consistent with the
+    ground-truth trajectory up to noise:
+        delta R = R_i R_j^T,  delta v = R_i (v_j - v_i - g T),  delta p = R_i (c_j - c_i - v_i T - g T^2 / 2)
+    (R = world -> camera; the residual of src/ImuFactor.cpp:66-69 vanishes on them).  Covariances are random SPD
+    matrices of realistic scale, the bias Jacobians random, and the current bias estimates differ slightly from the
+    biases used at preintegration so that the first-order bias correction (:49-61) is exercised.  Also returns the
+    perturbed initial velocities / biases per camera (cam_velocity [C][3], cam_bias [C][6]) and gravity."""
+    rng = np.random.default_rng(0x1A2B0000 + seed)
+    cams_true = window["cams_true"]
+    C = len(cams_true)
+    T = float(duration)
+    g = np.array([0.0, 0.0, -9.80665])
+    Rcw = np.stack([rodrigues(cams_true[c, :3]) for c in range(C)])
+    ctr = cams_true[:, 3:]
+    v_true = np.zeros((C, 3))
+    for c in range(C):
+        n = min(c + 1, C - 1)
+        p = max(n - 1, 0)
+        v_true[c] = (ctr[n] - ctr[p]) / T if n != p else 0.0
+    free = np.flatnonzero(window["cam_free"])
+    fac = dict(cam_i=[], cam_j=[], duration=[], rotation=[], velocity=[], position=[], covariance=[], bias_gyro=[],
+               bias_accel=[], bias_jacobian=[])
+    for a, b in zip(free[:-1], free[1:]):
+        if b != a + 1 or (int(a), int(b)) in skip:
+            continue
+        dR = Rcw[a] @ Rcw[b].T @ rodrigues(rng.normal(0, sigma_rot, 3))
+        dv = Rcw[a] @ (v_true[b] - v_true[a] - g * T) + rng.normal(0, sigma_vel, 3)
+        dp = Rcw[a] @ (ctr[b] - ctr[a] - v_true[a] * T - 0.5 * g * T * T) + rng.normal(0, sigma_pos, 3)
+        A = rng.normal(0, 1, (9, 9)) * np.array([sigma_rot] * 3 + [sigma_vel] * 3 + [sigma_pos] * 3)[:, None] * 0.3
+        cov = A @ A.T + np.diag(np.array([sigma_rot] * 3 + [sigma_vel] * 3 + [sigma_pos] * 3) ** 2)
+        bj = rng.normal(0, 1, (9, 6)) * np.array([T] * 3 + [T] * 3 + [T * T] * 3)[:, None] * 0.5
+        fac["cam_i"].append(a); fac["cam_j"].append(b); fac["duration"].append(T)
+        fac["rotation"].append(dR.reshape(9)); fac["velocity"].append(dv); fac["position"].append(dp)
+        fac["covariance"].append(cov.reshape(81)); fac["bias_gyro"].append(rng.normal(0, 1e-3, 3))
+        fac["bias_accel"].append(rng.normal(0, 1e-2, 3)); fac["bias_jacobian"].append(bj.reshape(54))
+    out = {k: np.array(v, np.int32 if k.startswith("cam_") else np.float64) for k, v in fac.items()}
+    nF = len(out["cam_i"])
+    bias = np.zeros((C, 6))
+    for f in range(nF):
+        i = out["cam_i"][f]
+        bias[i, :3] = out["bias_gyro"][f] + rng.normal(0, 2e-4, 3)
+        bias[i, 3:] = out["bias_accel"][f] + rng.normal(0, 2e-3, 3)
+    if nF:
+        bias[out["cam_j"][-1]] = bias[out["cam_i"][-1]] + rng.normal(0, 1e-4, 6)
+    out.update(cam_velocity=v_true + rng.normal(0, 0.05, (C, 3)), cam_bias=bias, gravity=g, cam_velocity_true=v_true,
+               gyro_bias_sigma=2.78e-5, accel_bias_sigma=2.79e-3)      # imu::NoiseDensity defaults, src/Imu.h:42-49
+    return out
+
+
 def shard_ba_by_landmark(prob, n_shards, shard):
     """Landmark shard `shard` of `n_shards` (contiguous blocks of landmarks;
     cameras replicated) — SURVEY.md §8(e)."""

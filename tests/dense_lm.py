@@ -14,7 +14,9 @@ Nothing here shares code or formulation with oracle/ba.c or the HIP kernels:
     factor that doubles.
 The residual is the reference functor (src/Optimization.cpp:35-52) with ceres::HuberLoss
 (a = sqrt(5.991), :311) applied through Ceres' corrector (rho'' <= 0: scale r and J by sqrt(rho')).
-Small problems only (dense (6C+3P)^2 system).
+Small problems only (dense (6C+3P)^2 system).  The inertial residual blocks of the reference (IMU preintegration +
+bias random walk in bundle_adjust, RotationPrior / InertialDelta in refine_pose) are covered the same way: numpy
+restatements differentiated by complex step.
 """
 import numpy as np
 
@@ -60,6 +62,73 @@ def jacobian_blocks(cams, pts, obs_cam, obs_pt, obs_uv, K, h=1e-30):
     return jc, jp
 
 
+def aa_to_matrix(aa):
+    """ceres::AngleAxisToRotationMatrix for ONE angle-axis vector (complex-capable), as a 3x3 array."""
+    th2 = aa @ aa
+    if np.real(th2) > EPS:
+        th = np.sqrt(th2)
+        w = aa / th
+        c, s = np.cos(th), np.sin(th)
+        K = np.array([[0, -w[2], w[1]], [w[2], 0, -w[0]], [-w[1], w[0], 0]], dtype=aa.dtype)
+        return c * np.eye(3) + s * K + (1 - c) * np.outer(w, w)
+    return np.array([[1, -aa[2], aa[1]], [aa[2], 1, -aa[0]], [-aa[1], aa[0], 1]], dtype=aa.dtype)
+
+
+def matrix_to_aa(R):
+    """ceres::RotationMatrixToAngleAxis (through the quaternion; branches decided on real parts)."""
+    tr = R[0, 0] + R[1, 1] + R[2, 2]
+    q = np.zeros(4, dtype=R.dtype)
+    if np.real(tr) >= 0:
+        t = np.sqrt(tr + 1.0)
+        q[0] = 0.5 * t
+        t = 0.5 / t
+        q[1], q[2], q[3] = (R[2, 1] - R[1, 2]) * t, (R[0, 2] - R[2, 0]) * t, (R[1, 0] - R[0, 1]) * t
+    else:
+        i = 0
+        if np.real(R[1, 1]) > np.real(R[0, 0]):
+            i = 1
+        if np.real(R[2, 2]) > np.real(R[i, i]):
+            i = 2
+        j, k = (i + 1) % 3, (i + 2) % 3
+        t = np.sqrt(R[i, i] - R[j, j] - R[k, k] + 1.0)
+        q[i + 1] = 0.5 * t
+        t = 0.5 / t
+        q[0] = (R[k, j] - R[j, k]) * t
+        q[j + 1] = (R[j, i] + R[i, j]) * t
+        q[k + 1] = (R[k, i] + R[i, k]) * t
+    s2 = q[1:] @ q[1:]
+    if np.real(s2) > 0:
+        s = np.sqrt(s2)
+        # complex-capable atan2(s, c) for |angle| < pi: 2 atan(s / (sqrt(s^2 + c^2) + c)); the reference's own
+        # cos < 0 branch (atan2(-s, -c)) is the same angle minus pi, handled by the sign flip below
+        c = q[0]
+        if np.real(c) < 0:
+            s_, c_ = -s, -c
+        else:
+            s_, c_ = s, c
+        two_theta = 2.0 * 2.0 * np.arctan(s_ / (np.sqrt(s_ * s_ + c_ * c_) + c_))
+        return q[1:] * (two_theta / s)
+    return q[1:] * 2.0
+
+
+def imu_preintegration(f, gravity, pose_i, vel_i, bias_i, pose_j, vel_j):
+    """PreintegrationError (reference src/ImuFactor.cpp:27-81) for one factor dict (row-major fields), whitened;
+    complex-capable in every argument."""
+    dt = np.result_type(pose_i, vel_i, bias_i, pose_j, vel_j)
+    Ri, Rj = aa_to_matrix(pose_i[:3].astype(dt)), aa_to_matrix(pose_j[:3].astype(dt))
+    db = np.concatenate([bias_i[:3] - f["bias_gyro"], bias_i[3:] - f["bias_accel"]])
+    corr = f["bias_jacobian"].reshape(9, 6) @ db
+    Rm = f["rotation"].reshape(3, 3) @ aa_to_matrix(corr[:3].astype(dt))
+    mvel, mpos = f["velocity"] + corr[3:6], f["position"] + corr[6:9]
+    T = f["duration"]
+    Rs = Ri @ Rj.T
+    sv = Ri @ (vel_j - vel_i - gravity * T)
+    sp = Ri @ (pose_j[3:] - pose_i[3:] - vel_i * T - 0.5 * gravity * T * T)
+    res = np.concatenate([matrix_to_aa(Rm.T @ Rs), sv - mvel, sp - mpos])
+    L = np.linalg.cholesky(f["covariance"].reshape(9, 9))
+    return np.linalg.solve(L, res)
+
+
 def huber(s, a):
     b = a * a
     out = s > b
@@ -70,7 +139,12 @@ def huber(s, a):
 
 
 class Problem:
-    def __init__(self, cams, cam_free, pts, obs_ptr, obs_cam, obs_uv, K, huber_a=np.sqrt(5.991)):
+    def __init__(self, cams, cam_free, pts, obs_ptr, obs_cam, obs_uv, K, huber_a=np.sqrt(5.991), imu=None,
+                 points_constant=False, prior=None, delta=None):
+        """imu: synth.make_imu dict (bundle_adjust with IMU factor pairs).  refine_pose forms: points_constant=True
+        with prior=(predicted 3x3, sigma) (PredictedRotationError, src/Optimization.cpp:75-94) or
+        delta=dict(imu=one-factor dict, prev_pose, prev_velocity, prev_bias, velocity) (src/Optimization.cpp:237-251)."""
+        self.points_constant, self.prior, self.delta = points_constant, prior, delta
         self.cams0 = np.array(cams, np.float64)
         self.pts0 = np.array(pts, np.float64)
         self.obs_cam = np.asarray(obs_cam, np.int64)
@@ -81,25 +155,103 @@ class Problem:
         # parameter blocks of the reduced program: free cameras that carry a residual, then all points
         seen = np.zeros(len(cams), bool)
         seen[self.obs_cam] = True
+        # inertial factor pairs (src/Optimization.cpp:317-346): velocity (3) + bias (6) blocks of the frames they touch
+        self.imu = imu
+        self.inert = np.zeros(0, np.int64)
+        if imu is not None and len(imu["cam_i"]):
+            seen[imu["cam_i"]] = True
+            seen[imu["cam_j"]] = True
+            self.inert = np.unique(np.concatenate([imu["cam_i"], imu["cam_j"]])).astype(np.int64)
+            self.vel0 = np.array(imu["cam_velocity"], np.float64)
+            self.bias0 = np.array(imu["cam_bias"], np.float64)
+            self.factors = [{k: np.asarray(imu[k][f], np.float64) for k in ("rotation", "velocity", "position", "covariance",
+                                                                           "bias_gyro", "bias_accel", "bias_jacobian")} |
+                            dict(duration=float(imu["duration"][f]), i=int(imu["cam_i"][f]), j=int(imu["cam_j"][f]))
+                            for f in range(len(imu["cam_i"]))]
+        if delta is not None:                       # this frame's velocity is a free block; bias is not in the problem
+            self.inert = np.array([0], np.int64)
+            self.vel0 = np.array([delta["velocity"]], np.float64)
+            self.bias0 = np.zeros((1, 6))
+            f = {k: np.asarray(delta["imu"][k][0], np.float64) for k in ("rotation", "velocity", "position", "covariance",
+                                                                         "bias_gyro", "bias_accel", "bias_jacobian")}
+            self.delta_factor = f | dict(duration=float(delta["imu"]["duration"][0]))
         self.active = np.flatnonzero(np.asarray(cam_free, bool) & seen)
         self.col_of_cam = -np.ones(len(cams), np.int64)
         self.col_of_cam[self.active] = 6 * np.arange(len(self.active))
-        self.nc = 6 * len(self.active)
-        self.n = self.nc + 3 * len(pts)
+        self.npose = 6 * len(self.active)
+        self.col_of_inert = -np.ones(len(cams), np.int64)
+        self.col_of_inert[self.inert] = self.npose + 9 * np.arange(len(self.inert))
+        self.nv = 3 if delta is not None else 9     # unknowns per inertial frame
+        self.nc = self.npose + self.nv * len(self.inert)
+        self.n = self.nc + (0 if points_constant else 3 * len(pts))
 
-    def pack(self, cams, pts):
-        return np.concatenate([cams[self.active].ravel(), pts.ravel()])
+    def pack(self, cams, pts, vel=None, bias=None):
+        parts = [cams[self.active].ravel()]
+        if len(self.inert):
+            vel = self.vel0 if vel is None else vel
+            bias = self.bias0 if bias is None else bias
+            parts.append((vel[self.inert] if self.delta is not None else
+                          np.concatenate([vel[self.inert], bias[self.inert]], axis=1)).ravel())
+        return np.concatenate(parts + ([] if self.points_constant else [pts.ravel()]))
 
     def unpack(self, x):
-        cams = self.cams0.copy()
-        cams[self.active] = x[:self.nc].reshape(-1, 6)
-        return cams, x[self.nc:].reshape(-1, 3)
+        cams = self.cams0.astype(x.dtype)
+        cams[self.active] = x[:self.npose].reshape(-1, 6)
+        return cams, (self.pts0.astype(x.dtype) if self.points_constant else x[self.nc:].reshape(-1, 3))
+
+    def unpack_inertial(self, x):
+        vel, bias = self.vel0.astype(x.dtype), self.bias0.astype(x.dtype)
+        vb = x[self.npose:self.nc].reshape(-1, self.nv)
+        vel[self.inert] = vb[:, :3]
+        if self.nv == 9:
+            bias[self.inert] = vb[:, 3:]
+        return vel, bias
+
+    def extra_residuals(self, x):
+        """Residuals of the inertial blocks (no loss function), stacked: 9 + 6 per factor pair."""
+        if self.prior is not None:
+            cams, _ = self.unpack(x)
+            P = np.asarray(self.prior[0], np.float64)
+            return matrix_to_aa(P.T @ aa_to_matrix(cams[0, :3])) / self.prior[1]
+        if self.delta is not None:
+            cams, _ = self.unpack(x)
+            vel, _ = self.unpack_inertial(x)
+            d = self.delta
+            return imu_preintegration(self.delta_factor, np.asarray(d["imu"]["gravity"], np.float64),
+                                      np.asarray(d["prev_pose"], np.float64), np.asarray(d["prev_velocity"], np.float64),
+                                      np.asarray(d["prev_bias"], np.float64), cams[0], vel[0])
+        if not len(self.inert):
+            return np.zeros(0, x.dtype)
+        cams, _ = self.unpack(x)
+        vel, bias = self.unpack_inertial(x)
+        g = np.asarray(self.imu["gravity"], np.float64)
+        out = []
+        for f in self.factors:
+            i, j = f["i"], f["j"]
+            out.append(imu_preintegration(f, g, cams[i], vel[i], bias[i], cams[j], vel[j]))
+            el = np.sqrt(max(f["duration"], 1e-9))
+            sg, sa = self.imu["gyro_bias_sigma"] * el, self.imu["accel_bias_sigma"] * el
+            out.append(np.concatenate([(bias[j, :3] - bias[i, :3]) / sg, (bias[j, 3:] - bias[i, 3:]) / sa]))
+        return np.concatenate(out)
+
+    def has_extras(self):
+        return len(self.inert) > 0 or self.prior is not None
+
+    def extra_jacobian(self, x, h=1e-30):
+        r0 = np.real(self.extra_residuals(x.astype(np.complex128)))
+        J = np.zeros((len(r0), self.n))
+        for k in range(self.nc):                 # the inertial blocks only depend on camera-side unknowns
+            xz = x.astype(np.complex128)
+            xz[k] += 1j * h
+            J[:, k] = np.imag(self.extra_residuals(xz)) / h
+        return r0, J
 
     def cost(self, x):
         cams, pts = self.unpack(x)
         r = residuals(cams, pts, self.obs_cam, self.obs_pt, self.obs_uv, self.K)
         rho, _ = huber(np.sum(r * r, axis=1), self.a)
-        return 0.5 * float(np.sum(rho))
+        e = np.real(self.extra_residuals(x.astype(np.complex128))) if self.has_extras() else np.zeros(0)
+        return 0.5 * float(np.sum(rho)) + 0.5 * float(e @ e)
 
     def linearize(self, x):
         """Corrected residual vector r [2M], dense corrected Jacobian J [2M, n], cost."""
@@ -114,9 +266,14 @@ class Problem:
             c0 = self.col_of_cam[self.obs_cam[o]]
             if c0 >= 0:
                 J[2 * o:2 * o + 2, c0:c0 + 6] = jc[o] * sr[o]
-            p0 = self.nc + 3 * self.obs_pt[o]
-            J[2 * o:2 * o + 2, p0:p0 + 3] = jp[o] * sr[o]
-        return (r * sr[:, None]).ravel(), J, 0.5 * float(np.sum(rho))
+            if not self.points_constant:
+                p0 = self.nc + 3 * self.obs_pt[o]
+                J[2 * o:2 * o + 2, p0:p0 + 3] = jp[o] * sr[o]
+        rv, cost = (r * sr[:, None]).ravel(), 0.5 * float(np.sum(rho))
+        if self.has_extras():
+            re, Je = self.extra_jacobian(x)
+            rv, J, cost = np.concatenate([rv, re]), np.vstack([J, Je]), cost + 0.5 * float(re @ re)
+        return rv, J, cost
 
 
 def solve(prob, max_iter=10, r0=1e4, rmax=1e16, rmin=1e-32, min_rel=1e-3, dmin=1e-6, dmax=1e32,

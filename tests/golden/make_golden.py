@@ -68,11 +68,71 @@ def make_ba_trace():
     np.savez_compressed(os.path.join(OUT, "bundle_adjust_trace.npz"), **blob)
 
 
+IMU_KEYS = ("cam_i", "cam_j", "duration", "rotation", "velocity", "position", "covariance", "bias_gyro", "bias_accel",
+            "bias_jacobian", "cam_velocity", "cam_bias", "gravity")
+
+
+def imu_blob(prefix, imu):
+    b = {f"{prefix}_{k}": np.asarray(imu[k]) for k in IMU_KEYS}
+    b[f"{prefix}_sigmas"] = np.array([imu["gyro_bias_sigma"], imu["accel_bias_sigma"]])
+    return b
+
+
+def make_inertial():
+    """§8(f) rank 2: the inertial residual blocks.  A 7-key-frame window with IMU factor pairs between consecutive free
+    frames (one pair left out, like a gap in the stream), solved by the oracle (jets) and, beside it, by the dense numpy
+    LM with complex-step Jacobians; refine_pose with a RotationPrior and with an InertialDelta."""
+    import dense_lm as D
+    blob = {}
+    w = synth.make_ba_window(n_kf=7, n_points=150, run_max=5, config_id=62, outlier_frac=0.08, rot_noise_deg=1.5)
+    imu = synth.make_imu(w, skip={(4, 5)})
+    args = (w["cams"], w["cam_free"], w["points"], w["obs_ptr"], w["obs_cam"], w["obs_uv"], w["K"])
+    c, p, v, b, s, tr = O.bundle_adjust_inertial(*args, imu, trace=True)
+    prob = D.Problem(*args, imu=imu)
+    x, s2, tr2 = D.solve(prob)
+    assert [t["outcome"] for t in tr] == [t["outcome"] for t in tr2]
+    for k in ("cams", "cam_free", "points", "obs_ptr", "obs_cam", "obs_uv", "K"):
+        blob[f"ba_{k}"] = w[k]
+    blob.update(imu_blob("ba_imu", imu))
+    blob.update(ba_out_cams=c, ba_out_points=p, ba_out_velocity=v, ba_out_bias=b,
+                ba_summary=np.array([s["termination"], s["iterations"], s["successful_steps"], s["usable"]], np.int32),
+                ba_costs=np.array([s["initial_cost"], s["final_cost"], s["final_radius"]]))
+    for k, a in trace_arrays(tr).items():
+        blob[f"ba_oracle_{k}"] = a
+    for k, a in trace_arrays(tr2).items():
+        blob[f"ba_dense_{k}"] = a
+    print("inertial BA", "".join({1: "A", 0: "R", -1: "I", 2: "T"}[t["outcome"]] for t in tr), s["final_cost"])
+    # refine_pose forms on camera 3 of a 4-camera window
+    w4 = synth.make_ba_window(n_kf=4, n_points=50, run_max=4, config_id=21, outlier_frac=0.05)
+    sel = np.flatnonzero(w4["obs_cam"] == 3)
+    obs_pt = np.repeat(np.arange(50), np.diff(w4["obs_ptr"]))[sel]
+    pts, uv = w4["points_true"][obs_pt], w4["obs_uv"][sel]
+    pred = synth.rodrigues(w4["cams_true"][3, :3]) @ synth.rodrigues(np.array([0.004, -0.003, 0.002]))
+    cam1, _, s1 = O.refine_pose_inertial(w4["cams"][3], pts, uv, w4["K"], prior=(pred, 0.01))
+    imu4 = synth.make_imu(w4)
+    f = [i for i in range(len(imu4["cam_i"])) if imu4["cam_j"][i] == 3][0]
+    one = {k: (np.asarray(imu4[k])[f:f + 1] if k in IMU_KEYS[:10] else imu4[k]) for k in imu4}
+    d = dict(imu=one, prev_pose=w4["cams_true"][2], prev_velocity=imu4["cam_velocity_true"][2], prev_bias=imu4["cam_bias"][2],
+             velocity=imu4["cam_velocity"][3])
+    cam2, vel2, s2r = O.refine_pose_inertial(w4["cams"][3], pts, uv, w4["K"], delta=d)
+    blob.update(rp_cam=w4["cams"][3], rp_points=pts, rp_uv=uv, rp_K=w4["K"], rp_predicted=pred, rp_sigma=np.float64(0.01),
+                rp_prior_out_cam=cam1, rp_prior_summary=np.array([s1["termination"], s1["iterations"], s1["successful_steps"], s1["usable"]], np.int32),
+                rp_prior_costs=np.array([s1["initial_cost"], s1["final_cost"]]),
+                rp_prev_pose=d["prev_pose"], rp_prev_velocity=d["prev_velocity"], rp_prev_bias=d["prev_bias"], rp_velocity=d["velocity"],
+                rp_delta_out_cam=cam2, rp_delta_out_velocity=vel2,
+                rp_delta_summary=np.array([s2r["termination"], s2r["iterations"], s2r["successful_steps"], s2r["usable"]], np.int32),
+                rp_delta_costs=np.array([s2r["initial_cost"], s2r["final_cost"]]))
+    blob.update(imu_blob("rp_imu", one))
+    np.savez_compressed(os.path.join(OUT, "inertial.npz"), **blob)
+
+
 def main():
     O.build()
     only = set(sys.argv[1:])
     if not only or "ba_trace" in only:
         make_ba_trace()
+    if not only or "inertial" in only:
+        make_inertial()
     if only and only != {"all"}:
         return
     # -- a4: descriptor matching, 96 x 80 rows incl. exact ties and threshold boundaries

@@ -531,3 +531,71 @@ def test_reanchor_points_vs_numpy(oracle, rs, synth):
     rs.unpack_poses(w["cams"], mask, buf)
     for c in range(6):
         assert np.array_equal(buf[c], rs.unpack_pose(w["cams"][c]).reshape(16) if mask[c] else np.zeros(16, np.float32))
+
+
+def _fd(f, x, h=1e-6):
+    x = np.array(x, float)
+    cols = []
+    for k in range(len(x)):
+        xp, xm = x.copy(), x.copy()
+        xp[k] += h
+        xm[k] -= h
+        cols.append((f(xp) - f(xm)) / (2 * h))
+    return np.array(cols).T
+
+
+def test_inertial_factor_jets_vs_finite_differences(oracle, synth):
+    """oracle/imu.c: the 24-wide jets through PreintegrationError (src/ImuFactor.cpp:27-81), BiasRandomWalk (:89-118)
+    and PredictedRotationError (src/Optimization.cpp:75-94) against central differences; the whitener against its
+    definition; the residual vanishing (up to the synthetic noise) on the ground-truth trajectory."""
+    w = synth.make_ba_window(n_kf=8, n_points=100, run_max=5, config_id=61)
+    imu = synth.make_imu(w)
+    assert len(imu["cam_i"]) == 5
+    for f in (0, 3):
+        i, j = int(imu["cam_i"][f]), int(imu["cam_j"][f])
+        x0 = np.concatenate([w["cams"][i], imu["cam_velocity"][i], imu["cam_bias"][i], w["cams"][j], imu["cam_velocity"][j]])
+        fun = lambda x: oracle.imu_preintegration(imu, f, x[0:6], x[6:9], x[9:15], x[15:21], x[21:24])[0]   # noqa: E731
+        r, J = oracle.imu_preintegration(imu, f, x0[0:6], x0[6:9], x0[9:15], x0[15:21], x0[21:24])
+        assert np.abs(J - _fd(fun, x0)).max() < 1e-6 * np.abs(J).max()
+        W = oracle.imu_whitener(imu["covariance"][f].reshape(9, 9))
+        assert np.allclose(W @ imu["covariance"][f].reshape(9, 9) @ W.T, np.eye(9), atol=1e-9)
+        assert np.allclose(np.triu(W, 1), 0)
+        rt, _ = oracle.imu_preintegration(imu, f, w["cams_true"][i], imu["cam_velocity_true"][i],
+                                          np.concatenate([imu["bias_gyro"][f], imu["bias_accel"][f]]), w["cams_true"][j],
+                                          imu["cam_velocity_true"][j])
+        assert np.abs(rt).max() < 8.0            # whitened noise: a few sigma
+        bw, Jb = oracle.imu_bias_walk(imu, f, imu["cam_bias"][i], imu["cam_bias"][j])
+        fb = lambda x: oracle.imu_bias_walk(imu, f, x[:6], x[6:])[0]   # noqa: E731
+        assert np.allclose(Jb, _fd(fb, np.concatenate([imu["cam_bias"][i], imu["cam_bias"][j]]), h=1e-7), rtol=1e-5, atol=1e-3)
+    # a covariance that is not positive definite -> identity whitener (src/ImuFactor.cpp:13-15)
+    assert np.array_equal(oracle.imu_whitener(-np.eye(9)), np.eye(9))
+    # rotation prior, incl. a large rotation (trace < 0 branch of RotationMatrixToQuaternion) and the zero rotation
+    rng = np.random.default_rng(3)
+    for aa in (rng.normal(0, 0.3, 3), np.array([2.9, 0.3, -0.4]), np.zeros(3), np.array([1e-9, 0, 0])):
+        pred = synth.rodrigues(rng.normal(0, 0.2, 3))
+        pose = np.concatenate([aa, rng.normal(0, 1, 3)])
+        r, J = oracle.rotation_prior(pred, 0.02, pose)
+        fr = lambda x: oracle.rotation_prior(pred, 0.02, x)[0]   # noqa: E731
+        assert np.allclose(J, _fd(fr, pose, h=1e-7), rtol=2e-5, atol=2e-4)
+        assert np.allclose(J[:, 3:], 0)
+        R = synth.rodrigues(aa) if np.linalg.norm(aa) > 1e-7 else np.eye(3) + np.array([[0, -aa[2], aa[1]], [aa[2], 0, -aa[0]], [-aa[1], aa[0], 0]])
+        assert np.allclose(synth.rodrigues(r * 0.02) if np.linalg.norm(r) > 1e-7 else np.eye(3), pred.T @ R, atol=1e-7)
+
+
+def test_inertial_bundle_adjust_reduces_to_vision_only_without_factors(oracle, synth):
+    """No factor pairs -> the inertial entry point IS bundle_adjust (InertialInput::usable() false, :317)."""
+    w = synth.make_ba_window(n_kf=6, n_points=200, run_max=5)
+    imu = synth.make_imu(w)
+    empty = dict(imu)
+    for k in ("cam_i", "cam_j", "duration", "rotation", "velocity", "position", "covariance", "bias_gyro", "bias_accel", "bias_jacobian"):
+        empty[k] = imu[k][:0]
+    args = (w["cams"], w["cam_free"], w["points"], w["obs_ptr"], w["obs_cam"], w["obs_uv"], w["K"])
+    c, p, v, b, s = oracle.bundle_adjust_inertial(*args, empty)
+    c0, p0, s0 = oracle.bundle_adjust(*args)
+    assert s == s0 and np.array_equal(c, c0) and np.array_equal(p, p0)
+    assert np.array_equal(v, imu["cam_velocity"]) and np.array_equal(b, imu["cam_bias"])
+    # with the factors the velocities move towards the truth
+    c, p, v, b, s = oracle.bundle_adjust_inertial(*args, imu)
+    fr = np.flatnonzero(w["cam_free"])
+    assert s["usable"] == 1
+    assert np.abs(v - imu["cam_velocity_true"])[fr].max() < 0.7 * np.abs(imu["cam_velocity"] - imu["cam_velocity_true"])[fr].max()
