@@ -417,9 +417,7 @@ def bench_pass(e, args):
         roofline = dict(roofline, timing="hip events per launch on the library stream, %d instrumented passes" % args.steps,
                         traffic_source=pmc_file, traffic_matches_kernel_sources=pmc_fresh)
 
-    boundary = None
-    if e.rank == 0 and e.world == 1 and args.boundary:
-        boundary = boundary_timings()
+    boundary = getattr(args, "boundary_result", None)     # measured in main() before this process touched the GPU
     cpu = None
     if e.rank == 0 and e.world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline(cpu_pass, 1.0, "passes/s", "full passes of the same workload (all stages incl. both "
@@ -614,6 +612,10 @@ def main():
                     help="skip the end-to-end interface timings (tests/host_cpp/bench_boundary.bin) of --config pass")
     ap.add_argument("--cpu-seconds", type=float, default=25.0, help="time budget of the CPU baseline leg")
     args = ap.parse_args()
+    # The end-to-end interface timings run in a child process (tests/host_cpp/bench_boundary.bin).  It is started
+    # BEFORE this process initialises the GPU: a process that holds a GPU context must not fork + exec on the box.
+    if args.config == "pass" and args.boundary and int(os.environ.get("WORLD_SIZE", "1")) == 1:
+        args.boundary_result = boundary_timings()
     e = setup(args)
     if args.config == "pass":
         bench_pass(e, args)

@@ -405,6 +405,59 @@ int rs_refine_pose(rs_context* ctx, double h_camera[6],
                    const float h_intrinsics[4],
                    const rs_ba_options* options, rs_ba_summary* h_summary);
 
+/* ------------------------------------------- a15 / §8(f) rank 2: inertial residual blocks */
+
+/* One IMU factor pair between two consecutive OPTIMISED frames of rs_bundle_adjust_inertial's camera list
+ * (reference src/Optimization.cpp:317-346): imu::Preintegrated exactly as imu::preintegrate left it (src/Imu.h:30-40,
+ * src/Imu.cpp:71-134 — that small sequential host code stays the reference's), matrices ROW-major, plus the two bias
+ * random-walk densities of imu::NoiseDensity (src/Imu.h:46-48).  Each factor adds the 9-residual preintegration block
+ * over (pose_i, velocity_i, bias_i, pose_j, velocity_j) whitened by L^-1 of the covariance's LLT (identity when it is not
+ * positive definite, src/ImuFactor.cpp:10-17) and the 6-residual bias random walk over (bias_i, bias_j) with
+ * sigma = density * sqrt(max(duration, 1e-9)) (:111-117); no loss function on either. */
+typedef struct rs_imu_factor {
+    int cam_i, cam_j;
+    double duration;
+    double rotation[9];
+    double velocity[3], position[3];
+    double covariance[81];
+    double bias_gyro[3], bias_accel[3];     /* bias the preintegration was run with */
+    double bias_jacobian[54];               /* 9 x 6 */
+    double gyro_bias_sigma, accel_bias_sigma;
+} rs_imu_factor;
+
+/* optimization::bundle_adjust with InertialInput::usable() (src/Optimization.cpp:269-374 incl. :317-346).  As
+ * rs_bundle_adjust, plus per-camera velocity (3) and bias (6: gyro, accel) parameter blocks for the frames the factors
+ * touch: h_velocity [C][3], h_bias [C][6] in/out (host: they live in Frame::inertial(), src/Frame.h:13-16), written
+ * back for the free frames on a usable solve (unpack_inertial, :363-368).  n_factors == 0 is rs_bundle_adjust.
+ * The reduced camera system has 6 unknowns per free camera + 9 per inertial frame. */
+int rs_bundle_adjust_inertial(rs_context* ctx,
+                              int n_cameras, int n_points, int n_obs,
+                              double* d_cameras, const uint8_t* h_cam_free,
+                              double* d_points,
+                              const int32_t* d_obs_ptr, const int32_t* d_obs_cam,
+                              const float* d_obs_uv,
+                              const float h_intrinsics[4],
+                              double* h_velocity, double* h_bias,
+                              const rs_imu_factor* h_factors, int n_factors,
+                              const double h_gravity[3],
+                              const rs_ba_options* options /*NULL = defaults*/,
+                              rs_ba_summary* h_summary);
+
+/* optimization::refine_pose with an InertialConstraint (src/Optimization.cpp:231-267).
+ *   kind 0: none (= rs_refine_pose)
+ *   kind 1: RotationPrior — h_predicted [9] row-major world->camera rotation, sigma_radians (> 0, else ignored)
+ *   kind 2: InertialDelta — the previous frame's pose / velocity / bias are constant blocks (h_prev_pose [6] packed
+ *           like a camera, h_prev_velocity [3], h_prev_bias [6]), h_delta its preintegration summary, h_gravity [3];
+ *           this frame's velocity h_velocity [3] is a free block, written back on a usable solve (ignored when
+ *           h_delta->duration <= 0, InertialDelta::enabled) */
+int rs_refine_pose_inertial(rs_context* ctx, double h_camera[6],
+                            const double* d_points, const float* d_uv, int n,
+                            const float h_intrinsics[4], int kind,
+                            const double h_predicted[9], double sigma_radians,
+                            const double h_prev_pose[6], const double h_prev_velocity[3], const double h_prev_bias[6],
+                            const rs_imu_factor* h_delta, const double h_gravity[3], double h_velocity[3],
+                            const rs_ba_options* options, rs_ba_summary* h_summary);
+
 /* pack_pose / unpack_pose (src/Optimization.cpp:144-159, a10).  Host only:
  * R -> angle-axis in f32 through a quaternion (ceres::RotationMatrixToAngleAxis<float>),
  * centre = -R^T t (src/Frame.cpp:39-42), widened to f64; and back. */

@@ -51,7 +51,7 @@ def build(force=False, verbose=False):
     cc = hipcc()
     objdir = os.path.join(HERE, "build")
     os.makedirs(objdir, exist_ok=True)
-    headers = [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "tri_core.h"), os.path.join(CSRC, "ba_common.h"), os.path.join(HERE, "..", "include", "rsgpu.h"), __file__]
+    headers = [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "tri_core.h"), os.path.join(CSRC, "ba_common.h"), os.path.join(CSRC, "imu_dual.h"), os.path.join(HERE, "..", "include", "rsgpu.h"), __file__]
     objs = []
     rebuilt = False
     for src, extra in SOURCES:

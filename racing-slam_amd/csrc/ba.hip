@@ -32,6 +32,7 @@
 #include <stdlib.h>
 
 #include "ba_common.h"
+#include "imu_dual.h"
 
 // ---------------------------------------------------------------------- K0
 __global__ void ba_init(BaDims d, BaBufs b, BaOpt opt, const double* __restrict__ cams_in,
@@ -420,7 +421,7 @@ __global__ __launch_bounds__(BA_THREADS) void ba_backsub_cost(BaDims d, BaBufs b
 // -------------------------------------------------------------------- finalize
 __global__ void ba_finalize(BaDims d, BaBufs b, BaOpt opt, int it, double* __restrict__ cams_out,
                             const uint8_t* __restrict__ cam_free, double* __restrict__ pts_out, BaState* host_st,
-                            BaTrace* host_trace, double* __restrict__ host_cams)
+                            BaTrace* host_trace, double* __restrict__ host_cams, double* __restrict__ host_vb)
 {
     __shared__ int usable, cur;
     __shared__ BaState st_fin;
@@ -453,6 +454,8 @@ __global__ void ba_finalize(BaDims d, BaBufs b, BaOpt opt, int it, double* __res
     // the cameras as the caller will see them in d_cameras, mirrored into pinned host memory: poses are host-owned
     // objects in the reference (Frame::set_pose, src/Optimization.cpp:363-368), so the shim needs them there anyway
     for (int i = tid; i < d.C * 6; i += nth) host_cams[i] = (usable && cam_free[i / 6]) ? Xc[i] : cams_out[i];
+    if (host_vb)        // inertial solve: velocity | bias of the accepted state (the host applies the write-back rule)
+        for (int i = tid; i < d.C * 9; i += nth) host_vb[i] = b.imu.Xv[(size_t)cur * d.C * 9 + i];
     if (!usable) return;
     for (int i = tid; i < d.C * 6; i += nth)
         if (cam_free[i / 6]) cams_out[i] = Xc[i];
@@ -491,14 +494,52 @@ extern "C" int rs_prof_counters(rs_context* ctx, uint64_t* h_out, int n)
 
 static size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
-extern "C" int rs_bundle_adjust(rs_context* ctx, int n_cameras, int n_points, int n_obs, double* d_cameras,
-                                const uint8_t* h_cam_free, double* d_points, const int32_t* d_obs_ptr,
-                                const int32_t* d_obs_cam, const float* d_obs_uv, const float h_intrinsics[4],
-                                const rs_ba_options* options, rs_ba_summary* h_summary)
+// the inertial residual blocks of one solve (null for a vision-only solve)
+struct BaInertialArgs {
+    double* h_velocity;            // [C][3] in/out
+    double* h_bias;                // [C][6] in/out
+    const rs_imu_factor* factors;
+    int n_factors;
+    const double* gravity;
+};
+
+// whitener of src/ImuFactor.cpp:10-17: L^-1 of the covariance's LLT, identity when it is not positive definite
+static void imu_whitener(const double cov[81], double W[81])
+{
+    double L[81];
+    memcpy(L, cov, sizeof L);
+    bool ok = true;
+    for (int j = 0; j < 9 && ok; j++) {
+        double dd = L[j * 9 + j];
+        for (int k = 0; k < j; k++) dd -= L[j * 9 + k] * L[j * 9 + k];
+        if (!(dd > 0.0) || !std::isfinite(dd)) { ok = false; break; }
+        dd = sqrt(dd);
+        L[j * 9 + j] = dd;
+        for (int i = j + 1; i < 9; i++) {
+            double t = L[i * 9 + j];
+            for (int k = 0; k < j; k++) t -= L[i * 9 + k] * L[j * 9 + k];
+            L[i * 9 + j] = t / dd;
+        }
+    }
+    memset(W, 0, sizeof(double) * 81);
+    if (!ok) { for (int i = 0; i < 9; i++) W[i * 9 + i] = 1.0; return; }
+    for (int c = 0; c < 9; c++)
+        for (int i = 0; i < 9; i++) {
+            double t = (i == c) ? 1.0 : 0.0;
+            for (int k = 0; k < i; k++) t -= L[i * 9 + k] * W[k * 9 + c];
+            W[i * 9 + c] = t / L[i * 9 + i];
+        }
+}
+
+static int ba_solve_impl(rs_context* ctx, int n_cameras, int n_points, int n_obs, double* d_cameras,
+                         const uint8_t* h_cam_free, double* d_points, const int32_t* d_obs_ptr,
+                         const int32_t* d_obs_cam, const float* d_obs_uv, const float h_intrinsics[4],
+                         const rs_ba_options* options, rs_ba_summary* h_summary, const BaInertialArgs* in)
 {
     if (!ctx || !h_summary) return RS_ERR_INVALID;
     memset(h_summary, 0, sizeof *h_summary);
     if (n_cameras < 0 || n_points < 0 || n_obs < 0) return rs_fail(ctx, RS_ERR_INVALID, "negative size");
+    if (in && rs_comm_active(ctx)) return rs_fail(ctx, RS_ERR_UNSUPPORTED, "inertial factors in a landmark-sharded solve");
     if (n_cameras == 0 || n_points == 0 || n_obs == 0) {   // nothing to optimise
         if (ctx->n_ranks > 1) return rs_fail(ctx, RS_ERR_UNSUPPORTED, "empty shard in a multi-rank solve");
         h_summary->usable = 0;
@@ -535,8 +576,22 @@ extern "C" int rs_bundle_adjust(rs_context* ctx, int n_cameras, int n_points, in
     const bool k8_lds = ba_backsub_lds_bytes(d.C, d.n) <= 64 * 1024;
     const bool solve_lds = d.n >= 6 && d.n <= BA_MAX_LDS_N;
     const bool solve_big = d.n > BA_MAX_LDS_N;
+    // inertial frames: the cameras an IMU factor touches get a velocity (3) + bias (6) block
+    std::vector<int32_t> inert(n_cameras, -1);
+    int Ci = 0;
+    if (in) {
+        for (int f = 0; f < in->n_factors; f++) {
+            const int i = in->factors[f].cam_i, j = in->factors[f].cam_j;
+            if (i < 0 || j < 0 || i >= n_cameras || j >= n_cameras || i == j || !h_cam_free[i] || !h_cam_free[j])
+                return rs_fail(ctx, RS_ERR_INVALID, "IMU factor %d must join two distinct optimised cameras", f);
+        }
+        std::vector<uint8_t> touched(n_cameras, 0);
+        for (int f = 0; f < in->n_factors; f++) { touched[in->factors[f].cam_i] = 1; touched[in->factors[f].cam_j] = 1; }
+        for (int c = 0; c < n_cameras; c++) if (touched[c]) inert[c] = Ci++;
+    }
+    const int N_in = d.n + 9 * Ci;
     int ns = 1;
-    if (use_mfma && k8_lds && solve_lds) {
+    if (use_mfma && k8_lds && solve_lds && !in) {
         ns = ctx->ba_sets > 0 ? ctx->ba_sets : BA_DEFAULT_SETS;
         if (ns > BA_MAXSETS) ns = BA_MAXSETS;
         if (ns > opt.max_iter) ns = opt.max_iter > 0 ? opt.max_iter : 1;
@@ -564,13 +619,14 @@ extern "C" int rs_bundle_adjust(rs_context* ctx, int n_cameras, int n_points, in
     const size_t o_dbg = carve(sizeof(unsigned long long) * 64);
     const size_t o_free = carve(C);
     const size_t o_grp = carve(use_mfma ? ba_group_bytes(d.P, d.Cf, d.M) : 16);
-    const size_t o_big = carve(solve_big ? ba_big_bytes(d.n) : 16);
+    const size_t o_big = carve(in ? ba_inertial_bytes(N_in, in->n_factors, d.C) : (solve_big ? ba_big_bytes(d.n) : 16));
     void* wsv = nullptr;
     int rc = rs_workspace(ctx, off, &wsv);
     if (rc) return rc;
     char* ws = (char*)wsv;
     BaBufs b;
     b.ns = ns;
+    memset(&b.imu, 0, sizeof b.imu);
     b.obs_ptr = d_obs_ptr; b.obs_cam = d_obs_cam; b.obs_uv = (const float2*)d_obs_uv;
     b.Xc = (double*)(ws + o_Xc); b.Xp = (double*)(ws + o_Xp); b.prep = (double*)(ws + o_prep);
     b.slot = (int32_t*)(ws + o_slot); b.sc = (double*)(ws + o_sc); b.sp = (double*)(ws + o_sp);
@@ -600,8 +656,10 @@ extern "C" int rs_bundle_adjust(rs_context* ctx, int n_cameras, int n_points, in
     const size_t pin_prog = align_up(sizeof(BaState) + sizeof(int32_t) * C + C, 64);
     const size_t pin_trace = pin_prog + 64;
     const size_t pin_cams = pin_trace + sizeof(BaTrace) * (size_t)(opt.max_iter + 1);
-    rc = rs_pinned(ctx, pin_cams + sizeof(double) * 6 * C, &pin);
+    const size_t pin_vb = align_up(pin_cams + sizeof(double) * 6 * C, 64);
+    rc = rs_pinned(ctx, pin_vb + (in ? sizeof(double) * 9 * C : 0), &pin);
     if (rc) return rc;
+    double* h_vb = in ? (double*)((char*)pin + pin_vb) : nullptr;
     ctx->ba_cams = nullptr;
     ctx->ba_cams_n = 0;
     BaProgress* h_prog = (BaProgress*)((char*)pin + pin_prog);
@@ -639,6 +697,27 @@ extern "C" int rs_bundle_adjust(rs_context* ctx, int n_cameras, int n_points, in
     int zero_n = 0;
     if (use_mfma) ba_group_zero_range(grp, &zero_ptr, &zero_n);
     hipStream_t s = ctx->stream;
+    std::vector<ImuFactorDev> fac_host;
+    std::vector<double> xv_host;
+    if (in) {
+        ImuFactorDev* d_fac = nullptr;
+        int32_t* d_inert = nullptr;
+        ba_inertial_carve(ws + o_big, N_in, in->n_factors, d.C, &b.imu, &d_fac, &d_inert);
+        b.imu.n_fac = in->n_factors; b.imu.Ci = Ci; b.imu.N = N_in;
+        for (int k = 0; k < 3; k++) b.imu.gravity[k] = in->gravity[k];
+        fac_host.resize((size_t)in->n_factors);
+        for (int f = 0; f < in->n_factors; f++) { fac_host[(size_t)f].f = in->factors[f]; imu_whitener(in->factors[f].covariance, fac_host[(size_t)f].W); }
+        xv_host.resize(9 * C);
+        for (size_t c = 0; c < C; c++) {
+            for (int k = 0; k < 3; k++) xv_host[9 * c + k] = in->h_velocity[3 * c + k];
+            for (int k = 0; k < 6; k++) xv_host[9 * c + 3 + k] = in->h_bias[6 * c + k];
+        }
+        // (pageable sources: the copies complete before the call returns — it synchronises below)
+        RS_HIP(ctx, hipMemcpyAsync(d_fac, fac_host.data(), sizeof(ImuFactorDev) * fac_host.size(), hipMemcpyHostToDevice, s));
+        RS_HIP(ctx, hipMemcpyAsync(d_inert, inert.data(), sizeof(int32_t) * C, hipMemcpyHostToDevice, s));
+        RS_HIP(ctx, hipMemcpyAsync(b.imu.Xv, xv_host.data(), sizeof(double) * 9 * C, hipMemcpyHostToDevice, s));
+        RS_HIP(ctx, hipMemcpyAsync(b.imu.Xv + 9 * C, xv_host.data(), sizeof(double) * 9 * C, hipMemcpyHostToDevice, s));
+    }
     {
         rs_prof_scope ps(ctx, "K0_ba_init");
         hipLaunchKernelGGL(ba_init, dim3(64), dim3(256), 0, s, d, b, opt, (const double*)d_cameras, (const double*)d_points,
@@ -672,7 +751,11 @@ extern "C" int rs_bundle_adjust(rs_context* ctx, int n_cameras, int n_points, in
             int rc2 = rs_allreduce_f64(ctx, b.acc, b.acc_count, false);
             if (rc2) return rc2;
         }
-        if (solve_lds) {
+        if (in) {
+            rs_prof_scope ps(ctx, "K7_ba_reduced_solve_inertial");
+            int rc2 = ba_launch_reduced_solve_inertial(ctx, d, b, opt, ws + o_big);
+            if (rc2) return rc2;
+        } else if (solve_lds) {
             rs_prof_scope ps(ctx, "K7_ba_reduced_solve");
             ba_launch_reduced_solve_lds(s, d, b, opt);
         } else if (solve_big) {
@@ -725,7 +808,7 @@ extern "C" int rs_bundle_adjust(rs_context* ctx, int n_cameras, int n_points, in
         b.set_prev = set_base + (size_t)((itf + 1) & 1) * BA_MAXSETS;
         b.prog = nullptr;
         hipLaunchKernelGGL(ba_finalize, dim3(32), dim3(256), 0, s, d, b, opt, itf, d_cameras, (const uint8_t*)d_cam_free, d_points, h_st, h_trace,
-                           (double*)((char*)pin + pin_cams));
+                           (double*)((char*)pin + pin_cams), h_vb);
     }
     RS_HIP(ctx, hipStreamSynchronize(s));        // ba_finalize wrote the state block into the pinned h_st
     RS_HIP(ctx, hipGetLastError());
@@ -742,7 +825,38 @@ extern "C" int rs_bundle_adjust(rs_context* ctx, int n_cameras, int n_points, in
     ctx->ba_stats[3] = rounds;
     ctx->ba_cams = (const double*)((char*)pin + pin_cams);
     ctx->ba_cams_n = n_cameras;
+    if (in && h_st->usable)                                  // unpack_inertial for the optimised frames, src/Optimization.cpp:363-368
+        for (size_t c = 0; c < C; c++) {
+            if (!h_cam_free[c]) continue;
+            for (int k = 0; k < 3; k++) in->h_velocity[3 * c + k] = h_vb[9 * c + k];
+            for (int k = 0; k < 6; k++) in->h_bias[6 * c + k] = h_vb[9 * c + 3 + k];
+        }
     return RS_OK;
+}
+
+extern "C" int rs_bundle_adjust(rs_context* ctx, int n_cameras, int n_points, int n_obs, double* d_cameras,
+                                const uint8_t* h_cam_free, double* d_points, const int32_t* d_obs_ptr,
+                                const int32_t* d_obs_cam, const float* d_obs_uv, const float h_intrinsics[4],
+                                const rs_ba_options* options, rs_ba_summary* h_summary)
+{
+    return ba_solve_impl(ctx, n_cameras, n_points, n_obs, d_cameras, h_cam_free, d_points, d_obs_ptr, d_obs_cam, d_obs_uv,
+                         h_intrinsics, options, h_summary, nullptr);
+}
+
+extern "C" int rs_bundle_adjust_inertial(rs_context* ctx, int n_cameras, int n_points, int n_obs, double* d_cameras,
+                                         const uint8_t* h_cam_free, double* d_points, const int32_t* d_obs_ptr,
+                                         const int32_t* d_obs_cam, const float* d_obs_uv, const float h_intrinsics[4],
+                                         double* h_velocity, double* h_bias, const rs_imu_factor* h_factors, int n_factors,
+                                         const double h_gravity[3], const rs_ba_options* options, rs_ba_summary* h_summary)
+{
+    if (n_factors < 0) return ctx ? rs_fail(ctx, RS_ERR_INVALID, "negative n_factors") : RS_ERR_INVALID;
+    if (n_factors == 0)                                      // InertialInput::usable() false / no pair with >= 2 samples
+        return ba_solve_impl(ctx, n_cameras, n_points, n_obs, d_cameras, h_cam_free, d_points, d_obs_ptr, d_obs_cam, d_obs_uv,
+                             h_intrinsics, options, h_summary, nullptr);
+    if (!h_velocity || !h_bias || !h_factors || !h_gravity) return ctx ? rs_fail(ctx, RS_ERR_INVALID, "null pointer") : RS_ERR_INVALID;
+    const BaInertialArgs in{h_velocity, h_bias, h_factors, n_factors, h_gravity};
+    return ba_solve_impl(ctx, n_cameras, n_points, n_obs, d_cameras, h_cam_free, d_points, d_obs_ptr, d_obs_cam, d_obs_uv,
+                         h_intrinsics, options, h_summary, &in);
 }
 
 static_assert(sizeof(BaTrace) == sizeof(rs_ba_iteration), "BaTrace mirrors rs_ba_iteration");
@@ -997,6 +1111,299 @@ extern "C" int rs_refine_pose(rs_context* ctx, double h_camera[6], const double*
     RS_HIP(ctx, hipStreamSynchronize(s));
     RS_HIP(ctx, hipGetLastError());
     if (h_st->usable) memcpy(h_camera, h_cam, 6 * sizeof(double));
+    h_summary->termination = h_st->termination;
+    h_summary->iterations = h_st->iter;
+    h_summary->successful_steps = h_st->successful;
+    h_summary->usable = h_st->usable;
+    h_summary->initial_cost = h_st->initial_cost;
+    h_summary->final_cost = h_st->x_cost;
+    h_summary->final_radius = h_st->radius;
+    return RS_OK;
+}
+
+// ------------------------------------------------- refine_pose with an InertialConstraint
+// optimization::refine_pose (src/Optimization.cpp:194-267) with a RotationPrior (:252-258: 3 more residuals on the
+// pose block) or an InertialDelta (:237-251: the 9-residual preintegration block with the previous frame constant and
+// this frame's velocity as a second free block -> 9 unknowns).  Same single-launch LM as ba_refine_pose; thread 0
+// evaluates the one extra block with dual numbers and solves the nu x nu system (nu = 6 or 9).
+struct RpInertial {
+    int kind;                 // 1 rotation prior, 2 inertial delta
+    double predicted[9], sigma;
+    double prev_pose[6], prev_vel[3], prev_bias[6], gravity[3];
+    ImuFactorDev fac;
+};
+
+__global__ __launch_bounds__(RP_THREADS) void ba_refine_pose_inertial(BaDims d, BaOpt opt, const double* __restrict__ pts,
+                                                                     const float2* __restrict__ uv, int n,
+                                                                     const RpInertial* __restrict__ ext,
+                                                                     double* __restrict__ cam_io /*[9]: pose, velocity*/,
+                                                                     BaState* __restrict__ st_out)
+{
+    __shared__ double x[9], xn[9], prep[BA_PREP], prepn[BA_PREP], scratch[4 * 32];
+    __shared__ BaState st;
+    __shared__ double sc[9];
+    const int tid = threadIdx.x;
+    const int nu = ext->kind == 2 ? 9 : 6;
+    if (tid == 0) {
+        for (int k = 0; k < 9; k++) x[k] = cam_io[k];
+        cam_prepare(x, prep);
+        st.radius = opt.r0; st.decrease_factor = 2.0; st.x_cost = 0.0; st.initial_cost = 0.0;
+        st.iter = 0; st.successful = 0; st.invalid_steps = 0; st.done = 0; st.termination = 0; st.cur = 0;
+        st.have_scale = 0; st.solver_failed = 0; st.fresh = 1; st.usable = 0; st.consec_accepts = 0; st.nact = 1;
+        st.n_rounds = 0; st.n_fresh = 0; st.n_sets = 0; st.pad = 0;
+    }
+    __syncthreads();
+    double acc[28];
+    while (true) {
+        for (int k = 0; k < 28; k++) acc[k] = 0.0;
+        ObsLin o;
+        for (int i = tid; i < n; i += RP_THREADS) {
+            const double X[3] = {pts[3 * (size_t)i], pts[3 * (size_t)i + 1], pts[3 * (size_t)i + 2]};
+            obs_eval<true>(prep, X, uv[i], d, o);
+            int q = 0;
+#pragma unroll
+            for (int a = 0; a < 6; a++) {
+#pragma unroll
+                for (int e = a; e < 6; e++) acc[q++] += o.w * (o.jc[a] * o.jc[e] + o.jc[6 + a] * o.jc[6 + e]);
+            }
+#pragma unroll
+            for (int a = 0; a < 6; a++) acc[21 + a] += o.w * (o.jc[a] * o.r0 + o.jc[6 + a] * o.r1);
+            acc[27] += 0.5 * o.rho;
+        }
+        block_sum(acc, 28, scratch);
+        if (tid == 0) {
+            double H[9][9], gv[9], lam[9], dlt[9];
+            for (int a = 0; a < 9; a++) { gv[a] = 0.0; for (int e = 0; e < 9; e++) H[a][e] = 0.0; }
+            int q = 0;
+            for (int a = 0; a < 6; a++)
+                for (int e = a; e < 6; e++) { H[a][e] = acc[q]; H[e][a] = acc[q]; q++; }
+            for (int a = 0; a < 6; a++) gv[a] = acc[21 + a];
+            double cost = acc[27];
+            // the extra residual block at x
+            if (ext->kind == 1) {
+                double r[3], J[18];
+                imu_rotation_prior(ext->predicted, ext->sigma, x, r, J);
+                for (int a = 0; a < 3; a++) {
+                    cost += 0.5 * r[a] * r[a];
+                    for (int k = 0; k < 6; k++) { gv[k] += J[a * 6 + k] * r[a]; for (int l = 0; l < 6; l++) H[k][l] += J[a * 6 + k] * J[a * 6 + l]; }
+                }
+            } else {
+                double r[9], J[9 * IMU_NP];
+                imu_preintegration(ext->fac, ext->gravity, ext->prev_pose, ext->prev_vel, ext->prev_bias, x, x + 6, r, J);
+                for (int a = 0; a < 9; a++) {
+                    cost += 0.5 * r[a] * r[a];
+                    for (int k = 0; k < 9; k++) {            // local parameters 15..23 = pose_j (6), velocity_j (3)
+                        const double jk = J[a * IMU_NP + 15 + k];
+                        gv[k] += jk * r[a];
+                        for (int l = 0; l < 9; l++) H[k][l] += jk * J[a * IMU_NP + 15 + l];
+                    }
+                }
+            }
+            if (st.fresh) {
+                st.x_cost = cost;
+                if (st.iter == 0) st.initial_cost = st.x_cost;
+                if (!st.have_scale)
+                    for (int a = 0; a < nu; a++) sc[a] = opt.jacobi ? 1.0 / (1.0 + sqrt(H[a][a])) : 1.0;
+                double gm = 0.0;
+                for (int a = 0; a < nu; a++) gm = fmax(gm, fabs(gv[a]));
+                if (!isfinite(st.x_cost)) { st.done = 1; st.termination = RS_BA_FAILURE; }
+                else if (gm <= opt.gtol) { st.done = 1; st.termination = RS_BA_CONVERGENCE_GRADIENT; }
+            }
+            if (!st.done && st.iter >= opt.max_iter) { st.done = 1; st.termination = RS_BA_NO_CONVERGENCE; }
+            if (!st.done) {
+                bool fail = false;
+                for (int a = 0; a < nu; a++) {
+                    const double s2 = sc[a] * sc[a];
+                    lam[a] = clampd(s2 * H[a][a], opt.dmin, opt.dmax) / (st.radius * s2);
+                    H[a][a] += lam[a];
+                }
+                for (int j = 0; j < nu && !fail; j++) {     // Cholesky nu x nu
+                    double dj = H[j][j];
+                    for (int k = 0; k < j; k++) dj -= H[j][k] * H[j][k];
+                    if (!(dj > 0.0) || !isfinite(dj)) { fail = true; break; }
+                    dj = sqrt(dj);
+                    H[j][j] = dj;
+                    for (int i = j + 1; i < nu; i++) {
+                        double t = H[i][j];
+                        for (int k = 0; k < j; k++) t -= H[i][k] * H[j][k];
+                        H[i][j] = t / dj;
+                    }
+                }
+                if (!fail) {
+                    for (int i = 0; i < nu; i++) {
+                        double t = gv[i];
+                        for (int k = 0; k < i; k++) t -= H[i][k] * dlt[k];
+                        dlt[i] = t / H[i][i];
+                    }
+                    for (int i = nu - 1; i >= 0; i--) {
+                        double t = dlt[i];
+                        for (int k = i + 1; k < nu; k++) t -= H[k][i] * dlt[k];
+                        dlt[i] = t / H[i][i];
+                    }
+                    double mcc = 0.0, ssq = 0.0, xsq = 0.0;
+                    for (int a = 0; a < 9; a++) xn[a] = x[a];
+                    for (int a = 0; a < nu; a++) {
+                        dlt[a] = -dlt[a];
+                        if (!isfinite(dlt[a])) fail = true;
+                        mcc += 0.5 * (dlt[a] * dlt[a] * lam[a] - dlt[a] * gv[a]);
+                        xn[a] = x[a] + dlt[a];
+                        ssq += (x[a] - xn[a]) * (x[a] - xn[a]);
+                        xsq += x[a] * x[a];
+                    }
+                    st.cam_scal[0] = mcc; st.cam_scal[1] = ssq; st.cam_scal[2] = xsq;
+                    cam_prepare(xn, prepn);
+                    // the extra block at the candidate
+                    double ce = 0.0;
+                    if (!fail) {
+                        if (ext->kind == 1) {
+                            double r[3];
+                            imu_rotation_prior(ext->predicted, ext->sigma, xn, r, nullptr);
+                            for (int a = 0; a < 3; a++) ce += 0.5 * r[a] * r[a];
+                        } else {
+                            double r[9];
+                            imu_preintegration(ext->fac, ext->gravity, ext->prev_pose, ext->prev_vel, ext->prev_bias, xn, xn + 6, r, nullptr);
+                            for (int a = 0; a < 9; a++) ce += 0.5 * r[a] * r[a];
+                        }
+                    }
+                    st.cam_scal[3] = ce;
+                }
+                st.solver_failed = fail ? 1 : 0;
+            }
+        }
+        __syncthreads();
+        if (st.done) break;
+        double cc[1] = {0.0};
+        if (!st.solver_failed) {
+            for (int i = tid; i < n; i += RP_THREADS) {
+                const double X[3] = {pts[3 * (size_t)i], pts[3 * (size_t)i + 1], pts[3 * (size_t)i + 2]};
+                obs_eval<false>(prepn, X, uv[i], d, o);
+                cc[0] += 0.5 * o.rho;
+            }
+        }
+        block_sum(cc, 1, scratch);
+        if (tid == 0) {
+            st.iter++;
+            const double cand = cc[0] + st.cam_scal[3], mcc = st.cam_scal[0];
+            st.fresh = 0;
+            if (st.solver_failed || !(mcc > 0.0)) {
+                if (++st.invalid_steps >= opt.max_invalid) { st.done = 1; st.termination = RS_BA_FAILURE; }
+                else { st.radius /= st.decrease_factor; st.decrease_factor *= 2.0; }
+            } else {
+                st.invalid_steps = 0;
+                const double step_norm = sqrt(st.cam_scal[1]), x_norm = sqrt(st.cam_scal[2]);
+                if (step_norm <= opt.ptol * (x_norm + opt.ptol)) { st.done = 1; st.termination = RS_BA_CONVERGENCE_PARAMETER; }
+                else if (fabs(st.x_cost - cand) <= opt.ftol * st.x_cost) { st.done = 1; st.termination = RS_BA_CONVERGENCE_FUNCTION; }
+                else {
+                    const double rel = (st.x_cost - cand) / mcc;
+                    if (rel > opt.min_rel && isfinite(cand)) {
+                        for (int a = 0; a < 9; a++) x[a] = xn[a];
+                        for (int a = 0; a < BA_PREP; a++) prep[a] = prepn[a];
+                        st.successful++;
+                        const double t = 2.0 * rel - 1.0;
+                        st.radius = fmin(opt.rmax, st.radius / fmax(1.0 / 3.0, 1.0 - t * t * t));
+                        st.decrease_factor = 2.0;
+                        st.fresh = 1;
+                        st.x_cost = cand;
+                    } else {
+                        st.radius /= st.decrease_factor;
+                        st.decrease_factor *= 2.0;
+                        if (st.radius < opt.rmin) { st.done = 1; st.termination = RS_BA_CONVERGENCE_RADIUS; }
+                    }
+                }
+            }
+            st.solver_failed = 0;
+            st.have_scale = 1;
+        }
+        __syncthreads();
+        if (st.done) break;
+    }
+    if (tid == 0) {
+        st.usable = (st.termination != RS_BA_FAILURE && isfinite(st.x_cost) && st.x_cost <= st.initial_cost) ? 1 : 0;
+        if (st.usable)
+            for (int k = 0; k < 9; k++) cam_io[k] = x[k];
+        *st_out = st;
+    }
+}
+
+extern "C" int rs_refine_pose_inertial(rs_context* ctx, double h_camera[6], const double* d_points, const float* d_uv, int n,
+                                       const float h_intrinsics[4], int kind, const double h_predicted[9], double sigma_radians,
+                                       const double h_prev_pose[6], const double h_prev_velocity[3], const double h_prev_bias[6],
+                                       const rs_imu_factor* h_delta, const double h_gravity[3], double h_velocity[3],
+                                       const rs_ba_options* options, rs_ba_summary* h_summary)
+{
+    if (!ctx || !h_summary || !h_camera) return RS_ERR_INVALID;
+    if (kind < 0 || kind > 2) return rs_fail(ctx, RS_ERR_INVALID, "kind must be 0, 1 or 2");
+    // RotationPrior::enabled / InertialDelta::enabled (src/Optimization.h:50-53,60-63): a disabled constraint is no constraint
+    if (kind == 1 && (!h_predicted || !(sigma_radians > 0.0))) kind = 0;
+    if (kind == 2 && (!h_delta || !(h_delta->duration > 0.0))) kind = 0;
+    if (kind == 0) return rs_refine_pose(ctx, h_camera, d_points, d_uv, n, h_intrinsics, options, h_summary);
+    memset(h_summary, 0, sizeof *h_summary);
+    if (n < 0) return rs_fail(ctx, RS_ERR_INVALID, "negative n");
+    if (n == 0) return RS_OK;   // "nothing to constrain", src/Optimization.cpp:227-229 (checked before the inertial block is added)
+    if (!d_points || !d_uv || !h_intrinsics) return rs_fail(ctx, RS_ERR_INVALID, "null pointer");
+    if (kind == 2 && (!h_prev_pose || !h_prev_velocity || !h_prev_bias || !h_gravity || !h_velocity))
+        return rs_fail(ctx, RS_ERR_INVALID, "null pointer (inertial delta)");
+    rs_ba_options def;
+    if (!options) { rs_ba_default_options(&def); options = &def; }
+    RS_HIP(ctx, hipSetDevice(ctx->device));
+    BaDims d;
+    d.C = 1; d.Cf = 1; d.P = n; d.M = n; d.n = 6;
+    d.fx = h_intrinsics[0]; d.fy = h_intrinsics[1]; d.cx = h_intrinsics[2]; d.cy = h_intrinsics[3];
+    d.huber_a = options->huber_delta;
+    BaOpt opt;
+    opt.max_iter = options->max_num_iterations; opt.max_invalid = options->max_num_consecutive_invalid_steps;
+    opt.jacobi = options->jacobi_scaling; opt.r0 = options->initial_trust_region_radius;
+    opt.rmax = options->max_trust_region_radius; opt.rmin = options->min_trust_region_radius;
+    opt.min_rel = options->min_relative_decrease; opt.dmin = options->min_lm_diagonal;
+    opt.dmax = options->max_lm_diagonal; opt.ftol = options->function_tolerance;
+    opt.gtol = options->gradient_tolerance; opt.ptol = options->parameter_tolerance;
+    const size_t ext_off = 512, ws_bytes = ext_off + ((sizeof(RpInertial) + 255) & ~(size_t)255);
+    void* wsv = nullptr;
+    int rc = rs_workspace(ctx, ws_bytes, &wsv);
+    if (rc) return rc;
+    double* d_cam = (double*)wsv;
+    BaState* d_st = (BaState*)((char*)wsv + 256);
+    RpInertial* d_ext = (RpInertial*)((char*)wsv + ext_off);
+    void* pin = nullptr;
+    rc = rs_pinned(ctx, 1024 + sizeof(RpInertial), &pin);
+    if (rc) return rc;
+    ctx->ba_trace_n = 0;
+    ctx->ba_cams = nullptr;
+    ctx->ba_cams_n = 0;
+    double* h_cam = (double*)pin;
+    BaState* h_st = (BaState*)((char*)pin + 256);
+    RpInertial* h_ext = (RpInertial*)((char*)pin + 1024);
+    memset(h_ext, 0, sizeof *h_ext);
+    h_ext->kind = kind;
+    if (kind == 1) {
+        memcpy(h_ext->predicted, h_predicted, sizeof h_ext->predicted);
+        h_ext->sigma = sigma_radians;
+    } else {
+        memcpy(h_ext->prev_pose, h_prev_pose, sizeof h_ext->prev_pose);
+        memcpy(h_ext->prev_vel, h_prev_velocity, sizeof h_ext->prev_vel);
+        memcpy(h_ext->prev_bias, h_prev_bias, sizeof h_ext->prev_bias);
+        memcpy(h_ext->gravity, h_gravity, sizeof h_ext->gravity);
+        h_ext->fac.f = *h_delta;
+        imu_whitener(h_delta->covariance, h_ext->fac.W);
+    }
+    memcpy(h_cam, h_camera, 6 * sizeof(double));
+    for (int k = 0; k < 3; k++) h_cam[6 + k] = (kind == 2) ? h_velocity[k] : 0.0;
+    hipStream_t s = ctx->stream;
+    RS_HIP(ctx, hipMemcpyAsync(d_cam, h_cam, 9 * sizeof(double), hipMemcpyHostToDevice, s));
+    RS_HIP(ctx, hipMemcpyAsync(d_ext, h_ext, sizeof(RpInertial), hipMemcpyHostToDevice, s));
+    {
+        rs_prof_scope ps(ctx, "K11_refine_pose_inertial");
+        hipLaunchKernelGGL(ba_refine_pose_inertial, dim3(1), dim3(RP_THREADS), 0, s, d, opt, d_points, (const float2*)d_uv, n,
+                           (const RpInertial*)d_ext, d_cam, d_st);
+    }
+    RS_HIP(ctx, hipMemcpyAsync(h_cam, d_cam, 9 * sizeof(double), hipMemcpyDeviceToHost, s));
+    RS_HIP(ctx, hipMemcpyAsync(h_st, d_st, sizeof(BaState), hipMemcpyDeviceToHost, s));
+    RS_HIP(ctx, hipStreamSynchronize(s));
+    RS_HIP(ctx, hipGetLastError());
+    if (h_st->usable) {
+        memcpy(h_camera, h_cam, 6 * sizeof(double));
+        if (kind == 2) memcpy(h_velocity, h_cam + 6, 3 * sizeof(double));    // unpack_inertial, :263-265
+    }
     h_summary->termination = h_st->termination;
     h_summary->iterations = h_st->iter;
     h_summary->successful_steps = h_st->successful;

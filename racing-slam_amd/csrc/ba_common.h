@@ -18,7 +18,7 @@
 
 struct BaState {
     double radius, decrease_factor, x_cost, initial_cost;
-    double cam_scal[4];       // K7 (set 0): mcc_c, step_sq_c, x_sq_c, unused
+    double cam_scal[4];       // K7 (set 0): mcc_c, step_sq_c, x_sq_c, candidate cost of the inertial blocks
     int iter, successful, invalid_steps, done;
     int termination, cur, have_scale, solver_failed;
     int fresh, usable;
@@ -60,7 +60,28 @@ struct BaDims {
     double huber_a;
 };
 
+// Inertial residual blocks (reference src/Optimization.cpp:317-346, src/ImuFactor.cpp): the reduced camera system
+// grows from 6 unknowns per free camera to N = 6 Cf + 9 Ci (velocity 3 + bias 6 for each of the Ci frames an IMU
+// factor touches).  The landmark side (K5, K8) is unchanged — the factors only involve camera-side blocks — and the
+// reduced solve runs on the blocked solver with its own prologue / finish (ba_solve_big.hip).  All null / zero on a
+// vision-only solve.
+struct ImuFactorDev;
+struct BaImu {
+    int n_fac, Ci, N;
+    const ImuFactorDev* fac;       // [n_fac] factors + whiteners
+    const int32_t* inert_slot;     // [C] index among the inertial frames or -1
+    double* Xv;                    // [2][C][9] velocity (3) | bias (6) per camera, state buffers cur / cur ^ 1
+    double* A;                     // [N][N] damped reduced matrix (lower triangle)
+    double* yv;                    // [N + 1] right-hand side
+    double* lam;                   // [N] damping
+    double* sc;                    // [N] Jacobi scale
+    double* gtot;                  // [N] camera-side gradient incl. the inertial blocks
+    double* Jf;                    // [n_fac][9][24] preintegration Jacobians of this round
+    double gravity[3];
+};
+
 struct BaBufs {
+    BaImu imu;
     const int32_t* obs_ptr;   // [P+1]
     const int32_t* obs_cam;   // [M]
     const float2* obs_uv;     // [M]
@@ -243,6 +264,7 @@ __device__ __forceinline__ void ba_apply_decision(BaState& st, double cand, doub
     if (st.done) return;
     BaTrace* tr = trace ? trace + st.iter : nullptr;
     st.iter++;
+    cand += st.cam_scal[3];       // cost of the camera-side (inertial) residual blocks at the candidate; 0 without them
     const double mcc = mcc_p + st.cam_scal[0];
     const double step_norm = sqrt(ssq_p + st.cam_scal[1]);
     const double x_norm = sqrt(xsq_p + st.cam_scal[2]);
@@ -437,6 +459,10 @@ void ba_launch_schur(hipStream_t s, const BaDims& d, const BaBufs& b, const BaOp
 struct rs_context;
 size_t ba_big_bytes(int n);
 int ba_launch_reduced_solve_big(rs_context* ctx, const BaDims& d, const BaBufs& b, const BaOpt& opt, char* ws);
+// ---- inertial reduced solve (ba_solve_big.hip): N = 6 Cf + 9 Ci unknowns
+size_t ba_inertial_bytes(int N, int n_fac, int C);
+void ba_inertial_carve(char* ws, int N, int n_fac, int C, BaImu* imu, ImuFactorDev** d_fac, int32_t** d_inert);
+int ba_launch_reduced_solve_inertial(rs_context* ctx, const BaDims& d, const BaBufs& b, const BaOpt& opt, char* ws);
 // ---- LDS-resident reduced solve (ba_solve.hip), n = 6*Cf <= BA_MAX_LDS_N
 size_t ba_reduced_solve_lds_bytes(int n);
 int ba_prepare_reduced_solve_lds(int n);

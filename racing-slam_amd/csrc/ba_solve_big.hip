@@ -18,6 +18,7 @@
 // ~2 + 2 NB + 1 launches (29 at n = 588): launch-bound (~4.4 us each) rather than flop-bound
 // (68 MFLOP), 25.9 ms -> ~0.3 ms per solve against the single-workgroup global-memory Cholesky it replaces.
 #include "ba_common.h"
+#include "imu_dual.h"
 
 #define BB 48                 // block size: 8 cameras
 #define BBS 49                // LDS row stride of a block
@@ -353,23 +354,10 @@ __global__ __launch_bounds__(256) void ba_big_update(BaDims d, BaBufs b, BigBufs
     }
 }
 
-// ------------------------------------------------------------------ finish
-__global__ __launch_bounds__(1024) void ba_big_finish(BaDims d, BaBufs b, BaOpt opt, BigBufs g)
+// block backward substitution L^T x = D^-1 L^-1 g by one workgroup: y (LDS, [n]) becomes x; Lb is an LDS block buffer
+static __device__ __forceinline__ void big_backsub(const BigBufs& g, int n, double* y, double* Lb)
 {
-    extern __shared__ __attribute__((aligned(16))) double sm[];
-    const int n = d.n, tid = threadIdx.x, nt = blockDim.x;
-    double* y = sm;                   // [n] becomes x
-    double* Lb = y + n;               // [BB][BBS] current diagonal block
-    __shared__ BaState st;
-    __shared__ int s_fail;
-    __shared__ double red3[16][3];
-    if (tid == 0) { st = *b.st; s_fail = *g.fail; }
-    __syncthreads();
-    if (st.done) return;
-    if (s_fail) {
-        if (tid == 0) { st.solver_failed = 1; *b.st = st; }
-        return;
-    }
+    const int tid = threadIdx.x, nt = blockDim.x;
     for (int i = tid; i < n; i += nt) y[i] = g.yf[i];
     const int NBLK = (n + BB - 1) / BB;
     for (int J = NBLK - 1; J >= 0; J--) {
@@ -400,6 +388,26 @@ __global__ __launch_bounds__(1024) void ba_big_finish(BaDims d, BaBufs b, BaOpt 
         }
         __syncthreads();
     }
+}
+
+// ------------------------------------------------------------------ finish
+__global__ __launch_bounds__(1024) void ba_big_finish(BaDims d, BaBufs b, BaOpt opt, BigBufs g)
+{
+    extern __shared__ __attribute__((aligned(16))) double sm[];
+    const int n = d.n, tid = threadIdx.x, nt = blockDim.x;
+    double* y = sm;                   // [n] becomes x
+    double* Lb = y + n;               // [BB][BBS] current diagonal block
+    __shared__ BaState st;
+    __shared__ int s_fail;
+    __shared__ double red3[16][3];
+    if (tid == 0) { st = *b.st; s_fail = *g.fail; }
+    __syncthreads();
+    if (st.done) return;
+    if (s_fail) {
+        if (tid == 0) { st.solver_failed = 1; *b.st = st; }
+        return;
+    }
+    big_backsub(g, n, y, Lb);
     // delta_c = -x, candidate cameras, camera part of the step scalars (as ba_solve.hip (5))
     const double* lam = b.rhs;
     double mcc = 0.0, ssq = 0.0, xsq = 0.0;
@@ -441,6 +449,30 @@ __global__ __launch_bounds__(1024) void ba_big_finish(BaDims d, BaBufs b, BaOpt 
 }
 
 // ------------------------------------------------------------------ host glue
+// the factorisation proper: per 48-column block a diagonal-block launch and a trailing-update launch.  Works on
+// d.n, b.S (matrix, lower triangle), b.dc (right-hand side) and the BigBufs; nothing in it knows what the unknowns are.
+static void big_launch_factor(hipStream_t s, const BaDims& d, const BaBufs& b, const BigBufs& g, size_t lds_upd)
+{
+    const int NBLK = (d.n + BB - 1) / BB;
+    for (int J = 0; J < NBLK; J++) {
+        hipLaunchKernelGGL(ba_big_diag, dim3(1), dim3(256), 0, s, d, b, g, J);
+        const int nb = NBLK - J - 1;                       // trailing column blocks
+        const int pairs = nb * (nb + 1) / 2 + nb;          // (bi >= bk) pairs + one right-hand-side pair per bk
+        if (pairs > 0) hipLaunchKernelGGL(ba_big_update, dim3(pairs), dim3(256), lds_upd, s, d, b, g, J);
+    }
+}
+
+static void big_carve(char* ws, size_t n, BigBufs* g)
+{
+    auto al = [](size_t v) { return (v + 255) & ~(size_t)255; };
+    size_t off = 0;
+    g->Ls = (double*)(ws + off); off += al(sizeof(double) * n * n);
+    g->M = (double*)(ws + off); off += al(sizeof(double) * BB * BB);
+    g->dv = (double*)(ws + off); off += al(sizeof(double) * n);
+    g->yf = (double*)(ws + off); off += al(sizeof(double) * n);
+    g->fail = (int*)(ws + off);
+}
+
 size_t ba_big_bytes(int n)
 {
     return sizeof(double) * ((size_t)n * n + BB * BB + 2 * (size_t)n) + 256 * 5;
@@ -449,16 +481,9 @@ size_t ba_big_bytes(int n)
 int ba_launch_reduced_solve_big(rs_context* ctx, const BaDims& d, const BaBufs& b, const BaOpt& opt, char* ws)
 {
     const size_t n = (size_t)d.n;
-    auto al = [](size_t v) { return (v + 255) & ~(size_t)255; };
     BigBufs g;
-    size_t off = 0;
-    g.Ls = (double*)(ws + off); off += al(sizeof(double) * n * n);
-    g.M = (double*)(ws + off); off += al(sizeof(double) * BB * BB);
-    g.dv = (double*)(ws + off); off += al(sizeof(double) * n);
-    g.yf = (double*)(ws + off); off += al(sizeof(double) * n);
-    g.fail = (int*)(ws + off);
+    big_carve(ws, n, &g);
     hipStream_t s = ctx->stream;
-    const int NBLK = (d.n + BB - 1) / BB;
     const size_t lds_fin = sizeof(double) * (n + BB * BBS);
     if (lds_fin > 48 * 1024)
         RS_HIP(ctx, hipFuncSetAttribute((const void*)ba_big_finish, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_fin));
@@ -466,12 +491,261 @@ int ba_launch_reduced_solve_big(rs_context* ctx, const BaDims& d, const BaBufs& 
     RS_HIP(ctx, hipFuncSetAttribute((const void*)ba_big_update, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_upd));
     hipLaunchKernelGGL(ba_big_prologue, dim3(1), dim3(1024), 0, s, d, b, opt, g);
     hipLaunchKernelGGL(ba_big_assemble, dim3(256), dim3(256), 0, s, d, b);
-    for (int J = 0; J < NBLK; J++) {
-        hipLaunchKernelGGL(ba_big_diag, dim3(1), dim3(256), 0, s, d, b, g, J);
-        const int nb = NBLK - J - 1;                       // trailing column blocks
-        const int pairs = nb * (nb + 1) / 2 + nb;          // (bi >= bk) pairs + one right-hand-side pair per bk
-        if (pairs > 0) hipLaunchKernelGGL(ba_big_update, dim3(pairs), dim3(256), lds_upd, s, d, b, g, J);
-    }
+    big_launch_factor(s, d, b, g, lds_upd);
     hipLaunchKernelGGL(ba_big_finish, dim3(1), dim3(1024), lds_fin, s, d, b, opt, g);
+    return RS_OK;
+}
+
+// =============================================================================== inertial reduced solve
+// bundle_adjust with IMU factor pairs (reference src/Optimization.cpp:317-346): the camera side of the problem has,
+// besides the 6-unknown pose blocks, a velocity (3) and a bias (6) block per frame the factors touch.  The landmark
+// side is untouched (K5 / K8 as in the vision-only solve; the factors involve no point), so only this reduced solve
+// differs:  N = 6 Cf + 9 Ci unknowns,  A = [U + S_schur on the pose part] + J_imu^T J_imu + Lambda,  y = g_total,
+// factorised by the same blocked L D L^T (diag / update launches above).
+//   ba_imu_prologue (1 WG)  replica fold, linearisation of every factor (one thread per factor, dual numbers),
+//                           total cost / gradient / Jacobi scale / damping, assembly of A and y
+//   ba_imu_finish   (1 WG)  backward substitution, pose / velocity / bias step and candidates, step scalars, cost of
+//                           the inertial blocks at the candidate (-> BaState::cam_scal[3], added to K8's cost)
+// Ceres semantics restated in oracle/ba.c (extra residual blocks): Jacobi scale and LM diagonal per column from the
+// TOTAL J^T J diagonal (reprojection + inertial), gradient tolerance on the total gradient, x-norm over all blocks.
+__device__ __forceinline__ void imu_columns(const BaDims& d, const BaBufs& b, int i, int j, int col[IMU_NP])
+{
+    const int n6 = d.n, qi = b.imu.inert_slot[i], qj = b.imu.inert_slot[j], si = b.slot[i], sj = b.slot[j];
+    for (int k = 0; k < 6; k++) { col[k] = 6 * si + k; col[9 + k] = n6 + 9 * qi + 3 + k; col[15 + k] = 6 * sj + k; }
+    for (int k = 0; k < 3; k++) { col[6 + k] = n6 + 9 * qi + k; col[21 + k] = n6 + 9 * qj + k; }
+}
+
+__global__ __launch_bounds__(1024) void ba_imu_prologue(BaDims d, BaBufs b, BaOpt opt, BigBufs g)
+{
+    const int n6 = d.n, N = b.imu.N, tid = threadIdx.x, nt = blockDim.x;
+    __shared__ BaState st;
+    __shared__ double red[16];
+    __shared__ double s_cost;
+    if (tid == 0) { st = *b.st; *g.fail = 0; s_cost = 0.0; }
+    __syncthreads();
+    if (st.done) return;
+    for (int i = tid; i < BA_NSLOT * BA_SLOT_STRIDE; i += nt) b.pt_scal[i] = 0.0;     // K8 of this round accumulates here
+    for (size_t i = tid; i < b.cam_stride; i += nt) {                                  // fold the accumulator replicas
+        double v = 0.0;
+        for (int r = 0; r < BA_UREP; r++) v += b.rhs[(size_t)r * b.cam_stride + i];
+        if ((int)i >= n6) { if (st.fresh) b.Ukeep[i - n6] = v; else v = b.Ukeep[i - n6]; }
+        b.rhs[i] = v;
+    }
+    for (size_t i = tid; i < (size_t)N * N; i += nt) b.imu.A[i] = 0.0;
+    for (int i = tid; i < N; i += nt) b.imu.gtot[i] = 0.0;
+    __syncthreads();
+    // ---- linearise the factors at x: J^T J into the lower triangle of A, J^T r into gtot, 1/2 |r|^2 into the cost
+    const double* Xc = b.Xc + (size_t)st.cur * d.C * 6;
+    const double* Xv = b.imu.Xv + (size_t)st.cur * d.C * 9;
+    if (tid < b.imu.n_fac) {
+        const ImuFactorDev& F = b.imu.fac[tid];
+        const int i = F.f.cam_i, j = F.f.cam_j;
+        double r[9], rw[6], is[2];
+        double* J = b.imu.Jf + (size_t)tid * 9 * IMU_NP;
+        imu_preintegration(F, b.imu.gravity, Xc + 6 * i, Xv + 9 * i, Xv + 9 * i + 3, Xc + 6 * j, Xv + 9 * j, r, J);
+        imu_bias_walk(F.f, Xv + 9 * i + 3, Xv + 9 * j + 3, rw, is);
+        int col[IMU_NP];
+        imu_columns(d, b, i, j, col);
+        double c = 0.0;
+        for (int a = 0; a < 9; a++) {
+            c += 0.5 * r[a] * r[a];
+            for (int k = 0; k < IMU_NP; k++) {
+                const double jk = J[a * IMU_NP + k];
+                atomicAdd(&b.imu.gtot[col[k]], jk * r[a]);
+                for (int l = 0; l < IMU_NP; l++)
+                    if (col[k] >= col[l]) atomicAdd(&b.imu.A[(size_t)col[k] * N + col[l]], jk * J[a * IMU_NP + l]);
+            }
+        }
+        for (int a = 0; a < 6; a++) {                       // bias walk: -1/sigma on bias_i[a], +1/sigma on bias_j[a]
+            c += 0.5 * rw[a] * rw[a];
+            const double sg = is[a / 3], s2 = sg * sg;
+            const int ci = col[9 + a], cj = n6 + 9 * b.imu.inert_slot[j] + 3 + a;
+            atomicAdd(&b.imu.gtot[ci], -sg * rw[a]);
+            atomicAdd(&b.imu.gtot[cj], sg * rw[a]);
+            atomicAdd(&b.imu.A[(size_t)ci * N + ci], s2);
+            atomicAdd(&b.imu.A[(size_t)cj * N + cj], s2);
+            atomicAdd(&b.imu.A[(size_t)max(ci, cj) * N + min(ci, cj)], -s2);
+        }
+        atomicAdd(&s_cost, c);
+    }
+    __syncthreads();
+    // ---- totals per column: diagonal of J^T J, gradient; Jacobi scale (first linearisation), damping, right-hand side
+    double gm = 0.0;
+    for (int i = tid; i < N; i += nt) {
+        const double h = b.imu.A[(size_t)i * N + i] + (i < n6 ? b.U[(i / 6) * 36 + (i % 6) * 7] : 0.0);
+        const double gi = b.imu.gtot[i] + (i < n6 ? b.gc[i] : 0.0);
+        double sc = b.imu.sc[i];
+        if (!st.have_scale) { sc = opt.jacobi ? 1.0 / (1.0 + sqrt(h)) : 1.0; b.imu.sc[i] = sc; }
+        const double s2 = sc * sc;
+        b.imu.lam[i] = clampd(s2 * h, opt.dmin, opt.dmax) / (st.radius * s2);
+        b.imu.gtot[i] = gi;
+        b.imu.yv[i] = gi + (i < n6 ? b.rhs[i] : 0.0);
+        gm = fmax(gm, fabs(gi));
+    }
+    if (st.fresh) {
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) gm = fmax(gm, __shfl_down(gm, off, 64));
+        if ((tid & 63) == 0) red[tid >> 6] = gm;
+        __syncthreads();
+        double cslots = 0.0, gslots = 0.0;
+        if (tid < 64) { cslots = slot_sum(b.scal, 0); gslots = slot_max_all(b); }
+        if (tid == 0) {
+            st.x_cost = cslots + s_cost;
+            if (st.iter == 0) st.initial_cost = st.x_cost;
+            double gg = gslots;
+            for (int w = 0; w < (nt + 63) / 64; w++) gg = fmax(gg, red[w]);
+            if (!isfinite(st.x_cost)) { st.done = 1; st.termination = RS_BA_FAILURE; }
+            else if (gg <= opt.gtol) { st.done = 1; st.termination = RS_BA_CONVERGENCE_GRADIENT; }
+        }
+    }
+    __syncthreads();
+    if (tid < 64) { const double f = slot_sum(b.scal, 1); if (f > 0.0 && tid == 0) *g.fail = 1; }   // K5 saw a bad landmark block
+    if (tid == 0) *b.st = st;
+    if (st.done) return;
+    __syncthreads();
+    // ---- the lower triangle of the damped matrix: inertial part (already there) + U + S_schur (pose part) + Lambda
+    for (size_t idx = tid; idx < (size_t)N * N; idx += nt) {
+        const int i = (int)(idx / N), j = (int)(idx % N);
+        if (i < j) continue;
+        double v = b.imu.A[idx];
+        if (i < n6) {                                       // j <= i < n6: both are pose columns
+            v += b.S[(size_t)j * n6 + i];                   // K5 accumulates S in its upper triangle
+            if (i / 6 == j / 6) v += b.U[(i / 6) * 36 + (j % 6) * 6 + (i % 6)];
+        }
+        if (i == j) v += b.imu.lam[i];
+        b.imu.A[idx] = v;
+    }
+}
+
+__global__ __launch_bounds__(1024) void ba_imu_finish(BaDims d, BaBufs b, BaOpt opt, BigBufs g)
+{
+    extern __shared__ __attribute__((aligned(16))) double sm[];
+    const int n6 = d.n, N = b.imu.N, tid = threadIdx.x, nt = blockDim.x;
+    double* y = sm;                   // [N] becomes x
+    double* Lb = y + N;               // [BB][BBS]
+    __shared__ BaState st;
+    __shared__ int s_fail;
+    __shared__ double red3[16][3];
+    __shared__ double s_cand;
+    if (tid == 0) { st = *b.st; s_fail = *g.fail; s_cand = 0.0; }
+    __syncthreads();
+    if (st.done) return;
+    if (s_fail) {
+        if (tid == 0) { st.solver_failed = 1; *b.st = st; }
+        return;
+    }
+    big_backsub(g, N, y, Lb);
+    double mcc = 0.0, ssq = 0.0, xsq = 0.0;
+    bool bad = false;
+    const double* Xc = b.Xc + (size_t)st.cur * d.C * 6;
+    double* Xn = b.Xc + (size_t)(st.cur ^ 1) * d.C * 6;
+    const double* Xv = b.imu.Xv + (size_t)st.cur * d.C * 9;
+    double* Xvn = b.imu.Xv + (size_t)(st.cur ^ 1) * d.C * 9;
+    for (int c = tid; c < d.C; c += nt) {
+        const int s = b.slot[c], q = b.imu.inert_slot[c];
+        bool active = q >= 0;                               // a frame with an inertial block is in the problem
+        if (s >= 0)
+            for (int k = 0; k < 6; k++) active = active || b.U[s * 36 + k * 7] > 0.0;
+        for (int k = 0; k < 6; k++) {
+            const double x = Xc[6 * c + k];
+            if (s >= 0) {
+                const double dlt = -y[6 * s + k];
+                if (!isfinite(dlt)) bad = true;
+                mcc += 0.5 * (dlt * dlt * b.imu.lam[6 * s + k] - dlt * b.imu.gtot[6 * s + k]);
+                const double xn = x + dlt;
+                if (active) { ssq += (x - xn) * (x - xn); xsq += x * x; }
+                Xn[6 * c + k] = xn;
+                b.dc[6 * s + k] = dlt;                       // K8 back-substitutes the points with the pose step
+            } else {
+                Xn[6 * c + k] = x;
+            }
+        }
+        for (int k = 0; k < 9; k++) {
+            const double x = Xv[9 * c + k];
+            if (q >= 0) {
+                const int col = n6 + 9 * q + k;
+                const double dlt = -y[col];
+                if (!isfinite(dlt)) bad = true;
+                mcc += 0.5 * (dlt * dlt * b.imu.lam[col] - dlt * b.imu.gtot[col]);
+                const double xn = x + dlt;
+                ssq += (x - xn) * (x - xn); xsq += x * x;
+                Xvn[9 * c + k] = xn;
+            } else {
+                Xvn[9 * c + k] = x;
+            }
+        }
+        cam_prepare(Xn + 6 * c, b.prep + ((size_t)(st.cur ^ 1) * d.C + c) * BA_PREP);
+    }
+    __syncthreads();                                         // candidates written (same workgroup reads them below)
+    if (tid < b.imu.n_fac) {                                // cost of the inertial blocks at the candidate
+        const ImuFactorDev& F = b.imu.fac[tid];
+        const int i = F.f.cam_i, j = F.f.cam_j;
+        double r[9], rw[6], is[2], c = 0.0;
+        imu_preintegration(F, b.imu.gravity, Xn + 6 * i, Xvn + 9 * i, Xvn + 9 * i + 3, Xn + 6 * j, Xvn + 9 * j, r, nullptr);
+        imu_bias_walk(F.f, Xvn + 9 * i + 3, Xvn + 9 * j + 3, rw, is);
+        for (int a = 0; a < 9; a++) c += 0.5 * r[a] * r[a];
+        for (int a = 0; a < 6; a++) c += 0.5 * rw[a] * rw[a];
+        atomicAdd(&s_cand, c);
+    }
+    mcc = wave_sum(mcc); ssq = wave_sum(ssq); xsq = wave_sum(xsq);
+    if (__any(bad) && (tid & 63) == 0) s_fail = 1;
+    if ((tid & 63) == 0) { red3[tid >> 6][0] = mcc; red3[tid >> 6][1] = ssq; red3[tid >> 6][2] = xsq; }
+    __syncthreads();
+    if (tid == 0) {
+        double a0 = 0, a1 = 0, a2 = 0;
+        for (int w = 0; w < nt / 64; w++) { a0 += red3[w][0]; a1 += red3[w][1]; a2 += red3[w][2]; }
+        st.cam_scal[0] = a0; st.cam_scal[1] = a1; st.cam_scal[2] = a2; st.cam_scal[3] = s_cand;
+        st.solver_failed = s_fail;
+        *b.st = st;
+    }
+}
+
+size_t ba_inertial_bytes(int N, int n_fac, int C)
+{
+    auto al = [](size_t v) { return (v + 255) & ~(size_t)255; };
+    return ba_big_bytes(N) + al(sizeof(double) * (size_t)N * N) + 4 * al(sizeof(double) * ((size_t)N + 1)) +
+           al(sizeof(double) * (size_t)(n_fac + 1) * 9 * IMU_NP) + al(sizeof(ImuFactorDev) * (size_t)(n_fac + 1)) +
+           al(sizeof(int32_t) * (size_t)(C + 1)) + al(sizeof(double) * 2 * 9 * (size_t)(C + 1)) + 256;
+}
+
+// carves the inertial buffers out of `ws` (after the BigBufs region); returns the device addresses the host uploads to
+void ba_inertial_carve(char* ws, int N, int n_fac, int C, BaImu* imu, ImuFactorDev** d_fac, int32_t** d_inert)
+{
+    auto al = [](size_t v) { return (v + 255) & ~(size_t)255; };
+    size_t off = ba_big_bytes(N);
+    off = al(off);
+    imu->A = (double*)(ws + off); off += al(sizeof(double) * (size_t)N * N);
+    imu->yv = (double*)(ws + off); off += al(sizeof(double) * ((size_t)N + 1));
+    imu->lam = (double*)(ws + off); off += al(sizeof(double) * ((size_t)N + 1));
+    imu->sc = (double*)(ws + off); off += al(sizeof(double) * ((size_t)N + 1));
+    imu->gtot = (double*)(ws + off); off += al(sizeof(double) * ((size_t)N + 1));
+    imu->Jf = (double*)(ws + off); off += al(sizeof(double) * (size_t)(n_fac + 1) * 9 * IMU_NP);
+    *d_fac = (ImuFactorDev*)(ws + off); off += al(sizeof(ImuFactorDev) * (size_t)(n_fac + 1));
+    *d_inert = (int32_t*)(ws + off); off += al(sizeof(int32_t) * (size_t)(C + 1));
+    imu->Xv = (double*)(ws + off);
+    imu->fac = *d_fac;
+    imu->inert_slot = *d_inert;
+}
+
+int ba_launch_reduced_solve_inertial(rs_context* ctx, const BaDims& d, const BaBufs& b, const BaOpt& opt, char* ws)
+{
+    const int N = b.imu.N;
+    BigBufs g;
+    big_carve(ws, (size_t)N, &g);
+    hipStream_t s = ctx->stream;
+    const size_t lds_fin = sizeof(double) * ((size_t)N + BB * BBS);
+    if (lds_fin > 48 * 1024)
+        RS_HIP(ctx, hipFuncSetAttribute((const void*)ba_imu_finish, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_fin));
+    const size_t lds_upd = sizeof(double) * (6 * BB * BBS + 2 * BB * 17 + BB);
+    RS_HIP(ctx, hipFuncSetAttribute((const void*)ba_big_update, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_upd));
+    hipLaunchKernelGGL(ba_imu_prologue, dim3(1), dim3(1024), 0, s, d, b, opt, g);
+    // the factorisation runs on the N x N system: same kernels, their view of (n, matrix, right-hand side) swapped
+    BaDims dN = d;
+    dN.n = N;
+    BaBufs bN = b;
+    bN.S = b.imu.A;
+    bN.dc = b.imu.yv;
+    big_launch_factor(s, dN, bN, g, lds_upd);
+    hipLaunchKernelGGL(ba_imu_finish, dim3(1), dim3(1024), lds_fin, s, d, b, opt, g);
     return RS_OK;
 }

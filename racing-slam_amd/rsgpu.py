@@ -16,7 +16,7 @@ EXPORTS = [
     "rs_abi_version", "rs_context_create", "rs_context_destroy", "rs_context_set_stream",
     "rs_context_synchronize", "rs_context_set_int", "rs_stage_begin", "rs_stage_alloc", "rs_stage_upload", "rs_stage_download", "rs_stage_sync", "rs_last_error", "rs_hamming_knn2", "rs_match_descriptors",
     "rs_kdtree_build", "rs_reproj_match", "rs_triangulate", "rs_triangulate_matches", "rs_triangulate_matches_batch", "rs_triangulate_tracks", "rs_point_errors", "rs_ba_default_options",
-    "rs_bundle_adjust", "rs_ba_get_trace", "rs_ba_get_stats", "rs_ba_get_cameras", "rs_reanchor_points", "rs_refine_pose", "rs_pack_pose", "rs_unpack_pose", "rs_pack_poses", "rs_unpack_poses", "rs_build_local_window",
+    "rs_bundle_adjust", "rs_ba_get_trace", "rs_ba_get_stats", "rs_ba_get_cameras", "rs_reanchor_points", "rs_refine_pose", "rs_bundle_adjust_inertial", "rs_refine_pose_inertial", "rs_pack_pose", "rs_unpack_pose", "rs_pack_poses", "rs_unpack_poses", "rs_build_local_window",
     "rs_comm_get_unique_id", "rs_comm_init_rank", "rs_comm_destroy", "rs_comm_init_local", "rs_prof_begin", "rs_prof_end", "rs_prof_counters",
 ]
 
@@ -82,6 +82,27 @@ class BaIteration(C.Structure):
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_ if not k.startswith("reserved")}
+
+
+class ImuFactor(C.Structure):
+    """rs_imu_factor"""
+    _fields_ = [("cam_i", C.c_int), ("cam_j", C.c_int), ("duration", C.c_double), ("rotation", C.c_double * 9),
+                ("velocity", C.c_double * 3), ("position", C.c_double * 3), ("covariance", C.c_double * 81),
+                ("bias_gyro", C.c_double * 3), ("bias_accel", C.c_double * 3), ("bias_jacobian", C.c_double * 54),
+                ("gyro_bias_sigma", C.c_double), ("accel_bias_sigma", C.c_double)]
+
+
+def imu_factor_array(imu):
+    """synth.make_imu(...) dict -> ctypes array of rs_imu_factor."""
+    n = len(imu["cam_i"])
+    arr = (ImuFactor * max(n, 1))()
+    for f in range(n):
+        a = arr[f]
+        a.cam_i, a.cam_j, a.duration = int(imu["cam_i"][f]), int(imu["cam_j"][f]), float(imu["duration"][f])
+        for name in ("rotation", "velocity", "position", "covariance", "bias_gyro", "bias_accel", "bias_jacobian"):
+            getattr(a, name)[:] = list(np.asarray(imu[name][f], np.float64).ravel())
+        a.gyro_bias_sigma, a.accel_bias_sigma = float(imu["gyro_bias_sigma"]), float(imu["accel_bias_sigma"])
+    return arr, n
 
 
 class ProfEntry(C.Structure):
@@ -357,6 +378,50 @@ class Context:
                                               None if options is None else C.byref(options), C.byref(s)),
                     "rs_bundle_adjust")
         return s.as_dict()
+
+    def bundle_adjust_inertial(self, d_cams, cam_free, d_points, d_obs_ptr, d_obs_cam, d_obs_uv, K, imu, options=None):
+        """rs_bundle_adjust_inertial; imu = synth.make_imu dict.  Returns (summary, velocity [C][3], bias [C][6])."""
+        cam_free = np.ascontiguousarray(cam_free, np.uint8)
+        Kc = (C.c_float * 4)(*[float(v) for v in K])
+        vel = np.array(imu["cam_velocity"], np.float64, order="C")
+        bias = np.array(imu["cam_bias"], np.float64, order="C")
+        g = np.ascontiguousarray(imu["gravity"], np.float64)
+        arr, nf = imu_factor_array(imu)
+        s = BaSummary()
+        self._check(self.lib.rs_bundle_adjust_inertial(
+            self.h, int(d_cams.shape[0]), int(d_points.shape[0]), int(d_obs_cam.shape[0]), _dp(d_cams),
+            cam_free.ctypes.data_as(C.c_void_p), _dp(d_points), _dp(d_obs_ptr), _dp(d_obs_cam), _dp(d_obs_uv), Kc,
+            vel.ctypes.data_as(C.c_void_p), bias.ctypes.data_as(C.c_void_p), arr, nf, g.ctypes.data_as(C.c_void_p),
+            None if options is None else C.byref(options), C.byref(s)), "rs_bundle_adjust_inertial")
+        return s.as_dict(), vel, bias
+
+    def refine_pose_inertial(self, cam, d_points, d_uv, K, prior=None, delta=None, options=None):
+        """rs_refine_pose_inertial; prior = (predicted 3x3, sigma) or delta = dict(imu=<one-factor dict>, prev_pose,
+        prev_velocity, prev_bias, velocity).  Returns cam, velocity, summary."""
+        cam = np.array(cam, np.float64, order="C")
+        Kc = (C.c_float * 4)(*[float(v) for v in K])
+        s = BaSummary()
+        vel = np.zeros(3)
+        vp = lambda a: np.ascontiguousarray(a, np.float64).ctypes.data_as(C.c_void_p)      # noqa: E731
+        kind, pred, sigma, keep, args = 0, None, 0.0, [], [None, None, None, None, None]
+        if prior is not None:
+            kind, sigma = 1, float(prior[1])
+            keep.append(np.ascontiguousarray(prior[0], np.float64))
+            pred = keep[-1].ctypes.data_as(C.c_void_p)
+        if delta is not None:
+            kind = 2
+            farr, _ = imu_factor_array(delta["imu"])
+            keep += [np.ascontiguousarray(delta[k], np.float64) for k in ("prev_pose", "prev_velocity", "prev_bias")]
+            keep.append(np.ascontiguousarray(delta["imu"]["gravity"], np.float64))
+            vel = np.array(delta["velocity"], np.float64)
+            args = [keep[-4].ctypes.data_as(C.c_void_p), keep[-3].ctypes.data_as(C.c_void_p), keep[-2].ctypes.data_as(C.c_void_p),
+                    farr, keep[-1].ctypes.data_as(C.c_void_p)]
+        del vp
+        self._check(self.lib.rs_refine_pose_inertial(
+            self.h, cam.ctypes.data_as(C.c_void_p), _dp(d_points), _dp(d_uv), int(d_points.shape[0]), Kc, kind, pred,
+            C.c_double(sigma), args[0], args[1], args[2], args[3], args[4], vel.ctypes.data_as(C.c_void_p),
+            None if options is None else C.byref(options), C.byref(s)), "rs_refine_pose_inertial")
+        return cam, vel, s.as_dict()
 
     def ba_trace(self):
         """Per-iteration record of the last bundle_adjust on this context (list of dicts)."""

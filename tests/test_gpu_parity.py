@@ -682,6 +682,61 @@ def test_bundle_adjust_landmark_shards_in_process_group(rs, synth, n_shards, kw)
             assert np.array_equal(cr, out[0][2]), "ranks must end with bit-identical cameras (redundant reduced solves)"
 
 
+@pytest.mark.parametrize("kw,skip", [(dict(n_kf=7, n_points=150, run_max=5, config_id=62, outlier_frac=0.08, rot_noise_deg=1.5), {(4, 5)}),
+                                     (dict(n_kf=8, n_points=400, run_max=6, config_id=61), set()),
+                                     (dict(), set())])
+def test_bundle_adjust_inertial(ctx, oracle, synth, kw, skip):
+    """§8(f) rank 2 / a15: bundle_adjust with IMU factor pairs (preintegration 9 + bias walk 6 residuals per pair,
+    velocity 3 + bias 6 unknowns per frame; reference src/Optimization.cpp:317-346, src/ImuFactor.cpp:19-118) through
+    rs_bundle_adjust_inertial against the oracle: identical schedule per iteration, poses / velocities / biases / cost to
+    f64 reformulation noise.  Cases: a gap in the factor chain, a full chain of 5, and the 20-key-frame benchmark window
+    with 17 factor pairs (N = 108 + 162 = 270 camera-side unknowns on the blocked solve)."""
+    w = synth.make_ba_window(**kw)
+    imu = synth.make_imu(w, skip=skip)
+    args = (w["cams"], w["cam_free"], w["points"], w["obs_ptr"], w["obs_cam"], w["obs_uv"], w["K"])
+    rc, rp, rv, rb, rs_, otr = oracle.bundle_adjust_inertial(*args, imu, trace=True)
+    dc, dp = ctx.dev(w["cams"]), ctx.dev(w["points"])
+    s, v, b = ctx.bundle_adjust_inertial(dc, w["cam_free"], dp, ctx.dev(w["obs_ptr"]), ctx.dev(w["obs_cam"]), ctx.dev(w["obs_uv"]), w["K"], imu)
+    tr = ctx.ba_trace()
+    assert (s["iterations"], s["successful_steps"], s["termination"], s["usable"]) == \
+           (rs_["iterations"], rs_["successful_steps"], rs_["termination"], rs_["usable"])
+    assert s["usable"] == 1
+    assert [t["outcome"] for t in tr] == [t["outcome"] for t in otr]
+    for k, tol in (("radius", 1e-7), ("cost", 1e-9), ("candidate_cost", 1e-6), ("model_cost_change", 1e-6), ("x_norm", 1e-6)):
+        assert np.allclose([t[k] for t in tr], [t[k] for t in otr], rtol=tol), k
+    assert np.isclose(s["initial_cost"], rs_["initial_cost"], rtol=1e-12) and np.isclose(s["final_cost"], rs_["final_cost"], rtol=1e-8)
+    assert np.allclose(to_np(dc), rc, rtol=1e-7, atol=1e-9)
+    assert np.allclose(to_np(dp), rp, rtol=1e-6, atol=1e-7)
+    assert np.allclose(v, rv, rtol=1e-7, atol=1e-9) and np.allclose(b, rb, rtol=1e-6, atol=1e-9)
+    # fixed frames keep velocity / bias; the IMU pulls the velocities towards the truth
+    fixed = np.flatnonzero(np.asarray(w["cam_free"]) == 0)
+    assert np.array_equal(v[fixed], imu["cam_velocity"][fixed]) and np.array_equal(b[fixed], imu["cam_bias"][fixed])
+    free = np.flatnonzero(w["cam_free"])
+    assert np.abs(v - imu["cam_velocity_true"])[free].max() < np.abs(imu["cam_velocity"] - imu["cam_velocity_true"])[free].max()
+    # no factors: the inertial entry point is rs_bundle_adjust
+    empty = dict(imu)
+    for k in ("cam_i", "cam_j", "duration", "rotation", "velocity", "position", "covariance", "bias_gyro", "bias_accel", "bias_jacobian"):
+        empty[k] = imu[k][:0]
+    dc2, dp2 = ctx.dev(w["cams"]), ctx.dev(w["points"])
+    s2, v2, b2 = ctx.bundle_adjust_inertial(dc2, w["cam_free"], dp2, ctx.dev(w["obs_ptr"]), ctx.dev(w["obs_cam"]), ctx.dev(w["obs_uv"]), w["K"], empty)
+    dc3, dp3 = ctx.dev(w["cams"]), ctx.dev(w["points"])
+    s3 = ctx.bundle_adjust(dc3, w["cam_free"], dp3, ctx.dev(w["obs_ptr"]), ctx.dev(w["obs_cam"]), ctx.dev(w["obs_uv"]), w["K"])
+    assert (s2["iterations"], s2["successful_steps"]) == (s3["iterations"], s3["successful_steps"])
+    assert np.allclose(to_np(dc2), to_np(dc3), rtol=1e-9, atol=1e-11)
+    assert np.array_equal(v2, imu["cam_velocity"]) and np.array_equal(b2, imu["cam_bias"])
+
+
+def test_bundle_adjust_inertial_rejects_bad_factors(ctx, rs, synth):
+    w = synth.make_ba_window(n_kf=5, n_points=80, run_max=4)
+    imu = synth.make_imu(w)
+    bad = dict(imu, cam_i=imu["cam_i"].copy())
+    bad["cam_i"][0] = 0                     # camera 0 is fixed: the reference only links optimised frames (:321-325)
+    dc, dp = ctx.dev(w["cams"]), ctx.dev(w["points"])
+    with pytest.raises(rs.RsError):
+        ctx.bundle_adjust_inertial(dc, w["cam_free"], dp, ctx.dev(w["obs_ptr"]), ctx.dev(w["obs_cam"]), ctx.dev(w["obs_uv"]), w["K"], bad)
+    assert np.array_equal(to_np(dc), w["cams"])
+
+
 def test_bundle_adjust_through_rccl_single_rank(ctx, rs, synth):
     """The multi-GPU code path on one GPU: a 1-rank RCCL communicator (dlopen of librccl,
     ncclCommInitRank, sum and max ncclAllReduce of the reduced system / scalar slots on the library
