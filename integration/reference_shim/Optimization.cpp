@@ -1,8 +1,9 @@
 // Drop-in replacement of the reference's src/Optimization.cpp (keeps src/Optimization.h).
 // Compiled only in the reference's tree; syntax-checked here, see rs_shim_common.h.
-//  * Vision-only: when InertialInput::usable() or an InertialConstraint is set, the IMU residual blocks
-//    (src/Optimization.cpp:237-258,317-346) are not yet supported by the GPU solver — the shim
-//    logs and returns false (nothing written), like a rejected solve.
+//  * Inertial residual blocks (a15): InertialInput::usable() -> rs_bundle_adjust_inertial (one IMU factor pair per
+//    consecutive pair of optimised frames with >= 2 samples, src/Optimization.cpp:317-346), RotationPrior /
+//    InertialDelta -> rs_refine_pose_inertial (:231-267).  imu::preintegrate and imu::Stream::between
+//    (src/Imu.cpp, src/ImuStream.cpp: small sequential host code) stay the reference's and are called from here.
 //  * pose_graph (a14, src/Optimization.cpp:376-639) is DEFINED here as the documented stub SURVEY.md §8 a14 allows:
 //    it logs and returns false.  The only caller (Slam::step, src/Slam.cpp:259-283) then records
 //    `loop_closed = false` and skips fuse_loop and the fix_oldest bundle adjustment: loop candidates are detected
@@ -25,6 +26,39 @@ constexpr size_t MIN_OBSERVATIONS_TO_OPTIMIZE = 2;
 
 void intrinsics(const Camera& camera, float K[4]) { rs_shim::intrinsics(camera.get_intrinsic_matrix(), K); }
 
+// imu::Preintegrated (Eigen, column-major) -> rs_imu_factor (row-major)
+rs_imu_factor to_factor(const imu::Preintegrated& d, const imu::NoiseDensity& noise, int cam_i, int cam_j)
+{
+    rs_imu_factor f{};
+    f.cam_i = cam_i; f.cam_j = cam_j; f.duration = d.duration;
+    for (int r = 0; r < 3; r++) {
+        f.velocity[r] = d.velocity[r]; f.position[r] = d.position[r];
+        f.bias_gyro[r] = d.bias.gyro[r]; f.bias_accel[r] = d.bias.accel[r];
+        for (int c = 0; c < 3; c++) f.rotation[3 * r + c] = d.rotation(r, c);
+    }
+    for (int r = 0; r < 9; r++) {
+        for (int c = 0; c < 9; c++) f.covariance[9 * r + c] = d.covariance(r, c);
+        for (int c = 0; c < 6; c++) f.bias_jacobian[6 * r + c] = d.bias_jacobian(r, c);
+    }
+    f.gyro_bias_sigma = noise.gyro_bias; f.accel_bias_sigma = noise.accel_bias;
+    return f;
+}
+
+void pack_inertial(const Frame& frame, double velocity[3], double bias[6])
+{
+    const auto& st = frame.inertial();
+    for (int k = 0; k < 3; k++) { velocity[k] = st.velocity[k]; bias[k] = st.bias.gyro[k]; bias[3 + k] = st.bias.accel[k]; }
+}
+
+void unpack_inertial(const double velocity[3], const double bias[6], Frame& frame)     // src/Optimization.cpp:182-190
+{
+    InertialState st;
+    st.velocity = Eigen::Vector3d(velocity[0], velocity[1], velocity[2]);
+    st.bias.gyro = Eigen::Vector3d(bias[0], bias[1], bias[2]);
+    st.bias.accel = Eigen::Vector3d(bias[3], bias[4], bias[5]);
+    frame.set_inertial(st);
+}
+
 bool report(const char* what, const rs_ba_summary& s)
 {
     std::printf("%s: iterations %d, cost %.6e -> %.6e, termination %d\n", what, s.iterations, s.initial_cost, s.final_cost, s.termination);
@@ -36,10 +70,6 @@ bool report(const char* what, const rs_ba_summary& s)
 bool refine_pose(Frame& frame, const Camera& camera, const InertialConstraint& inertial)
 {
     using namespace rs_shim;
-    if (!std::holds_alternative<std::monostate>(inertial)) {
-        std::printf("refine_pose: inertial constraints are not supported by the GPU path yet\n");
-        return false;
-    }
     std::vector<double> pts;
     std::vector<float> uv;
     for (const auto& m : frame.map_matches()) {
@@ -58,20 +88,40 @@ bool refine_pose(Frame& frame, const Camera& camera, const InertialConstraint& i
     DevBuf<double> dp(pts);
     DevBuf<float> duv(uv);
     rs_ba_summary s{};
-    if (!ok(rs_refine_pose(context(), cam, dp.p, duv.p, (int)(uv.size() / 2), K, nullptr, &s), "rs_refine_pose")) return false;
+    // the InertialConstraint (:231-258): an enabled InertialDelta wins over a RotationPrior, a disabled one is nothing
+    const auto* prior = std::get_if<RotationPrior>(&inertial);
+    const auto* delta = std::get_if<InertialDelta>(&inertial);
+    int kind = 0;
+    double predicted[9] = {}, prev_pose[6] = {}, prev_velocity[3] = {}, prev_bias[6] = {}, velocity[3] = {}, bias_unused[6] = {}, gravity[3] = {};
+    rs_imu_factor factor{};
+    if (delta != nullptr && delta->enabled()) {
+        kind = 2;
+        float Tp[16];
+        pose_to_row_major(delta->previous->pose(), Tp);
+        rs_pack_pose(Tp, prev_pose);
+        pack_inertial(*delta->previous, prev_velocity, prev_bias);
+        pack_inertial(frame, velocity, bias_unused);
+        factor = to_factor(delta->summary, delta->noise, 0, 0);
+        for (int k = 0; k < 3; k++) gravity[k] = delta->gravity[k];
+    } else if (prior != nullptr && prior->enabled()) {
+        kind = 1;
+        for (int r = 0; r < 3; r++)
+            for (int c = 0; c < 3; c++) predicted[3 * r + c] = prior->predicted(r, c);
+    }
+    if (!ok(rs_refine_pose_inertial(context(), cam, dp.p, duv.p, (int)(uv.size() / 2), K, kind, predicted,
+                                    prior != nullptr ? prior->sigma_radians : 0.0, prev_pose, prev_velocity, prev_bias, &factor,
+                                    gravity, velocity, nullptr, &s), "rs_refine_pose_inertial"))
+        return false;
     if (!report("refine_pose", s)) return false;
     rs_unpack_pose(cam, T);
     frame.set_pose(pose_from_row_major(T));
+    if (kind == 2) unpack_inertial(velocity, prev_bias, frame);           // :263-265: this frame takes the previous bias
     return true;
 }
 
 bool bundle_adjust(const std::vector<FrameConfig>& frames, const Camera& camera, Map&, const InertialInput& inertial)
 {
     using namespace rs_shim;
-    if (inertial.usable()) {
-        std::printf("bundle_adjust: IMU factors are not supported by the GPU path yet\n");
-        return false;
-    }
     const size_t C = frames.size();
     std::vector<double> cams(6 * C);
     std::vector<uint8_t> cam_free(C);
@@ -113,8 +163,21 @@ bool bundle_adjust(const std::vector<FrameConfig>& frames, const Camera& camera,
     DevBuf<int32_t> dptr(obs_ptr), dcam(obs_cam);
     DevBuf<float> duv(obs_uv);
     rs_ba_summary s{};
-    if (!ok(rs_bundle_adjust(context(), (int)C, (int)P, (int)obs_cam.size(), dc.p, cam_free.data(), dp.p, dptr.p, dcam.p, duv.p, K,
-                             nullptr, &s), "rs_bundle_adjust"))
+    // IMU factor pairs between consecutive optimised frames (:317-346); none when the input is not usable
+    std::vector<rs_imu_factor> factors;
+    std::vector<double> velocity(3 * C), bias(6 * C);
+    for (size_t c = 0; c < C; c++) pack_inertial(*frames[c].frame, &velocity[3 * c], &bias[6 * c]);
+    if (inertial.usable())
+        for (size_t i = 0; i + 1 < C; i++) {
+            if (!frames[i].optimize || !frames[i + 1].optimize) continue;
+            const auto samples = inertial.stream->between(inertial.time_of(frames[i].frame->index()), inertial.time_of(frames[i + 1].frame->index()));
+            if (samples.size() < 2) continue;
+            factors.push_back(to_factor(imu::preintegrate(samples, inertial.noise, frames[i].frame->inertial().bias), inertial.noise, (int)i, (int)(i + 1)));
+        }
+    const double gravity[3] = {inertial.gravity[0], inertial.gravity[1], inertial.gravity[2]};
+    if (!ok(rs_bundle_adjust_inertial(context(), (int)C, (int)P, (int)obs_cam.size(), dc.p, cam_free.data(), dp.p, dptr.p, dcam.p, duv.p, K,
+                                      velocity.data(), bias.data(), factors.data(), (int)factors.size(), gravity, nullptr, &s),
+            "rs_bundle_adjust_inertial"))
         return false;
     if (!report("bundle_adjust", s)) return false;
     std::vector<double> hc(6 * C);
@@ -126,6 +189,7 @@ bool bundle_adjust(const std::vector<FrameConfig>& frames, const Camera& camera,
             float T[16];
             rs_unpack_pose(&hc[6 * c], T);
             frames[c].frame->set_pose(pose_from_row_major(T));
+            unpack_inertial(&velocity[3 * c], &bias[6 * c], *frames[c].frame);      // :366 (unchanged values without factors)
         }
     for (size_t p = 0; p < P; p++) free_pts[p]->set_position(Eigen::Vector3f((float)hp[3 * p], (float)hp[3 * p + 1], (float)hp[3 * p + 2]));
     return true;
