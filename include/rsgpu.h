@@ -194,6 +194,47 @@ int rs_reproj_match(rs_context* ctx, const rs_frame_view* frame,
                     int32_t* d_match_kp, int32_t* d_match_point,
                     int32_t* d_match_count);
 
+/* ---------------------------------------- §8(f) rank 4: the map, resident on the device */
+
+/* MapMatcher::match walks the whole map twice per frame (src/MapMatcher.cpp:165-175); flattening the reference's
+ * pointer graph for rs_reproj_match on every call costs ~100x the kernels.  rs_map keeps the flat map on the device
+ * across frames; the calls below mirror, one for one, the operations the reference performs on Map / MapPoint / KeyFrame
+ * (src/Map.cpp:44-124, src/MapPoint.cpp, src/Frame.cpp:80-116), each O(1) on the host; the device image is brought up
+ * to date lazily, at the next use, and only for what changed (topology once per key frame; positions / key-frame
+ * centres after a bundle adjustment).  Handles are small integers: point slots are never reused and ascending slot =
+ * creation order = the reference's map order, which decides ties; observations of a point keep insertion order.
+ * rs_frame holds a frame's keypoints, descriptors and KD-tree on the device (built and uploaded once, shared by the
+ * calls of that frame); a frame promoted to a key frame hands its descriptor rows to the map device-to-device. */
+typedef struct rs_map rs_map;
+typedef struct rs_frame rs_frame;
+int rs_map_create(rs_context* ctx, rs_map** out_map);
+int rs_map_destroy(rs_map* map);
+int rs_frame_create(rs_context* ctx, const float* h_keypoints /*[n][2]*/, const uint8_t* h_descriptors /*[n][32]*/, int n,
+                    rs_frame** out_frame);                                        /* Frame::Frame, src/Frame.cpp:8-15 */
+int rs_frame_destroy(rs_frame* frame);
+int rs_map_add_keyframe(rs_map* map, const rs_frame* frame, const float h_pose[16], int* out_kf);
+int rs_map_set_keyframe_pose(rs_map* map, int kf, const float h_pose[16]);      /* Frame::set_pose */
+int rs_map_add_point(rs_map* map, const float h_xyz[3], int* out_point);        /* Map::add_point / create_point */
+int rs_map_set_position(rs_map* map, int point, const float h_xyz[3]);         /* MapPoint::set_position */
+int rs_map_remove_point(rs_map* map, int point);                                /* Map::remove_point, src/Map.cpp:63-76 */
+int rs_map_add_observation(rs_map* map, int point, int kf, int keypoint);       /* Map::associate, src/Map.cpp:95-113 */
+int rs_map_remove_observation(rs_map* map, int point, int kf);                 /* Map::disassociate, src/Map.cpp:115-124 */
+int rs_map_counts(const rs_map* map, int h_out[4]);   /* point slots, alive points, observations, key frames */
+
+/* MapMatcher::match_map / match_key_frame / match_for_fuse (src/MapMatcher.cpp:107-127,165-175) against the resident
+ * map; results identical to rs_reproj_match on the flattened map.
+ *   h_kp_matched [n] or NULL: Frame::is_matched(keypoint) (:81);  h_matched_points: slots of the points the frame already
+ *   matches (:53);  required_observer_kf >= 0: match_key_frame (:169);  n_only >= 0: match_for_fuse — only the listed
+ *   slots take part (they compete for a keypoint in MAP order; the reference's list order comes from an unordered_set,
+ *   src/Mapper.cpp:208, i.e. is unspecified);  replace as rs_reproj_match.
+ * Outputs (host, capacity n each): the accepted matches in ascending keypoint order as (keypoint, point slot). */
+int rs_map_match(rs_context* ctx, rs_map* map, rs_frame* frame, const float h_pose[16], const float h_intrinsics[4],
+                 int width, int height, const uint8_t* h_kp_matched, const int32_t* h_matched_points, int n_matched_points,
+                 int required_observer_kf, const int32_t* h_only_points, int n_only, int replace, int max_distance,
+                 int32_t* h_match_kp, int32_t* h_match_point, int* h_count);
+
+/* (rs_map_bundle_adjust: see the optimisation section below) */
+
 /* ------------------------------------------------------ a5-a7: triangulation */
 
 /* triangulation::triangulate_points (src/Triangulation.cpp:37-106), batched.
@@ -369,6 +410,16 @@ int rs_bundle_adjust(rs_context* ctx,
                      const float h_intrinsics[4],
                      const rs_ba_options* options /*NULL = defaults*/,
                      rs_ba_summary* h_summary);
+
+/* optimization::bundle_adjust (src/Optimization.cpp:269-374, vision-only) on the resident map: the window
+ * (h_kfs [n_kfs] key-frame handles in FrameConfig order, h_free [n_kfs] = FrameConfig::optimize) is flattened from the
+ * library's mirror, solved with rs_bundle_adjust, and on a usable solve the map takes the result.  The caller gets the
+ * same for its own objects: h_out_poses [n_kfs][16] (unchanged rows for fixed key frames / unusable solves) and the
+ * free points with their new positions (h_out_points / h_out_xyz, `capacity` entries; *h_n_points = how many there
+ * were). */
+int rs_map_bundle_adjust(rs_context* ctx, rs_map* map, const int32_t* h_kfs, const uint8_t* h_free, int n_kfs,
+                         const float h_intrinsics[4], const rs_ba_options* options, rs_ba_summary* h_summary,
+                         float* h_out_poses, int32_t* h_out_points, float* h_out_xyz, int capacity, int* h_n_points);
 
 /* Per-iteration record of the last rs_bundle_adjust on this context: what ceres::Solve prints with
  * minimizer_progress_to_stdout (the reference prints summary.BriefReport(), src/Optimization.cpp:135).

@@ -27,6 +27,7 @@ SOURCES = [
     ("ba_solve_big.hip", ["-munsafe-fp-atomics"]),
     ("ba_schur.hip", ["-munsafe-fp-atomics"]),
     ("ba_update.hip", ["-munsafe-fp-atomics"]),
+    ("map.hip", []),
     ("host.cpp", ["-ffp-contract=off"]),
 ]
 STAMPS = ["-DRS_STAMPS=1"] if os.environ.get("RS_STAMPS") else []

@@ -15,7 +15,9 @@ LIB_PATH = os.path.join(_HERE, "librsgpu.so")
 EXPORTS = [
     "rs_abi_version", "rs_context_create", "rs_context_destroy", "rs_context_set_stream",
     "rs_context_synchronize", "rs_context_set_int", "rs_stage_begin", "rs_stage_alloc", "rs_stage_upload", "rs_stage_download", "rs_stage_sync", "rs_last_error", "rs_hamming_knn2", "rs_match_descriptors",
-    "rs_kdtree_build", "rs_reproj_match", "rs_triangulate", "rs_triangulate_matches", "rs_triangulate_matches_batch", "rs_triangulate_tracks", "rs_point_errors", "rs_ba_default_options",
+    "rs_kdtree_build", "rs_reproj_match", "rs_map_create", "rs_map_destroy", "rs_frame_create", "rs_frame_destroy",
+    "rs_map_add_keyframe", "rs_map_set_keyframe_pose", "rs_map_add_point", "rs_map_set_position", "rs_map_remove_point",
+    "rs_map_add_observation", "rs_map_remove_observation", "rs_map_counts", "rs_map_match", "rs_map_bundle_adjust", "rs_triangulate", "rs_triangulate_matches", "rs_triangulate_matches_batch", "rs_triangulate_tracks", "rs_point_errors", "rs_ba_default_options",
     "rs_bundle_adjust", "rs_ba_get_trace", "rs_ba_get_stats", "rs_ba_get_cameras", "rs_reanchor_points", "rs_refine_pose", "rs_bundle_adjust_inertial", "rs_refine_pose_inertial", "rs_pack_pose", "rs_unpack_pose", "rs_pack_poses", "rs_unpack_poses", "rs_build_local_window",
     "rs_comm_get_unique_id", "rs_comm_init_rank", "rs_comm_destroy", "rs_comm_init_local", "rs_prof_begin", "rs_prof_end", "rs_prof_counters",
 ]
@@ -500,3 +502,100 @@ class Context:
 
     def synchronize(self):
         self._check(self.lib.rs_context_synchronize(self.h), "rs_context_synchronize")
+
+
+# ---- §8(f) rank 4: the resident map (rs_map / rs_frame) -----------------------------------------------------
+class ResidentFrame:
+    def __init__(self, ctx, keypoints, descriptors):
+        self.ctx = ctx
+        kp = np.ascontiguousarray(keypoints, np.float32)
+        de = np.ascontiguousarray(descriptors, np.uint8)
+        self.n = len(kp)
+        self.h = C.c_void_p()
+        ctx._check(ctx.lib.rs_frame_create(ctx.h, kp.ctypes.data_as(C.c_void_p), de.ctypes.data_as(C.c_void_p), self.n, C.byref(self.h)), "rs_frame_create")
+
+    def close(self):
+        if self.h:
+            self.ctx.lib.rs_frame_destroy(self.h)
+            self.h = C.c_void_p()
+
+
+class ResidentMap:
+    """Thin wrapper of rs_map: every method is one C-ABI call."""
+
+    def __init__(self, ctx):
+        self.ctx, self.lib = ctx, ctx.lib
+        self.h = C.c_void_p()
+        ctx._check(self.lib.rs_map_create(ctx.h, C.byref(self.h)), "rs_map_create")
+
+    def close(self):
+        if self.h:
+            self.lib.rs_map_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def _f3(self, v):
+        return (C.c_float * 3)(*[float(x) for x in v])
+
+    def add_keyframe(self, frame, pose):
+        out = C.c_int(-1)
+        p = np.ascontiguousarray(pose, np.float32).reshape(16)
+        self.ctx._check(self.lib.rs_map_add_keyframe(self.h, frame.h, p.ctypes.data_as(C.c_void_p), C.byref(out)), "rs_map_add_keyframe")
+        return out.value
+
+    def set_keyframe_pose(self, kf, pose):
+        p = np.ascontiguousarray(pose, np.float32).reshape(16)
+        self.ctx._check(self.lib.rs_map_set_keyframe_pose(self.h, int(kf), p.ctypes.data_as(C.c_void_p)), "rs_map_set_keyframe_pose")
+
+    def add_point(self, xyz):
+        out = C.c_int(-1)
+        self.ctx._check(self.lib.rs_map_add_point(self.h, self._f3(xyz), C.byref(out)), "rs_map_add_point")
+        return out.value
+
+    def set_position(self, point, xyz):
+        self.ctx._check(self.lib.rs_map_set_position(self.h, int(point), self._f3(xyz)), "rs_map_set_position")
+
+    def remove_point(self, point):
+        self.ctx._check(self.lib.rs_map_remove_point(self.h, int(point)), "rs_map_remove_point")
+
+    def add_observation(self, point, kf, keypoint):
+        self.ctx._check(self.lib.rs_map_add_observation(self.h, int(point), int(kf), int(keypoint)), "rs_map_add_observation")
+
+    def remove_observation(self, point, kf):
+        self.ctx._check(self.lib.rs_map_remove_observation(self.h, int(point), int(kf)), "rs_map_remove_observation")
+
+    def counts(self):
+        buf = (C.c_int * 4)()
+        self.ctx._check(self.lib.rs_map_counts(self.h, buf), "rs_map_counts")
+        return dict(slots=buf[0], alive=buf[1], observations=buf[2], key_frames=buf[3])
+
+    def match(self, frame, pose, K, width, height, kp_matched=None, matched_points=(), required_observer=-1, only_points=None,
+              replace=0, max_distance=64):
+        n = frame.n
+        mk, mp = np.zeros(max(n, 1), np.int32), np.zeros(max(n, 1), np.int32)
+        cnt = C.c_int(0)
+        p = np.ascontiguousarray(pose, np.float32).reshape(16)
+        Kc = (C.c_float * 4)(*[float(v) for v in K])
+        km = None if kp_matched is None else np.ascontiguousarray(kp_matched, np.uint8)
+        mpts = np.ascontiguousarray(matched_points, np.int32)
+        only = None if only_points is None else np.ascontiguousarray(only_points, np.int32)
+        self.ctx._check(self.lib.rs_map_match(
+            self.ctx.h, self.h, frame.h, p.ctypes.data_as(C.c_void_p), Kc, int(width), int(height),
+            None if km is None else km.ctypes.data_as(C.c_void_p), mpts.ctypes.data_as(C.c_void_p), len(mpts), int(required_observer),
+            None if only is None else only.ctypes.data_as(C.c_void_p), -1 if only is None else len(only), int(replace), int(max_distance),
+            mk.ctypes.data_as(C.c_void_p), mp.ctypes.data_as(C.c_void_p), C.byref(cnt)), "rs_map_match")
+        return mk[:cnt.value].copy(), mp[:cnt.value].copy()
+
+    def bundle_adjust(self, kfs, free, K, options=None):
+        kfs = np.ascontiguousarray(kfs, np.int32)
+        free = np.ascontiguousarray(free, np.uint8)
+        Kc = (C.c_float * 4)(*[float(v) for v in K])
+        s = BaSummary()
+        cap = self.counts()["slots"]
+        poses = np.zeros((len(kfs), 16), np.float32)
+        pts, xyz = np.zeros(max(cap, 1), np.int32), np.zeros((max(cap, 1), 3), np.float32)
+        n = C.c_int(0)
+        self.ctx._check(self.lib.rs_map_bundle_adjust(
+            self.ctx.h, self.h, kfs.ctypes.data_as(C.c_void_p), free.ctypes.data_as(C.c_void_p), len(kfs), Kc,
+            None if options is None else C.byref(options), C.byref(s), poses.ctypes.data_as(C.c_void_p),
+            pts.ctypes.data_as(C.c_void_p), xyz.ctypes.data_as(C.c_void_p), cap, C.byref(n)), "rs_map_bundle_adjust")
+        return s.as_dict(), poses, pts[:n.value].copy(), xyz[:n.value].copy()
