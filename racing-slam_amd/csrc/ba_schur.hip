@@ -174,7 +174,8 @@ __device__ __forceinline__ double rsqrt_nr(double x)
     return y;
 }
 
-__device__ __forceinline__ bool chol3_inv(const double V[6], double Li[6], double I[6])
+// L[6] (same order as Li) also returns the factor itself: sqrt(x) = x * rsqrt(x)
+__device__ __forceinline__ bool chol3_inv(const double V[6], double Li[6], double I[6], double L[6])
 {
     const double l00s = V[0];
     if (!(l00s > 0.0)) return false;
@@ -191,6 +192,7 @@ __device__ __forceinline__ bool chol3_inv(const double V[6], double Li[6], doubl
     const double i21 = -l21 * i11 * i22;
     const double i20 = -(l20 * i00 + l21 * i10) * i22;
     Li[0] = i00; Li[1] = i10; Li[2] = i11; Li[3] = i20; Li[4] = i21; Li[5] = i22;
+    L[0] = l00s * i00; L[1] = l10; L[2] = l11s * i11; L[3] = l20; L[4] = l21; L[5] = l22s * i22;
     I[0] = i00 * i00 + i10 * i10 + i20 * i20;
     I[1] = i10 * i11 + i20 * i21;
     I[2] = i20 * i22;
@@ -401,11 +403,18 @@ static __device__ __forceinline__ void ba_schur_body(const BaDims& d, const BaBu
         }
     }
     // ---- per speculative radius (set): damped V^-1, Y, SYRK into the set's own S / rhs (ba_common.h "Speculative radii")
+    // Sets >= 1 do not recompute Y: with V + Lambda_s = L_s L_s^T,  Y_s = W L_s^-T = Y_{s-1} (L_{s-1}^T L_s^-T), i.e. the
+    // three tile columns of a landmark are recombined by a 3x3 upper-triangular matrix M^T, M = L_s^-1 L_{s-1}; the
+    // rhs row (g^T L^-T) transforms the same way.  One pass over the tile in LDS instead of zeroing it and evaluating
+    // every observation again (compact 4x4-tile items only: the 8x8 class reuses the tile for two half batches).
+    double Lprev[6] = {0, 0, 0, 0, 0, 0};
+    bool prev_all_ok = false;
+    double* Mt = (double*)(gslot + 32);                       // [it_l][6] behind the slot table
     for (int set = 0; set < st.nact; set++) {
     const double radius = ba_set_radius(st, set);
     double* const S_set = b.S + (size_t)set * d.n * d.n;
     double* const rhs_set = rhs_rep + (size_t)set * d.n;
-    double Li[6] = {0, 0, 0, 0, 0, 0}, I[6] = {0, 0, 0, 0, 0, 0};
+    double Li[6] = {0, 0, 0, 0, 0, 0}, I[6] = {0, 0, 0, 0, 0, 0}, Lc[6] = {0, 0, 0, 0, 0, 0};
     bool ok = false;
     if (p >= 0) {
         double lam[3];
@@ -415,10 +424,10 @@ static __device__ __forceinline__ void ba_schur_body(const BaDims& d, const BaBu
             lam[k] = clampd(s2 * Vd[k], opt.dmin, opt.dmax) / (radius * s2);
         }
         const double Vdm[6] = {V[0] + lam[0], V[1], V[2], V[3] + lam[1], V[4], V[5] + lam[2]};
-        ok = chol3_inv(Vdm, Li, I);
+        ok = chol3_inv(Vdm, Li, I, Lc);
         if (!ok) {
 #pragma unroll
-            for (int k = 0; k < 6; k++) { I[k] = 0.0; Li[k] = 0.0; }
+            for (int k = 0; k < 6; k++) { I[k] = 0.0; Li[k] = 0.0; Lc[k] = 0.0; }
             if (sub == 0) {
 #pragma unroll
                 for (int k = 0; k < BA_MAXSETS; k++) fail[k] = (k == set) ? 1.0 : fail[k];
@@ -442,6 +451,33 @@ static __device__ __forceinline__ void ba_schur_body(const BaDims& d, const BaBu
         const bool big = ns > 10;
         const int nbatch = big ? 2 : 1, lb_n = big ? g.it_l / 2 : g.it_l;
         const int stride = big ? YT_STRIDE8 : YT_STRIDE4;
+        const bool transform = !big && set > 0 && prev_all_ok;
+        if (transform) {
+            const int ncol = 3 * lb_n, nrow1 = 6 * ns + 1;     // rows incl. the rhs row
+            if (p >= 0 && sub == 0) {                          // M = L_s^-1 L_{s-1} (lower), row-major 00 10 11 20 21 22
+                double* mt = Mt + 6 * wl;
+                mt[0] = Li[0] * Lprev[0];
+                mt[1] = Li[1] * Lprev[0] + Li[2] * Lprev[1];
+                mt[2] = Li[2] * Lprev[2];
+                mt[3] = Li[3] * Lprev[0] + Li[4] * Lprev[1] + Li[5] * Lprev[3];
+                mt[4] = Li[4] * Lprev[2] + Li[5] * Lprev[4];
+                mt[5] = Li[5] * Lprev[5];
+            }
+            __syncthreads();                                   // previous SYRK has consumed the tile; Mt is written
+            for (int idx = threadIdx.x; idx < lb_n * nrow1; idx += blockDim.x) {
+                const int lbq = idx / nrow1, r = idx - lbq * nrow1;
+                if (item * g.it_l + lbq >= d.P) continue;       // no landmark in this slot of the last item
+                double* c0 = yt + (size_t)(3 * lbq) * YT_STRIDE4 + r;
+                const double* mt = Mt + 6 * lbq;
+                const double y0 = c0[0], y1 = c0[YT_STRIDE4], y2 = c0[2 * YT_STRIDE4];
+                c0[0] = y0 * mt[0];
+                c0[YT_STRIDE4] = y0 * mt[1] + y1 * mt[2];
+                c0[2 * YT_STRIDE4] = y0 * mt[3] + y1 * mt[4] + y2 * mt[5];
+            }
+            prev_all_ok = __syncthreads_or((p >= 0 && !ok) ? 1 : 0) == 0;
+            const int nw = (int)(blockDim.x >> 6);
+            syrk_scatter<4, 2, YT_STRIDE4>(yt, ncol / 4, ns, gslot, d.n, wave, nw, S_set, rhs_set);
+        } else
         for (int bt = 0; bt < nbatch; bt++) {
             const int ncol = 3 * lb_n;
             if (bt > 0 || set > 0) {                           // the very first tile was zeroed at kernel start
@@ -482,7 +518,7 @@ static __device__ __forceinline__ void ba_schur_body(const BaDims& d, const BaBu
                     dst[0] = t0; dst[stride] = t1; dst[2 * stride] = t2;
                 }
             }
-            __syncthreads();
+            prev_all_ok = __syncthreads_or((p >= 0 && !ok) ? 1 : 0) == 0;      // (the barrier the SYRK needs anyway)
             BA_STAMP(b, 4);
             const int nw = (int)(blockDim.x >> 6);            // 8 (64 landmarks) or 5 (40 landmarks)
             if (big) {
@@ -530,6 +566,8 @@ static __device__ __forceinline__ void ba_schur_body(const BaDims& d, const BaBu
             }
         }
     }
+#pragma unroll
+    for (int k = 0; k < 6; k++) Lprev[k] = Lc[k];
     }   // sets
     BA_STAMP(b, 5);
     cost = wave_sum(cost);
@@ -719,7 +757,7 @@ size_t ba_schur_lds_bytes(int C, int Cf)
 {
     (void)Cf;
     const size_t prep = C <= SCH_MAXC_LDS ? (size_t)C * BA_PREP : 0;
-    return sizeof(double) * ((size_t)YT_DOUBLES + (size_t)SCH_UCAP * 42 + prep) + sizeof(int) * 32;
+    return sizeof(double) * ((size_t)YT_DOUBLES + (size_t)SCH_UCAP * 42 + prep + 6 * IT_L) + sizeof(int) * 32;   // + Mt
 }
 
 int ba_prepare_schur(int C, int Cf)

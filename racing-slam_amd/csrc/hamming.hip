@@ -72,7 +72,10 @@ __global__ __launch_bounds__(64 * K1_WAVES) void k1_hamming_knn2(
 
 // One workgroup per batch item: merge the split partials, decode, apply the
 // filters of src/MapMatcher.cpp:150-161 and emit the accepted matches in
-// ascending query order.
+// ascending query order.  Every thread owns a CONTIGUOUS chunk of queries (<= K1B_CH per pass), all partial loads
+// of a pass are issued together (their latencies overlap), and the ordered compaction is one workgroup scan per
+// pass: one pass for up to 4096 queries (2000 at the metric's size: two queries per thread).
+#define K1B_CH 4
 __global__ __launch_bounds__(1024) void k1_merge_filter(
     const uint2* __restrict__ part, int nq, int nt, int nsplit, int max_distance, int do_filter,
     int32_t* __restrict__ idx0, int32_t* __restrict__ dist0, int32_t* __restrict__ idx1,
@@ -80,51 +83,60 @@ __global__ __launch_bounds__(1024) void k1_merge_filter(
     int32_t* __restrict__ match_count)
 {
     const int b = blockIdx.x;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    __shared__ int wave_count[16];
-    __shared__ int running;
-    if (threadIdx.x == 0) running = 0;
-    __syncthreads();
-    for (int base = 0; base < nq; base += 1024) {
-        const int qi = base + threadIdx.x;
-        uint32_t k0 = K1_KEY_NONE, k1 = K1_KEY_NONE;
-        if (qi < nq) {
-            for (int s = 0; s < nsplit; ++s) {
-                const uint2 p = part[((size_t)b * nsplit + s) * nq + qi];
-                top2_insert(k0, k1, p.x);
-                top2_insert(k0, k1, p.y);
-            }
+    int running = 0;                                         // matches emitted by earlier passes (same in every thread)
+    for (int base = 0; base < nq; base += 1024 * K1B_CH) {
+        const int span = min(nq - base, 1024 * K1B_CH);
+        const int ch = (span + 1023) / 1024;                 // queries per thread in this pass (1 .. K1B_CH)
+        const int q0 = base + (int)threadIdx.x * ch;
+        uint32_t k0[K1B_CH], k1[K1B_CH];
+#pragma unroll
+        for (int u = 0; u < K1B_CH; u++) { k0[u] = K1_KEY_NONE; k1[u] = K1_KEY_NONE; }
+        for (int s0 = 0; s0 < nsplit; s0 += 8) {
+            uint2 pv[K1B_CH][8];
+#pragma unroll
+            for (int u = 0; u < K1B_CH; u++)
+#pragma unroll
+                for (int s = 0; s < 8; s++) {
+                    const int qi = min(q0 + u, nq - 1), sp = min(s0 + s, nsplit - 1);     // clamped: no branches around the loads
+                    pv[u][s] = part[((size_t)b * nsplit + sp) * nq + qi];
+                }
+#pragma unroll
+            for (int u = 0; u < K1B_CH; u++)
+#pragma unroll
+                for (int s = 0; s < 8; s++)
+                    if (s0 + s < nsplit) { top2_insert(k0[u], k1[u], pv[u][s].x); top2_insert(k0[u], k1[u], pv[u][s].y); }
         }
-        const int i0 = (int)(k0 & K1_IDX_MASK), d0 = (int)(k0 >> K1_IDX_BITS);
-        const bool has1 = k1 != K1_KEY_NONE;
-        const int i1 = has1 ? (int)(k1 & K1_IDX_MASK) : -1, d1 = has1 ? (int)(k1 >> K1_IDX_BITS) : -1;
-        if (qi < nq) {
-            const size_t o = (size_t)b * nq + qi;
-            if (idx0) idx0[o] = i0;
-            if (dist0) dist0[o] = d0;
-            if (idx1) idx1[o] = i1;
-            if (dist1) dist1[o] = d1;
+        int cnt = 0;
+        bool ok[K1B_CH];
+#pragma unroll
+        for (int u = 0; u < K1B_CH; u++) {
+            const int qi = q0 + u;
+            const bool live = u < ch && qi < base + span;
+            const int i0 = (int)(k0[u] & K1_IDX_MASK), d0 = (int)(k0[u] >> K1_IDX_BITS);
+            const bool has1 = k1[u] != K1_KEY_NONE;
+            const int i1 = has1 ? (int)(k1[u] & K1_IDX_MASK) : -1, d1 = has1 ? (int)(k1[u] >> K1_IDX_BITS) : -1;
+            if (live) {
+                const size_t o = (size_t)b * nq + qi;
+                if (idx0) idx0[o] = i0;
+                if (dist0) dist0[o] = d0;
+                if (idx1) idx1[o] = i1;
+                if (dist1) dist1[o] = d1;
+            }
+            ok[u] = do_filter && live && d0 <= max_distance;                      // :152
+            if (ok[u] && nt >= 2 && 4 * d0 > 3 * d1) ok[u] = false;               // :156, 0.75 = 3/4 exactly
+            cnt += ok[u] ? 1 : 0;
         }
         if (!do_filter) continue;
-        bool ok = qi < nq && d0 <= max_distance;              // :152
-        if (ok && nt >= 2 && 4 * d0 > 3 * d1) ok = false;     // :156, 0.75 = 3/4 exactly
-        const unsigned long long m = __ballot(ok);
-        if (lane == 0) wave_count[wave] = __popcll(m);
-        __syncthreads();
-        int off = running;
-        for (int w = 0; w < wave; ++w) off += wave_count[w];
-        off += __popcll(m & ((1ull << lane) - 1ull));
-        if (ok) {
-            match_query[(size_t)b * nq + off] = qi;
-            match_train[(size_t)b * nq + off] = i0;
-        }
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            int tot = 0;
-            for (int w = 0; w < 16; ++w) tot += wave_count[w];
-            running += tot;
-        }
-        __syncthreads();
+        int total;
+        int off = running + rs_block_exclusive_scan(cnt, &total);
+#pragma unroll
+        for (int u = 0; u < K1B_CH; u++)
+            if (ok[u]) {
+                match_query[(size_t)b * nq + off] = q0 + u;
+                match_train[(size_t)b * nq + off] = (int)(k0[u] & K1_IDX_MASK);
+                off++;
+            }
+        running += total;
     }
     if (do_filter && threadIdx.x == 0) match_count[b] = running;
 }

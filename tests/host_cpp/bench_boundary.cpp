@@ -141,6 +141,78 @@ int main(int argc, char** argv)
     std::snprintf(ex, sizeof ex, "\"train_rows\": %zu, \"matches\": %zu", kfs[NKF - 1]->map_matches().size(), n_md);
     add("match_descriptors", s_md, ex);
 
+    // ---- the same calls against the device-resident map (rs_map / rs_frame): the map is built
+    // once, incrementally, with the calls a maintainer adds next to Map::create_point / Map::associate; per frame only
+    // the frame itself travels
+    {
+        rs_context* ctx = Session::get().ctx();
+        rs_map* rmap = nullptr;
+        rs_map_create(ctx, &rmap);
+        std::vector<int> kf_handle;
+        for (int k = 0; k < NKF; k++) {
+            std::vector<float> kp;
+            for (const auto& q : kfs[(size_t)k]->features().keypoints) { kp.push_back(q.pt.x); kp.push_back(q.pt.y); }
+            rs_frame* fr = nullptr;
+            rs_frame_create(ctx, kp.data(), kfs[(size_t)k]->features().descriptors.data(), (int)kfs[(size_t)k]->features().keypoints.size(), &fr);
+            int h = -1;
+            rs_map_add_keyframe(rmap, fr, kfs[(size_t)k]->pose().data(), &h);
+            rs_frame_destroy(fr);
+            kf_handle.push_back(h);
+        }
+        for (size_t i = 0; i < map.size(); i++) {
+            int h = -1;
+            const Vec3f& X = map[i].position();
+            const float xyz[3] = {X.x, X.y, X.z};
+            rs_map_add_point(rmap, xyz, &h);
+            for (const auto& o : map[i].observations()) {
+                int kfi = 0;
+                for (int k = 0; k < NKF; k++) if (kfs[(size_t)k].get() == o.first) kfi = k;
+                rs_map_add_observation(rmap, h, kf_handle[(size_t)kfi], (int)o.second);
+            }
+        }
+        const size_t N = new_frame.features().keypoints.size();
+        std::vector<float> kp;
+        for (const auto& q : new_frame.features().keypoints) { kp.push_back(q.pt.x); kp.push_back(q.pt.y); }
+        const float K[4] = {1000.f, 1000.f, 960.f, 540.f};
+        std::vector<int32_t> mk(N), mp(N);
+        int cnt = 0;
+        rs_frame* fr = nullptr;
+        // per frame, once: keypoints + descriptors + KD-tree to the device (the reference builds the tree in Frame::Frame)
+        const Stat s_fr = measure(reps, [&] { if (fr) rs_frame_destroy(fr); rs_frame_create(ctx, kp.data(), new_frame.features().descriptors.data(), (int)N, &fr); });
+        add("frame_create_resident", s_fr, "\"note\": \"KD-tree build + upload, once per frame\"");
+        std::vector<uint8_t> kpm(N, 0);
+        const Stat s_rm = measure(reps, [&] {
+            rs_map_match(ctx, rmap, fr, new_frame.pose().data(), K, W, H, kpm.data(), nullptr, 0, -1, nullptr, -1, 0, 64, mk.data(), mp.data(), &cnt);
+        });
+        std::snprintf(ex, sizeof ex, "\"matches\": %d", cnt);
+        add("match_map_resident", s_rm, ex);
+        const Stat s_rk = measure(reps, [&] {
+            rs_map_match(ctx, rmap, fr, new_frame.pose().data(), K, W, H, kpm.data(), nullptr, 0, kf_handle[NKF - 1], nullptr, -1, 0, 64, mk.data(), mp.data(), &cnt);
+        });
+        std::snprintf(ex, sizeof ex, "\"matches\": %d", cnt);
+        add("match_key_frame_resident", s_rk, ex);
+        // local BA on the resident map; the perturbed poses are restored before every repetition (set_keyframe_pose)
+        std::vector<Mat4f> pert;
+        for (int k = 0; k < NKF; k++) pert.push_back(k < 2 ? kfs[(size_t)k]->pose() : make_pose(0.026 * k + 0.004 * gauss(rng), 0.02 * k + 0.01 * gauss(rng), 0.01 * gauss(rng), 0.5 * k + 0.01 * gauss(rng)));
+        std::vector<int32_t> wk(NKF), outp(map.size());
+        std::vector<uint8_t> wf(NKF, 1);
+        wf[0] = wf[1] = 0;
+        for (int k = 0; k < NKF; k++) wk[(size_t)k] = kf_handle[(size_t)k];
+        std::vector<float> outpose(16 * NKF), outxyz(3 * map.size());
+        rs_ba_summary bs{};
+        int npts = 0;
+        const Stat s_rb = measure(std::max(reps / 3, 5), [&] {
+            for (int k = 0; k < NKF; k++) rs_map_set_keyframe_pose(rmap, kf_handle[(size_t)k], pert[(size_t)k].data());
+            for (size_t i = 0; i < map.size(); i++) { const Vec3f& X = map[i].position(); const float xyz[3] = {X.x, X.y, X.z}; rs_map_set_position(rmap, (int)i, xyz); }
+            rs_map_bundle_adjust(ctx, rmap, wk.data(), wf.data(), NKF, K, nullptr, &bs, outpose.data(), outp.data(), outxyz.data(), (int)map.size(), &npts);
+        });
+        std::snprintf(ex, sizeof ex, "\"iterations\": %d, \"usable\": %d, \"free_points\": %d, \"note\": \"includes restoring 20 poses and all positions in the mirror\"",
+                      bs.iterations, bs.usable, npts);
+        add("bundle_adjust_resident", s_rb, ex);
+        rs_frame_destroy(fr);
+        rs_map_destroy(rmap);
+    }
+
     // triangulate_points with N = 1 (what Mapper::triangulate_tracks and pose::recover_pose call, src/Mapper.cpp:253)
     // and N = 2000 (one call for a whole frame pair)
     std::vector<Vec2f> p1, p2;
