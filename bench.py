@@ -583,6 +583,29 @@ def bench_ba(e, args, cfg):
     roofline = rl.get(dom)
     if roofline is not None:
         roofline = dict(roofline, traffic_source=pmc_file, traffic_matches_kernel_sources=pmc_fresh)
+    # throughput mode (reported beside `value`, never instead of it): B independent windows per call on the library's
+    # lanes (rs_bundle_adjust_batch) — what a server holding several sessions on one GPU gets
+    batch = None
+    if e.world == 1 and cfg == "cfg3":
+        batch = {}
+        for B in (8, 32):
+            clones = [(c0.clone(), p0.clone()) for _ in range(B)]
+            probs = [(bc, w["cam_free"], bp, *dev, w["K"]) for bc, bp in clones]
+
+            def bstep():
+                for bc, bp in clones:
+                    bc.copy_(c0)
+                    bp.copy_(p0)
+                torch.cuda.synchronize()
+                ctx.bundle_adjust_batch(probs)
+
+            n_rep = max(3, args.steps // 5)
+            dtb = timed(e, bstep, n_rep, 2)
+            batch["B%d" % B] = dict(windows=B, solves_per_s=B * n_rep / dtb, ms_per_call=1e3 * dtb / n_rep,
+                                    speedup_vs_sequential=(B * n_rep / dtb) / (args.steps / elapsed))
+        batch["lanes"] = 8
+        batch["note"] = ("B copies of the same cfg-3 window solved by one rs_bundle_adjust_batch call (8 lanes = child contexts "
+                         "with their own streams, one host thread each); includes the 2B state-reset copies")
     cpu = None
     if e.rank == 0 and e.world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline(cpu_step, 1.0, "solves/s", "the same window, whole 10-iteration solve", args.cpu_seconds)
@@ -598,7 +621,7 @@ def bench_ba(e, args, cfg):
         "roofline": roofline, "cpu_baseline": cpu["one"] if cpu else None, "cpu_baseline_all_cores": cpu["all"] if cpu else None,
         "per_kernel_us": {k: round(v["avg_us"], 2) for k, v in sorted(per_kernel.items())},
         "per_kernel_launches_per_solve": {k: v["launches"] / max(args.steps, 1) for k, v in sorted(per_kernel.items())},
-        "ba_summary": last.get("ba"), "ba_rounds": stats, "roofline_all": rl})
+        "ba_summary": last.get("ba"), "ba_rounds": stats, "roofline_all": rl, "batch_throughput": batch})
 
 
 def main():

@@ -421,6 +421,25 @@ int rs_map_bundle_adjust(rs_context* ctx, rs_map* map, const int32_t* h_kfs, con
                          const float h_intrinsics[4], const rs_ba_options* options, rs_ba_summary* h_summary,
                          float* h_out_poses, int32_t* h_out_points, float* h_out_xyz, int capacity, int* h_n_points);
 
+/* Throughput mode: B INDEPENDENT windows (several sessions / maps served by one GPU) in one call.  A local-window
+ * solve is a chain of small dependent launches that leaves most of the 256 CUs idle; independent windows overlap on
+ * the device.  The library keeps up to `RS_BA_BATCH_LANES` child contexts (own stream, own workspace) and runs the
+ * windows on them from as many host threads; results per window are those of rs_bundle_adjust, bit for bit for the
+ * schedule and to summation-order noise for the values.  h_problems[i] is the argument list of rs_bundle_adjust. */
+#define RS_BA_BATCH_LANES 8
+typedef struct rs_ba_problem {
+    int n_cameras, n_points, n_obs;
+    double* d_cameras;
+    const uint8_t* h_cam_free;
+    double* d_points;
+    const int32_t* d_obs_ptr;
+    const int32_t* d_obs_cam;
+    const float* d_obs_uv;
+    float intrinsics[4];
+} rs_ba_problem;
+int rs_bundle_adjust_batch(rs_context* ctx, int n_problems, const rs_ba_problem* h_problems,
+                           const rs_ba_options* options /*NULL = defaults*/, rs_ba_summary* h_summaries /*[n_problems]*/);
+
 /* Per-iteration record of the last rs_bundle_adjust on this context: what ceres::Solve prints with
  * minimizer_progress_to_stdout (the reference prints summary.BriefReport(), src/Optimization.cpp:135).
  * Entry i describes LM iteration i + 1.  outcome: 1 successful step, 0 rejected step, -1 invalid step

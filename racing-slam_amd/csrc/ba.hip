@@ -859,6 +859,55 @@ extern "C" int rs_bundle_adjust_inertial(rs_context* ctx, int n_cameras, int n_p
                          h_intrinsics, options, h_summary, &in);
 }
 
+// ---------------------------------------------------------------- batch of independent windows
+// Several sessions served by one GPU: the windows are independent problems, each a latency chain of small launches
+// that fills a fraction of the chip, so they overlap on the device when they sit on different streams.  Lanes = child
+// contexts (stream + workspace + pinned block each); one host thread per lane walks its share of the windows with the
+// ordinary solve (incl. the round-following logic), which keeps every lane's stream fed.
+#include <thread>
+
+extern "C" int rs_bundle_adjust_batch(rs_context* ctx, int n_problems, const rs_ba_problem* h_problems,
+                                      const rs_ba_options* options, rs_ba_summary* h_summaries)
+{
+    if (!ctx || n_problems < 0 || (n_problems > 0 && (!h_problems || !h_summaries))) return RS_ERR_INVALID;
+    if (n_problems == 0) return RS_OK;
+    if (rs_comm_active(ctx)) return rs_fail(ctx, RS_ERR_UNSUPPORTED, "batch of windows on a landmark-sharded context");
+    RS_HIP(ctx, hipSetDevice(ctx->device));
+    const int lanes = n_problems < RS_BA_BATCH_LANES ? n_problems : RS_BA_BATCH_LANES;
+    while ((int)ctx->batch_lanes.size() < lanes) {
+        rs_context* c = nullptr;
+        int rc = rs_context_create(ctx->device, &c);
+        if (rc) return rs_fail(ctx, rc, "cannot create batch lane");
+        hipStream_t st = nullptr;
+        if (hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess) { rs_context_destroy(c); return rs_fail(ctx, RS_ERR_HIP, "hipStreamCreate"); }
+        c->stream = st;
+        c->ba_sets = ctx->ba_sets;
+        ctx->batch_lanes.push_back(c);
+        ctx->batch_streams.push_back(st);
+    }
+    // the inputs were produced on the parent's stream: the lanes start after it
+    RS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    std::vector<int> status((size_t)lanes, RS_OK);
+    auto work = [&](int lane) {
+        (void)hipSetDevice(ctx->device);
+        rs_context* c = ctx->batch_lanes[(size_t)lane];
+        c->ba_sets = ctx->ba_sets;
+        for (int i = lane; i < n_problems; i += lanes) {
+            const rs_ba_problem& q = h_problems[i];
+            const int rc = rs_bundle_adjust(c, q.n_cameras, q.n_points, q.n_obs, q.d_cameras, q.h_cam_free, q.d_points, q.d_obs_ptr,
+                                            q.d_obs_cam, q.d_obs_uv, q.intrinsics, options, &h_summaries[i]);
+            if (rc && !status[(size_t)lane]) status[(size_t)lane] = rc;
+        }
+    };
+    std::vector<std::thread> threads;
+    for (int l = 1; l < lanes; l++) threads.emplace_back(work, l);
+    work(0);
+    for (auto& t : threads) t.join();
+    for (int l = 0; l < lanes; l++)
+        if (status[(size_t)l]) return rs_fail(ctx, status[(size_t)l], "window on lane %d failed: %s", l, rs_last_error(ctx->batch_lanes[(size_t)l]));
+    return RS_OK;
+}
+
 static_assert(sizeof(BaTrace) == sizeof(rs_ba_iteration), "BaTrace mirrors rs_ba_iteration");
 
 extern "C" int rs_ba_get_trace(rs_context* ctx, rs_ba_iteration* h_out, int capacity, int* h_count)

@@ -61,6 +61,9 @@ struct rs_context {
     int ba_cams_n = 0;
     // speculative trust-region radii per BA round (0 = library default; rs_context_set_int "ba_speculative_sets")
     int ba_sets = 0;
+    // child contexts of rs_bundle_adjust_batch (own stream / workspace each), created on first use
+    std::vector<rs_context*> batch_lanes;
+    std::vector<hipStream_t> batch_streams;
     // proposal table of rs_reproj_match: persistent, always left at all-ones by the accept tail
     unsigned long long* prop = nullptr;
     size_t prop_cap = 0;

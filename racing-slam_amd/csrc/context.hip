@@ -54,6 +54,10 @@ extern "C" int rs_context_destroy(rs_context* ctx)
     (void)hipSetDevice(ctx->device);
     rs_comm_destroy(ctx);
     rs_ba_cache_free(ctx);
+    for (rs_context* lane : ctx->batch_lanes) rs_context_destroy(lane);
+    for (hipStream_t st : ctx->batch_streams) (void)hipStreamDestroy(st);
+    ctx->batch_lanes.clear();
+    ctx->batch_streams.clear();
     arena_free(ctx->stage_dev, false);
     arena_free(ctx->stage_pin, true);
     if (ctx->ws) (void)hipFree(ctx->ws);

@@ -18,7 +18,7 @@ EXPORTS = [
     "rs_kdtree_build", "rs_reproj_match", "rs_map_create", "rs_map_destroy", "rs_frame_create", "rs_frame_destroy",
     "rs_map_add_keyframe", "rs_map_set_keyframe_pose", "rs_map_add_point", "rs_map_set_position", "rs_map_remove_point",
     "rs_map_add_observation", "rs_map_remove_observation", "rs_map_counts", "rs_map_match", "rs_map_bundle_adjust", "rs_triangulate", "rs_triangulate_matches", "rs_triangulate_matches_batch", "rs_triangulate_tracks", "rs_point_errors", "rs_ba_default_options",
-    "rs_bundle_adjust", "rs_ba_get_trace", "rs_ba_get_stats", "rs_ba_get_cameras", "rs_reanchor_points", "rs_refine_pose", "rs_bundle_adjust_inertial", "rs_refine_pose_inertial", "rs_pack_pose", "rs_unpack_pose", "rs_pack_poses", "rs_unpack_poses", "rs_build_local_window",
+    "rs_bundle_adjust", "rs_bundle_adjust_batch", "rs_ba_get_trace", "rs_ba_get_stats", "rs_ba_get_cameras", "rs_reanchor_points", "rs_refine_pose", "rs_bundle_adjust_inertial", "rs_refine_pose_inertial", "rs_pack_pose", "rs_unpack_pose", "rs_pack_poses", "rs_unpack_poses", "rs_build_local_window",
     "rs_comm_get_unique_id", "rs_comm_init_rank", "rs_comm_destroy", "rs_comm_init_local", "rs_prof_begin", "rs_prof_end", "rs_prof_counters",
 ]
 
@@ -105,6 +105,13 @@ def imu_factor_array(imu):
             getattr(a, name)[:] = list(np.asarray(imu[name][f], np.float64).ravel())
         a.gyro_bias_sigma, a.accel_bias_sigma = float(imu["gyro_bias_sigma"]), float(imu["accel_bias_sigma"])
     return arr, n
+
+
+class BaProblem(C.Structure):
+    """rs_ba_problem"""
+    _fields_ = [("n_cameras", C.c_int), ("n_points", C.c_int), ("n_obs", C.c_int), ("d_cameras", C.c_void_p),
+                ("h_cam_free", C.c_void_p), ("d_points", C.c_void_p), ("d_obs_ptr", C.c_void_p), ("d_obs_cam", C.c_void_p),
+                ("d_obs_uv", C.c_void_p), ("intrinsics", C.c_float * 4)]
 
 
 class ProfEntry(C.Structure):
@@ -424,6 +431,25 @@ class Context:
             C.c_double(sigma), args[0], args[1], args[2], args[3], args[4], vel.ctypes.data_as(C.c_void_p),
             None if options is None else C.byref(options), C.byref(s)), "rs_refine_pose_inertial")
         return cam, vel, s.as_dict()
+
+    def bundle_adjust_batch(self, problems, options=None):
+        """rs_bundle_adjust_batch; problems = list of (d_cams, cam_free, d_points, d_obs_ptr, d_obs_cam, d_obs_uv, K).
+        Returns the list of summaries."""
+        n = len(problems)
+        arr = (BaProblem * max(n, 1))()
+        keep = []
+        for i, (dc, free, dp, optr, ocam, ouv, K) in enumerate(problems):
+            f = np.ascontiguousarray(free, np.uint8)
+            keep.append(f)
+            a = arr[i]
+            a.n_cameras, a.n_points, a.n_obs = int(dc.shape[0]), int(dp.shape[0]), int(ocam.shape[0])
+            a.d_cameras, a.h_cam_free, a.d_points = dc.data_ptr(), f.ctypes.data, dp.data_ptr()
+            a.d_obs_ptr, a.d_obs_cam, a.d_obs_uv = optr.data_ptr(), ocam.data_ptr(), ouv.data_ptr()
+            a.intrinsics[:] = [float(v) for v in K]
+        out = (BaSummary * max(n, 1))()
+        self._check(self.lib.rs_bundle_adjust_batch(self.h, n, arr, None if options is None else C.byref(options), out),
+                    "rs_bundle_adjust_batch")
+        return [out[i].as_dict() for i in range(n)]
 
     def ba_trace(self):
         """Per-iteration record of the last bundle_adjust on this context (list of dicts)."""

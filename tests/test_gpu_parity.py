@@ -737,6 +737,38 @@ def test_bundle_adjust_inertial_rejects_bad_factors(ctx, rs, synth):
     assert np.array_equal(to_np(dc), w["cams"])
 
 
+def test_bundle_adjust_batch_of_windows(ctx, oracle, synth):
+    """rs_bundle_adjust_batch: 11 independent windows of different sizes (more than the 8 lanes, so lanes take several)
+    against single solves: identical schedules, values to summation-order noise; three of them against the oracle."""
+    import torch
+    kws = [dict(n_kf=6, n_points=200 + 37 * i, run_max=5, config_id=80 + i) for i in range(9)] + \
+          [dict(), dict(n_kf=8, n_points=150, run_max=5, config_id=36, outlier_frac=0.1, rot_noise_deg=2.0)]
+    ws = [synth.make_ba_window(**k) for k in kws]
+    single, probs, keep = [], [], []
+    for w in ws:
+        dev = [ctx.dev(w[k]) for k in ("obs_ptr", "obs_cam", "obs_uv")]
+        dc, dp = ctx.dev(w["cams"]), ctx.dev(w["points"])
+        s = ctx.bundle_adjust(dc, w["cam_free"], dp, *dev, w["K"])
+        single.append((s, to_np(dc), to_np(dp)))
+        bc, bp = ctx.dev(w["cams"]), ctx.dev(w["points"])
+        probs.append((bc, w["cam_free"], bp, *dev, w["K"]))
+        keep.append((bc, bp))
+    torch.cuda.synchronize()
+    out = ctx.bundle_adjust_batch(probs)
+    for i, (w, s) in enumerate(zip(ws, out)):
+        s1, c1, p1 = single[i]
+        assert (s["iterations"], s["successful_steps"], s["termination"], s["usable"]) == \
+               (s1["iterations"], s1["successful_steps"], s1["termination"], s1["usable"]), i
+        assert np.isclose(s["final_cost"], s1["final_cost"], rtol=1e-9), i
+        assert np.allclose(to_np(keep[i][0]), c1, rtol=1e-8, atol=1e-10) and np.allclose(to_np(keep[i][1]), p1, rtol=1e-7, atol=1e-9), i
+    for i in (0, 5, 10):
+        w = ws[i]
+        rc, rp, rs_ = oracle.bundle_adjust(w["cams"], w["cam_free"], w["points"], w["obs_ptr"], w["obs_cam"], w["obs_uv"], w["K"])
+        assert (out[i]["iterations"], out[i]["successful_steps"]) == (rs_["iterations"], rs_["successful_steps"])
+        assert np.allclose(to_np(keep[i][0]), rc, rtol=1e-6, atol=1e-8)
+    assert ctx.bundle_adjust_batch([]) == []
+
+
 def test_bundle_adjust_through_rccl_single_rank(ctx, rs, synth):
     """The multi-GPU code path on one GPU: a 1-rank RCCL communicator (dlopen of librccl,
     ncclCommInitRank, sum and max ncclAllReduce of the reduced system / scalar slots on the library
