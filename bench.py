@@ -76,9 +76,12 @@ def pmc_traffic(config):
                     if "kernel_source_hash=" in line:
                         src_hash = line.strip().split("kernel_source_hash=")[1].split()[0]
                     continue
-                f = line.strip().split(",")
-                if len(f) >= 5 and f[0] != "kernel":
-                    out[f[0]] = float(f[4])
+                f = line.strip().rsplit(",", 4)          # kernel names may contain commas (template arguments)
+                if len(f) == 5 and f[0] != "kernel":
+                    try:
+                        out[f[0]] = float(f[4])
+                    except ValueError:
+                        pass
     except OSError:
         return {}, None, None
     return out, os.path.relpath(path, ROOT), (src_hash == kernel_source_hash())
@@ -299,7 +302,7 @@ def build_pass(e):
     seen_by_last = np.zeros(P, bool)
     seen_by_last[obs_pt[mp["obs_kf"] == n_kf - 1]] = True
     mp_a = dict(mp, eligible=(mp["eligible"].astype(bool) & seen_by_last).astype(np.uint8))
-    fv_a, keep_fa = ctx.make_frame_view(frame)
+    fv_a, keep_fa = ctx.make_frame_view(frame, pack=True)
     mv_a, keep_ma = ctx.make_map_view(mp_a)
     r_a = ctx.reproj_match(fv_a, mv_a)
     cnt_a = int(r_a["count"].cpu()[0])
@@ -310,7 +313,7 @@ def build_pass(e):
     elig_b = mp["eligible"].copy()
     elig_b[pt_a] = 0
     mp_b = dict(mp, eligible=elig_b)
-    fv_b, keep_fb = ctx.make_frame_view(frame_b)
+    fv_b, keep_fb = ctx.make_frame_view(frame_b, pack=True)
     mv_b, keep_mb = ctx.make_map_view(mp_b)
     r_b = ctx.reproj_match(fv_b, mv_b)
 

@@ -40,7 +40,7 @@
 extern "C" {
 #endif
 
-#define RSGPU_ABI_VERSION 1
+#define RSGPU_ABI_VERSION 2
 #define RS_DESC_BYTES 32
 
 typedef enum rs_status {
@@ -154,7 +154,15 @@ typedef struct rs_frame_view {
     const int32_t* d_kd_left;      /* [n] */
     const int32_t* d_kd_right;     /* [n] */
     int kd_root;
+    const void* d_kd_packed;       /* optional (NULL = not provided): the tree packed by rs_kdtree_pack for this frame,
+                                      20 * n bytes, 16-byte aligned.  A frame is matched at least twice
+                                      (src/Tracker.cpp:232-248): packing once saves every workgroup of both calls the
+                                      dependent gathers node -> keypoint -> coordinates */
 } rs_frame_view;
+
+/* Packs the flattened KD-tree of `frame` (its d_keypoints, d_kd_* arrays) into d_packed [n] x 20 bytes for
+ * rs_frame_view::d_kd_packed. */
+int rs_kdtree_pack(rs_context* ctx, const rs_frame_view* frame, void* d_packed);
 
 typedef struct rs_map_view {
     int n_points;                  /* candidate points, in MAP ORDER (src/Map.h:66) */

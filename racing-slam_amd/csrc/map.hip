@@ -62,6 +62,7 @@ struct rs_frame {
     int n = 0;
     float* d_kp = nullptr; uint8_t* d_desc = nullptr; int32_t* d_kd = nullptr;   // node_kp | left | right
     uint8_t* d_matched = nullptr;
+    void* d_packed = nullptr;           // {x, y, left, right}[n] + keypoint[n]: what K2 stages in LDS (rs_kdtree_pack layout)
     int kd_root = -1;
     std::vector<float> kp;
 };
@@ -128,6 +129,16 @@ extern "C" int rs_frame_create(rs_context* ctx, const float* h_kp, const uint8_t
         RS_HIP(ctx, hipMemcpyAsync(f->d_kp, h_kp, sizeof(float) * 2 * m, hipMemcpyHostToDevice, ctx->stream));
         RS_HIP(ctx, hipMemcpyAsync(f->d_desc, h_desc, 32 * m, hipMemcpyHostToDevice, ctx->stream));
         RS_HIP(ctx, hipMemcpyAsync(f->d_kd, kd.data(), sizeof(int32_t) * 3 * m, hipMemcpyHostToDevice, ctx->stream));
+        std::vector<int32_t> packed(5 * m);
+        for (size_t i = 0; i < m; i++) {
+            const int32_t kpi = kd[i];
+            memcpy(&packed[4 * i], &h_kp[2 * (size_t)kpi], 8);
+            packed[4 * i + 2] = kd[m + i];
+            packed[4 * i + 3] = kd[2 * m + i];
+            packed[4 * m + i] = kpi;
+        }
+        if (hipMalloc(&f->d_packed, 20 * m) != hipSuccess) { delete f; return rs_fail(ctx, RS_ERR_NOMEM, "frame buffers"); }
+        RS_HIP(ctx, hipMemcpyAsync(f->d_packed, packed.data(), 20 * m, hipMemcpyHostToDevice, ctx->stream));
         RS_HIP(ctx, hipStreamSynchronize(ctx->stream));       // the sources are the caller's / this function's memory
     }
     *out = f;
@@ -139,7 +150,7 @@ extern "C" int rs_frame_destroy(rs_frame* f)
     if (!f) return RS_OK;
     (void)hipSetDevice(f->ctx->device);
     (void)hipStreamSynchronize(f->ctx->stream);
-    for (void* p : {(void*)f->d_kp, (void*)f->d_desc, (void*)f->d_kd, (void*)f->d_matched})
+    for (void* p : {(void*)f->d_kp, (void*)f->d_desc, (void*)f->d_kd, (void*)f->d_matched, f->d_packed})
         if (p) (void)hipFree(p);
     delete f;
     return RS_OK;
@@ -427,6 +438,7 @@ extern "C" int rs_map_match(rs_context* ctx, rs_map* m, rs_frame* f, const float
     fv.width = width; fv.height = height; fv.n_keypoints = N;
     fv.d_keypoints = f->d_kp; fv.d_descriptors = f->d_desc; fv.d_kp_matched = d_matched;
     fv.d_kd_node_kp = f->d_kd; fv.d_kd_left = f->d_kd + N; fv.d_kd_right = f->d_kd + 2 * (size_t)N; fv.kd_root = f->kd_root;
+    fv.d_kd_packed = f->d_packed;
     rs_map_view mv{P, m->d_pos, m->d_elig, m->d_obs_ptr, m->d_obs_kf, m->d_obs_desc, m->d_centres, m->d_pool};
     rc = rs_reproj_match(ctx, &fv, &mv, replace, max_distance, pk, pd, pp, pdist, mkp, mpt, cnt);
     if (rc) return rc;

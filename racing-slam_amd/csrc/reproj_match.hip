@@ -34,6 +34,7 @@ struct K2Frame {
     const int32_t* kd_node_kp;
     const int32_t* kd_left;
     const int32_t* kd_right;
+    const float4* packed;      // optional: {x, y, left, right}[n] then int32 keypoint[n] (rs_kdtree_pack), or null
 };
 
 struct K2Map {
@@ -158,11 +159,16 @@ __global__ __launch_bounds__(K2_THREADS) void k2_reproj_match(K2Frame f, K2Map m
         }
     }
     if (tree_in_lds) {
-        for (int i = threadIdx.x; i < f.n_keypoints; i += blockDim.x) {
-            const int kpi = f.kd_node_kp[i];
-            const float2 q = f.kp[kpi];
-            tree[i] = make_float4(q.x, q.y, __int_as_float(f.kd_left[i]), __int_as_float(f.kd_right[i]));
-            tree_kp[i] = kpi;
+        if (f.packed) {        // packed once per frame: a straight copy (independent wide loads) instead of dependent gathers
+            const int* pk = (const int*)(f.packed + f.n_keypoints);
+            for (int i = threadIdx.x; i < f.n_keypoints; i += blockDim.x) { tree[i] = f.packed[i]; tree_kp[i] = pk[i]; }
+        } else {
+            for (int i = threadIdx.x; i < f.n_keypoints; i += blockDim.x) {
+                const int kpi = f.kd_node_kp[i];
+                const float2 q = f.kp[kpi];
+                tree[i] = make_float4(q.x, q.y, __int_as_float(f.kd_left[i]), __int_as_float(f.kd_right[i]));
+                tree_kp[i] = kpi;
+            }
         }
         __syncthreads();
     }
@@ -333,6 +339,8 @@ extern "C" int rs_reproj_match(rs_context* ctx, const rs_frame_view* fr, const r
         f.kp = (const float2*)fr->d_keypoints; f.desc = (const uint4*)fr->d_descriptors;
         f.kp_matched = fr->d_kp_matched; f.kd_node_kp = fr->d_kd_node_kp; f.kd_left = fr->d_kd_left;
         f.kd_right = fr->d_kd_right;
+        f.packed = (const float4*)fr->d_kd_packed;
+        if (((uintptr_t)f.packed) & 15) return rs_fail(ctx, RS_ERR_INVALID, "d_kd_packed must be 16-byte aligned");
         K2Map m;
         m.n_points = P; m.pos = mp->d_positions; m.eligible = mp->d_eligible; m.obs_ptr = mp->d_obs_ptr;
         m.obs_kf = mp->d_obs_kf; m.obs_desc = mp->d_obs_desc; m.kf_centers = mp->d_kf_centers;
@@ -350,6 +358,35 @@ extern "C" int rs_reproj_match(rs_context* ctx, const rs_frame_view* fr, const r
         hipLaunchKernelGGL(k3_accept, dim3(1), dim3(1024), 0, ctx->stream, prop, N, max_distance, d_prop_point,
                            d_prop_dist, d_match_kp, d_match_point, d_match_count);
     }
+    RS_HIP(ctx, hipGetLastError());
+    return RS_OK;
+}
+
+// rs_kdtree_pack: the frame's KD-tree as K2 wants it in LDS — {x, y, left, right} per node, then the node's keypoint
+// index — so that the workgroups of the (two) match calls of a frame copy it instead of gathering it.
+__global__ __launch_bounds__(256) void k2_pack_tree(int n, const float2* __restrict__ kp, const int32_t* __restrict__ node_kp,
+                                                    const int32_t* __restrict__ left, const int32_t* __restrict__ right,
+                                                    float4* __restrict__ out)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int kpi = node_kp[i];
+    const float2 q = kp[kpi];
+    out[i] = make_float4(q.x, q.y, __int_as_float(left[i]), __int_as_float(right[i]));
+    ((int*)(out + n))[i] = kpi;
+}
+
+extern "C" int rs_kdtree_pack(rs_context* ctx, const rs_frame_view* fr, void* d_packed)
+{
+    if (!ctx || !fr) return RS_ERR_INVALID;
+    const int n = fr->n_keypoints;
+    if (n < 0) return rs_fail(ctx, RS_ERR_INVALID, "negative size");
+    if (n == 0) return RS_OK;
+    if (!d_packed || !fr->d_keypoints || !fr->d_kd_node_kp || !fr->d_kd_left || !fr->d_kd_right) return rs_fail(ctx, RS_ERR_INVALID, "null pointer");
+    if (((uintptr_t)d_packed) & 15) return rs_fail(ctx, RS_ERR_INVALID, "d_packed must be 16-byte aligned");
+    RS_HIP(ctx, hipSetDevice(ctx->device));
+    hipLaunchKernelGGL(k2_pack_tree, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, n, (const float2*)fr->d_keypoints,
+                       fr->d_kd_node_kp, fr->d_kd_left, fr->d_kd_right, (float4*)d_packed);
     RS_HIP(ctx, hipGetLastError());
     return RS_OK;
 }

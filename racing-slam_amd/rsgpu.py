@@ -15,7 +15,7 @@ LIB_PATH = os.path.join(_HERE, "librsgpu.so")
 EXPORTS = [
     "rs_abi_version", "rs_context_create", "rs_context_destroy", "rs_context_set_stream",
     "rs_context_synchronize", "rs_context_set_int", "rs_stage_begin", "rs_stage_alloc", "rs_stage_upload", "rs_stage_download", "rs_stage_sync", "rs_last_error", "rs_hamming_knn2", "rs_match_descriptors",
-    "rs_kdtree_build", "rs_reproj_match", "rs_map_create", "rs_map_destroy", "rs_frame_create", "rs_frame_destroy",
+    "rs_kdtree_build", "rs_kdtree_pack", "rs_reproj_match", "rs_map_create", "rs_map_destroy", "rs_frame_create", "rs_frame_destroy",
     "rs_map_add_keyframe", "rs_map_set_keyframe_pose", "rs_map_add_point", "rs_map_set_position", "rs_map_remove_point",
     "rs_map_add_observation", "rs_map_remove_observation", "rs_map_counts", "rs_map_match", "rs_map_bundle_adjust", "rs_triangulate", "rs_triangulate_matches", "rs_triangulate_matches_batch", "rs_triangulate_tracks", "rs_point_errors", "rs_ba_default_options",
     "rs_bundle_adjust", "rs_bundle_adjust_batch", "rs_ba_get_trace", "rs_ba_get_stats", "rs_ba_get_cameras", "rs_reanchor_points", "rs_refine_pose", "rs_bundle_adjust_inertial", "rs_refine_pose_inertial", "rs_pack_pose", "rs_unpack_pose", "rs_pack_poses", "rs_unpack_poses", "rs_build_local_window",
@@ -49,7 +49,7 @@ class FrameView(C.Structure):
                 ("cy", C.c_float), ("width", C.c_int), ("height", C.c_int), ("n_keypoints", C.c_int),
                 ("d_keypoints", C.c_void_p), ("d_descriptors", C.c_void_p), ("d_kp_matched", C.c_void_p),
                 ("d_kd_node_kp", C.c_void_p), ("d_kd_left", C.c_void_p), ("d_kd_right", C.c_void_p),
-                ("kd_root", C.c_int)]
+                ("kd_root", C.c_int), ("d_kd_packed", C.c_void_p)]
 
 
 class MapView(C.Structure):
@@ -247,7 +247,7 @@ class Context:
         return out
 
     # -- a2/a3
-    def make_frame_view(self, frame):
+    def make_frame_view(self, frame, pack=False):
         """frame: dict of numpy arrays (synth.make_match_scene); returns (FrameView, keepalive)."""
         fv = FrameView()
         keep = {}
@@ -261,6 +261,11 @@ class Context:
             keep[name] = self.dev(frame[key], dt)
             setattr(fv, name, keep[name].data_ptr())
         fv.kd_root = int(frame["kd_root"])
+        fv.d_kd_packed = None
+        if pack and fv.n_keypoints > 0:        # once per frame: shared by the match calls of that frame
+            keep["d_kd_packed"] = self.empty((5 * fv.n_keypoints,), self.torch.int32)
+            self._check(self.lib.rs_kdtree_pack(self.h, C.byref(fv), _dp(keep["d_kd_packed"])), "rs_kdtree_pack")
+            fv.d_kd_packed = keep["d_kd_packed"].data_ptr()
         return fv, keep
 
     def make_map_view(self, mp):

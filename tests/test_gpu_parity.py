@@ -241,6 +241,12 @@ def _reproj_case(ctx, oracle, rs, frame, mp, replace):
     assert cnt == len(ref["match_kp"])
     assert np.array_equal(to_np(out["match_kp"])[:cnt], ref["match_kp"])
     assert np.array_equal(to_np(out["match_point"])[:cnt], ref["match_point"])
+    # the same with the KD-tree packed once for the frame (rs_kdtree_pack): identical outputs
+    fvp, k3 = ctx.make_frame_view(frame, pack=True)
+    outp = ctx.reproj_match(fvp, mv, replace=replace)
+    for k in ("point_kp", "point_dist", "prop_point", "prop_dist"):
+        assert np.array_equal(to_np(outp[k]), to_np(out[k])), k
+    assert int(to_np(outp["count"])[0]) == cnt and np.array_equal(to_np(outp["match_point"])[:cnt], ref["match_point"])
     return cnt
 
 

@@ -30,7 +30,7 @@ def per_kernel(d, counter):
             for row in csv.DictReader(fh):
                 if row.get("Counter_Name") != counter:
                     continue
-                name = row["Kernel_Name"].split("(")[0].strip()
+                name = row["Kernel_Name"].split("(")[0].strip().replace(",", ";")
                 a = acc[name]
                 a[0] += float(row["Counter_Value"])
                 a[1] += 1
