@@ -228,6 +228,9 @@ int rs_map_remove_point(rs_map* map, int point);                                
 int rs_map_add_observation(rs_map* map, int point, int kf, int keypoint);       /* Map::associate, src/Map.cpp:95-113 */
 int rs_map_remove_observation(rs_map* map, int point, int kf);                 /* Map::disassociate, src/Map.cpp:115-124 */
 int rs_map_counts(const rs_map* map, int h_out[4]);   /* point slots, alive points, observations, key frames */
+/* MapPoint::position() of the point slots [first, first + count) from the library's mirror (removed points keep
+ * their last position); what a caller copies into its own objects after rs_map_pose_graph moved the whole map. */
+int rs_map_get_positions(const rs_map* map, int first, int count, float* h_xyz /*[count][3]*/);
 
 /* MapMatcher::match_map / match_key_frame / match_for_fuse (src/MapMatcher.cpp:107-127,165-175) against the resident
  * map; results identical to rs_reproj_match on the flattened map.
@@ -535,6 +538,48 @@ int rs_refine_pose_inertial(rs_context* ctx, double h_camera[6],
                             const double h_prev_pose[6], const double h_prev_velocity[3], const double h_prev_bias[6],
                             const rs_imu_factor* h_delta, const double h_gravity[3], double h_velocity[3],
                             const rs_ba_options* options, rs_ba_summary* h_summary);
+
+/* ------------------------------------------------------------------ a14: pose graph
+ * optimization::pose_graph (src/Optimization.cpp:540-639), called once per detected loop (src/Slam.cpp:258-268).
+ * HOST function (no GPU work, no context): a few hundred 6-residual edges whose sparse normal equations factor in a
+ * short dependent chain; the reference runs Ceres' SPARSE_NORMAL_CHOLESKY on the CPU at the same place.  The
+ * data-parallel part of a loop closure, moving the map points, is rs_transform_points below.
+ *   h_poses [n_kf][16]     Frame::pose() of ALL key frames in index order (Mapper::key_frames())
+ *   h_loops                PoseGraphConstraint: from / to = positions in that list, relative = measured
+ *                          T_from T_to^-1, row-major; entries out of range or with from == to are skipped (:590-592)
+ *   four_dof, h_gravity    yaw + position only, about up = -gravity / |gravity| (falls back to SE(3) when
+ *                          |gravity|^2 < 1e-6, :550-557)
+ *   options                NULL = Ceres defaults with PGO_ITERATIONS = 20 (:120)
+ *   h_out_poses [n_kf][16] the corrected poses, written as apply_corrected_pose (:499-504) writes them; equal to the
+ *                          input when summary.usable == 0 (<=> the reference returns false and changes nothing) and
+ *                          for n_kf < 3 or no loops (:546-548).  May alias h_poses.
+ *   h_velocity_rotation    optional [n_kf][9] row-major R_delta of :505-509 (the caller rotates
+ *                          InertialState::velocity by it); identity where nothing moved
+ *   h_trace                optional per-iteration record, as rs_ba_get_trace; *h_trace_count = iterations recorded */
+typedef struct rs_pose_graph_edge {
+    int32_t from, to;
+    double relative[16];
+} rs_pose_graph_edge;
+int rs_pose_graph(int n_kf, const float* h_poses, const rs_pose_graph_edge* h_loops, int n_loops, int four_dof,
+                  const double h_gravity[3], const rs_ba_options* options, float* h_out_poses,
+                  float* h_velocity_rotation, rs_ba_summary* h_summary, rs_ba_iteration* h_trace, int trace_capacity,
+                  int* h_trace_count);
+/* pose_relative (:494-497): T_from (widened) * inverse(T_to) (f32 cofactor inverse, widened) — what the sequential
+ * edges measure; exposed so that a caller can build loop constraints the same way. */
+void rs_pose_relative(const float h_from[16], const float h_to[16], double h_relative[16]);
+/* transform_points (:512-536) on the device: every point with observations moves rigidly with its owner, the
+ * observing key frame of smallest index:  X' = R_after^T ((R_before X + t_before) - t_after), f32.
+ * Observation CSR as in rs_map_view (d_obs_ptr [n_points + 1], d_obs_kf [.] = position in the key-frame list);
+ * d_poses_before / d_poses_after [n_kf][16], 16-byte aligned. */
+int rs_transform_points(rs_context* ctx, int n_points, const int32_t* d_obs_ptr, const int32_t* d_obs_kf,
+                        const float* d_poses_before, const float* d_poses_after, int n_kf, float* d_positions);
+/* pose_graph on the resident map: poses from the mirror (every key frame of the map, in handle order), rs_pose_graph,
+ * and on a usable solve the key frames take the corrected poses and K14 moves the points on the device (the mirror
+ * follows).  h_out_poses [n_kf][16] / h_velocity_rotation [n_kf][9] (optional) are for the caller's own objects;
+ * returns summary.usable == 0 and changes nothing exactly when the reference returns false. */
+int rs_map_pose_graph(rs_context* ctx, rs_map* map, const rs_pose_graph_edge* h_loops, int n_loops, int four_dof,
+                      const double h_gravity[3], const rs_ba_options* options, float* h_out_poses,
+                      float* h_velocity_rotation, rs_ba_summary* h_summary);
 
 /* pack_pose / unpack_pose (src/Optimization.cpp:144-159, a10).  Host only:
  * R -> angle-axis in f32 through a quaternion (ceres::RotationMatrixToAngleAxis<float>),

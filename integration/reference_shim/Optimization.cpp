@@ -4,13 +4,13 @@
 //    consecutive pair of optimised frames with >= 2 samples, src/Optimization.cpp:317-346), RotationPrior /
 //    InertialDelta -> rs_refine_pose_inertial (:231-267).  imu::preintegrate and imu::Stream::between
 //    (src/Imu.cpp, src/ImuStream.cpp: small sequential host code) stay the reference's and are called from here.
-//  * pose_graph (a14, src/Optimization.cpp:376-639) is DEFINED here as the documented stub SURVEY.md §8 a14 allows:
-//    it logs and returns false.  The only caller (Slam::step, src/Slam.cpp:259-283) then records
-//    `loop_closed = false` and skips fuse_loop and the fix_oldest bundle adjustment: loop candidates are detected
-//    but not applied.  A project that needs loop closure keeps the reference's Ceres implementation of this one
-//    function (move it into a file of its own); it does not touch the accelerated path.
+//  * pose_graph (a14, src/Optimization.cpp:376-639): the solve is rs_pose_graph (a host function of the library —
+//    sparse envelope Cholesky, same Ceres trust-region schedule), the point transform (transform_points, :512-536) runs
+//    on the device through rs_reanchor_points with the owner chosen here exactly as the reference chooses it
+//    (smallest KeyFrame::index among the observers).
 #include "Optimization.h"
 
+#include <algorithm>
 #include <unordered_map>
 
 #include "Camera.h"
@@ -195,14 +195,83 @@ bool bundle_adjust(const std::vector<FrameConfig>& frames, const Camera& camera,
     return true;
 }
 
-// a14: documented stub (see the header of this file).  Returning false is the reference's own "rejected" outcome
-// (src/Optimization.cpp:612-615): nothing is moved, the caller carries on without the loop correction.
-bool pose_graph(const std::vector<std::shared_ptr<KeyFrame>>& key_frames, const std::vector<PoseGraphConstraint>& loops, Map&,
-                bool four_dof, const Eigen::Vector3d&)
+// a14: optimization::pose_graph, src/Optimization.cpp:540-639.
+bool pose_graph(const std::vector<std::shared_ptr<KeyFrame>>& key_frames, const std::vector<PoseGraphConstraint>& loops, Map& map,
+                bool four_dof, const Eigen::Vector3d& gravity)
 {
-    std::printf("Pose graph %s not run: not part of the GPU drop-in (%zu key frames, %zu loops); loop not applied\n",
-                four_dof ? "4-DOF" : "SE3", key_frames.size(), loops.size());
-    return false;
+    if (key_frames.size() < 3 || loops.empty()) return false;                                           // :546-548
+    const size_t n = key_frames.size();
+    std::vector<float> before(16 * n), after(16 * n), r_delta(9 * n);
+    std::unordered_map<const Frame*, int32_t> slot;
+    slot.reserve(n);
+    for (size_t i = 0; i < n; i++) {
+        rs_shim::pose_to_row_major(key_frames[i]->pose(), &before[16 * i]);
+        slot[key_frames[i].get()] = (int32_t)i;
+    }
+    std::vector<rs_pose_graph_edge> edges(loops.size());
+    for (size_t l = 0; l < loops.size(); l++) {
+        edges[l].from = loops[l].from < n ? (int32_t)loops[l].from : -1;                                // out of range: skipped (:590-592)
+        edges[l].to = loops[l].to < n ? (int32_t)loops[l].to : -1;
+        for (int r = 0; r < 4; r++)
+            for (int c = 0; c < 4; c++) edges[l].relative[4 * r + c] = loops[l].relative(r, c);
+    }
+    const double g[3] = {gravity[0], gravity[1], gravity[2]};
+    rs_ba_summary summary{};
+    if (!rs_shim::ok(rs_pose_graph((int)n, before.data(), edges.data(), (int)edges.size(), four_dof ? 1 : 0, g, nullptr, after.data(),
+                                   r_delta.data(), &summary, nullptr, 0, nullptr), "rs_pose_graph"))
+        return false;
+    const bool ran_four_dof = four_dof && (g[0] * g[0] + g[1] * g[1] + g[2] * g[2]) >= 1e-6;              // :552-553
+    std::printf("Pose graph %s iterations %d cost %g -> %g\n", ran_four_dof ? "4-DOF" : "SE3", summary.iterations,
+                summary.initial_cost, summary.final_cost);
+    if (!summary.usable) {                                                                              // :610-616
+        std::printf("Pose graph rejected, unusable or non-improving solution\n");
+        return false;
+    }
+
+    // transform_points, :512-536: owner = observer of smallest index; listed only when it is one of the key frames
+    std::vector<MapPoint*> moved;
+    std::vector<int32_t> owner_slot;
+    std::vector<float> positions;
+    for (auto& point : map) {
+        if (point.observations().empty()) continue;
+        KeyFrame* owner = nullptr;
+        for (const auto& [observer, _] : point.observations())
+            if (owner == nullptr || observer->index() < owner->index()) owner = observer;
+        const auto it = slot.find(owner);
+        if (it == slot.end()) continue;
+        const Eigen::Vector3f p = point.position();
+        moved.push_back(&point);
+        owner_slot.push_back(it->second);
+        positions.insert(positions.end(), {p[0], p[1], p[2]});
+    }
+    {
+        rs_shim::Stage stage;
+        rs_shim::DevBuf<float> d_before(before), d_after(after), d_pos(positions);
+        rs_shim::DevBuf<int32_t> d_owner(owner_slot);
+        if (!rs_shim::ok(rs_reanchor_points(rs_shim::context(), (int)moved.size(), nullptr, d_owner.p, d_before.p, d_after.p, (int)n, d_pos.p),
+                         "rs_reanchor_points"))
+            return false;
+        std::vector<float> out = d_pos.fetch(positions.size());
+        stage.sync();
+        for (size_t i = 0; i < moved.size(); i++) moved[i]->set_position(Eigen::Vector3f(out[3 * i], out[3 * i + 1], out[3 * i + 2]));
+    }
+
+    float max_correction = 0.0F;
+    for (size_t i = 0; i < n; i++) {                                                                    // apply_corrected_pose, :499-510
+        Frame& frame = *key_frames[i];
+        const Eigen::Vector3f c0 = frame.camera_center();
+        frame.set_pose(rs_shim::pose_from_row_major(&after[16 * i]));
+        InertialState inertial = frame.inertial();
+        const double v[3] = {inertial.velocity[0], inertial.velocity[1], inertial.velocity[2]};
+        for (int r = 0; r < 3; r++)
+            inertial.velocity[r] = (double)r_delta[9 * i + 3 * r] * v[0] + (double)r_delta[9 * i + 3 * r + 1] * v[1] + (double)r_delta[9 * i + 3 * r + 2] * v[2];
+        frame.set_inertial(inertial);
+        const Eigen::Vector3f c1 = frame.camera_center();
+        const float d[3] = {c1[0] - c0[0], c1[1] - c0[1], c1[2] - c0[2]};
+        max_correction = std::max(max_correction, std::sqrt(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]));
+    }
+    std::printf("Pose graph applied, max snap %g loops %zu\n", max_correction, loops.size());
+    return true;
 }
 
 }  // namespace slam::optimization

@@ -132,6 +132,7 @@ void orc_ba_default_options(orc_ba_options* o)
 }
 
 /* ------------------------------------------------------------------ trace */
+/* (orc__trace_push is shared with pose_graph.c) */
 static __thread orc_ba_iteration* g_trace = NULL;
 static __thread int g_trace_cap = 0;
 static __thread int* g_trace_count = NULL;
@@ -140,7 +141,7 @@ void orc_ba_set_trace(orc_ba_iteration* buf, int capacity, int* count)
     g_trace = buf; g_trace_cap = buf ? capacity : 0; g_trace_count = count;
     if (count) *count = 0;
 }
-static void trace_push(double cost, double cand, double mcc, double radius, double step_norm, double x_norm, int outcome)
+void orc__trace_push(double cost, double cand, double mcc, double radius, double step_norm, double x_norm, int outcome)
 {
     if (!g_trace || !g_trace_count || *g_trace_count >= g_trace_cap) return;
     orc_ba_iteration* e = g_trace + (*g_trace_count)++;
@@ -610,7 +611,7 @@ static int lm_solve(problem* pr, double* cams, double* pts, double* vel, double*
         }
         if (solver_failed || !(model_cost_change > 0.0)) {
             /* TrustRegionMinimizer::HandleInvalidStep */
-            trace_push(x_cost, 0.0, solver_failed ? 0.0 : model_cost_change, radius, 0.0, 0.0, -1);
+            orc__trace_push(x_cost, 0.0, solver_failed ? 0.0 : model_cost_change, radius, 0.0, 0.0, -1);
             if (++invalid_steps >= opt->max_num_consecutive_invalid_steps) { sum->termination = 5; break; }
             radius = radius / decrease_factor; decrease_factor *= 2.0;   /* StepIsInvalid -> StepRejected(0) */
             continue;
@@ -653,16 +654,16 @@ static int lm_solve(problem* pr, double* cams, double* pts, double* vel, double*
         const double step_norm = sqrt(step_sq), x_norm = sqrt(x_sq);
         /* ParameterToleranceReached */
         if (step_norm <= opt->parameter_tolerance * (x_norm + opt->parameter_tolerance)) {
-            trace_push(x_cost, cand_cost, model_cost_change, radius, step_norm, x_norm, 2);
+            orc__trace_push(x_cost, cand_cost, model_cost_change, radius, step_norm, x_norm, 2);
             sum->termination = 2; break;
         }
         /* FunctionToleranceReached */
         if (fabs(x_cost - cand_cost) <= opt->function_tolerance * x_cost) {
-            trace_push(x_cost, cand_cost, model_cost_change, radius, step_norm, x_norm, 2);
+            orc__trace_push(x_cost, cand_cost, model_cost_change, radius, step_norm, x_norm, 2);
             sum->termination = 1; break;
         }
         const double rel = (x_cost - cand_cost) / model_cost_change;
-        trace_push(x_cost, cand_cost, model_cost_change, radius, step_norm, x_norm,
+        orc__trace_push(x_cost, cand_cost, model_cost_change, radius, step_norm, x_norm,
                    (rel > opt->min_relative_decrease && isfinite(cand_cost)) ? 1 : 0);
         if (rel > opt->min_relative_decrease && isfinite(cand_cost)) {
             /* HandleSuccessfulStep */

@@ -12,7 +12,7 @@
  *   write-back   apply_corrected_pose :499-510 (f32), per key frame
  * Third-party semantics restated (Ceres 2.x): forward-mode jets (12 wide), rotation.h conversions (jetn.h), HuberLoss +
  * Corrector (rho'' <= 0: residual and Jacobian scaled by sqrt(rho')), TrustRegionMinimizer / LevenbergMarquardtStrategy.
- * Specified here: Eigen's 4x4 float inverse in pose_relative (:494-497) is restated as adjugate / determinant.
+ * Specified here: Eigen's 4x4 float inverse in pose_relative (:494-497) is restated as adjugate / determinant (inv4f).
  */
 #include <math.h>
 #include <stdlib.h>
@@ -23,37 +23,46 @@
 #define NJ 12
 #include "jetn.h"
 
+void orc__trace_push(double cost, double cand, double mcc, double radius, double step_norm, double x_norm, int outcome);   /* ba.c */
+
 #define SEQ_SIGMA_ROT 0.02
 #define SEQ_SIGMA_TRANS 0.2
 #define LOOP_SIGMA_ROT 0.05
 #define LOOP_SIGMA_TRANS 0.5
 
-/* general inverse of a row-major 4x4 float matrix: adjugate / determinant */
+/* General inverse of a row-major 4x4 float matrix.  Eigen's fixed-size Matrix4f::inverse() is cofactor based (its
+ * operation order is an implementation detail upstream); SPECIFIED HERE as adjugate / determinant in f32 with
+ *   minor(r, k)  = the 3x3 determinant of the rows != r and columns != k in ascending order, expanded along its first
+ *                  row:  (a (e i - f h) - b (d i - f g)) + c (d h - e g)
+ *   adj[k][r]    = (-1)^(r+k) minor(r, k),   det = ((m00 adj00 + m01 adj10) + m02 adj20) + m03 adj30,   inv = adj / det. */
+static float minor3(const float* m, int r, int k)
+{
+    int rows[3], cols[3], nr = 0, nc = 0;
+    for (int i = 0; i < 4; i++) {
+        if (i != r) rows[nr++] = i;
+        if (i != k) cols[nc++] = i;
+    }
+#define E(i, j) m[4 * rows[i] + cols[j]]
+    const float t0 = E(0, 0) * (E(1, 1) * E(2, 2) - E(1, 2) * E(2, 1));
+    const float t1 = E(0, 1) * (E(1, 0) * E(2, 2) - E(1, 2) * E(2, 0));
+    const float t2 = E(0, 2) * (E(1, 0) * E(2, 1) - E(1, 1) * E(2, 0));
+#undef E
+    return (t0 - t1) + t2;
+}
 static void inv4f(const float* m, float* out)
 {
-    float inv[16];
-    inv[0] = m[5] * m[10] * m[15] - m[5] * m[11] * m[14] - m[9] * m[6] * m[15] + m[9] * m[7] * m[14] + m[13] * m[6] * m[11] - m[13] * m[7] * m[10];
-    inv[4] = -m[4] * m[10] * m[15] + m[4] * m[11] * m[14] + m[8] * m[6] * m[15] - m[8] * m[7] * m[14] - m[12] * m[6] * m[11] + m[12] * m[7] * m[10];
-    inv[8] = m[4] * m[9] * m[15] - m[4] * m[11] * m[13] - m[8] * m[5] * m[15] + m[8] * m[7] * m[13] + m[12] * m[5] * m[11] - m[12] * m[7] * m[9];
-    inv[12] = -m[4] * m[9] * m[14] + m[4] * m[10] * m[13] + m[8] * m[5] * m[14] - m[8] * m[6] * m[13] - m[12] * m[5] * m[10] + m[12] * m[6] * m[9];
-    inv[1] = -m[1] * m[10] * m[15] + m[1] * m[11] * m[14] + m[9] * m[2] * m[15] - m[9] * m[3] * m[14] - m[13] * m[2] * m[11] + m[13] * m[3] * m[10];
-    inv[5] = m[0] * m[10] * m[15] - m[0] * m[11] * m[14] - m[8] * m[2] * m[15] + m[8] * m[3] * m[14] + m[12] * m[2] * m[11] - m[12] * m[3] * m[10];
-    inv[9] = -m[0] * m[9] * m[15] + m[0] * m[11] * m[13] + m[8] * m[1] * m[15] - m[8] * m[3] * m[13] - m[12] * m[1] * m[11] + m[12] * m[3] * m[9];
-    inv[13] = m[0] * m[9] * m[14] - m[0] * m[10] * m[13] - m[8] * m[1] * m[14] + m[8] * m[2] * m[13] + m[12] * m[1] * m[10] - m[12] * m[2] * m[9];
-    inv[2] = m[1] * m[6] * m[15] - m[1] * m[7] * m[14] - m[5] * m[2] * m[15] + m[5] * m[3] * m[14] + m[13] * m[2] * m[7] - m[13] * m[3] * m[6];
-    inv[6] = -m[0] * m[6] * m[15] + m[0] * m[7] * m[14] + m[4] * m[2] * m[15] - m[4] * m[3] * m[14] - m[12] * m[2] * m[7] + m[12] * m[3] * m[6];
-    inv[10] = m[0] * m[5] * m[15] - m[0] * m[7] * m[13] - m[4] * m[1] * m[15] + m[4] * m[3] * m[13] + m[12] * m[1] * m[7] - m[12] * m[3] * m[5];
-    inv[14] = -m[0] * m[5] * m[14] + m[0] * m[6] * m[13] + m[4] * m[1] * m[14] - m[4] * m[2] * m[13] - m[12] * m[1] * m[6] + m[12] * m[2] * m[5];
-    inv[3] = -m[1] * m[6] * m[11] + m[1] * m[7] * m[10] + m[5] * m[2] * m[11] - m[5] * m[3] * m[10] - m[9] * m[2] * m[7] + m[9] * m[3] * m[6];
-    inv[7] = m[0] * m[6] * m[11] - m[0] * m[7] * m[10] - m[4] * m[2] * m[11] + m[4] * m[3] * m[10] + m[8] * m[2] * m[7] - m[8] * m[3] * m[6];
-    inv[11] = -m[0] * m[5] * m[11] + m[0] * m[7] * m[9] + m[4] * m[1] * m[11] - m[4] * m[3] * m[9] - m[8] * m[1] * m[7] + m[8] * m[3] * m[5];
-    inv[15] = m[0] * m[5] * m[10] - m[0] * m[6] * m[9] - m[4] * m[1] * m[10] + m[4] * m[2] * m[9] + m[8] * m[1] * m[6] - m[8] * m[2] * m[5];
-    const float det = m[0] * inv[0] + m[1] * inv[4] + m[2] * inv[8] + m[3] * inv[12];
-    for (int i = 0; i < 16; i++) out[i] = inv[i] / det;
+    float adj[16];
+    for (int r = 0; r < 4; r++)
+        for (int k = 0; k < 4; k++) {
+            const float mn = minor3(m, r, k);
+            adj[4 * k + r] = ((r + k) % 2) ? -mn : mn;
+        }
+    const float det = ((m[0] * adj[0] + m[1] * adj[4]) + m[2] * adj[8]) + m[3] * adj[12];
+    for (int i = 0; i < 16; i++) out[i] = adj[i] / det;
 }
 
 /* pose_relative, :494-497: from.pose (as double) * inverse(to.pose) (inverse in f32, then widened) */
-static void pose_relative(const float* from, const float* to, double rel[16])
+void orc_pose_relative(const float from[16], const float to[16], double rel[16])
 {
     float ti[16];
     inv4f(to, ti);
@@ -160,6 +169,24 @@ static int chol_solve_dense(double* A, int n, double* b)
     return 0;
 }
 
+void orc_pose_graph_edge(int four_dof, const double* x_from, const double* x_to, const double R0_from[9], const double R0_to[9],
+                         const double up[3], const double relative[16], int loop, double r[6], double J[72])
+{
+    pg_problem pr;
+    pg_edge e;
+    double x[12], R0[18];
+    memset(&pr, 0, sizeof pr);
+    memset(R0, 0, sizeof R0);
+    const int bs = four_dof ? 4 : 6;
+    pr.n = 2; pr.ne = 1; pr.four_dof = four_dof; pr.bs = bs; pr.e = &e; pr.R0 = R0;
+    if (four_dof) { memcpy(R0, R0_from, sizeof(double) * 9); memcpy(R0 + 9, R0_to, sizeof(double) * 9); memcpy(pr.up, up, sizeof pr.up); }
+    memcpy(x, x_from, sizeof(double) * bs);
+    memcpy(x + bs, x_to, sizeof(double) * bs);
+    e.from = 0; e.to = 1; e.loop = loop;
+    for (int rr = 0; rr < 3; rr++) { for (int c = 0; c < 3; c++) e.Rm[3 * rr + c] = relative[4 * rr + c]; e.tm[rr] = relative[4 * rr + 3]; }
+    edge_eval(&pr, 0, x, r, J);
+}
+
 int orc_pose_graph(int n, const float* poses, const orc_pg_edge* loops, int n_loops, int four_dof, const double gravity[3],
                    const orc_ba_options* options, float* out_poses, orc_ba_summary* sum)
 {
@@ -195,7 +222,7 @@ int orc_pose_graph(int n, const float* poses, const orc_pg_edge* loops, int n_lo
     int ne = 0;
     for (int i = 0; i + 1 < n; i++) {                                                                 /* :586-588 */
         double rel[16];
-        pose_relative(poses + 16 * (size_t)i, poses + 16 * (size_t)(i + 1), rel);
+        orc_pose_relative(poses + 16 * (size_t)i, poses + 16 * (size_t)(i + 1), rel);
         E[ne].from = i; E[ne].to = i + 1; E[ne].loop = 0;
         for (int rr = 0; rr < 3; rr++) { for (int c = 0; c < 3; c++) E[ne].Rm[3 * rr + c] = rel[4 * rr + c]; E[ne].tm[rr] = rel[4 * rr + 3]; }
         ne++;
@@ -278,6 +305,7 @@ int orc_pose_graph(int n, const float* poses, const orc_pg_edge* loops, int n_lo
                 }
         }
         if (failed || !(mcc > 0.0)) {
+            orc__trace_push(x_cost, 0.0, failed ? 0.0 : mcc, radius, 0.0, 0.0, -1);
             if (++invalid >= options->max_num_consecutive_invalid_steps) { sum->termination = 5; break; }
             radius /= factor; factor *= 2.0;
             continue;
@@ -293,9 +321,16 @@ int orc_pose_graph(int n, const float* poses, const orc_pg_edge* loops, int n_lo
                 ssq += df * df; xsq += x[bs * kf + q] * x[bs * kf + q];
             }
         const double cand_cost = pg_eval(&pr, cand, Rc, NULL);
-        if (sqrt(ssq) <= options->parameter_tolerance * (sqrt(xsq) + options->parameter_tolerance)) { sum->termination = 2; break; }
-        if (fabs(x_cost - cand_cost) <= options->function_tolerance * x_cost) { sum->termination = 1; break; }
+        if (sqrt(ssq) <= options->parameter_tolerance * (sqrt(xsq) + options->parameter_tolerance)) {
+            orc__trace_push(x_cost, cand_cost, mcc, radius, sqrt(ssq), sqrt(xsq), 2);
+            sum->termination = 2; break;
+        }
+        if (fabs(x_cost - cand_cost) <= options->function_tolerance * x_cost) {
+            orc__trace_push(x_cost, cand_cost, mcc, radius, sqrt(ssq), sqrt(xsq), 2);
+            sum->termination = 1; break;
+        }
         const double rel = (x_cost - cand_cost) / mcc;
+        orc__trace_push(x_cost, cand_cost, mcc, radius, sqrt(ssq), sqrt(xsq), (rel > options->min_relative_decrease && isfinite(cand_cost)) ? 1 : 0);
         if (rel > options->min_relative_decrease && isfinite(cand_cost)) {
             memcpy(x, cand, sizeof(double) * (size_t)bs * n);
             x_cost = pg_eval(&pr, x, Rv, Jv);

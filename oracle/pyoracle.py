@@ -554,3 +554,67 @@ def build_local_window(n_kf, new_frame, window, fix_oldest, frame_ptr, frame_pt,
     assert rc == 0
     n = int(cnt[0])
     return of[:n].copy(), oo[:n].copy()
+
+
+class PgEdge(C.Structure):
+    """orc_pg_edge / rs_pose_graph_edge (identical layout)."""
+    _fields_ = [("from_", C.c_int32), ("to", C.c_int32), ("relative", C.c_double * 16)]
+
+
+def pg_edge_array(loops, cls=PgEdge):
+    """[(from, to, relative 4x4), ...] -> ctypes array."""
+    arr = (cls * max(len(loops), 1))()
+    for i, (a, b, rel) in enumerate(loops):
+        arr[i].from_ = int(a)
+        arr[i].to = int(b)
+        arr[i].relative[:] = list(np.asarray(rel, np.float64).reshape(16))
+    return arr
+
+
+def pose_graph(poses, loops, four_dof=False, gravity=(0.0, 0.0, 0.0), options=None, trace=False):
+    """optimization::pose_graph.  Returns (poses' [n,4,4] f32, summary[, trace])."""
+    poses = np.ascontiguousarray(poses, np.float32).reshape(-1, 16)
+    out = np.zeros_like(poses)
+    g = np.ascontiguousarray(gravity, np.float64)
+    arr = pg_edge_array(loops)
+    s = BaSummary()
+    L = lib()
+    cap = 256
+    buf = (BaIteration * cap)()
+    cnt = C.c_int(0)
+    if trace:
+        L.orc_ba_set_trace(buf, cap, C.byref(cnt))
+    try:
+        rc = L.orc_pose_graph(len(poses), _p(poses, f32p), arr, len(loops), int(bool(four_dof)), _p(g, f64p),
+                              None if options is None else C.byref(options), _p(out, f32p), C.byref(s))
+    finally:
+        if trace:
+            L.orc_ba_set_trace(None, 0, None)
+    assert rc == 0
+    res = (out.reshape(-1, 4, 4), s.as_dict())
+    return res + ([buf[i].as_dict() for i in range(cnt.value)],) if trace else res
+
+
+def pose_graph_edge(four_dof, x_from, x_to, R0_from, R0_to, up, relative, loop):
+    r = np.zeros(6)
+    J = np.zeros((6, 12))
+    a = [np.ascontiguousarray(v, np.float64) for v in (x_from, x_to, R0_from, R0_to, up, relative)]
+    lib().orc_pose_graph_edge(int(bool(four_dof)), *[_p(v, f64p) for v in a], int(bool(loop)), _p(r, f64p), _p(J, f64p))
+    return r, J
+
+
+def transform_points(obs_ptr, obs_kf, before, after, positions):
+    pos = np.array(positions, np.float32, order="C")
+    op = np.ascontiguousarray(obs_ptr, np.int32)
+    ok = np.ascontiguousarray(obs_kf, np.int32)
+    rc = lib().orc_transform_points(len(op) - 1, _p(op, i32p), _p(ok, i32p), _p(np.ascontiguousarray(before, np.float32), f32p),
+                                    _p(np.ascontiguousarray(after, np.float32), f32p), _p(pos, f32p))
+    assert rc == 0
+    return pos
+
+
+def pose_relative(pose_from, pose_to):
+    rel = np.zeros(16)
+    lib().orc_pose_relative(_p(np.ascontiguousarray(pose_from, np.float32).reshape(16), f32p),
+                            _p(np.ascontiguousarray(pose_to, np.float32).reshape(16), f32p), _p(rel, f64p))
+    return rel.reshape(4, 4)

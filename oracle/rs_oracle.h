@@ -92,6 +92,11 @@ int orc_point_errors(int n_points, const float* positions, const int32_t* obs_pt
                      double sums[2]);
 int orc_reanchor_points(int n, const int32_t* point_idx, const int32_t* frame_idx, const float* before,
                         const float* after, float* positions);
+/* transform_points of the pose graph, reference src/Optimization.cpp:512-536: every point with observations moves rigidly
+ * with its OWNER = the observing key frame of smallest index (obs_kf holds positions in the key-frame list, which is in
+ * index order; an owner < 0, i.e. not in the list, leaves the point alone). */
+int orc_transform_points(int n_points, const int32_t* obs_ptr, const int32_t* obs_kf, const float* before,
+                         const float* after, float* positions);
 /* 4x4 f64 one-sided Jacobi SVD null vector (exposed for tests): v = right
  * singular vector of the smallest singular value of row-major A. */
 void orc_null_vector4(const double A[16], double v[4], double sigma[4]);
@@ -186,6 +191,22 @@ int orc_refine_pose_inertial(double camera[6], const double* points, const float
                              const double prev_velocity[3], const double prev_bias[6], const orc_imu_factor* delta,
                              const double gravity[3], double velocity[3], const orc_ba_options* options,
                              orc_ba_summary* summary);
+
+/* -- pose_graph.c: optimization::pose_graph, reference src/Optimization.cpp:376-639 -------------------------------
+ * poses [n][16] f32 row-major world->camera of ALL key frames in index order; loops: from / to = positions in that
+ * list, relative = measured from * to^-1 (row-major 4x4 f64).  out_poses = input when the result is not usable
+ * (summary->usable == 0 <=> the reference returns false).  options NULL = Ceres defaults with 20 iterations. */
+typedef struct orc_pg_edge {
+    int32_t from, to;
+    double relative[16];
+} orc_pg_edge;
+int orc_pose_graph(int n, const float* poses, const orc_pg_edge* loops, int n_loops, int four_dof, const double gravity[3],
+                   const orc_ba_options* options, float* out_poses, orc_ba_summary* summary);
+/* pose_relative, :494-497: from (widened) * inverse(to) (f32 cofactor inverse, widened); row-major 4x4 */
+void orc_pose_relative(const float from[16], const float to[16], double rel[16]);
+/* residual [6] and Jacobian [6][12] (SE3: from 0-5 | to 6-11; 4-DoF: from 0-3 | to 4-7, rest 0) of one edge, for tests */
+void orc_pose_graph_edge(int four_dof, const double* x_from, const double* x_to, const double R0_from[9], const double R0_to[9],
+                         const double up[3], const double relative[16], int loop, double r[6], double J[72]);
 
 /* One linearisation at the given state (no update), for tests and for the
  * multi-GPU sharding tests: fills the UNDAMPED normal equations

@@ -217,3 +217,19 @@ int orc_reanchor_points(int n, const int32_t* point_idx, const int32_t* frame_id
     }
     return 0;
 }
+
+/* transform_points, reference src/Optimization.cpp:512-536 (the point loop of optimization::pose_graph). */
+int orc_transform_points(int n_points, const int32_t* obs_ptr, const int32_t* obs_kf, const float* before,
+                         const float* after, float* positions)
+{
+    for (int p = 0; p < n_points; p++) {
+        if (obs_ptr[p + 1] == obs_ptr[p]) continue;                                  /* :515-517 */
+        int owner = obs_kf[obs_ptr[p]];
+        for (int o = obs_ptr[p] + 1; o < obs_ptr[p + 1]; o++)
+            if (obs_kf[o] < owner) owner = obs_kf[o];                                /* :518-523 */
+        if (owner < 0) continue;                                                     /* :524-527 */
+        const int32_t one = owner;
+        orc_reanchor_points(1, &p, &one, before, after, positions);                  /* :528-534, same arithmetic as Mapper.cpp:389-390 */
+    }
+    return 0;
+}

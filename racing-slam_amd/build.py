@@ -29,6 +29,7 @@ SOURCES = [
     ("ba_update.hip", ["-munsafe-fp-atomics"]),
     ("map.hip", []),
     ("host.cpp", ["-ffp-contract=off"]),
+    ("pose_graph.cpp", ["-ffp-contract=off"]),
 ]
 STAMPS = ["-DRS_STAMPS=1"] if os.environ.get("RS_STAMPS") else []
 COMMON = STAMPS + ["-O3", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function", "-Wno-pass-failed", f"--offload-arch={ARCH}"]

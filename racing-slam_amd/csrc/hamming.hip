@@ -27,19 +27,33 @@ __device__ __forceinline__ void top2_insert(uint32_t& k0, uint32_t& k1, uint32_t
 
 __global__ __launch_bounds__(64 * K1_WAVES) void k1_hamming_knn2(
     const uint4* __restrict__ query, int nq, const uint4* __restrict__ train, int nt,
-    int rows_per_wave, int nsplit, uint2* __restrict__ part)
+    int rows_per_wave, int nsplit, int nqb, int xcd_groups, uint2* __restrict__ part)
 {
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const int b = blockIdx.z;
-    const int qi = blockIdx.x * 64 + lane;
+    // 1-D grid -> (query block, train split, pair).  Blocks are dealt round-robin over the 8 XCDs (blocks id and id + 8
+    // share one, each XCD with its own L2): with xcd_groups set (batch % 8 == 0) all blocks of a pair carry the same
+    // id % 8, so a pair's descriptor rows are fetched into ONE L2 instead of all eight (speed only, any placement is
+    // correct).  Otherwise the plain order.
+    const int per_pair = nqb * nsplit;
+    int b, rem;
+    if (xcd_groups) {
+        const int j = (int)blockIdx.x >> 3;
+        b = (j / per_pair) * 8 + ((int)blockIdx.x & 7);
+        rem = j % per_pair;
+    } else {
+        b = (int)blockIdx.x / per_pair;
+        rem = (int)blockIdx.x % per_pair;
+    }
+    const int split = rem / nqb, qblock = rem % nqb;
+    const int qi = qblock * 64 + lane;
     const uint4* q = query + (size_t)b * nq * 2;
     const uint4* t = train + (size_t)b * nt * 2;
 
     uint4 qa = make_uint4(0, 0, 0, 0), qb = make_uint4(0, 0, 0, 0);
     if (qi < nq) { qa = q[2 * qi]; qb = q[2 * qi + 1]; }
 
-    const int t0 = (blockIdx.y * K1_WAVES + wave) * rows_per_wave;
+    const int t0 = (split * K1_WAVES + wave) * rows_per_wave;
     const int t1 = min(t0 + rows_per_wave, nt);
     uint32_t k0 = K1_KEY_NONE, k1 = K1_KEY_NONE;
 #pragma unroll 4
@@ -66,7 +80,7 @@ __global__ __launch_bounds__(64 * K1_WAVES) void k1_hamming_knn2(
             top2_insert(k0, k1, sk[w][0][lane]);
             top2_insert(k0, k1, sk[w][1][lane]);
         }
-        if (qi < nq) part[((size_t)b * nsplit + blockIdx.y) * nq + qi] = make_uint2(k0, k1);
+        if (qi < nq) part[((size_t)b * nsplit + split) * nq + qi] = make_uint2(k0, k1);
     }
 }
 
@@ -165,13 +179,15 @@ static int knn2_launch(rs_context* ctx, const uint8_t* d_query, int nq, const ui
     if (nsplit > max_split) nsplit = max_split;
     if (nsplit < 1) nsplit = 1;
     const int rows_per_wave = (nt + nsplit * K1_WAVES - 1) / (nsplit * K1_WAVES);
+    if ((size_t)nqb * nsplit * batch > 0x7fffffffu) return rs_fail(ctx, RS_ERR_UNSUPPORTED, "too many query blocks for one launch");
     void* ws = nullptr;
     int rc = rs_workspace(ctx, sizeof(uint2) * (size_t)batch * nsplit * nq, &ws);
     if (rc) return rc;
     {
         rs_prof_scope ps(ctx, "K1_hamming_knn2");
-        hipLaunchKernelGGL(k1_hamming_knn2, dim3(nqb, nsplit, batch), dim3(64 * K1_WAVES), 0, ctx->stream,
-                           (const uint4*)d_query, nq, (const uint4*)d_train, nt, rows_per_wave, nsplit, (uint2*)ws);
+        hipLaunchKernelGGL(k1_hamming_knn2, dim3((unsigned)((size_t)nqb * nsplit * batch)), dim3(64 * K1_WAVES), 0, ctx->stream,
+                           (const uint4*)d_query, nq, (const uint4*)d_train, nt, rows_per_wave, nsplit, nqb,
+                           (batch % 8 == 0) ? 1 : 0, (uint2*)ws);
     }
     {
         rs_prof_scope ps(ctx, "K1b_merge_filter");

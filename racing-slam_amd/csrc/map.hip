@@ -274,6 +274,13 @@ extern "C" int rs_map_counts(const rs_map* m, int h_out[4])
     return RS_OK;
 }
 
+extern "C" int rs_map_get_positions(const rs_map* m, int first, int count, float* h_xyz)
+{
+    if (!m || first < 0 || count < 0 || (size_t)first + (size_t)count > m->alive.size() || (count > 0 && !h_xyz)) return RS_ERR_INVALID;
+    if (count) memcpy(h_xyz, &m->pos[3 * (size_t)first], sizeof(float) * 3 * (size_t)count);
+    return RS_OK;
+}
+
 // ------------------------------------------------------------------------------------------------ device image
 static int map_sync_device(rs_map* m)
 {
@@ -542,4 +549,33 @@ extern "C" int rs_map_bundle_adjust(rs_context* ctx, rs_map* m, const int32_t* h
     m->dirty_positions = true;
     *h_n_points = (int)P;
     return RS_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ loop closure
+// optimization::pose_graph (src/Optimization.cpp:540-639) on the resident map.
+extern "C" int rs_map_pose_graph(rs_context* ctx, rs_map* m, const rs_pose_graph_edge* h_loops, int n_loops, int four_dof,
+                                 const double h_gravity[3], const rs_ba_options* options, float* h_out_poses,
+                                 float* h_velocity_rotation, rs_ba_summary* h_summary)
+{
+    if (!ctx || !m || m->ctx != ctx || !h_summary || n_loops < 0 || (n_loops > 0 && !h_loops)) return RS_ERR_INVALID;
+    const size_t KF = m->kfs.size(), P = m->alive.size();
+    std::vector<float> before(16 * (KF ? KF : 1)), after(16 * (KF ? KF : 1));
+    for (size_t k = 0; k < KF; k++) memcpy(&before[16 * k], m->kfs[k].pose, sizeof(float) * 16);
+    int rc = rs_pose_graph((int)KF, before.data(), h_loops, n_loops, four_dof, h_gravity, options, after.data(),
+                           h_velocity_rotation, h_summary, nullptr, 0, nullptr);
+    if (rc) return rs_fail(ctx, rc, "rs_pose_graph rejected its arguments");
+    if (h_out_poses && KF) memcpy(h_out_poses, after.data(), sizeof(float) * 16 * KF);
+    if (!h_summary->usable) return RS_OK;
+    RS_HIP(ctx, hipSetDevice(ctx->device));
+    if ((rc = map_sync_device(m))) return rc;                 // the device image (positions, observation CSR) is current
+    for (size_t k = 0; k < KF; k++) memcpy(m->kfs[k].pose, &after[16 * k], sizeof(float) * 16);      // Frame::set_pose, :503
+    m->dirty_centres = true;
+    if (P == 0) return RS_OK;
+    if ((rc = rs_stage_begin(ctx))) return rc;
+    float *d_before = nullptr, *d_after = nullptr;
+    if ((rc = rs_stage_upload(ctx, before.data(), sizeof(float) * 16 * KF, (void**)&d_before))) return rc;
+    if ((rc = rs_stage_upload(ctx, after.data(), sizeof(float) * 16 * KF, (void**)&d_after))) return rc;
+    if ((rc = rs_transform_points(ctx, (int)P, m->d_obs_ptr, m->d_obs_kf, d_before, d_after, (int)KF, m->d_pos))) return rc;
+    if ((rc = rs_stage_download(ctx, m->d_pos, sizeof(float) * 3 * P, m->pos.data()))) return rc;     // the mirror follows
+    return rs_stage_sync(ctx);
 }

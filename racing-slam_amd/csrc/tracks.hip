@@ -314,3 +314,55 @@ extern "C" int rs_reanchor_points(rs_context* ctx, int n, const int32_t* d_point
     RS_HIP(ctx, hipGetLastError());
     return RS_OK;
 }
+
+// ------------------------------------------------------------------------------------------------ K14
+// transform_points of the pose graph (reference src/Optimization.cpp:512-536): after a loop closure moved the key
+// frames, every map point that has observations moves rigidly with its OWNER, the observing key frame of smallest
+// index — same arithmetic as K13, one lane per point over the whole map, the owner found by a scan of the point's
+// (short) observation list.  obs_kf holds positions in the key-frame list handed to pose_graph, which is in index
+// order (Mapper::key_frames(), src/Slam.cpp:263); a point whose owner is not in [0, n_kf) stays (:524-527).
+// HBM-bound: 8 B of obs_ptr + 4 B per observation + 24 B of position per point; the two 4x4 poses come from L2.
+__global__ __launch_bounds__(256) void k14_transform_points(int n_points, const int32_t* __restrict__ obs_ptr,
+                                                            const int32_t* __restrict__ obs_kf, int n_kf,
+                                                            const float* __restrict__ before, const float* __restrict__ after,
+                                                            float* __restrict__ pos)
+{
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n_points) return;
+    const int lo = obs_ptr[p], hi = obs_ptr[p + 1];
+    if (hi <= lo) return;                                                                             // :515-517
+    int owner = obs_kf[lo];
+    for (int o = lo + 1; o < hi; o++) owner = min(owner, obs_kf[o]);                                  // :518-523
+    if (owner < 0 || owner >= n_kf) return;
+    float B[16], A[16];
+    load_pose(before, owner, B);
+    load_pose(after, owner, A);
+    const float X[3] = {pos[3 * (size_t)p], pos[3 * (size_t)p + 1], pos[3 * (size_t)p + 2]};
+    float c[3], d[3];
+#pragma unroll
+    for (int r = 0; r < 3; r++) {
+        c[r] = ((B[4 * r] * X[0] + B[4 * r + 1] * X[1]) + B[4 * r + 2] * X[2]) + B[4 * r + 3];     // :531
+        d[r] = c[r] - A[4 * r + 3];
+    }
+#pragma unroll
+    for (int r = 0; r < 3; r++)                                                                       // :532
+        pos[3 * (size_t)p + r] = (A[r] * d[0] + A[4 + r] * d[1]) + A[8 + r] * d[2];
+}
+
+extern "C" int rs_transform_points(rs_context* ctx, int n_points, const int32_t* d_obs_ptr, const int32_t* d_obs_kf,
+                                   const float* d_poses_before, const float* d_poses_after, int n_kf, float* d_positions)
+{
+    if (!ctx) return RS_ERR_INVALID;
+    if (n_points < 0 || n_kf < 0) return rs_fail(ctx, RS_ERR_INVALID, "negative size");
+    if (n_points == 0 || n_kf == 0) return RS_OK;
+    if (!d_obs_ptr || !d_obs_kf || !d_poses_before || !d_poses_after || !d_positions) return rs_fail(ctx, RS_ERR_INVALID, "null pointer");
+    if (((uintptr_t)d_poses_before | (uintptr_t)d_poses_after) & 15) return rs_fail(ctx, RS_ERR_INVALID, "poses must be 16-byte aligned");
+    RS_HIP(ctx, hipSetDevice(ctx->device));
+    {
+        rs_prof_scope ps(ctx, "K14_transform_points");
+        hipLaunchKernelGGL(k14_transform_points, dim3((n_points + 255) / 256), dim3(256), 0, ctx->stream, n_points, d_obs_ptr,
+                           d_obs_kf, n_kf, d_poses_before, d_poses_after, d_positions);
+    }
+    RS_HIP(ctx, hipGetLastError());
+    return RS_OK;
+}

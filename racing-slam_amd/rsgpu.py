@@ -17,7 +17,7 @@ EXPORTS = [
     "rs_context_synchronize", "rs_context_set_int", "rs_stage_begin", "rs_stage_alloc", "rs_stage_upload", "rs_stage_download", "rs_stage_sync", "rs_last_error", "rs_hamming_knn2", "rs_match_descriptors",
     "rs_kdtree_build", "rs_kdtree_pack", "rs_reproj_match", "rs_map_create", "rs_map_destroy", "rs_frame_create", "rs_frame_destroy",
     "rs_map_add_keyframe", "rs_map_set_keyframe_pose", "rs_map_add_point", "rs_map_set_position", "rs_map_remove_point",
-    "rs_map_add_observation", "rs_map_remove_observation", "rs_map_counts", "rs_map_match", "rs_map_bundle_adjust", "rs_triangulate", "rs_triangulate_matches", "rs_triangulate_matches_batch", "rs_triangulate_tracks", "rs_point_errors", "rs_ba_default_options",
+    "rs_map_add_observation", "rs_map_remove_observation", "rs_map_counts", "rs_map_get_positions", "rs_map_match", "rs_map_pose_graph", "rs_pose_graph", "rs_pose_relative", "rs_transform_points", "rs_map_bundle_adjust", "rs_triangulate", "rs_triangulate_matches", "rs_triangulate_matches_batch", "rs_triangulate_tracks", "rs_point_errors", "rs_ba_default_options",
     "rs_bundle_adjust", "rs_bundle_adjust_batch", "rs_ba_get_trace", "rs_ba_get_stats", "rs_ba_get_cameras", "rs_reanchor_points", "rs_refine_pose", "rs_bundle_adjust_inertial", "rs_refine_pose_inertial", "rs_pack_pose", "rs_unpack_pose", "rs_pack_poses", "rs_unpack_poses", "rs_build_local_window",
     "rs_comm_get_unique_id", "rs_comm_init_rank", "rs_comm_destroy", "rs_comm_init_local", "rs_prof_begin", "rs_prof_end", "rs_prof_counters",
 ]
@@ -133,6 +133,47 @@ def _dp(t):
 
 
 # ---- host-only helpers (no GPU needed) ---------------------------------------
+class PoseGraphEdge(C.Structure):
+    """rs_pose_graph_edge"""
+    _fields_ = [("from_", C.c_int32), ("to", C.c_int32), ("relative", C.c_double * 16)]
+
+
+def pose_graph_edges(loops):
+    """[(from, to, relative 4x4), ...] -> ctypes array of rs_pose_graph_edge"""
+    arr = (PoseGraphEdge * max(len(loops), 1))()
+    for i, (a, b, rel) in enumerate(loops):
+        arr[i].from_, arr[i].to = int(a), int(b)
+        arr[i].relative[:] = list(np.asarray(rel, np.float64).reshape(16))
+    return arr
+
+
+def pose_graph(poses, loops, four_dof=False, gravity=(0.0, 0.0, 0.0), options=None):
+    """optimization::pose_graph (host function).  Returns (poses' [n,4,4] f32, velocity rotations [n,3,3] f32, summary, trace)."""
+    P = np.ascontiguousarray(poses, np.float32).reshape(-1, 16)
+    out, rot = np.zeros_like(P), np.zeros((len(P), 9), np.float32)
+    g = (C.c_double * 3)(*[float(v) for v in gravity])
+    s = BaSummary()
+    cap = 256
+    buf = (BaIteration * cap)()
+    cnt = C.c_int(0)
+    L = load()
+    L.rs_pose_graph.restype = C.c_int
+    rc = L.rs_pose_graph(len(P), P.ctypes.data_as(C.c_void_p), pose_graph_edges(loops), len(loops), int(bool(four_dof)), g,
+                         None if options is None else C.byref(options), out.ctypes.data_as(C.c_void_p),
+                         rot.ctypes.data_as(C.c_void_p), C.byref(s), buf, cap, C.byref(cnt))
+    if rc:
+        raise RuntimeError(f"rs_pose_graph failed with {rc}")
+    return out.reshape(-1, 4, 4), rot.reshape(-1, 3, 3), s.as_dict(), [buf[i].as_dict() for i in range(min(cnt.value, cap))]
+
+
+def pose_relative(pose_from, pose_to):
+    rel = np.zeros(16)
+    a = np.ascontiguousarray(pose_from, np.float32).reshape(16)
+    b = np.ascontiguousarray(pose_to, np.float32).reshape(16)
+    load().rs_pose_relative(a.ctypes.data_as(C.c_void_p), b.ctypes.data_as(C.c_void_p), rel.ctypes.data_as(C.c_void_p))
+    return rel.reshape(4, 4)
+
+
 def pack_pose(pose):
     p = np.ascontiguousarray(pose, np.float32).reshape(16)
     cam = np.zeros(6)
@@ -482,6 +523,11 @@ class Context:
                                                 _dp(d_frame_idx), _dp(d_before), _dp(d_after), int(d_before.shape[0]),
                                                 _dp(d_positions)), "rs_reanchor_points")
 
+    def transform_points(self, d_obs_ptr, d_obs_kf, d_before, d_after, d_positions):
+        """transform_points of the pose graph (src/Optimization.cpp:512-536); d_positions [P][3] f32 is updated in place."""
+        self._check(self.lib.rs_transform_points(self.h, int(d_positions.shape[0]), _dp(d_obs_ptr), _dp(d_obs_kf), _dp(d_before),
+                                                 _dp(d_after), int(d_before.shape[0]), _dp(d_positions)), "rs_transform_points")
+
     def refine_pose(self, cam, d_points, d_uv, K, options=None):
         cam = np.array(cam, np.float64, order="C")
         Kc = (C.c_float * 4)(*[float(v) for v in K])
@@ -599,6 +645,12 @@ class ResidentMap:
         self.ctx._check(self.lib.rs_map_counts(self.h, buf), "rs_map_counts")
         return dict(slots=buf[0], alive=buf[1], observations=buf[2], key_frames=buf[3])
 
+    def positions(self):
+        n = self.counts()["slots"]
+        out = np.zeros((max(n, 1), 3), np.float32)
+        self.ctx._check(self.lib.rs_map_get_positions(self.h, 0, n, out.ctypes.data_as(C.c_void_p)), "rs_map_get_positions")
+        return out[:n]
+
     def match(self, frame, pose, K, width, height, kp_matched=None, matched_points=(), required_observer=-1, only_points=None,
               replace=0, max_distance=64):
         n = frame.n
@@ -615,6 +667,16 @@ class ResidentMap:
             None if only is None else only.ctypes.data_as(C.c_void_p), -1 if only is None else len(only), int(replace), int(max_distance),
             mk.ctypes.data_as(C.c_void_p), mp.ctypes.data_as(C.c_void_p), C.byref(cnt)), "rs_map_match")
         return mk[:cnt.value].copy(), mp[:cnt.value].copy()
+
+    def pose_graph(self, loops, four_dof=False, gravity=(0.0, 0.0, 0.0), options=None):
+        n = self.counts()["key_frames"]
+        poses, rot = np.zeros((max(n, 1), 16), np.float32), np.zeros((max(n, 1), 9), np.float32)
+        g = (C.c_double * 3)(*[float(v) for v in gravity])
+        s = BaSummary()
+        self.ctx._check(self.lib.rs_map_pose_graph(self.ctx.h, self.h, pose_graph_edges(loops), len(loops), int(bool(four_dof)), g,
+                                                   None if options is None else C.byref(options), poses.ctypes.data_as(C.c_void_p),
+                                                   rot.ctypes.data_as(C.c_void_p), C.byref(s)), "rs_map_pose_graph")
+        return s.as_dict(), poses[:n].reshape(-1, 4, 4), rot[:n].reshape(-1, 3, 3)
 
     def bundle_adjust(self, kfs, free, K, options=None):
         kfs = np.ascontiguousarray(kfs, np.int32)

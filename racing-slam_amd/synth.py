@@ -367,3 +367,44 @@ def make_tracks(n_tracks=2000, n_frames=12, config_id=6, outlier_frac=0.05, nois
                 sight_pose=np.array(sight_pose, np.int32).reshape(-1),
                 sight_uv=np.array(sight_uv, np.float32).reshape(-1, 2), poses=poses, kf_pose=kf,
                 K=np.array(K, np.float32))
+
+
+def make_pose_graph(n_kf=60, n_loops=3, laps=1.25, drift_rot=2e-3, drift_trans=2e-2, loop_noise=(2e-3, 1e-2),
+                    outlier_loops=0, seed=0):
+    """Key frames of a camera driving `laps` laps of an oval (y up, gravity = -y), odometry with accumulated drift, and
+    loop constraints between key frames that see the same place one lap apart (reference LoopDetector -> pose_graph,
+    src/Slam.cpp:258-268).  Returns dict(poses [n,4,4] f32 drifted world->camera, poses_true, loops [(from, to,
+    relative 4x4 f64)], gravity): relative = T_from T_to^-1 measured on the TRUE trajectory plus noise, `from` the newer
+    key frame as the detector emits them.  `outlier_loops` of them get a gross error (exercises the Huber loss)."""
+    rng = np.random.default_rng(0x50600000 + seed)
+    per_lap = int(round(n_kf / laps))
+    T_true = []
+    for i in range(n_kf):
+        a = 2 * np.pi * i / per_lap
+        centre = np.array([40.0 * np.cos(a), 0.3 * np.sin(3 * a), 25.0 * np.sin(a)])
+        R_wc = yaw_matrix(-np.rad2deg(a)) @ rodrigues(np.array([0.02 * np.sin(2 * a), 0.0, 0.03 * np.cos(a)]))
+        T_true.append(make_pose(R_wc, centre).astype(np.float64))
+    T_true = np.stack(T_true)
+    # odometry: true relative motion + noise, chained from the first true pose
+    T = [T_true[0]]
+    for i in range(1, n_kf):
+        rel = T_true[i] @ np.linalg.inv(T_true[i - 1])               # T_i = rel T_{i-1}
+        N = np.eye(4)
+        N[:3, :3] = rodrigues(rng.normal(0, drift_rot, 3))
+        N[:3, 3] = rng.normal(0, drift_trans, 3)
+        T.append(N @ rel @ T[-1])
+    poses = np.stack(T).astype(np.float32)
+    loops = []
+    cand = [i for i in range(per_lap, n_kf)]
+    pick = rng.choice(cand, size=min(n_loops, len(cand)), replace=False) if cand else []
+    for k, i in enumerate(sorted(int(v) for v in pick)):
+        j = i - per_lap
+        rel = T_true[i] @ np.linalg.inv(T_true[j])
+        N = np.eye(4)
+        N[:3, :3] = rodrigues(rng.normal(0, loop_noise[0], 3))
+        N[:3, 3] = rng.normal(0, loop_noise[1], 3)
+        if k < outlier_loops:
+            N[:3, :3] = rodrigues(np.array([0.0, 0.4, 0.0]))
+            N[:3, 3] = np.array([3.0, 0.0, -2.0])
+        loops.append((i, j, N @ rel))
+    return dict(poses=poses, poses_true=T_true, loops=loops, gravity=np.array([0.0, -9.80665, 0.0]))

@@ -361,3 +361,84 @@ def solve(prob, max_iter=10, r0=1e4, rmax=1e16, rmin=1e-32, min_rel=1e-3, dmin=1
     summary["final_radius"] = radius
     summary["usable"] = int(summary["termination"] != 5 and np.isfinite(best_cost) and best_cost <= summary["initial_cost"])
     return best_x, summary, trace
+
+
+class PoseGraphProblem:
+    """optimization::pose_graph (reference src/Optimization.cpp:376-639) for `solve`: residuals RelativePoseError /
+    RelativePose4DoFError by complex step, sequential edges measured as T_i T_{i+1}^-1 (numpy f32 inverse, widened; or
+    handed in as `seq_relative`, so that a comparison is not limited by two f32 inverses differing in their last bits), loop
+    edges with HuberLoss(1.0) through the corrector; the first key frame is constant.  x0 [n][6] = pack_pose of the f32
+    poses (passed in, so that this file needs no f32 rotation conversions of its own) or [n][4] = (0, centre)."""
+
+    def __init__(self, poses_f32, x0, loops, four_dof=False, up=(0.0, 0.0, 1.0), seq_relative=None):
+        P = np.asarray(poses_f32, np.float32).reshape(-1, 4, 4)
+        self.n = len(P)
+        self.bs = 4 if four_dof else 6
+        self.four_dof = bool(four_dof)
+        self.up = np.asarray(up, np.float64)
+        self.R0 = P[:, :3, :3].astype(np.float64)
+        self.x0 = np.asarray(x0, np.float64).reshape(self.n, self.bs)
+        self.edges = []
+        for i in range(self.n - 1):
+            rel = (P[i].astype(np.float64) @ np.linalg.inv(P[i + 1]).astype(np.float64) if seq_relative is None
+                   else np.asarray(seq_relative[i], np.float64).reshape(4, 4))
+            self.edges.append((i, i + 1, rel[:3, :3], rel[:3, 3], 0.02, 0.2, False))
+        for a, b, rel in loops:
+            if a == b or not (0 <= a < self.n and 0 <= b < self.n):
+                continue
+            rel = np.asarray(rel, np.float64).reshape(4, 4)
+            self.edges.append((int(a), int(b), rel[:3, :3], rel[:3, 3], 0.05, 0.5, True))
+        self.cams0, self.pts0 = None, None
+
+    def pack(self, *_):
+        return self.x0[1:].ravel().copy()
+
+    def full(self, x):
+        return np.concatenate([self.x0[0].astype(x.dtype), x]).reshape(self.n, self.bs)
+
+    def rot(self, xb, i):
+        if not self.four_dof:
+            return aa_to_matrix(xb[:3])
+        return self.R0[i] @ aa_to_matrix(-self.up * xb[0])
+
+    def edge_residual(self, e, X):
+        a, b, Rm, tm, sr, st, _ = e
+        Rf, Rt = self.rot(X[a], a), self.rot(X[b], b)
+        cf, ct = X[a][-3:], X[b][-3:]
+        rv = matrix_to_aa(Rm.T @ (Rf @ Rt.T))
+        return np.concatenate([rv / sr, (Rf @ (ct - cf) - tm) / st])
+
+    def blocks(self, x):
+        X = self.full(x.astype(np.complex128) if np.iscomplexobj(x) else x)
+        return [self.edge_residual(e, X) for e in self.edges]
+
+    def cost(self, x):
+        c = 0.0
+        for e, r in zip(self.edges, self.blocks(x)):
+            s = float(np.real(r) @ np.real(r))
+            c += 0.5 * (huber(np.array(s), 1.0)[0] if e[6] else s)
+        return float(c)
+
+    def linearize(self, x, h=1e-30):
+        nb, bs = len(self.edges), self.bs
+        r0 = [np.real(r) for r in self.blocks(x)]
+        J = np.zeros((6 * nb, len(x)))
+        for k, e in enumerate(self.edges):
+            for kf in (e[0], e[1]):
+                if kf == 0:
+                    continue
+                for q in range(bs):
+                    col = bs * (kf - 1) + q
+                    xz = x.astype(np.complex128)
+                    xz[col] += 1j * h
+                    J[6 * k:6 * k + 6, col] = np.imag(self.edge_residual(e, self.full(xz))) / h
+        cost = 0.0
+        rv = np.zeros(6 * nb)
+        for k, (e, r) in enumerate(zip(self.edges, r0)):
+            s = float(r @ r)
+            rho, rho1 = (huber(np.array(s), 1.0) if e[6] else (s, 1.0))
+            cost += 0.5 * float(rho)
+            sc = np.sqrt(float(rho1))
+            rv[6 * k:6 * k + 6] = r * sc
+            J[6 * k:6 * k + 6] *= sc
+        return rv, J, cost

@@ -126,9 +126,33 @@ def make_inertial():
     np.savez_compressed(os.path.join(OUT, "inertial.npz"), **blob)
 
 
+def make_pose_graph():
+    """a14: 30 key frames / 4 loop constraints that contradict the odometry grossly (rejected first step, Huber branch),
+    SE(3) and 4-DoF; outputs = the oracle's (pinned by tests/dense_lm.py in tests/test_pose_graph.py)."""
+    g = synth.make_pose_graph(n_kf=30, n_loops=4, laps=1.4, seed=2, drift_rot=2e-2, drift_trans=0.3)
+    loops = []
+    for a, b, rel in g["loops"]:
+        N = np.eye(4)
+        N[:3, :3] = synth.rodrigues(np.array([0.3, 2.6, 0.2]))
+        N[:3, 3] = [8.0, 1.0, -6.0]
+        loops.append((a, b, N @ rel))
+    blob = dict(poses=g["poses"].reshape(-1, 16), gravity=g["gravity"], loops_ft=np.array([(a, b) for a, b, _ in loops], np.int32),
+                loops_rel=np.stack([r for _, _, r in loops]))
+    for tag, fd in (("se3", False), ("dof4", True)):
+        out, s, tr = O.pose_graph(g["poses"], loops, four_dof=fd, gravity=g["gravity"], trace=True)
+        assert s["usable"] == 1 and 0 in [t["outcome"] for t in tr]
+        blob[f"{tag}_poses"] = out.reshape(-1, 16)
+        blob[f"{tag}_outcomes"] = np.array([t["outcome"] for t in tr], np.int32)
+        blob[f"{tag}_costs"] = np.array([t["cost"] for t in tr])
+        blob[f"{tag}_final_cost"] = np.float64(s["final_cost"])
+    np.savez_compressed(os.path.join(OUT, "pose_graph.npz"), **blob)
+
+
 def main():
     O.build()
     only = set(sys.argv[1:])
+    if not only or "pose_graph" in only:
+        make_pose_graph()
     if not only or "ba_trace" in only:
         make_ba_trace()
     if not only or "inertial" in only:
