@@ -22,6 +22,7 @@
 #define K2_THREADS 128
 #define K2_STACK 40
 #define K2_PRE 8         // observations of a map point whose centre / descriptor row are preloaded
+#define K2_MAXC 16       // in-radius candidates queued per map point before their descriptors are compared (phase B)
 #define K2_MAX_LDS_NODES 6144    // 16 B per node: the whole KD-tree of a frame (2000 keypoints = 32 KB) sits in LDS
 
 struct K2Frame {
@@ -117,29 +118,35 @@ __device__ __forceinline__ void k3_accept_body(unsigned long long* __restrict__ 
     if (threadIdx.x == 0) *match_count = total;
 }
 
+// LDS node of the frame's KD-tree: everything a visit needs in ONE ds_read_b128.
+//   x, y     keypoint of the node
+//   lr       left | right << 16, 0xFFFF = no child (the tree has at most K2_MAX_LDS_NODES < 65535 nodes)
+//   kp       keypoint index | (already matched && !replace) << 31   (:65, :81 become a sign test)
+struct K2Node { float x, y; unsigned lr; int kp; };
+
 __global__ __launch_bounds__(K2_THREADS) void k2_reproj_match(K2Frame f, K2Map m, int replace, int max_distance, int tree_in_lds,
                                                              int32_t* __restrict__ point_kp,
                                                              int32_t* __restrict__ point_dist,
                                                              unsigned long long* __restrict__ prop)
 {
-    // dynamic LDS: [K2_STACK][K2_THREADS] traversal stacks, then the packed tree
-    // {x, y, left, right} per node (one ds_read_b128 per visited node instead of three
-    // dependent global loads)
+    // dynamic LDS: [K2_STACK][K2_THREADS] traversal stacks, [K2_MAXC][K2_THREADS] candidate queue and the candidates'
+    // running minima, then the tree
     extern __shared__ __attribute__((aligned(16))) int k2_lds[];
     int (*stack)[K2_THREADS] = (int (*)[K2_THREADS])k2_lds;
-    float4* tree = (float4*)(k2_lds + K2_STACK * K2_THREADS);
-    int* tree_kp = (int*)(tree + (tree_in_lds ? f.n_keypoints : 0));
+    int (*queue)[K2_THREADS] = (int (*)[K2_THREADS])(k2_lds + K2_STACK * K2_THREADS);
+    int (*qmin)[K2_THREADS] = (int (*)[K2_THREADS])(k2_lds + (K2_STACK + K2_MAXC) * K2_THREADS);
+    K2Node* tree = (K2Node*)(k2_lds + (K2_STACK + 2 * K2_MAXC) * K2_THREADS);
     // this lane's map point: every load that needs only p goes out before the tree is staged
     const int p = blockIdx.x * K2_THREADS + threadIdx.x;
     const bool have = p < m.n_points;
     const int pc = have ? p : 0;
     const bool elig = have && m.n_points > 0 && m.eligible[pc] != 0;
     const int o0 = m.n_points > 0 ? m.obs_ptr[pc] : 0, o1 = m.n_points > 0 ? m.obs_ptr[pc + 1] : 0;
-    const int nobs = o1 - o0;
+    const int nobs = elig ? o1 - o0 : 0;
     float X[3] = {0.f, 0.f, 0.f};
     if (m.n_points > 0) { X[0] = m.pos[3 * (size_t)pc]; X[1] = m.pos[3 * (size_t)pc + 1]; X[2] = m.pos[3 * (size_t)pc + 2]; }
     // the first K2_PRE observations of the point: keyframe centre and descriptor row, loaded as two
-    // batches (not as nobs dependent pairs inside the loops below); further observations load on demand
+    // batches (not as nobs dependent pairs inside the loops below); further observations come in batches of K2_PRE too
     int rowv[K2_PRE];
     float Cv[K2_PRE][3];
     {
@@ -147,27 +154,53 @@ __global__ __launch_bounds__(K2_THREADS) void k2_reproj_match(K2Frame f, K2Map m
 #pragma unroll
         for (int j = 0; j < K2_PRE; j++) {
             kfv[j] = 0; rowv[j] = 0;
-            if (elig && j < nobs) { kfv[j] = m.obs_kf[o0 + j]; rowv[j] = m.obs_desc[o0 + j]; }
+            if (j < nobs) { kfv[j] = m.obs_kf[o0 + j]; rowv[j] = m.obs_desc[o0 + j]; }
         }
 #pragma unroll
         for (int j = 0; j < K2_PRE; j++) {
             Cv[j][0] = Cv[j][1] = Cv[j][2] = 0.f;
-            if (elig && j < nobs) {
+            if (j < nobs) {
                 const float* C = m.kf_centers + 3 * (size_t)kfv[j];
                 Cv[j][0] = C[0]; Cv[j][1] = C[1]; Cv[j][2] = C[2];
             }
         }
     }
     if (tree_in_lds) {
-        if (f.packed) {        // packed once per frame: a straight copy (independent wide loads) instead of dependent gathers
-            const int* pk = (const int*)(f.packed + f.n_keypoints);
-            for (int i = threadIdx.x; i < f.n_keypoints; i += blockDim.x) { tree[i] = f.packed[i]; tree_kp[i] = pk[i]; }
-        } else {
-            for (int i = threadIdx.x; i < f.n_keypoints; i += blockDim.x) {
-                const int kpi = f.kd_node_kp[i];
-                const float2 q = f.kp[kpi];
-                tree[i] = make_float4(q.x, q.y, __int_as_float(f.kd_left[i]), __int_as_float(f.kd_right[i]));
-                tree_kp[i] = kpi;
+        // eight nodes per thread and pass, all loads of a level issued together
+        for (int base = threadIdx.x; base < f.n_keypoints; base += 8 * K2_THREADS) {
+            int kpi[8], l[8], r[8];
+            float x[8], y[8];
+            bool taken[8];
+#pragma unroll
+            for (int q = 0; q < 8; q++) {
+                const int i = base + q * K2_THREADS;
+                kpi[q] = 0; l[q] = -1; r[q] = -1; x[q] = 0.f; y[q] = 0.f;
+                if (i < f.n_keypoints) {
+                    if (f.packed) {        // packed once per frame (rs_kdtree_pack): straight copies instead of dependent gathers
+                        const float4 nd = f.packed[i];
+                        kpi[q] = ((const int*)(f.packed + f.n_keypoints))[i];
+                        x[q] = nd.x; y[q] = nd.y; l[q] = __float_as_int(nd.z); r[q] = __float_as_int(nd.w);
+                    } else {
+                        kpi[q] = f.kd_node_kp[i]; l[q] = f.kd_left[i]; r[q] = f.kd_right[i];
+                    }
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < 8; q++) {
+                const bool in = base + q * K2_THREADS < f.n_keypoints;
+                taken[q] = in && !replace && f.kp_matched[kpi[q]] != 0;
+                if (in && !f.packed) { const float2 k = f.kp[kpi[q]]; x[q] = k.x; y[q] = k.y; }
+            }
+#pragma unroll
+            for (int q = 0; q < 8; q++) {
+                const int i = base + q * K2_THREADS;
+                if (i < f.n_keypoints) {
+                    K2Node nd;
+                    nd.x = x[q]; nd.y = y[q];
+                    nd.lr = (unsigned)(l[q] & 0xFFFF) | ((unsigned)(r[q] & 0xFFFF) << 16);
+                    nd.kp = kpi[q] | (taken[q] ? (int)0x80000000 : 0);
+                    tree[i] = nd;
+                }
             }
         }
         __syncthreads();
@@ -218,9 +251,20 @@ __global__ __launch_bounds__(K2_THREADS) void k2_reproj_match(K2Frame f, K2Map m
 #pragma unroll
         for (int j = 0; j < K2_PRE; j++)
             if (j < nobs) add_obs(Cv[j][0], Cv[j][1], Cv[j][2]);
-        for (int o = o0 + K2_PRE; o < o1; o++) {
-            const float* C = m.kf_centers + 3 * (size_t)m.obs_kf[o];
-            add_obs(C[0], C[1], C[2]);
+        for (int ob = K2_PRE; ob < nobs; ob += K2_PRE) {                  // long-lived points: K2_PRE centres per round trip,
+            int kfv[K2_PRE];                                              // accumulated in observation order
+            float Cx[K2_PRE][3];
+#pragma unroll
+            for (int j = 0; j < K2_PRE; j++) kfv[j] = (ob + j < nobs) ? m.obs_kf[o0 + ob + j] : 0;
+#pragma unroll
+            for (int j = 0; j < K2_PRE; j++) {
+                const float* C = m.kf_centers + 3 * (size_t)kfv[j];
+                Cx[j][0] = Cx[j][1] = Cx[j][2] = 0.f;
+                if (ob + j < nobs) { Cx[j][0] = C[0]; Cx[j][1] = C[1]; Cx[j][2] = C[2]; }
+            }
+#pragma unroll
+            for (int j = 0; j < K2_PRE; j++)
+                if (ob + j < nobs) add_obs(Cx[j][0], Cx[j][1], Cx[j][2]);
         }
         normalize3f(normal);
         float rn[3] = {ray[0], ray[1], ray[2]};
@@ -232,51 +276,128 @@ __global__ __launch_bounds__(K2_THREADS) void k2_reproj_match(K2Frame f, K2Map m
         // KDTree2D::radius_search, r = 20 px (src/MapMatcher.cpp:75, src/KDTree.cpp:45-82)
         const float r2 = 20.0f * 20.0f;
         int best_kp = 0, best_d = max_distance;
+        // One candidate keypoint against every descriptor of the point (:84-91).  The reference keeps a running best with
+        // a strict '<' over (candidate, observation) pairs; the winner's keypoint is the FIRST candidate (in visiting
+        // order) whose minimum over the observations is the overall minimum, so per candidate only that minimum matters
+        // and the observations may be taken in any order.
+        auto rows_min = [&](const uint4 a0, const uint4 a1, const uint4* b0, const uint4* b1, int nb) {
+            int d = 0x7fffffff;
+#pragma unroll
+            for (int j = 0; j < K2_PRE; j++)
+                if (j < nb) d = min(d, hamming256(a0, a1, b0[j], b1[j]));
+            return d;
+        };
+        // Phase A: the traversal touches LDS only and QUEUES the candidates in visiting order.  (Comparing descriptors
+        // inside this loop costs one global-memory round trip per iteration in which ANY lane of the wave has a
+        // candidate — nearly every one; queued, the round trips are one per four candidates of the busiest lane.)
+        // The near child is visited next without going through the stack; only far children are pushed.
+        // Candidates beyond K2_MAXC are compared on the spot into a second running best, merged below: they come
+        // later in visiting order than every queued one, so the queue wins ties.
+        int nc = 0, over_kp = 0, over_d = max_distance;
         int sp = 0;
-        if (f.kd_root >= 0) stack[sp++][threadIdx.x] = f.kd_root;      // entry = node | depth parity << 30
-        while (sp > 0) {
-            const int e = stack[--sp][threadIdx.x];
-            const int node = e & 0x3FFFFFFF, odd = (e >> 30) & 1;
-            float qx, qy;
-            int l, r;
-            if (tree_in_lds) {
-                const float4 nd = tree[node];
-                qx = nd.x; qy = nd.y; l = __float_as_int(nd.z); r = __float_as_int(nd.w);
-            } else {
-                const float2 q = f.kp[f.kd_node_kp[node]];
-                qx = q.x; qy = q.y; l = f.kd_left[node]; r = f.kd_right[node];
+        int cur = f.kd_root, odd = 0;
+        if (tree_in_lds) {
+            // Both children of a node are read while the node is examined (their indices are in the node), so the LDS
+            // latency of the next visit overlaps this visit's arithmetic; only a node popped from the stack pays a
+            // read of its own.
+            K2Node nd;
+            if (cur >= 0) nd = tree[cur];
+            while (cur >= 0) {
+                int l = (int)(nd.lr & 0xFFFFu), r = (int)(nd.lr >> 16);
+                l = l == 0xFFFF ? -1 : l; r = r == 0xFFFF ? -1 : r;
+                const K2Node ndl = tree[l >= 0 ? l : 0], ndr = tree[r >= 0 ? r : 0];
+                const float dx = nd.x - u, dy = nd.y - v;
+                const float d2 = dx * dx + dy * dy;
+                if (d2 <= r2 && nd.kp >= 0) {                               // in range and open (:65, :81)
+                    const int kp = nd.kp;
+                    if (nc < K2_MAXC) queue[nc++][threadIdx.x] = kp;
+                    else {
+                        const uint4 a0 = f.desc[2 * (size_t)kp], a1 = f.desc[2 * (size_t)kp + 1];
+                        int d = 0x7fffffff;
+                        for (int o = o0; o < o1; o++) {
+                            const size_t row = (size_t)m.obs_desc[o];
+                            d = min(d, hamming256(a0, a1, m.pool[2 * row], m.pool[2 * row + 1]));
+                        }
+                        if (d < over_d) { over_d = d; over_kp = kp; }
+                    }
+                }
+                const float delta = odd ? dy : dx;
+                const bool left_near = delta > 0;
+                const int near_child = left_near ? l : r;
+                const int far_child = left_near ? r : l;
+                odd ^= 1;                                                 // depth parity of the children
+                if (delta * delta <= r2 && far_child >= 0 && sp < K2_STACK) stack[sp++][threadIdx.x] = far_child | (odd << 30);
+                if (near_child >= 0) { cur = near_child; nd = left_near ? ndl : ndr; }
+                else if (sp > 0) { const int e = stack[--sp][threadIdx.x]; cur = e & 0x3FFFFFFF; odd = (e >> 30) & 1; nd = tree[cur]; }
+                else cur = -1;
             }
-            const float dx = qx - u, dy = qy - v;
+        } else
+        while (cur >= 0) {                                                // trees too large for LDS: the same walk on global memory
+            const int kp = f.kd_node_kp[cur];
+            const float2 q = f.kp[kp];
+            const int l = f.kd_left[cur], r = f.kd_right[cur];
+            const float dx = q.x - u, dy = q.y - v;
             const float d2 = dx * dx + dy * dy;
-            const int kp = d2 <= r2 ? (tree_in_lds ? tree_kp[node] : f.kd_node_kp[node]) : 0;
-            if (d2 <= r2 && (replace || !f.kp_matched[kp])) {            // :65, :81
-                const uint4 a0 = f.desc[2 * (size_t)kp], a1 = f.desc[2 * (size_t)kp + 1];
-                // the point's descriptors: rows are already in registers, the loads of one candidate go out together
-                uint4 b0[K2_PRE], b1[K2_PRE];
-#pragma unroll
-                for (int j = 0; j < K2_PRE; j++) {
-                    b0[j] = make_uint4(0, 0, 0, 0); b1[j] = b0[j];
-                    if (j < nobs) { const size_t row = (size_t)rowv[j]; b0[j] = m.pool[2 * row]; b1[j] = m.pool[2 * row + 1]; }
-                }
-#pragma unroll
-                for (int j = 0; j < K2_PRE; j++) {
-                    if (j >= nobs) break;
-                    const int hd = hamming256(a0, a1, b0[j], b1[j]);
-                    if (hd < best_d) { best_d = hd; best_kp = kp; }       // :88-91
-                }
-                for (int o = o0 + K2_PRE; o < o1; o++) {
-                    const size_t row = (size_t)m.obs_desc[o];
-                    const int hd = hamming256(a0, a1, m.pool[2 * row], m.pool[2 * row + 1]);
-                    if (hd < best_d) { best_d = hd; best_kp = kp; }
+            if (d2 <= r2 && (replace || !f.kp_matched[kp])) {               // :65, :81
+                if (nc < K2_MAXC) queue[nc++][threadIdx.x] = kp;
+                else {
+                    const uint4 a0 = f.desc[2 * (size_t)kp], a1 = f.desc[2 * (size_t)kp + 1];
+                    int d = 0x7fffffff;
+                    for (int o = o0; o < o1; o++) {
+                        const size_t row = (size_t)m.obs_desc[o];
+                        d = min(d, hamming256(a0, a1, m.pool[2 * row], m.pool[2 * row + 1]));
+                    }
+                    if (d < over_d) { over_d = d; over_kp = kp; }
                 }
             }
             const float delta = odd ? dy : dx;
             const int near_child = (delta > 0) ? l : r;
             const int far_child = (delta > 0) ? r : l;
-            const int child_tag = (odd ^ 1) << 30;
-            if (delta * delta <= r2 && far_child >= 0 && sp < K2_STACK) stack[sp++][threadIdx.x] = far_child | child_tag;
-            if (near_child >= 0 && sp < K2_STACK) stack[sp++][threadIdx.x] = near_child | child_tag;
+            odd ^= 1;
+            if (delta * delta <= r2 && far_child >= 0 && sp < K2_STACK) stack[sp++][threadIdx.x] = far_child | (odd << 30);
+            if (near_child >= 0) cur = near_child;
+            else if (sp > 0) { const int e = stack[--sp][threadIdx.x]; cur = e & 0x3FFFFFFF; odd = (e >> 30) & 1; }
+            else cur = -1;
         }
+        // Phase B: K2_PRE descriptor rows of the point per pass (the first pass's row numbers are already here), the
+        // queued candidates four at a time (their row loads go out together); each candidate's minimum over the
+        // observations accumulates in LDS across passes
+        if (nc > 0) {
+            for (int ob = 0; ob < nobs; ob += K2_PRE) {
+                const int nb = min(K2_PRE, nobs - ob);
+                int rows[K2_PRE];
+#pragma unroll
+                for (int j = 0; j < K2_PRE; j++) rows[j] = ob == 0 ? rowv[j] : (j < nb ? m.obs_desc[o0 + ob + j] : 0);
+                uint4 b0[K2_PRE], b1[K2_PRE];
+#pragma unroll
+                for (int j = 0; j < K2_PRE; j++) {
+                    b0[j] = make_uint4(0, 0, 0, 0); b1[j] = b0[j];
+                    if (j < nb) { b0[j] = m.pool[2 * (size_t)rows[j]]; b1[j] = m.pool[2 * (size_t)rows[j] + 1]; }
+                }
+                for (int c = 0; c < nc; c += 4) {
+                    int kq[4];
+                    uint4 a0[4], a1[4];
+#pragma unroll
+                    for (int q = 0; q < 4; q++) {
+                        kq[q] = (c + q < nc) ? queue[c + q][threadIdx.x] : -1;
+                        a0[q] = make_uint4(0, 0, 0, 0); a1[q] = a0[q];
+                        if (kq[q] >= 0) { a0[q] = f.desc[2 * (size_t)kq[q]]; a1[q] = f.desc[2 * (size_t)kq[q] + 1]; }
+                    }
+#pragma unroll
+                    for (int q = 0; q < 4; q++)
+                        if (kq[q] >= 0) {
+                            const int d = rows_min(a0[q], a1[q], b0, b1, nb);
+                            qmin[c + q][threadIdx.x] = ob == 0 ? d : min(d, qmin[c + q][threadIdx.x]);
+                        }
+                }
+            }
+            if (nobs > 0)
+                for (int c = 0; c < nc; c++) {
+                    const int d = qmin[c][threadIdx.x];
+                    if (d < best_d) { best_d = d; best_kp = queue[c][threadIdx.x]; }     // :88-91, visiting order
+                }
+        }
+        if (over_d < best_d) { best_d = over_d; best_kp = over_kp; }
         if (best_d < max_distance) {
             out_kp = best_kp;
             out_d = best_d;
@@ -346,7 +467,7 @@ extern "C" int rs_reproj_match(rs_context* ctx, const rs_frame_view* fr, const r
         m.obs_kf = mp->d_obs_kf; m.obs_desc = mp->d_obs_desc; m.kf_centers = mp->d_kf_centers;
         m.pool = (const uint4*)mp->d_desc_pool;
         const int tree_in_lds = N <= K2_MAX_LDS_NODES ? 1 : 0;
-        const size_t lds = sizeof(int) * K2_STACK * K2_THREADS + (tree_in_lds ? (sizeof(float4) + sizeof(int)) * (size_t)N : 0);
+        const size_t lds = sizeof(int) * (K2_STACK + 2 * K2_MAXC) * K2_THREADS + (tree_in_lds ? sizeof(K2Node) * (size_t)N : 0);
         if (lds > 48 * 1024)
             RS_HIP(ctx, hipFuncSetAttribute((const void*)k2_reproj_match, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         rs_prof_scope ps(ctx, "K2_reproj_match");
