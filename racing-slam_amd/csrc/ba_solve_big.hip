@@ -123,81 +123,137 @@ __global__ __launch_bounds__(256) void ba_big_assemble(BaDims d, BaBufs b)
 }
 
 // ------------------------------------------------------------------ diagonal block
+// 1 / p to within an ulp or two: v_rcp_f64 + two Newton steps (the pivot reciprocal only scales a column of
+// multipliers; a full IEEE division is 40 instructions on the critical path of every column)
+__device__ __forceinline__ double rcp_nr(double p)
+{
+    double r = __builtin_amdgcn_rcp(p);
+    r = fma(fma(-p, r, 1.0), r, r);
+    r = fma(fma(-p, r, 1.0), r, r);
+    return r;
+}
+
 __global__ __launch_bounds__(256) void ba_big_diag(BaDims d, BaBufs b, BigBufs g, int J)
 {
     if (b.st->done) return;
-    // The block (rows 0..w-1, plus the right-hand side's entries as row w) lives in LDS; lane = row, and the four
-    // waves split the trailing columns of a row (column k belongs to wave (k - c - 1) & 3), so that one batch of
-    // <= 12 LDS loads per wave covers a whole column step.  (A register-resident row with fully unrolled columns
-    // spilled to scratch and was 10x slower.)
+    // The block lives in LDS — rows 0..w-1, identity padding up to row 47, and the right-hand side's entries as row 48 —
+    // and is factored as three 16-column sub-blocks, each in three phases (a column-by-column loop over all 48 columns
+    // with two workgroup barriers per column cost 1 us per column):
+    //   A  wave 0 factors the 16x16 diagonal sub-block with its rows in REGISTERS (lane = row, 16 fully unrolled
+    //      column steps, pivots and column entries broadcast with v_readlane: no LDS, no barriers, no branches);
+    //   B  waves 1-3, lane = a row below the sub-block (block rows and the right-hand side row): forward substitution
+    //      against the sub-block, T = R L^-T (16 steps, L read as LDS broadcasts), multipliers P = T D^-1;
+    //      wave 0 meanwhile inverts the sub-block's unit-lower L (row r of L^-1 by lane r, in registers) for the
+    //      trailing-update kernel;
+    //   C  all waves: the rest of the block  A[r][q] -= sum_j T[r][j] P[q][j].
+    // Padding rows / columns are the identity, so no phase needs to know the block's real width.
     __shared__ double Lm[(BB + 1) * BBS];
+    __shared__ double Mm[BB * BBS];
+    __shared__ double Tm[(BB + 1) * 17];
+    __shared__ double rdl[16];
     const int n = d.n, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int c0 = BB * J, w = min(BB, n - c0);
-    const bool row = lane < w, rhs = lane == w;            // w <= 48 < 64
-    for (int idx = tid; idx < (w + 1) * w; idx += 256) {
-        const int r = idx / w, k = idx % w;
-        Lm[r * BBS + k] = r < w ? b.S[(size_t)(c0 + r) * n + c0 + k] : b.dc[c0 + k];
+    {
+        // all loads of the block go out before the first one is used
+        constexpr int ROUNDS = ((BB + 1) * BB + 255) / 256;
+        double v[ROUNDS];
+#pragma unroll
+        for (int it = 0; it < ROUNDS; it++) {
+            const int idx = tid + 256 * it, r = idx / BB, k = idx % BB;
+            v[it] = (r == k) ? 1.0 : 0.0;
+            if (idx < (BB + 1) * BB && k < w) { if (r < w) v[it] = b.S[(size_t)(c0 + r) * n + c0 + k]; else if (r == BB) v[it] = b.dc[c0 + k]; }
+        }
+#pragma unroll
+        for (int it = 0; it < ROUNDS; it++) {
+            const int idx = tid + 256 * it;
+            if (idx < (BB + 1) * BB) Lm[(idx / BB) * BBS + idx % BB] = v[it];
+            if (idx < BB * BB) Mm[(idx / BB) * BBS + idx % BB] = (idx / BB == idx % BB) ? 1.0 : 0.0;
+        }
     }
     __syncthreads();
     bool bad = false;
-    for (int c = 0; c < w; c++) {
-        const double piv = Lm[c * BBS + c];
-        if (!(piv > 0.0) || !isfinite(piv)) bad = true;
-        const double rd = 1.0 / piv;
-        const bool below = (row || rhs) && lane > c;
-        double lc = 0.0;
-        if (below) {
-            lc = Lm[lane * BBS + c] * rd;
-            double rk[12], ck[12];
+    for (int c = 0; c < w; c += 16) {
+        const int r = lane & 15;
+        double a[16];
+        if (wave == 0) {                                                    // ---- A
 #pragma unroll
-            for (int u = 0; u < 12; u++) {
-                const int k = min(c + 1 + wave + 4 * u, w - 1);
-                rk[u] = Lm[lane * BBS + k];
-                ck[u] = Lm[k * BBS + c];                      // row k, column c: still l_kc * d_c
+            for (int k = 0; k < 16; k++) a[k] = Lm[(c + r) * BBS + c + k];
+            double my_rd = 1.0, my_piv = 1.0;
+#pragma unroll
+            for (int cc = 0; cc < 16; cc++) {
+                const double piv = rl64(a[cc], cc);
+                bad = bad || !(piv > 0.0) || !isfinite(piv);
+                const double rd = rcp_nr(piv);
+                const double lc = a[cc] * rd;                               // l_{r,cc} for r > cc
+#pragma unroll
+                for (int k = cc + 1; k < 16; k++) a[k] -= lc * rl64(a[cc], k);     // lane k holds a_{k,cc} = l_{k,cc} d_cc
+                a[cc] = r > cc ? lc : a[cc];
+                my_rd = r == cc ? rd : my_rd;
+                my_piv = r == cc ? piv : my_piv;
+                __builtin_amdgcn_sched_barrier(0);                          // keep the next steps' v_readlanes (SGPR pairs) from piling up
             }
+            if (lane < 16) {
 #pragma unroll
-            for (int u = 0; u < 12; u++) {
-                const int k = c + 1 + wave + 4 * u;
-                if (k < w) Lm[lane * BBS + k] = rk[u] - lc * ck[u];
+                for (int k = 0; k < 16; k++) Lm[(c + r) * BBS + c + k] = a[k];      // multipliers below the diagonal, d on it
+                rdl[r] = my_rd;
+                if (c + r < w) g.dv[c0 + c + r] = my_piv;
             }
         }
         __syncthreads();
-        if (below && wave == 0) Lm[lane * BBS + c] = lc;
-        if (tid == 0) g.dv[c0 + c] = piv;
+        const int below = max(0, w - c - 16);                               // block rows under the sub-block
+        const int nrows = below + 1;                                        // + the right-hand side row
+        if (wave > 0) {                                                     // ---- B
+            const int pr = tid - 64;
+            if (pr < nrows) {
+                const int row = pr < below ? c + 16 + pr : BB;
+                double x[16];
+#pragma unroll
+                for (int jj = 0; jj < 16; jj++) {
+                    double sacc = Lm[row * BBS + c + jj];
+#pragma unroll
+                    for (int k = 0; k < jj; k++) sacc -= x[k] * Lm[(c + jj) * BBS + c + k];
+                    x[jj] = sacc;
+                }
+#pragma unroll
+                for (int jj = 0; jj < 16; jj++) {
+                    Tm[pr * 17 + jj] = x[jj];
+                    Lm[row * BBS + c + jj] = x[jj] * rdl[jj];
+                }
+            }
+        } else if (lane < 16) {                                             // ---- row r of L_ss^-1, L_ss still in a[]'s image in LDS
+            double m[16];
+#pragma unroll
+            for (int k = 0; k < 16; k++) m[k] = (k == r) ? 1.0 : 0.0;
+#pragma unroll
+            for (int jj = 14; jj >= 0; jj--) {
+                double sacc = 0.0;
+#pragma unroll
+                for (int k = jj + 1; k < 16; k++) sacc -= m[k] * Lm[(c + k) * BBS + c + jj];   // m[k] = 0 beyond the row's diagonal
+                m[jj] = jj < r ? sacc : m[jj];
+            }
+#pragma unroll
+            for (int k = 0; k < 16; k++) Mm[(c + r) * BBS + c + k] = m[k];
+        }
+        __syncthreads();
+        for (int idx = tid; idx < nrows * below; idx += 256) {              // ---- C
+            const int pr = idx / below, qq = idx % below;
+            const int row = pr < below ? c + 16 + pr : BB;
+            if (pr < below && qq > pr) continue;                            // lower triangle (and the whole rhs row)
+            double acc = 0.0;
+#pragma unroll
+            for (int jj = 0; jj < 16; jj++) acc += Tm[pr * 17 + jj] * Lm[(c + 16 + qq) * BBS + c + jj];
+            Lm[row * BBS + c + 16 + qq] -= acc;
+        }
         __syncthreads();
     }
     for (int idx = tid; idx < w * w; idx += 256) {
         const int r = idx / w, k = idx % w;
         g.Ls[(size_t)(c0 + r) * n + c0 + k] = k < r ? Lm[r * BBS + k] : (k == r ? 1.0 : 0.0);
     }
-    if (tid < w) g.yf[c0 + tid] = Lm[w * BBS + tid];        // D^-1 L^-1 g of this block
+    if (tid < w) g.yf[c0 + tid] = Lm[BB * BBS + tid];       // D^-1 L^-1 g of this block
     if (__any(bad) && lane == 0) *g.fail = 1;
-    // Inverses of the three 16x16 diagonal sub-blocks of L (unit lower), row r by thread r:
-    // m[j] = -sum_{j < k <= r} m[k] L[k][j] with j, k inside r's sub-block (chains of <= 15 instead of 47).  The
-    // trailing-update kernel does the rest of the triangular solve as a block forward substitution on the matrix
-    // cores.  Everything outside the sub-blocks, and rows / columns >= w, is the identity / zero.
-    __shared__ double Mm[BB * BBS];
-    for (int idx = tid; idx < BB * BB; idx += 256) Mm[(idx / BB) * BBS + idx % BB] = (idx / BB == idx % BB) ? 1.0 : 0.0;
-    __syncthreads();
-    if (tid < w) {
-        const int sb = tid & ~15;
-        for (int j = tid - 1; j >= sb; j--) {
-            double sacc = 0.0;
-            for (int k0 = j + 1; k0 <= tid; k0 += 8) {
-                double mk[8], lk[8];
-#pragma unroll
-                for (int u = 0; u < 8; u++) {
-                    const int k = min(k0 + u, tid);
-                    mk[u] = Mm[tid * BBS + k];
-                    lk[u] = Lm[k * BBS + j];
-                }
-#pragma unroll
-                for (int u = 0; u < 8; u++) sacc -= (k0 + u <= tid) ? mk[u] * lk[u] : 0.0;
-            }
-            Mm[tid * BBS + j] = sacc;
-        }
-    }
-    __syncthreads();
+    // M: the inverses of the three 16x16 diagonal sub-blocks of L; the trailing-update kernel does the rest of the
+    // triangular solve as a block forward substitution on the matrix cores.  Identity outside the sub-blocks.
     for (int idx = tid; idx < BB * BB; idx += 256) g.M[idx] = Mm[(idx / BB) * BBS + idx % BB];
 }
 
@@ -357,35 +413,68 @@ __global__ __launch_bounds__(256) void ba_big_update(BaDims d, BaBufs b, BigBufs
 // block backward substitution L^T x = D^-1 L^-1 g by one workgroup: y (LDS, [n]) becomes x; Lb is an LDS block buffer
 static __device__ __forceinline__ void big_backsub(const BigBufs& g, int n, double* y, double* Lb)
 {
+    // 1024 threads.  Per 48-column block J, from the last: (1) L_JJ^T x_J = y_J by one wave with the block's columns in
+    // registers (lane = column, 48 unrolled v_readlane + fma steps); (2) y[0 : c0] -= L[block J rows, 0 : c0]^T x_J with
+    // four threads per column (12 rows each, their loads in flight together), partial sums combined through LDS.
+    // Lb: [BB][BBS] diagonal block, then [4][256] partial sums.
     const int tid = threadIdx.x, nt = blockDim.x;
+    double* part = Lb + BB * BBS;
     for (int i = tid; i < n; i += nt) y[i] = g.yf[i];
     const int NBLK = (n + BB - 1) / BB;
+    // diagonal block J of the factor -> registers (all loads issued together), registers -> Lb (zero padded)
+    auto fetch = [&](int J, double v[3]) {
+        const int c0 = BB * J, w = min(BB, n - c0);
+#pragma unroll
+        for (int it = 0; it < 3; it++) {
+            const int idx = tid + nt * it, r = idx / BB, k = idx % BB;
+            v[it] = (J >= 0 && r < w && k < w) ? g.Ls[(size_t)(c0 + r) * n + c0 + k] : 0.0;
+        }
+    };
+    auto stash = [&](const double v[3]) {
+#pragma unroll
+        for (int it = 0; it < 3; it++) {
+            const int idx = tid + nt * it;
+            if (idx < BB * BB) Lb[(idx / BB) * BBS + idx % BB] = v[it];
+        }
+    };
+    double nxt[3];
+    fetch(NBLK - 1, nxt);
+    stash(nxt);
+    __syncthreads();
     for (int J = NBLK - 1; J >= 0; J--) {
         const int c0 = BB * J, w = min(BB, n - c0);
-        for (int idx = tid; idx < w * w; idx += nt) { const int r = idx / w, k = idx % w; Lb[r * BBS + k] = g.Ls[(size_t)(c0 + r) * n + c0 + k]; }
-        __syncthreads();
-        // L_JJ^T x_J = y_J: one wave, column by column from the last
+        fetch(J - 1, nxt);                                  // the next block's loads fly during this block's work
         if (tid < 64) {
+            const int col = min(tid, BB - 1);
+            double l[BB];
+#pragma unroll
+            for (int t = 0; t < BB; t++) l[t] = Lb[t * BBS + col];          // column `col` of the block (only t > col is used)
             double v = tid < w ? y[c0 + tid] : 0.0;
-            for (int t = w - 1; t >= 0; t--) {
+#pragma unroll
+            for (int t = BB - 1; t >= 0; t--) {
                 const double xt = rl64(v, t);
-                if (tid < t) v -= Lb[t * BBS + tid] * xt;
+                v -= (tid < t) ? l[t] * xt : 0.0;
             }
             if (tid < w) y[c0 + tid] = v;
         }
         __syncthreads();
         // y[0 : c0] -= L[block J rows, 0 : c0]^T x_J
-        for (int k = tid; k < c0; k += nt) {
+        for (int k0 = 0; k0 < c0; k0 += 256) {
+            const int k = k0 + (tid & 255), grp = tid >> 8;
             double acc = 0.0;
-            {                                               // all (<= 48) loads of the column go out together
-                double l[BB];
+            if (k < c0) {
+                double l[12];
 #pragma unroll
-                for (int u = 0; u < BB; u++) l[u] = g.Ls[(size_t)(c0 + min(u, w - 1)) * n + k];
+                for (int u = 0; u < 12; u++) l[u] = g.Ls[(size_t)(c0 + min(12 * grp + u, w - 1)) * n + k];
 #pragma unroll
-                for (int u = 0; u < BB; u++) acc += (u < w) ? l[u] * y[c0 + u] : 0.0;
+                for (int u = 0; u < 12; u++) acc += (12 * grp + u < w) ? l[u] * y[c0 + 12 * grp + u] : 0.0;
             }
-            y[k] -= acc;
+            part[grp * 256 + (tid & 255)] = acc;
+            __syncthreads();
+            if (tid < 256 && k < c0) y[k] -= (part[tid] + part[256 + tid]) + (part[512 + tid] + part[768 + tid]);
+            __syncthreads();
         }
+        if (J > 0) stash(nxt);                              // Lb is free: the triangular solve above was its last reader
         __syncthreads();
     }
 }
@@ -484,7 +573,7 @@ int ba_launch_reduced_solve_big(rs_context* ctx, const BaDims& d, const BaBufs& 
     BigBufs g;
     big_carve(ws, n, &g);
     hipStream_t s = ctx->stream;
-    const size_t lds_fin = sizeof(double) * (n + BB * BBS);
+    const size_t lds_fin = sizeof(double) * (n + BB * BBS + 1024);       // y, diagonal block, backsub partial sums
     if (lds_fin > 48 * 1024)
         RS_HIP(ctx, hipFuncSetAttribute((const void*)ba_big_finish, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_fin));
     const size_t lds_upd = sizeof(double) * (6 * BB * BBS + 2 * BB * 17 + BB);
@@ -733,7 +822,7 @@ int ba_launch_reduced_solve_inertial(rs_context* ctx, const BaDims& d, const BaB
     BigBufs g;
     big_carve(ws, (size_t)N, &g);
     hipStream_t s = ctx->stream;
-    const size_t lds_fin = sizeof(double) * ((size_t)N + BB * BBS);
+    const size_t lds_fin = sizeof(double) * ((size_t)N + BB * BBS + 1024);
     if (lds_fin > 48 * 1024)
         RS_HIP(ctx, hipFuncSetAttribute((const void*)ba_imu_finish, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_fin));
     const size_t lds_upd = sizeof(double) * (6 * BB * BBS + 2 * BB * 17 + BB);
