@@ -173,7 +173,7 @@ __global__ __launch_bounds__(256) void ba_big_diag(BaDims d, BaBufs b, BigBufs g
     __syncthreads();
     bool bad = false;
     for (int c = 0; c < w; c += 16) {
-        const int r = lane & 15;
+        int r = lane & 15;
         double a[16];
         if (wave == 0) {                                                    // ---- A
 #pragma unroll
@@ -181,6 +181,7 @@ __global__ __launch_bounds__(256) void ba_big_diag(BaDims d, BaBufs b, BigBufs g
             double my_rd = 1.0, my_piv = 1.0;
 #pragma unroll
             for (int cc = 0; cc < 16; cc++) {
+                asm volatile("" : "+v"(r));      // per-step lane masks: hoisted, the 3 x 16 compare results lived in SGPR pairs and spilled
                 const double piv = rl64(a[cc], cc);
                 bad = bad || !(piv > 0.0) || !isfinite(piv);
                 const double rd = rcp_nr(piv);
@@ -226,6 +227,7 @@ __global__ __launch_bounds__(256) void ba_big_diag(BaDims d, BaBufs b, BigBufs g
             for (int k = 0; k < 16; k++) m[k] = (k == r) ? 1.0 : 0.0;
 #pragma unroll
             for (int jj = 14; jj >= 0; jj--) {
+                asm volatile("" : "+v"(r));
                 double sacc = 0.0;
 #pragma unroll
                 for (int k = jj + 1; k < 16; k++) sacc -= m[k] * Lm[(c + k) * BBS + c + jj];   // m[k] = 0 beyond the row's diagonal
@@ -269,17 +271,31 @@ __device__ __forceinline__ void gemm_nt_48(const double* X, const double* Z, int
 {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int lr = lane & 15, lk = lane >> 4;
+    // a wave's (up to three) tiles advance together: three independent accumulator chains instead of one 12-deep
+    // chain after the other (an f64 MFMA is ~64 cycles of latency)
+    d4 acc[3];
+    const double *xa[3], *zb[3];
+    int ntile = 0;
 #pragma unroll
     for (int ti = 0; ti < 3; ti++) {
         const int t = wave + 4 * ti;                 // wave 0 owns three tiles, the others two
-        if (t >= 9) break;
-        const int tr = t / 3, tc = t % 3;
-        d4 acc = {0.0, 0.0, 0.0, 0.0};
-        const double* xa = X + (16 * tr + lr) * BBS + lk;
-        const double* zb = Z + (16 * tc + lr) * BBS + lk;
-        for (int kc = 0; kc < nchunk; kc++) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(xa[4 * kc], zb[4 * kc], acc, 0, 0, 0);
+        acc[ti] = d4{0.0, 0.0, 0.0, 0.0};
+        const int tt = t < 9 ? t : 0;
+        xa[ti] = X + (16 * (tt / 3) + lr) * BBS + lk;
+        zb[ti] = Z + (16 * (tt % 3) + lr) * BBS + lk;
+        if (t < 9) ntile = ti + 1;
+    }
+    for (int kc = 0; kc < nchunk; kc++) {
 #pragma unroll
-        for (int reg = 0; reg < 4; reg++) store(16 * tr + lk + 4 * reg, 16 * tc + lr, acc[reg]);
+        for (int ti = 0; ti < 3; ti++)
+            if (ti < ntile) acc[ti] = __builtin_amdgcn_mfma_f64_16x16x4f64(xa[ti][4 * kc], zb[ti][4 * kc], acc[ti], 0, 0, 0);
+    }
+#pragma unroll
+    for (int ti = 0; ti < 3; ti++) {
+        const int t = wave + 4 * ti;
+        if (t >= 9) break;
+#pragma unroll
+        for (int reg = 0; reg < 4; reg++) store(16 * (t / 3) + lk + 4 * reg, 16 * (t % 3) + lr, acc[ti][reg]);
     }
 }
 
@@ -299,18 +315,28 @@ __global__ __launch_bounds__(256) void ba_big_update(BaDims d, BaBufs b, BigBufs
     const bool rhs = bi == NBLK;
     const int ri0 = BB * bi, hi = rhs ? 1 : min(BB, n - ri0);
     const int rk0 = BB * bk, hk = min(BB, n - rk0);
+    {
+        // 9 rounds x 4 operands, branch-free: every load goes to a clamped (valid) address and is masked afterwards, so
+        // all 36 are in flight together (conditional loads came out as one exec-masked block each)
+        double vm[9], vl[9], vi[9], vk[9];
+        const int rimax = rhs ? n - 1 : ri0 + hi - 1;
 #pragma unroll
-    for (int idx = tid; idx < BB * BB; idx += 256) {       // 9 rounds, fully unrolled: 27 loads in flight
-        const int r = idx / BB, k = idx % BB;
-        Mm[r * BBS + k] = g.M[idx];
-        Lj[r * BBS + k] = (r < w && k < w) ? g.Ls[(size_t)(c0 + r) * n + c0 + k] : (r == k ? 1.0 : 0.0);
-        double vi = 0.0, vk = 0.0;
-        if (k < w) {
-            if (!rhs && r < hi) vi = b.S[(size_t)(ri0 + r) * n + c0 + k];
-            if (r < hk) vk = b.S[(size_t)(rk0 + r) * n + c0 + k];
+        for (int it = 0; it < 9; it++) {
+            const int idx = tid + 256 * it, r = idx / BB, k = idx % BB;
+            const int kc = c0 + min(k, w - 1);
+            vm[it] = g.M[idx];
+            vl[it] = g.Ls[(size_t)(c0 + min(r, w - 1)) * n + kc];
+            vi[it] = b.S[(size_t)min(ri0 + r, rimax) * n + kc];
+            vk[it] = b.S[(size_t)(rk0 + min(r, hk - 1)) * n + kc];
         }
-        Ai[r * BBS + k] = vi;
-        Ak[r * BBS + k] = vk;
+#pragma unroll
+        for (int it = 0; it < 9; it++) {
+            const int idx = tid + 256 * it, r = idx / BB, k = idx % BB;
+            Mm[r * BBS + k] = vm[it];
+            Lj[r * BBS + k] = (r < w && k < w) ? vl[it] : (r == k ? 1.0 : 0.0);
+            Ai[r * BBS + k] = (k < w && !rhs && r < hi) ? vi[it] : 0.0;
+            Ak[r * BBS + k] = (k < w && r < hk) ? vk[it] : 0.0;
+        }
     }
     if (tid < BB) dvl[tid] = tid < w ? g.dv[c0 + tid] : 1.0;
     __syncthreads();
