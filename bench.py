@@ -591,24 +591,29 @@ def bench_ba(e, args, cfg):
     batch = None
     if e.world == 1 and cfg == "cfg3":
         batch = {}
-        for B in (8, 32):
-            clones = [(c0.clone(), p0.clone()) for _ in range(B)]
-            probs = [(bc, w["cam_free"], bp, *dev, w["K"]) for bc, bp in clones]
+        for mode, tag in ((0, "grid"), (1, "lanes")):
+            ctx.set_int("ba_batch_mode", mode)
+            for B in (8, 32, 128):
+                if mode == 1 and B > 32:
+                    continue
+                clones = [(c0.clone(), p0.clone()) for _ in range(B)]
+                probs = [(bc, w["cam_free"], bp, *dev, w["K"]) for bc, bp in clones]
 
-            def bstep():
-                for bc, bp in clones:
-                    bc.copy_(c0)
-                    bp.copy_(p0)
-                torch.cuda.synchronize()
-                ctx.bundle_adjust_batch(probs)
+                def bstep():
+                    for bc, bp in clones:
+                        bc.copy_(c0)
+                        bp.copy_(p0)
+                    torch.cuda.synchronize()
+                    ctx.bundle_adjust_batch(probs)
 
-            n_rep = max(3, args.steps // 5)
-            dtb = timed(e, bstep, n_rep, 2)
-            batch["B%d" % B] = dict(windows=B, solves_per_s=B * n_rep / dtb, ms_per_call=1e3 * dtb / n_rep,
-                                    speedup_vs_sequential=(B * n_rep / dtb) / (args.steps / elapsed))
-        batch["lanes"] = 8
-        batch["note"] = ("B copies of the same cfg-3 window solved by one rs_bundle_adjust_batch call (8 lanes = child contexts "
-                         "with their own streams, one host thread each); includes the 2B state-reset copies")
+                n_rep = max(3, args.steps // 5)
+                dtb = timed(e, bstep, n_rep, 2)
+                batch["%s_B%d" % (tag, B)] = dict(windows=B, solves_per_s=B * n_rep / dtb, ms_per_call=1e3 * dtb / n_rep,
+                                                  speedup_vs_sequential=(B * n_rep / dtb) / (args.steps / elapsed))
+        ctx.set_int("ba_batch_mode", 0)
+        batch["note"] = ("B copies of the same cfg-3 window solved by one rs_bundle_adjust_batch call, incl. the 2B state-reset "
+                         "copies.  grid: ONE launch sequence for all windows (blockIdx.z = window; the library's default); "
+                         "lanes: 8 child contexts with their own streams, one host thread each")
     cpu = None
     if e.rank == 0 and e.world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline(cpu_step, 1.0, "solves/s", "the same window, whole 10-iteration solve", args.cpu_seconds)

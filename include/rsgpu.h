@@ -69,7 +69,9 @@ int rs_context_set_stream(rs_context* ctx, void* hip_stream);
 int rs_context_synchronize(rs_context* ctx);
 /* Tuning knobs (integers by name).  "ba_speculative_sets": 1 .. 3 trust-region radii evaluated per round of
  * rs_bundle_adjust on the local-window path (0 = library default); the LM schedule, iteration count and
- * results do not depend on it (tests/test_gpu_parity.py), only the number of launches does. */
+ * results do not depend on it (tests/test_gpu_parity.py), only the number of launches does.
+ * "ba_batch_mode": how rs_bundle_adjust_batch runs its windows — 0 (default) one launch sequence for all of them
+ * where the windows allow it, 1 always the lanes. */
 int rs_context_set_int(rs_context* ctx, const char* name, int value);
 const char* rs_last_error(const rs_context* ctx);
 
@@ -433,10 +435,15 @@ int rs_map_bundle_adjust(rs_context* ctx, rs_map* map, const int32_t* h_kfs, con
                          float* h_out_poses, int32_t* h_out_points, float* h_out_xyz, int capacity, int* h_n_points);
 
 /* Throughput mode: B INDEPENDENT windows (several sessions / maps served by one GPU) in one call.  A local-window
- * solve is a chain of small dependent launches that leaves most of the 256 CUs idle; independent windows overlap on
- * the device.  The library keeps up to `RS_BA_BATCH_LANES` child contexts (own stream, own workspace) and runs the
- * windows on them from as many host threads; results per window are those of rs_bundle_adjust, bit for bit for the
- * schedule and to summation-order noise for the values.  h_problems[i] is the argument list of rs_bundle_adjust. */
+ * solve is a chain of small dependent launches that leaves most of the 256 CUs idle.
+ *   grid mode (default)  every kernel of the solve runs ONCE for all windows (grid z = window, per-window arguments in a
+ *                        device table): B x 157 workgroups in the Schur kernel, B x 3 in the reduced solve, one launch
+ *                        per round instead of one per window and round.  For windows of at most 64 cameras on the
+ *                        local-window kernels (what a local window is); the host follows the slowest window's progress.
+ *   lanes                otherwise (or "ba_batch_mode" = 1): up to `RS_BA_BATCH_LANES` child contexts (own stream, own
+ *                        workspace), one host thread each, ordinary solves side by side.
+ * Results per window are those of rs_bundle_adjust: the same schedule, values to summation-order noise.
+ * h_problems[i] is the argument list of rs_bundle_adjust.  rs_ba_get_trace / _cameras refer to single solves only. */
 #define RS_BA_BATCH_LANES 8
 typedef struct rs_ba_problem {
     int n_cameras, n_points, n_obs;

@@ -35,9 +35,9 @@
 #include "imu_dual.h"
 
 // ---------------------------------------------------------------------- K0
-__global__ void ba_init(BaDims d, BaBufs b, BaOpt opt, const double* __restrict__ cams_in,
-                        const double* __restrict__ pts_in, unsigned long long free_mask, int from_mask,
-                        uint8_t* __restrict__ cam_free, int32_t* __restrict__ zero_i32, int zero_n)
+static __device__ __forceinline__ void ba_init_body(const BaDims& d, const BaBufs& b, const BaOpt& opt, const double* __restrict__ cams_in,
+                                                    const double* __restrict__ pts_in, unsigned long long free_mask, int from_mask,
+                                                    uint8_t* __restrict__ cam_free, int32_t* __restrict__ zero_i32, int zero_n)
 {
     const int tid = blockIdx.x * blockDim.x + threadIdx.x, nth = gridDim.x * blockDim.x;
     if (from_mask && tid < d.C) {     // C <= 64: the free-camera table arrives as a kernel argument, not as two copies
@@ -65,6 +65,19 @@ __global__ void ba_init(BaDims d, BaBufs b, BaOpt opt, const double* __restrict_
         s.n_rounds = 0; s.n_fresh = 0; s.n_sets = 0; s.pad = 0;
         b.st[1] = s;      // the state iteration 0 starts from (st[(0 + 1) & 1])
     }
+}
+
+__global__ void ba_init(BaDims d, BaBufs b, BaOpt opt, const double* __restrict__ cams_in,
+                        const double* __restrict__ pts_in, unsigned long long free_mask, int from_mask,
+                        uint8_t* __restrict__ cam_free, int32_t* __restrict__ zero_i32, int zero_n)
+{
+    ba_init_body(d, b, opt, cams_in, pts_in, free_mask, from_mask, cam_free, zero_i32, zero_n);
+}
+// batched (blockIdx.z = window; windows of at most 64 cameras: the free-camera table is the mask)
+__global__ void ba_init_batch(const BaWin* w, BaOpt opt)
+{
+    const BaWin& x = w[blockIdx.z];
+    ba_init_body(x.d, x.b, opt, x.cams_in, x.pts_in, x.free_mask, 1, x.cam_free, x.zero_ptr, x.zero_n);
 }
 
 // ---------------------------------------------------------------------- K5
@@ -419,9 +432,9 @@ __global__ __launch_bounds__(BA_THREADS) void ba_backsub_cost(BaDims d, BaBufs b
 }
 
 // -------------------------------------------------------------------- finalize
-__global__ void ba_finalize(BaDims d, BaBufs b, BaOpt opt, int it, double* __restrict__ cams_out,
-                            const uint8_t* __restrict__ cam_free, double* __restrict__ pts_out, BaState* host_st,
-                            BaTrace* host_trace, double* __restrict__ host_cams, double* __restrict__ host_vb)
+static __device__ __forceinline__ void ba_finalize_body(const BaDims& d, const BaBufs& b, const BaOpt& opt, int it, double* __restrict__ cams_out,
+                                                        const uint8_t* __restrict__ cam_free, double* __restrict__ pts_out, BaState* host_st,
+                                                        BaTrace* host_trace, double* __restrict__ host_cams, double* __restrict__ host_vb)
 {
     __shared__ int usable, cur;
     __shared__ BaState st_fin;
@@ -460,6 +473,19 @@ __global__ void ba_finalize(BaDims d, BaBufs b, BaOpt opt, int it, double* __res
     for (int i = tid; i < d.C * 6; i += nth)
         if (cam_free[i / 6]) cams_out[i] = Xc[i];
     for (int i = tid; i < d.P * 3; i += nth) pts_out[i] = Xp[i];
+}
+
+__global__ void ba_finalize(BaDims d, BaBufs b, BaOpt opt, int it, double* __restrict__ cams_out,
+                            const uint8_t* __restrict__ cam_free, double* __restrict__ pts_out, BaState* host_st,
+                            BaTrace* host_trace, double* __restrict__ host_cams, double* __restrict__ host_vb)
+{
+    ba_finalize_body(d, b, opt, it, cams_out, cam_free, pts_out, host_st, host_trace, host_cams, host_vb);
+}
+__global__ void ba_finalize_batch(const BaWin* w, BaOpt opt, int it)
+{
+    const BaWin& x = w[blockIdx.z];
+    const BaBufs b = ba_win_round(x, it, true);
+    ba_finalize_body(x.d, b, opt, it, x.cams_out, x.cam_free, x.pts_out, x.h_st, x.h_trace, x.h_cams, nullptr);
 }
 
 // ------------------------------------------------------------------ host side
@@ -866,6 +892,183 @@ extern "C" int rs_bundle_adjust_inertial(rs_context* ctx, int n_cameras, int n_p
 // ordinary solve (incl. the round-following logic), which keeps every lane's stream fed.
 #include <thread>
 
+// Grid mode: the B windows run as ONE launch sequence, blockIdx.z = window (BaWin, ba_common.h).  Every kernel of the
+// local-window fast path has a batched entry point that takes its per-window arguments from a device array; a round's
+// K5 is then B x items workgroups (instead of 157-250), K7 B x sets workgroups (instead of <= 3), and a launch is paid
+// once per round, not once per window and round.  Eligible: windows of <= 64 cameras on the MFMA / LDS path (what a
+// local window is).  Returns 1 when the batch is not eligible (the caller falls back to the lanes), 0 when it ran.
+static int ba_solve_batch_grid(rs_context* ctx, int B, const rs_ba_problem* Q, const rs_ba_options* options, rs_ba_summary* out, int* rc_out)
+{
+    *rc_out = RS_OK;
+    rs_ba_options def;
+    if (!options) { rs_ba_default_options(&def); options = &def; }
+    BaOpt opt;
+    opt.max_iter = options->max_num_iterations; opt.max_invalid = options->max_num_consecutive_invalid_steps;
+    opt.jacobi = options->jacobi_scaling; opt.r0 = options->initial_trust_region_radius;
+    opt.rmax = options->max_trust_region_radius; opt.rmin = options->min_trust_region_radius;
+    opt.min_rel = options->min_relative_decrease; opt.dmin = options->min_lm_diagonal;
+    opt.dmax = options->max_lm_diagonal; opt.ftol = options->function_tolerance;
+    opt.gtol = options->gradient_tolerance; opt.ptol = options->parameter_tolerance;
+    if (opt.max_iter < 1 || opt.max_iter > 1000) return 1;
+    int ns = ctx->ba_sets > 0 ? ctx->ba_sets : BA_DEFAULT_SETS;
+    if (ns > BA_MAXSETS) ns = BA_MAXSETS;
+    if (ns > opt.max_iter) ns = opt.max_iter;
+    std::vector<BaWin> wins((size_t)B);
+    std::vector<size_t> ws_off((size_t)B), pin_off((size_t)B);
+    size_t ws_total = align_up(sizeof(BaWin) * (size_t)B, 256), pin_total = 0;
+    int max_P = 0, max_items = 0, max_n = 0, max_C = 0;
+    size_t k5_lds = 0, k8_lds = 0;
+    struct Lay { size_t Xc, Xp, prep, slot, sc, sp, Vinv, gp, lamp, Vc, Ukeep, acc, pts, dc, st, set, trace, dbg, fre, grp, total, acc_count, cam_stride, pts_block; };
+    std::vector<Lay> lay((size_t)B);
+    for (int i = 0; i < B; i++) {
+        const rs_ba_problem& q = Q[i];
+        if (q.n_cameras <= 0 || q.n_points <= 0 || q.n_obs <= 0 || q.n_cameras > 64) return 1;
+        if (!q.d_cameras || !q.h_cam_free || !q.d_points || !q.d_obs_ptr || !q.d_obs_cam || !q.d_obs_uv) return 1;
+        BaWin& w = wins[(size_t)i];
+        memset(&w, 0, sizeof w);
+        BaDims& d = w.d;
+        d.C = q.n_cameras; d.P = q.n_points; d.M = q.n_obs;
+        d.Cf = 0;
+        unsigned long long mask = 0;
+        for (int c = 0; c < d.C; c++) if (q.h_cam_free[c]) { mask |= 1ull << c; d.Cf++; }
+        d.n = 6 * d.Cf;
+        d.fx = q.intrinsics[0]; d.fy = q.intrinsics[1]; d.cx = q.intrinsics[2]; d.cy = q.intrinsics[3];
+        d.huber_a = options->huber_delta;
+        const bool use_mfma = d.Cf >= 1 && ba_schur_lds_bytes(d.C, d.Cf) <= 160 * 1024;
+        if (!use_mfma || ba_backsub_lds_bytes(d.C, d.n) > 64 * 1024 || d.n < 6 || d.n > BA_MAX_LDS_N) return 1;
+        w.free_mask = mask;
+        // the single-window layout (ba_solve_impl), one copy per window
+        const size_t n = (size_t)d.n, C = (size_t)d.C, P = (size_t)d.P, nb = (size_t)ns + 1;
+        Lay& L = lay[(size_t)i];
+        size_t off = 0;
+        auto carve = [&](size_t bytes) { size_t o = off; off += align_up(bytes, 256); return o; };
+        L.Xc = carve(sizeof(double) * nb * C * 6); L.Xp = carve(sizeof(double) * nb * P * 3);
+        L.prep = carve(sizeof(double) * nb * C * BA_PREP); L.slot = carve(sizeof(int32_t) * C);
+        L.sc = carve(sizeof(double) * (n + 1)); L.sp = carve(sizeof(double) * P * 3);
+        L.Vinv = carve(sizeof(double) * ns * P * 6); L.gp = carve(sizeof(double) * P * 3);
+        L.lamp = carve(sizeof(double) * ns * P * 3);
+        L.Vc = carve(sizeof(double) * P * 6); L.Ukeep = carve(sizeof(double) * ((size_t)d.Cf * 36 + n + 1));
+        L.cam_stride = (size_t)ns * n + (size_t)d.Cf * 36 + n;
+        L.acc_count = (size_t)ns * n * n + (size_t)BA_UREP * L.cam_stride + 2 * (size_t)BA_NSLOT * BA_SLOT_STRIDE;
+        L.acc = carve(sizeof(double) * L.acc_count);
+        L.pts_block = (size_t)ns * BA_NSLOT * BA_SLOT_STRIDE;
+        L.pts = carve(sizeof(double) * 2 * L.pts_block); L.dc = carve(sizeof(double) * ns * (n + 2));
+        L.st = carve(sizeof(BaState) * 2); L.set = carve(sizeof(BaSetOut) * 2 * BA_MAXSETS);
+        L.trace = carve(sizeof(BaTrace) * (size_t)(opt.max_iter + 1)); L.dbg = carve(sizeof(unsigned long long) * 64);
+        L.fre = carve(C); L.grp = carve(ba_group_bytes(d.P, d.Cf, d.M));
+        L.total = off;
+        ws_off[(size_t)i] = ws_total;
+        ws_total += L.total;
+        pin_off[(size_t)i] = pin_total;
+        pin_total += align_up(sizeof(BaState), 64) + 64 + align_up(sizeof(BaTrace) * (size_t)(opt.max_iter + 1), 64) + align_up(sizeof(double) * 6 * C, 64);
+        max_P = std::max(max_P, d.P); max_n = std::max(max_n, d.n); max_C = std::max(max_C, d.C);
+        k5_lds = std::max(k5_lds, ba_schur_lds_bytes(d.C, d.Cf));
+        k8_lds = std::max(k8_lds, ba_backsub_lds_bytes(d.C, d.n));
+    }
+    void* wsv = nullptr;
+    int rc = rs_workspace(ctx, ws_total, &wsv);
+    if (rc) { *rc_out = rc; return 0; }
+    char* ws = (char*)wsv;
+    void* pinv = nullptr;
+    const size_t pin_wins = align_up(pin_total, 256);
+    rc = rs_pinned(ctx, pin_wins + sizeof(BaWin) * (size_t)B, &pinv);
+    if (rc) { *rc_out = rc; return 0; }
+    char* pin = (char*)pinv;
+    for (int i = 0; i < B; i++) {
+        const rs_ba_problem& q = Q[i];
+        BaWin& w = wins[(size_t)i];
+        const Lay& L = lay[(size_t)i];
+        char* base = ws + ws_off[(size_t)i];
+        const BaDims& d = w.d;
+        const size_t n = (size_t)d.n;
+        BaBufs& b = w.b;
+        b.ns = ns;
+        b.obs_ptr = q.d_obs_ptr; b.obs_cam = q.d_obs_cam; b.obs_uv = (const float2*)q.d_obs_uv;
+        b.Xc = (double*)(base + L.Xc); b.Xp = (double*)(base + L.Xp); b.prep = (double*)(base + L.prep);
+        b.slot = (int32_t*)(base + L.slot); b.sc = (double*)(base + L.sc); b.sp = (double*)(base + L.sp);
+        b.Vinv = (double*)(base + L.Vinv); b.gp = (double*)(base + L.gp); b.lamp = (double*)(base + L.lamp);
+        b.Vc = (double*)(base + L.Vc); b.Ukeep = (double*)(base + L.Ukeep);
+        b.acc = (double*)(base + L.acc); b.acc_count = L.acc_count;
+        b.S = b.acc; b.rhs = b.S + (size_t)ns * n * n; b.U = b.rhs + (size_t)ns * n; b.gc = b.U + (size_t)d.Cf * 36;
+        b.cam_stride = L.cam_stride; b.scal = b.rhs + (size_t)BA_UREP * L.cam_stride;
+        b.gmax_all = b.scal + (size_t)BA_NSLOT * BA_SLOT_STRIDE; b.gmax_blocks = 1; b.gmax = b.gmax_all;
+        b.pt_scal = (double*)(base + L.pts); b.pt_prev = b.pt_scal; b.dc = (double*)(base + L.dc);
+        b.st = (BaState*)(base + L.st); b.st_prev = b.st;
+        b.trace = (BaTrace*)(base + L.trace);
+        b.set_out = (BaSetOut*)(base + L.set); b.set_prev = b.set_out;
+        b.dbg = (unsigned long long*)(base + L.dbg);
+        ba_group_carve(base + L.grp, d.P, d.Cf, d.M, &w.g);
+        ba_group_set_items(&w.g, d.P, true);
+        b.obs_cs = w.g.obs_cs;
+        max_items = std::max(max_items, w.g.n_items);
+        w.st_base = b.st; w.pts_base = b.pt_scal; w.set_base = b.set_out; w.pts_block = L.pts_block;
+        char* hp = pin + pin_off[(size_t)i];
+        w.h_st = (BaState*)hp;
+        w.prog = (BaProgress*)(hp + align_up(sizeof(BaState), 64));
+        w.h_trace = (BaTrace*)(hp + align_up(sizeof(BaState), 64) + 64);
+        w.h_cams = (double*)((char*)w.h_trace + align_up(sizeof(BaTrace) * (size_t)(opt.max_iter + 1), 64));
+        w.prog->round = 0; w.prog->done = 0; w.prog->iter = 0;
+        b.prog = w.prog;
+        w.cams_in = q.d_cameras; w.pts_in = q.d_points; w.cams_out = q.d_cameras; w.pts_out = q.d_points;
+        w.cam_free = (uint8_t*)(base + L.fre);
+        ba_group_zero_range(w.g, &w.zero_ptr, &w.zero_n);
+    }
+    if (ba_prepare_reduced_solve_lds_batch(max_n) != 0 || ba_prepare_schur_batch(k5_lds) != 0) { *rc_out = rs_fail(ctx, RS_ERR_HIP, "LDS attribute (batch)"); return 0; }
+    hipStream_t s = ctx->stream;
+    BaWin* h_wins = (BaWin*)(pin + pin_wins);
+    memcpy(h_wins, wins.data(), sizeof(BaWin) * (size_t)B);
+    const BaWin* d_wins = (const BaWin*)ws;
+    if (hipMemcpyAsync(ws, h_wins, sizeof(BaWin) * (size_t)B, hipMemcpyHostToDevice, s) != hipSuccess) { *rc_out = rs_fail(ctx, RS_ERR_HIP, "window table upload"); return 0; }
+    {
+        rs_prof_scope ps(ctx, "K0_ba_init");
+        hipLaunchKernelGGL(ba_init_batch, dim3(32, 1, B), dim3(256), 0, s, d_wins, opt);
+    }
+    {
+        rs_prof_scope ps(ctx, "K5s_group_landmarks");
+        ba_launch_grouping_batch(s, d_wins, B, max_P, max_items);
+    }
+    auto enqueue_round = [&](int it) {
+        { rs_prof_scope ps(ctx, "K5_ba_schur_mfma"); ba_launch_schur_batch(s, d_wins, B, opt, it, max_items, 64, k5_lds); }
+        { rs_prof_scope ps(ctx, "K7_ba_reduced_solve"); ba_launch_reduced_solve_lds_batch(s, d_wins, B, opt, it, ns, max_n); }
+        { rs_prof_scope ps(ctx, "K8_ba_backsub_cost"); ba_launch_backsub_batch(s, d_wins, B, it, ns, max_P, k8_lds); }
+    };
+    int rounds = 0;
+    const int min_rounds = (opt.max_iter + ns - 1) / ns;
+    for (; rounds < min_rounds; rounds++) enqueue_round(rounds);
+    while (ns > 1 && rounds < opt.max_iter) {
+        // as in the single solve, for the slowest window: wait until every window has started the last enqueued round
+        long spins = 0;
+        bool drained = false;
+        for (int i = 0; i < B && !drained; i++)
+            while (wins[(size_t)i].prog->round < rounds) {
+                if ((++spins & 0xFFFFF) == 0 && hipStreamQuery(s) != hipErrorNotReady) { drained = true; break; }
+            }
+        if (drained) break;
+        bool more = false;
+        for (int i = 0; i < B; i++) {
+            const BaProgress* pr = wins[(size_t)i].prog;
+            if (!pr->done && opt.max_iter - pr->iter > 1) more = true;
+        }
+        if (!more) break;
+        enqueue_round(rounds);
+        rounds++;
+    }
+    {
+        rs_prof_scope ps(ctx, "K10_ba_finalize");
+        hipLaunchKernelGGL(ba_finalize_batch, dim3(16, 1, B), dim3(256), 0, s, d_wins, opt, rounds);
+    }
+    if (hipStreamSynchronize(s) != hipSuccess || hipGetLastError() != hipSuccess) { *rc_out = rs_fail(ctx, RS_ERR_HIP, "batched bundle adjustment"); return 0; }
+    for (int i = 0; i < B; i++) {
+        const BaState* h = wins[(size_t)i].h_st;
+        rs_ba_summary& o = out[i];
+        o.termination = h->termination; o.iterations = h->iter; o.successful_steps = h->successful; o.usable = h->usable;
+        o.initial_cost = h->initial_cost; o.final_cost = h->x_cost; o.final_radius = h->radius;
+    }
+    ctx->ba_trace = nullptr; ctx->ba_trace_n = 0; ctx->ba_cams = nullptr; ctx->ba_cams_n = 0;
+    ctx->ba_stats[0] = ctx->ba_stats[1] = ctx->ba_stats[2] = 0; ctx->ba_stats[3] = rounds;
+    return 0;
+}
+
 extern "C" int rs_bundle_adjust_batch(rs_context* ctx, int n_problems, const rs_ba_problem* h_problems,
                                       const rs_ba_options* options, rs_ba_summary* h_summaries)
 {
@@ -873,6 +1076,11 @@ extern "C" int rs_bundle_adjust_batch(rs_context* ctx, int n_problems, const rs_
     if (n_problems == 0) return RS_OK;
     if (rs_comm_active(ctx)) return rs_fail(ctx, RS_ERR_UNSUPPORTED, "batch of windows on a landmark-sharded context");
     RS_HIP(ctx, hipSetDevice(ctx->device));
+    for (int i = 0; i < n_problems; i++) memset(&h_summaries[i], 0, sizeof(rs_ba_summary));
+    if (ctx->ba_batch_mode == 0 && n_problems > 1) {
+        int rc = RS_OK;
+        if (ba_solve_batch_grid(ctx, n_problems, h_problems, options, h_summaries, &rc) == 0) return rc;
+    }
     const int lanes = n_problems < RS_BA_BATCH_LANES ? n_problems : RS_BA_BATCH_LANES;
     while ((int)ctx->batch_lanes.size() < lanes) {
         rs_context* c = nullptr;

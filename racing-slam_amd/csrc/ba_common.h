@@ -448,6 +448,35 @@ struct BaGroup {
 };
 
 
+// ---- one window of a BATCHED solve (rs_bundle_adjust_batch, grid mode): the kernels of B independent windows run as
+// ONE launch each, blockIdx.z = window; the per-window arguments live in a device array of these.  `b` holds the
+// pointers as carved (round parity 0); the double-buffered blocks are re-pointed per round by ba_win_round.
+struct BaWin {
+    BaDims d;
+    BaBufs b;
+    BaGroup g;
+    BaState* st_base; double* pts_base; BaSetOut* set_base; size_t pts_block;
+    BaProgress* prog;
+    const double* cams_in; const double* pts_in; unsigned long long free_mask; uint8_t* cam_free; int32_t* zero_ptr; int zero_n;
+    double* cams_out; double* pts_out; BaState* h_st; BaTrace* h_trace; double* h_cams;
+};
+__device__ __forceinline__ BaBufs ba_win_round(const BaWin& w, int it, bool last)
+{
+    BaBufs b = w.b;
+    b.st = w.st_base + (it & 1); b.st_prev = w.st_base + ((it + 1) & 1);
+    b.pt_scal = w.pts_base + (size_t)(it & 1) * w.pts_block; b.pt_prev = w.pts_base + (size_t)((it + 1) & 1) * w.pts_block;
+    b.set_out = w.set_base + (size_t)(it & 1) * BA_MAXSETS; b.set_prev = w.set_base + (size_t)((it + 1) & 1) * BA_MAXSETS;
+    b.prog = last ? nullptr : w.prog;
+    return b;
+}
+void ba_launch_grouping_batch(hipStream_t s, const BaWin* d_wins, int B, int max_P, int max_items);
+void ba_launch_schur_batch(hipStream_t s, const BaWin* d_wins, int B, const BaOpt& opt, int it, int max_items, int it_l, size_t lds);
+void ba_launch_reduced_solve_lds_batch(hipStream_t s, const BaWin* d_wins, int B, const BaOpt& opt, int it, int ns, int max_n);
+int ba_prepare_reduced_solve_lds_batch(int max_n);
+int ba_prepare_schur_batch(size_t lds);
+void ba_launch_backsub_batch(hipStream_t s, const BaWin* d_wins, int B, int it, int ns, int max_P, size_t lds);
+void ba_group_set_items(BaGroup* g, int P, bool throughput);   // landmarks per item: 64 in throughput mode, else as ba_group_carve chose
+
 size_t ba_group_bytes(int P, int Cf, int M);
 void ba_group_carve(char* base, int P, int Cf, int M, BaGroup* g);
 void ba_group_zero_range(const BaGroup& g, int32_t** ptr, int* count);

@@ -48,7 +48,7 @@ typedef __attribute__((ext_vector_type(4))) double d4;
 #define GRP_REP 8
 #define GRP_LDS_BINS 4096
 
-__global__ __launch_bounds__(256) void ba_group_count(BaDims d, BaBufs b, BaGroup g)
+static __device__ __forceinline__ void ba_group_count_body(const BaDims& d, const BaBufs& b, const BaGroup& g)
 {
     __shared__ int lh[GRP_LDS_BINS];
     const int nb = g.n_buckets + 1;
@@ -80,7 +80,7 @@ __global__ __launch_bounds__(256) void ba_group_count(BaDims d, BaBufs b, BaGrou
         for (int i = threadIdx.x; i < nb; i += blockDim.x) { const int v = lh[i]; if (v) atomicAdd(&hist[i], v); }
 }
 
-__global__ __launch_bounds__(1024) void ba_group_scan(BaGroup g)
+static __device__ __forceinline__ void ba_group_scan_body(const BaGroup& g)
 {
     // exclusive scan over (bucket-major, replica-minor) of hist[rep][bucket] into cursor[rep][bucket]
     __shared__ int wsum[16];
@@ -111,7 +111,7 @@ __global__ __launch_bounds__(1024) void ba_group_scan(BaGroup g)
 }
 
 
-__global__ __launch_bounds__(256) void ba_group_scatter(BaDims d, BaBufs b, BaGroup g)
+static __device__ __forceinline__ void ba_group_scatter_body(const BaDims& d, const BaBufs& b, const BaGroup& g)
 {
     const int p = blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= d.P) return;
@@ -123,7 +123,7 @@ __global__ __launch_bounds__(256) void ba_group_scatter(BaDims d, BaBufs b, BaGr
 }
 
 // one wave per item: lanes = the item's 64 landmarks, 128-bit OR across the wave
-__global__ __launch_bounds__(256) void ba_group_items(BaDims d, BaGroup g)
+static __device__ __forceinline__ void ba_group_items_body(const BaDims& d, const BaGroup& g)
 {
     const int t = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (t >= g.n_items) return;
@@ -622,6 +622,24 @@ __global__ __launch_bounds__(64 * SCH_WAVES) void ba_schur_mfma_big(BaDims d, Ba
     ba_schur_body<false>(d, b, opt, g, it);
 }
 
+
+// single-window and batched (blockIdx.z = window, arguments from the device array) entry points of the grouping kernels
+__global__ __launch_bounds__(256) void ba_group_count(BaDims d, BaBufs b, BaGroup g) { ba_group_count_body(d, b, g); }
+__global__ __launch_bounds__(1024) void ba_group_scan(BaGroup g) { ba_group_scan_body(g); }
+__global__ __launch_bounds__(256) void ba_group_scatter(BaDims d, BaBufs b, BaGroup g) { ba_group_scatter_body(d, b, g); }
+__global__ __launch_bounds__(256) void ba_group_items(BaDims d, BaGroup g) { ba_group_items_body(d, g); }
+__global__ __launch_bounds__(256) void ba_group_count_batch(const BaWin* w) { const BaWin& x = w[blockIdx.z]; if ((int)(blockIdx.x * 256) < x.d.P) ba_group_count_body(x.d, x.b, x.g); }
+__global__ __launch_bounds__(1024) void ba_group_scan_batch(const BaWin* w) { ba_group_scan_body(w[blockIdx.z].g); }
+__global__ __launch_bounds__(256) void ba_group_scatter_batch(const BaWin* w) { const BaWin& x = w[blockIdx.z]; ba_group_scatter_body(x.d, x.b, x.g); }
+__global__ __launch_bounds__(256) void ba_group_items_batch(const BaWin* w) { const BaWin& x = w[blockIdx.z]; ba_group_items_body(x.d, x.g); }
+__global__ __launch_bounds__(64 * SCH_WAVES) void ba_schur_mfma_batch(const BaWin* w, BaOpt opt, int it)
+{
+    const BaWin& x = w[blockIdx.z];
+    if ((int)blockIdx.x >= x.g.n_items) return;
+    const BaBufs b = ba_win_round(x, it, false);
+    ba_schur_body<true>(x.d, b, opt, x.g, it);
+}
+
 // ------------------------------------------------------------------ host glue
 size_t ba_group_bytes(int P, int Cf, int M)
 {
@@ -772,4 +790,30 @@ void ba_launch_schur(hipStream_t s, const BaDims& d, const BaBufs& b, const BaOp
         hipLaunchKernelGGL(ba_schur_mfma, dim3(g.n_items), dim3(8 * g.it_l), ba_schur_lds_bytes(d.C, d.Cf), s, d, b, opt, g, it);
     else
         hipLaunchKernelGGL(ba_schur_mfma_big, dim3(g.n_items), dim3(8 * g.it_l), ba_schur_lds_bytes(d.C, d.Cf), s, d, b, opt, g, it);
+}
+
+// ---- batched launches (one per kernel for B windows)
+void ba_launch_grouping_batch(hipStream_t s, const BaWin* d_wins, int B, int max_P, int max_items)
+{
+    const int pb = (max_P + 255) / 256;
+    hipLaunchKernelGGL(ba_group_count_batch, dim3(pb, 1, B), dim3(256), 0, s, d_wins);
+    hipLaunchKernelGGL(ba_group_scan_batch, dim3(1, 1, B), dim3(1024), 0, s, d_wins);
+    hipLaunchKernelGGL(ba_group_scatter_batch, dim3(pb, 1, B), dim3(256), 0, s, d_wins);
+    hipLaunchKernelGGL(ba_group_items_batch, dim3((max_items + 3) / 4, 1, B), dim3(256), 0, s, d_wins);
+}
+
+int ba_prepare_schur_batch(size_t lds)
+{
+    return (int)hipFuncSetAttribute((const void*)ba_schur_mfma_batch, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+}
+
+void ba_launch_schur_batch(hipStream_t s, const BaWin* d_wins, int B, const BaOpt& opt, int it, int max_items, int it_l, size_t lds)
+{
+    hipLaunchKernelGGL(ba_schur_mfma_batch, dim3(max_items, 1, B), dim3(8 * it_l), lds, s, d_wins, opt, it);
+}
+
+void ba_group_set_items(BaGroup* g, int P, bool throughput)
+{
+    g->it_l = throughput ? IT_L : (P <= 256 * IT_L_SMALL ? IT_L_SMALL : IT_L);
+    g->n_items = (P + g->it_l - 1) / g->it_l;
 }

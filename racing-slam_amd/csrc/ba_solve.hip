@@ -48,7 +48,7 @@ __device__ __forceinline__ double fast_rcp(double x)
 }
 
 
-__global__ __launch_bounds__(K7_THREADS) void ba_reduced_solve_lds(BaDims d, BaBufs b, BaOpt opt)
+static __device__ __forceinline__ void ba_reduced_solve_lds_body(const BaDims& d, const BaBufs& b, const BaOpt& opt)
 {
     extern __shared__ __attribute__((aligned(16))) double sm[];
     const int n = d.n, tid = threadIdx.x, nt = K7_THREADS;
@@ -515,6 +515,15 @@ __global__ __launch_bounds__(K7_THREADS) void ba_reduced_solve_lds(BaDims d, BaB
     BA_STAMP_FLUSH(b, 0);
 }
 
+__global__ __launch_bounds__(K7_THREADS) void ba_reduced_solve_lds(BaDims d, BaBufs b, BaOpt opt) { ba_reduced_solve_lds_body(d, b, opt); }
+// batched: blockIdx.x = speculative set, blockIdx.z = window
+__global__ __launch_bounds__(K7_THREADS) void ba_reduced_solve_lds_batch(const BaWin* w, BaOpt opt, int it)
+{
+    const BaWin& x = w[blockIdx.z];
+    const BaBufs b = ba_win_round(x, it, false);
+    ba_reduced_solve_lds_body(x.d, b, opt);
+}
+
 size_t ba_reduced_solve_lds_bytes(int n)
 {
     const int LD = n + 1 + ((n & 1) ? 1 : 0);
@@ -531,4 +540,14 @@ int ba_prepare_reduced_solve_lds(int n)
 {
     const size_t lds = ba_reduced_solve_lds_bytes(n);
     return (int)hipFuncSetAttribute((const void*)ba_reduced_solve_lds, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+}
+
+int ba_prepare_reduced_solve_lds_batch(int max_n)
+{
+    return (int)hipFuncSetAttribute((const void*)ba_reduced_solve_lds_batch, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ba_reduced_solve_lds_bytes(max_n));
+}
+
+void ba_launch_reduced_solve_lds_batch(hipStream_t s, const BaWin* d_wins, int B, const BaOpt& opt, int it, int ns, int max_n)
+{
+    hipLaunchKernelGGL(ba_reduced_solve_lds_batch, dim3(ns, 1, B), dim3(K7_THREADS), ba_reduced_solve_lds_bytes(max_n), s, d_wins, opt, it);
 }

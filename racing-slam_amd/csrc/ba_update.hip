@@ -13,7 +13,7 @@
 
 #define K8_THREADS 256
 
-__global__ __launch_bounds__(K8_THREADS) void ba_backsub_cost4(BaDims d, BaBufs b)
+static __device__ __forceinline__ void ba_backsub_cost4_body(const BaDims& d, const BaBufs& b)
 {
     extern __shared__ __attribute__((aligned(16))) double lds[];
     // ---- loads that depend on nothing but the landmark index go out first, together with the state block
@@ -146,6 +146,15 @@ __global__ __launch_bounds__(K8_THREADS) void ba_backsub_cost4(BaDims d, BaBufs 
     }
 }
 
+__global__ __launch_bounds__(K8_THREADS) void ba_backsub_cost4(BaDims d, BaBufs b) { ba_backsub_cost4_body(d, b); }
+// batched: blockIdx.x = landmark block, blockIdx.y = speculative set, blockIdx.z = window
+__global__ __launch_bounds__(K8_THREADS) void ba_backsub_cost4_batch(const BaWin* w, int it)
+{
+    const BaWin& x = w[blockIdx.z];
+    const BaBufs b = ba_win_round(x, it, false);
+    ba_backsub_cost4_body(x.d, b);
+}
+
 size_t ba_backsub_lds_bytes(int C, int n)
 {
     return sizeof(double) * (2 * (size_t)C * BA_PREP + (size_t)n + 8);
@@ -154,4 +163,10 @@ size_t ba_backsub_lds_bytes(int C, int n)
 void ba_launch_backsub(hipStream_t s, const BaDims& d, const BaBufs& b)
 {
     hipLaunchKernelGGL(ba_backsub_cost4, dim3((d.P + 63) / 64, b.ns), dim3(K8_THREADS), ba_backsub_lds_bytes(d.C, d.n), s, d, b);
+}
+
+void ba_launch_backsub_batch(hipStream_t s, const BaWin* d_wins, int B, int it, int ns, int max_P, size_t lds)
+{
+    if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void*)ba_backsub_cost4_batch, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(ba_backsub_cost4_batch, dim3((max_P + 63) / 64, ns, B), dim3(K8_THREADS), lds, s, d_wins, it);
 }

@@ -743,10 +743,14 @@ def test_bundle_adjust_inertial_rejects_bad_factors(ctx, rs, synth):
     assert np.array_equal(to_np(dc), w["cams"])
 
 
-def test_bundle_adjust_batch_of_windows(ctx, oracle, synth):
-    """rs_bundle_adjust_batch: 11 independent windows of different sizes (more than the 8 lanes, so lanes take several)
-    against single solves: identical schedules, values to summation-order noise; three of them against the oracle."""
+@pytest.mark.parametrize("mode", [0, 1])
+def test_bundle_adjust_batch_of_windows(ctx, oracle, synth, mode):
+    """rs_bundle_adjust_batch: 11 independent windows of different sizes against single solves: identical schedules,
+    values to summation-order noise; three of them against the oracle.  mode 0: ONE launch sequence for all windows
+    (blockIdx.z = window; mixed sizes share the grids of the largest); mode 1: the lanes (more windows than the 8
+    lanes, so lanes take several)."""
     import torch
+    ctx.set_int("ba_batch_mode", mode)
     kws = [dict(n_kf=6, n_points=200 + 37 * i, run_max=5, config_id=80 + i) for i in range(9)] + \
           [dict(), dict(n_kf=8, n_points=150, run_max=5, config_id=36, outlier_frac=0.1, rot_noise_deg=2.0)]
     ws = [synth.make_ba_window(**k) for k in kws]
@@ -773,6 +777,7 @@ def test_bundle_adjust_batch_of_windows(ctx, oracle, synth):
         assert (out[i]["iterations"], out[i]["successful_steps"]) == (rs_["iterations"], rs_["successful_steps"])
         assert np.allclose(to_np(keep[i][0]), rc, rtol=1e-6, atol=1e-8)
     assert ctx.bundle_adjust_batch([]) == []
+    ctx.set_int("ba_batch_mode", 0)
 
 
 def test_bundle_adjust_through_rccl_single_rank(ctx, rs, synth):
