@@ -277,6 +277,32 @@ def test_reproj_match_dense_candidates_and_ties(ctx, oracle, rs, synth):
         _reproj_case(ctx, oracle, rs, frame, mp, replace)
 
 
+def test_reproj_match_integer_pixels_long_tracks_crowded_discs(ctx, oracle, rs, synth):
+    """What the reference's front end really produces: GFTT corners are INTEGER pixels
+    (src/features/OrbFeatureExtractor.h:25-26), so equal coordinates in the KD-tree build and traversal are routine, not
+    a corner case; long-lived points carry more observations than K2 preloads (8) or handles per batch (16); and a
+    crowded disc holds more candidates than K2 queues (16: the on-the-spot path and its tie rule against the queue)."""
+    w = synth.make_ba_window(n_kf=24, n_points=1500, run_min=2, run_max=24, config_id=91)
+    frame, mp = synth.make_match_scene(w, n_keypoints=1800, kdtree_build=rs.kdtree_build, matched_frac=0.2, config_id=91)
+    assert np.diff(mp["obs_ptr"]).max() > 16
+    rng = np.random.default_rng(91)
+    kp = frame["keypoints"]
+    # 30 clusters of ~60 integer-pixel corners each within +-7 px: > 16 candidates inside most 20-px discs, many equal x or y
+    centres = kp[rng.integers(0, len(kp), 30)]
+    kp[:] = np.round(centres[rng.integers(0, 30, len(kp))] + rng.integers(-7, 8, kp.shape))
+    frame["descriptors"][:] = frame["descriptors"][rng.integers(0, 40, len(kp))]          # duplicated descriptors: distance ties
+    mp["desc_pool"][:] = frame["descriptors"][rng.integers(0, 40, len(mp["desc_pool"]))]
+    mp["desc_pool"] ^= rng.integers(0, 256, mp["desc_pool"].shape, dtype=np.uint8) & rng.integers(0, 256, mp["desc_pool"].shape, dtype=np.uint8) & 0x21
+    node_kp, left, right, root = rs.kdtree_build(kp)
+    frame.update(kd_node_kp=node_kp, kd_left=left, kd_right=right, kd_root=root)
+    o_kd = oracle.kdtree_build(kp)
+    assert np.array_equal(node_kp, o_kd[0]) and np.array_equal(left, o_kd[1]) and np.array_equal(right, o_kd[2]) and root == o_kd[3]
+    total = 0
+    for replace in (0, 1):
+        total += _reproj_case(ctx, oracle, rs, frame, mp, replace)
+    assert total > 20
+
+
 # ----------------------------------------------------------------------- BA
 def _ba_case(ctx, oracle, w, options=None, o_options=None):
     ref_c, ref_p, ref_s = oracle.bundle_adjust(w["cams"], w["cam_free"], w["points"], w["obs_ptr"], w["obs_cam"],
