@@ -608,8 +608,18 @@ def bench_ba(e, args, cfg):
 
                 n_rep = max(3, args.steps // 5)
                 dtb = timed(e, bstep, n_rep, 2)
-                batch["%s_B%d" % (tag, B)] = dict(windows=B, solves_per_s=B * n_rep / dtb, ms_per_call=1e3 * dtb / n_rep,
-                                                  speedup_vs_sequential=(B * n_rep / dtb) / (args.steps / elapsed))
+                ent = dict(windows=B, solves_per_s=B * n_rep / dtb, ms_per_call=1e3 * dtb / n_rep,
+                           speedup_vs_sequential=(B * n_rep / dtb) / (args.steps / elapsed))
+                if mode == 0:
+                    # what the batched grids do to the kernels: one launch serves B windows (same schedule per window as the
+                    # single solve above, so the per-window work of a K5 launch is k5_flops)
+                    pk = profiled(e, bstep, 2)
+                    k5 = pk.get("K5_ba_schur_mfma")
+                    if k5:
+                        ent["per_kernel_us"] = {k: round(v["avg_us"], 1) for k, v in sorted(pk.items())}
+                        ent["K5_tflops"] = B * k5_flops / (k5["avg_us"] * 1e-6) / 1e12
+                        ent["K5_frac_of_f64_mfma_peak"] = ent["K5_tflops"] / 78.6
+                batch["%s_B%d" % (tag, B)] = ent
         ctx.set_int("ba_batch_mode", 0)
         batch["note"] = ("B copies of the same cfg-3 window solved by one rs_bundle_adjust_batch call, incl. the 2B state-reset "
                          "copies.  grid: ONE launch sequence for all windows (blockIdx.z = window; the library's default); "

@@ -1397,6 +1397,7 @@ __global__ __launch_bounds__(RP_THREADS) void ba_refine_pose_inertial(BaDims d, 
                                                                      BaState* __restrict__ st_out)
 {
     __shared__ double x[9], xn[9], prep[BA_PREP], prepn[BA_PREP], scratch[4 * 32];
+    __shared__ double s_extr[9], s_extJ[9][IMU_NP];
     __shared__ BaState st;
     __shared__ double sc[9];
     const int tid = threadIdx.x;
@@ -1427,6 +1428,19 @@ __global__ __launch_bounds__(RP_THREADS) void ba_refine_pose_inertial(BaDims d, 
             for (int a = 0; a < 6; a++) acc[21 + a] += o.w * (o.jc[a] * o.r0 + o.jc[6 + a] * o.r1);
             acc[27] += 0.5 * o.rho;
         }
+        // the extra residual block at x: the first 32 lanes evaluate it with one partial per lane (imu_dual.h) and
+        // leave residual + Jacobian in LDS for the solving thread
+        if (tid < 32) {
+            if (ext->kind == 1) {
+                double r[3], jl[3];
+                imu_rotation_prior_lanes(ext->predicted, ext->sigma, x, r, jl);
+                for (int a = 0; a < 3; a++) { if (tid < 3) s_extJ[a][tid] = jl[a]; if (tid == 0) s_extr[a] = r[a]; }
+            } else {
+                double r[9], jl[9];
+                imu_preintegration_lanes(ext->fac, ext->gravity, ext->prev_pose, ext->prev_vel, ext->prev_bias, x, x + 6, r, jl);
+                for (int a = 0; a < 9; a++) { if (tid < IMU_NP) s_extJ[a][tid] = jl[a]; if (tid == 0) s_extr[a] = r[a]; }
+            }
+        }
         block_sum(acc, 28, scratch);
         if (tid == 0) {
             double H[9][9], gv[9], lam[9], dlt[9];
@@ -1436,23 +1450,18 @@ __global__ __launch_bounds__(RP_THREADS) void ba_refine_pose_inertial(BaDims d, 
                 for (int e = a; e < 6; e++) { H[a][e] = acc[q]; H[e][a] = acc[q]; q++; }
             for (int a = 0; a < 6; a++) gv[a] = acc[21 + a];
             double cost = acc[27];
-            // the extra residual block at x
             if (ext->kind == 1) {
-                double r[3], J[18];
-                imu_rotation_prior(ext->predicted, ext->sigma, x, r, J);
                 for (int a = 0; a < 3; a++) {
-                    cost += 0.5 * r[a] * r[a];
-                    for (int k = 0; k < 6; k++) { gv[k] += J[a * 6 + k] * r[a]; for (int l = 0; l < 6; l++) H[k][l] += J[a * 6 + k] * J[a * 6 + l]; }
+                    cost += 0.5 * s_extr[a] * s_extr[a];
+                    for (int k = 0; k < 3; k++) { gv[k] += s_extJ[a][k] * s_extr[a]; for (int l = 0; l < 3; l++) H[k][l] += s_extJ[a][k] * s_extJ[a][l]; }
                 }
             } else {
-                double r[9], J[9 * IMU_NP];
-                imu_preintegration(ext->fac, ext->gravity, ext->prev_pose, ext->prev_vel, ext->prev_bias, x, x + 6, r, J);
                 for (int a = 0; a < 9; a++) {
-                    cost += 0.5 * r[a] * r[a];
+                    cost += 0.5 * s_extr[a] * s_extr[a];
                     for (int k = 0; k < 9; k++) {            // local parameters 15..23 = pose_j (6), velocity_j (3)
-                        const double jk = J[a * IMU_NP + 15 + k];
-                        gv[k] += jk * r[a];
-                        for (int l = 0; l < 9; l++) H[k][l] += jk * J[a * IMU_NP + 15 + l];
+                        const double jk = s_extJ[a][15 + k];
+                        gv[k] += jk * s_extr[a];
+                        for (int l = 0; l < 9; l++) H[k][l] += jk * s_extJ[a][15 + l];
                     }
                 }
             }

@@ -630,7 +630,7 @@ __device__ __forceinline__ void imu_columns(const BaDims& d, const BaBufs& b, in
     for (int k = 0; k < 3; k++) { col[6 + k] = n6 + 9 * qi + k; col[21 + k] = n6 + 9 * qj + k; }
 }
 
-__global__ __launch_bounds__(1024) void ba_imu_prologue(BaDims d, BaBufs b, BaOpt opt, BigBufs g)
+__global__ __launch_bounds__(512) void ba_imu_prologue(BaDims d, BaBufs b, BaOpt opt, BigBufs g)
 {
     const int n6 = d.n, N = b.imu.N, tid = threadIdx.x, nt = blockDim.x;
     __shared__ BaState st;
@@ -652,36 +652,51 @@ __global__ __launch_bounds__(1024) void ba_imu_prologue(BaDims d, BaBufs b, BaOp
     // ---- linearise the factors at x: J^T J into the lower triangle of A, J^T r into gtot, 1/2 |r|^2 into the cost
     const double* Xc = b.Xc + (size_t)st.cur * d.C * 6;
     const double* Xv = b.imu.Xv + (size_t)st.cur * d.C * 9;
-    if (tid < b.imu.n_fac) {
-        const ImuFactorDev& F = b.imu.fac[tid];
-        const int i = F.f.cam_i, j = F.f.cam_j;
-        double r[9], rw[6], is[2];
-        double* J = b.imu.Jf + (size_t)tid * 9 * IMU_NP;
-        imu_preintegration(F, b.imu.gravity, Xc + 6 * i, Xv + 9 * i, Xv + 9 * i + 3, Xc + 6 * j, Xv + 9 * j, r, J);
-        imu_bias_walk(F.f, Xv + 9 * i + 3, Xv + 9 * j + 3, rw, is);
-        int col[IMU_NP];
-        imu_columns(d, b, i, j, col);
-        double c = 0.0;
-        for (int a = 0; a < 9; a++) {
-            c += 0.5 * r[a] * r[a];
-            for (int k = 0; k < IMU_NP; k++) {
-                const double jk = J[a * IMU_NP + k];
-                atomicAdd(&b.imu.gtot[col[k]], jk * r[a]);
-                for (int l = 0; l < IMU_NP; l++)
-                    if (col[k] >= col[l]) atomicAdd(&b.imu.A[(size_t)col[k] * N + col[l]], jk * J[a * IMU_NP + l]);
+    // One 32-lane group per factor pair, lane k = local parameter k (24 of them): the functor runs on DualLane (value +
+    // this lane's partial), so the lane ends up with its COLUMN of the whitened 9 x 24 Jacobian in nine registers.  J^T J:
+    // lane k fetches the other columns with shuffles and adds its row of the 24 x 24 block.  (One thread per factor with
+    // all 24 partials and ~2800 serial atomics took 1.4 ms per launch.)
+    {
+        const int grp = tid >> 5, lk = tid & 31;
+        for (int fi = grp; fi < b.imu.n_fac; fi += nt >> 5) {
+            const ImuFactorDev& F = b.imu.fac[fi];
+            const int i = F.f.cam_i, j = F.f.cam_j;
+            double r[9], jl[9], rw[6], is[2];
+            imu_preintegration_lanes(F, b.imu.gravity, Xc + 6 * i, Xv + 9 * i, Xv + 9 * i + 3, Xc + 6 * j, Xv + 9 * j, r, jl);
+            imu_bias_walk(F.f, Xv + 9 * i + 3, Xv + 9 * j + 3, rw, is);
+            int col[IMU_NP];
+            imu_columns(d, b, i, j, col);
+            int mycol = 0;
+#pragma unroll
+            for (int k = 0; k < IMU_NP; k++) mycol = (lk == k) ? col[k] : mycol;
+            double gk = 0.0;
+#pragma unroll
+            for (int a = 0; a < 9; a++) gk += jl[a] * r[a];
+            if (lk < IMU_NP) atomicAdd(&b.imu.gtot[mycol], gk);
+#pragma unroll
+            for (int l = 0; l < IMU_NP; l++) {
+                double h = 0.0;
+#pragma unroll
+                for (int a = 0; a < 9; a++) h += jl[a] * __shfl(jl[a], l, 32);
+                if (lk < IMU_NP && mycol >= col[l]) atomicAdd(&b.imu.A[(size_t)mycol * N + col[l]], h);
+            }
+            if (lk < 6) {                                   // bias walk: -1/sigma on bias_i[a], +1/sigma on bias_j[a]
+                const int a = lk;
+                const double sg = is[a / 3], s2 = sg * sg;
+                const int ci = n6 + 9 * b.imu.inert_slot[i] + 3 + a, cj = n6 + 9 * b.imu.inert_slot[j] + 3 + a;
+                atomicAdd(&b.imu.gtot[ci], -sg * rw[a]);
+                atomicAdd(&b.imu.gtot[cj], sg * rw[a]);
+                atomicAdd(&b.imu.A[(size_t)ci * N + ci], s2);
+                atomicAdd(&b.imu.A[(size_t)cj * N + cj], s2);
+                atomicAdd(&b.imu.A[(size_t)max(ci, cj) * N + min(ci, cj)], -s2);
+            }
+            if (lk == 0) {
+                double c = 0.0;
+                for (int a = 0; a < 9; a++) c += 0.5 * r[a] * r[a];
+                for (int a = 0; a < 6; a++) c += 0.5 * rw[a] * rw[a];
+                atomicAdd(&s_cost, c);
             }
         }
-        for (int a = 0; a < 6; a++) {                       // bias walk: -1/sigma on bias_i[a], +1/sigma on bias_j[a]
-            c += 0.5 * rw[a] * rw[a];
-            const double sg = is[a / 3], s2 = sg * sg;
-            const int ci = col[9 + a], cj = n6 + 9 * b.imu.inert_slot[j] + 3 + a;
-            atomicAdd(&b.imu.gtot[ci], -sg * rw[a]);
-            atomicAdd(&b.imu.gtot[cj], sg * rw[a]);
-            atomicAdd(&b.imu.A[(size_t)ci * N + ci], s2);
-            atomicAdd(&b.imu.A[(size_t)cj * N + cj], s2);
-            atomicAdd(&b.imu.A[(size_t)max(ci, cj) * N + min(ci, cj)], -s2);
-        }
-        atomicAdd(&s_cost, c);
     }
     __syncthreads();
     // ---- totals per column: diagonal of J^T J, gradient; Jacobi scale (first linearisation), damping, right-hand side
@@ -718,10 +733,17 @@ __global__ __launch_bounds__(1024) void ba_imu_prologue(BaDims d, BaBufs b, BaOp
     if (tid == 0) *b.st = st;
     if (st.done) return;
     __syncthreads();
-    // ---- the lower triangle of the damped matrix: inertial part (already there) + U + S_schur (pose part) + Lambda
-    for (size_t idx = tid; idx < (size_t)N * N; idx += nt) {
-        const int i = (int)(idx / N), j = (int)(idx % N);
-        if (i < j) continue;
+}
+
+// the lower triangle of the damped matrix: inertial part (already there) + U + S_schur (pose part) + Lambda.  A grid of
+// its own: one workgroup streaming the N x N matrix with a load in flight per thread took 130 us of the prologue.
+__global__ __launch_bounds__(256) void ba_imu_assemble(BaDims d, BaBufs b)
+{
+    if (b.st->done) return;
+    const int n6 = d.n, N = b.imu.N;
+    const int i = blockIdx.x, tid = threadIdx.x;             // one row per workgroup
+    for (int j = tid; j <= i; j += blockDim.x) {
+        const size_t idx = (size_t)i * N + j;
         double v = b.imu.A[idx];
         if (i < n6) {                                       // j <= i < n6: both are pose columns
             v += b.S[(size_t)j * n6 + i];                   // K5 accumulates S in its upper triangle
@@ -792,8 +814,8 @@ __global__ __launch_bounds__(1024) void ba_imu_finish(BaDims d, BaBufs b, BaOpt 
         cam_prepare(Xn + 6 * c, b.prep + ((size_t)(st.cur ^ 1) * d.C + c) * BA_PREP);
     }
     __syncthreads();                                         // candidates written (same workgroup reads them below)
-    if (tid < b.imu.n_fac) {                                // cost of the inertial blocks at the candidate
-        const ImuFactorDev& F = b.imu.fac[tid];
+    for (int fi = tid; fi < b.imu.n_fac; fi += nt) {        // cost of the inertial blocks at the candidate (values only)
+        const ImuFactorDev& F = b.imu.fac[fi];
         const int i = F.f.cam_i, j = F.f.cam_j;
         double r[9], rw[6], is[2], c = 0.0;
         imu_preintegration(F, b.imu.gravity, Xn + 6 * i, Xvn + 9 * i, Xvn + 9 * i + 3, Xn + 6 * j, Xvn + 9 * j, r, nullptr);
@@ -853,7 +875,8 @@ int ba_launch_reduced_solve_inertial(rs_context* ctx, const BaDims& d, const BaB
         RS_HIP(ctx, hipFuncSetAttribute((const void*)ba_imu_finish, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_fin));
     const size_t lds_upd = sizeof(double) * (6 * BB * BBS + 2 * BB * 17 + BB);
     RS_HIP(ctx, hipFuncSetAttribute((const void*)ba_big_update, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_upd));
-    hipLaunchKernelGGL(ba_imu_prologue, dim3(1), dim3(1024), 0, s, d, b, opt, g);
+    hipLaunchKernelGGL(ba_imu_prologue, dim3(1), dim3(512), 0, s, d, b, opt, g);
+    hipLaunchKernelGGL(ba_imu_assemble, dim3(N), dim3(256), 0, s, d, b);
     // the factorisation runs on the N x N system: same kernels, their view of (n, matrix, right-hand side) swapped
     BaDims dN = d;
     dN.n = N;
