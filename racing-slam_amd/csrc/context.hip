@@ -62,6 +62,7 @@ extern "C" int rs_context_destroy(rs_context* ctx)
     arena_free(ctx->stage_pin, true);
     if (ctx->ws) (void)hipFree(ctx->ws);
     if (ctx->prop) (void)hipFree(ctx->prop);
+    if (ctx->k1_top) (void)hipFree(ctx->k1_top);
     if (ctx->pinned) (void)hipHostFree(ctx->pinned);
     for (auto& s : ctx->prof)
         for (auto e : s.ev) (void)hipEventDestroy(e);

@@ -27,7 +27,7 @@ __device__ __forceinline__ void top2_insert(uint32_t& k0, uint32_t& k1, uint32_t
 
 __global__ __launch_bounds__(64 * K1_WAVES) void k1_hamming_knn2(
     const uint4* __restrict__ query, int nq, const uint4* __restrict__ train, int nt,
-    int rows_per_wave, int nsplit, int nqb, int xcd_groups, uint2* __restrict__ part)
+    int rows_per_wave, int nsplit, int nqb, int xcd_groups, uint2* __restrict__ top)
 {
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -80,18 +80,32 @@ __global__ __launch_bounds__(64 * K1_WAVES) void k1_hamming_knn2(
             top2_insert(k0, k1, sk[w][0][lane]);
             top2_insert(k0, k1, sk[w][1][lane]);
         }
-        if (qi < nq) part[((size_t)b * nsplit + split) * nq + qi] = make_uint2(k0, k1);
+        // Merge into the per-query table {best, second} (all-ones before the launch).  Keys are unique (the train index
+        // sits in the low bits), so the table's top-2 of the union of all splits' top-2 is: best = min over the k0s;
+        // second = min over every k1 and every LOSER of a best-update — whichever of (old, new) a min displaced or
+        // failed to displace is a union element other than the final best, and the true second is among them.
+        if (qi < nq) {
+            uint32_t* t = (uint32_t*)&top[(size_t)b * nq + qi];
+            if (nsplit == 1) { t[0] = k0; t[1] = k1; }
+            else {
+                if (k0 != K1_KEY_NONE) {
+                    const uint32_t old = atomicMin(&t[0], k0);
+                    const uint32_t loser = max(old, k0);
+                    if (loser != K1_KEY_NONE) atomicMin(&t[1], loser);
+                }
+                if (k1 != K1_KEY_NONE) atomicMin(&t[1], k1);
+            }
+        }
     }
 }
 
-// One workgroup per batch item: merge the split partials, decode, apply the
-// filters of src/MapMatcher.cpp:150-161 and emit the accepted matches in
-// ascending query order.  Every thread owns a CONTIGUOUS chunk of queries (<= K1B_CH per pass), all partial loads
-// of a pass are issued together (their latencies overlap), and the ordered compaction is one workgroup scan per
-// pass: one pass for up to 4096 queries (2000 at the metric's size: two queries per thread).
+// One workgroup per batch item: read the merged {best, second} keys (and put the table back to all-ones), decode, apply
+// the filters of src/MapMatcher.cpp:150-161 and emit the accepted matches in ascending query order.  Every thread owns a
+// CONTIGUOUS chunk of queries (<= K1B_CH per pass); the ordered compaction is one workgroup scan per pass: one pass for
+// up to 4096 queries (2000 at the metric's size: two queries per thread).
 #define K1B_CH 4
 __global__ __launch_bounds__(1024) void k1_merge_filter(
-    const uint2* __restrict__ part, int nq, int nt, int nsplit, int max_distance, int do_filter,
+    uint2* __restrict__ top, int nq, int nt, int max_distance, int do_filter,
     int32_t* __restrict__ idx0, int32_t* __restrict__ dist0, int32_t* __restrict__ idx1,
     int32_t* __restrict__ dist1, int32_t* __restrict__ match_query, int32_t* __restrict__ match_train,
     int32_t* __restrict__ match_count)
@@ -104,22 +118,14 @@ __global__ __launch_bounds__(1024) void k1_merge_filter(
         const int q0 = base + (int)threadIdx.x * ch;
         uint32_t k0[K1B_CH], k1[K1B_CH];
 #pragma unroll
-        for (int u = 0; u < K1B_CH; u++) { k0[u] = K1_KEY_NONE; k1[u] = K1_KEY_NONE; }
-        for (int s0 = 0; s0 < nsplit; s0 += 8) {
-            uint2 pv[K1B_CH][8];
-#pragma unroll
-            for (int u = 0; u < K1B_CH; u++)
-#pragma unroll
-                for (int s = 0; s < 8; s++) {
-                    const int qi = min(q0 + u, nq - 1), sp = min(s0 + s, nsplit - 1);     // clamped: no branches around the loads
-                    pv[u][s] = part[((size_t)b * nsplit + sp) * nq + qi];
-                }
-#pragma unroll
-            for (int u = 0; u < K1B_CH; u++)
-#pragma unroll
-                for (int s = 0; s < 8; s++)
-                    if (s0 + s < nsplit) { top2_insert(k0[u], k1[u], pv[u][s].x); top2_insert(k0[u], k1[u], pv[u][s].y); }
+        for (int u = 0; u < K1B_CH; u++) {
+            const int qi = min(q0 + u, nq - 1);              // clamped: no branches around the loads
+            const uint2 v = top[(size_t)b * nq + qi];
+            k0[u] = v.x; k1[u] = v.y;
         }
+#pragma unroll
+        for (int u = 0; u < K1B_CH; u++)
+            if (u < ch && q0 + u < base + span) top[(size_t)b * nq + q0 + u] = make_uint2(K1_KEY_NONE, K1_KEY_NONE);
         int cnt = 0;
         bool ok[K1B_CH];
 #pragma unroll
@@ -180,9 +186,17 @@ static int knn2_launch(rs_context* ctx, const uint8_t* d_query, int nq, const ui
     if (nsplit < 1) nsplit = 1;
     const int rows_per_wave = (nt + nsplit * K1_WAVES - 1) / (nsplit * K1_WAVES);
     if ((size_t)nqb * nsplit * batch > 0x7fffffffu) return rs_fail(ctx, RS_ERR_UNSUPPORTED, "too many query blocks for one launch");
-    void* ws = nullptr;
-    int rc = rs_workspace(ctx, sizeof(uint2) * (size_t)batch * nsplit * nq, &ws);
-    if (rc) return rc;
+    const size_t need = (size_t)batch * nq;
+    if (need > ctx->k1_top_cap) {        // grow-only; all-ones once, every call leaves it all-ones again
+        RS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        if (ctx->k1_top) RS_HIP(ctx, hipFree(ctx->k1_top));
+        ctx->k1_top = nullptr; ctx->k1_top_cap = 0;
+        const size_t cap = (need + 4095) & ~(size_t)4095;
+        if (hipMalloc(&ctx->k1_top, sizeof(uint2) * cap) != hipSuccess) return rs_fail(ctx, RS_ERR_NOMEM, "top-2 table of %zu entries", cap);
+        RS_HIP(ctx, hipMemsetAsync(ctx->k1_top, 0xFF, sizeof(uint2) * cap, ctx->stream));
+        ctx->k1_top_cap = cap;
+    }
+    void* ws = ctx->k1_top;
     {
         rs_prof_scope ps(ctx, "K1_hamming_knn2");
         hipLaunchKernelGGL(k1_hamming_knn2, dim3((unsigned)((size_t)nqb * nsplit * batch)), dim3(64 * K1_WAVES), 0, ctx->stream,
@@ -191,8 +205,8 @@ static int knn2_launch(rs_context* ctx, const uint8_t* d_query, int nq, const ui
     }
     {
         rs_prof_scope ps(ctx, "K1b_merge_filter");
-        hipLaunchKernelGGL(k1_merge_filter, dim3(batch), dim3(1024), 0, ctx->stream, (const uint2*)ws, nq, nt,
-                           nsplit, max_distance, do_filter, i0, d0, i1, d1, mq, mt, mc);
+        hipLaunchKernelGGL(k1_merge_filter, dim3(batch), dim3(1024), 0, ctx->stream, (uint2*)ws, nq, nt,
+                           max_distance, do_filter, i0, d0, i1, d1, mq, mt, mc);
     }
     RS_HIP(ctx, hipGetLastError());
     return RS_OK;
