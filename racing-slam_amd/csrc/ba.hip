@@ -557,6 +557,60 @@ static void imu_whitener(const double cov[81], double W[81])
         }
 }
 
+// Workspace layout of one window (all offsets multiples of 256 B) and the BaBufs pointers into it: shared by the single
+// solve and by every window of a batched solve.
+struct BaLayout {
+    size_t Xc, Xp, prep, slot, sc, sp, Vinv, gp, lamp, Vc, Ukeep, acc, pts, dc, st, set, trace, dbg, fre, grp;
+    size_t bytes;                       // end of the common part (callers may carve more behind it)
+    size_t acc_count, cam_stride, pts_block;
+};
+static BaLayout ba_layout(const BaDims& d, int ns, int max_iter, size_t n_ranks, size_t grp_bytes)
+{
+    BaLayout L;
+    const size_t n = (size_t)d.n, C = (size_t)d.C, P = (size_t)d.P, nb = (size_t)ns + 1;
+    size_t off = 0;
+    auto carve = [&](size_t bytes) { size_t o = off; off += align_up(bytes, 256); return o; };
+    L.Xc = carve(sizeof(double) * nb * C * 6); L.Xp = carve(sizeof(double) * nb * P * 3);
+    L.prep = carve(sizeof(double) * nb * C * BA_PREP); L.slot = carve(sizeof(int32_t) * C);
+    L.sc = carve(sizeof(double) * (n + 1)); L.sp = carve(sizeof(double) * P * 3);
+    L.Vinv = carve(sizeof(double) * ns * P * 6); L.gp = carve(sizeof(double) * P * 3);
+    L.lamp = carve(sizeof(double) * ns * P * 3);
+    L.Vc = carve(sizeof(double) * P * 6); L.Ukeep = carve(sizeof(double) * ((size_t)d.Cf * 36 + n + 1));
+    L.cam_stride = (size_t)ns * n + (size_t)d.Cf * 36 + n;
+    L.acc_count = (size_t)ns * n * n + (size_t)BA_UREP * L.cam_stride + (1 + n_ranks) * (size_t)BA_NSLOT * BA_SLOT_STRIDE;
+    L.acc = carve(sizeof(double) * L.acc_count);
+    L.pts_block = (size_t)ns * BA_NSLOT * BA_SLOT_STRIDE;
+    L.pts = carve(sizeof(double) * 2 * L.pts_block); L.dc = carve(sizeof(double) * ns * (n + 2));
+    L.st = carve(sizeof(BaState) * 2);
+    L.set = carve(sizeof(BaSetOut) * 2 * BA_MAXSETS);
+    L.trace = carve(sizeof(BaTrace) * (size_t)(max_iter + 1));
+    L.dbg = carve(sizeof(unsigned long long) * 64);
+    L.fre = carve(C);
+    L.grp = carve(grp_bytes);
+    L.bytes = off;
+    return L;
+}
+// pointers of round parity 0 (the double-buffered blocks are re-pointed per round); rank = this rank's gradient-max block
+static void ba_bind(BaBufs& b, char* ws, const BaLayout& L, const BaDims& d, int ns, int n_ranks, int rank)
+{
+    const size_t n = (size_t)d.n;
+    b.ns = ns;
+    b.Xc = (double*)(ws + L.Xc); b.Xp = (double*)(ws + L.Xp); b.prep = (double*)(ws + L.prep);
+    b.slot = (int32_t*)(ws + L.slot); b.sc = (double*)(ws + L.sc); b.sp = (double*)(ws + L.sp);
+    b.Vinv = (double*)(ws + L.Vinv); b.gp = (double*)(ws + L.gp); b.lamp = (double*)(ws + L.lamp);
+    b.Vc = (double*)(ws + L.Vc); b.Ukeep = (double*)(ws + L.Ukeep);
+    b.acc = (double*)(ws + L.acc); b.acc_count = L.acc_count;
+    b.S = b.acc; b.rhs = b.S + (size_t)ns * n * n; b.U = b.rhs + (size_t)ns * n; b.gc = b.U + (size_t)d.Cf * 36;
+    b.cam_stride = L.cam_stride; b.scal = b.rhs + (size_t)BA_UREP * L.cam_stride;
+    b.gmax_all = b.scal + (size_t)BA_NSLOT * BA_SLOT_STRIDE; b.gmax_blocks = n_ranks;
+    b.gmax = b.gmax_all + (size_t)rank * BA_NSLOT * BA_SLOT_STRIDE;
+    b.pt_scal = (double*)(ws + L.pts); b.pt_prev = b.pt_scal; b.dc = (double*)(ws + L.dc);
+    b.st = (BaState*)(ws + L.st); b.st_prev = b.st;
+    b.trace = (BaTrace*)(ws + L.trace);
+    b.set_out = (BaSetOut*)(ws + L.set); b.set_prev = b.set_out;
+    b.dbg = (unsigned long long*)(ws + L.dbg);
+}
+
 static int ba_solve_impl(rs_context* ctx, int n_cameras, int n_points, int n_obs, double* d_cameras,
                          const uint8_t* h_cam_free, double* d_points, const int32_t* d_obs_ptr,
                          const int32_t* d_obs_cam, const float* d_obs_uv, const float h_intrinsics[4],
@@ -622,57 +676,23 @@ static int ba_solve_impl(rs_context* ctx, int n_cameras, int n_points, int n_obs
         if (ns > BA_MAXSETS) ns = BA_MAXSETS;
         if (ns > opt.max_iter) ns = opt.max_iter > 0 ? opt.max_iter : 1;
     }
-    // workspace carve (all offsets multiples of 256 B)
-    const size_t n = (size_t)d.n, C = (size_t)d.C, P = (size_t)d.P;
-    const size_t nb = (size_t)ns + 1;
-    size_t off = 0;
-    auto carve = [&](size_t bytes) { size_t o = off; off += align_up(bytes, 256); return o; };
-    const size_t o_Xc = carve(sizeof(double) * nb * C * 6), o_Xp = carve(sizeof(double) * nb * P * 3);
-    const size_t o_prep = carve(sizeof(double) * nb * C * BA_PREP), o_slot = carve(sizeof(int32_t) * C);
-    const size_t o_sc = carve(sizeof(double) * (n + 1)), o_sp = carve(sizeof(double) * P * 3);
-    const size_t o_Vinv = carve(sizeof(double) * ns * P * 6), o_gp = carve(sizeof(double) * P * 3);
-    const size_t o_lamp = carve(sizeof(double) * ns * P * 3);
-    const size_t o_Vc = carve(sizeof(double) * P * 6), o_Ukeep = carve(sizeof(double) * ((size_t)d.Cf * 36 + n + 1));
-    const size_t cam_stride = (size_t)ns * n + (size_t)d.Cf * 36 + n;
+    const size_t C = (size_t)d.C;
     const size_t n_ranks = rs_comm_active(ctx) ? (size_t)ctx->n_ranks : 1;
-    const size_t acc_count = (size_t)ns * n * n + (size_t)BA_UREP * cam_stride + (1 + n_ranks) * (size_t)BA_NSLOT * BA_SLOT_STRIDE;
-    const size_t o_acc = carve(sizeof(double) * acc_count);
-    const size_t pts_block = (size_t)ns * BA_NSLOT * BA_SLOT_STRIDE;
-    const size_t o_pts = carve(sizeof(double) * 2 * pts_block), o_dc = carve(sizeof(double) * ns * (n + 2));
-    const size_t o_st = carve(sizeof(BaState) * 2);
-    const size_t o_set = carve(sizeof(BaSetOut) * 2 * BA_MAXSETS);
-    const size_t o_trace = carve(sizeof(BaTrace) * (size_t)(opt.max_iter + 1));
-    const size_t o_dbg = carve(sizeof(unsigned long long) * 64);
-    const size_t o_free = carve(C);
-    const size_t o_grp = carve(use_mfma ? ba_group_bytes(d.P, d.Cf, d.M) : 16);
-    const size_t o_big = carve(in ? ba_inertial_bytes(N_in, in->n_factors, d.C) : (solve_big ? ba_big_bytes(d.n) : 16));
+    const BaLayout L = ba_layout(d, ns, opt.max_iter, n_ranks, use_mfma ? ba_group_bytes(d.P, d.Cf, d.M) : 16);
+    const size_t o_grp = L.grp, o_free = L.fre, pts_block = L.pts_block;
+    const size_t o_big = L.bytes;
+    const size_t ws_bytes = L.bytes + align_up(in ? ba_inertial_bytes(N_in, in->n_factors, d.C) : (solve_big ? ba_big_bytes(d.n) : 16), 256);
     void* wsv = nullptr;
-    int rc = rs_workspace(ctx, off, &wsv);
+    int rc = rs_workspace(ctx, ws_bytes, &wsv);
     if (rc) return rc;
     char* ws = (char*)wsv;
     BaBufs b;
-    b.ns = ns;
     memset(&b.imu, 0, sizeof b.imu);
     b.obs_ptr = d_obs_ptr; b.obs_cam = d_obs_cam; b.obs_uv = (const float2*)d_obs_uv;
-    b.Xc = (double*)(ws + o_Xc); b.Xp = (double*)(ws + o_Xp); b.prep = (double*)(ws + o_prep);
-    b.slot = (int32_t*)(ws + o_slot); b.sc = (double*)(ws + o_sc); b.sp = (double*)(ws + o_sp);
-    b.Vinv = (double*)(ws + o_Vinv); b.gp = (double*)(ws + o_gp); b.lamp = (double*)(ws + o_lamp);
-    b.Vc = (double*)(ws + o_Vc); b.Ukeep = (double*)(ws + o_Ukeep);
-    b.acc = (double*)(ws + o_acc); b.acc_count = acc_count;
-    b.S = b.acc; b.rhs = b.S + (size_t)ns * n * n; b.U = b.rhs + (size_t)ns * n; b.gc = b.U + (size_t)d.Cf * 36;
-    b.cam_stride = cam_stride; b.scal = b.rhs + (size_t)BA_UREP * cam_stride;
-    b.gmax_all = b.scal + (size_t)BA_NSLOT * BA_SLOT_STRIDE; b.gmax_blocks = (int)n_ranks;
-    b.gmax = b.gmax_all + (size_t)(rs_comm_active(ctx) ? ctx->rank : 0) * BA_NSLOT * BA_SLOT_STRIDE;
-    b.pt_scal = (double*)(ws + o_pts); b.dc = (double*)(ws + o_dc);
-    b.st = (BaState*)(ws + o_st);
-    b.trace = (BaTrace*)(ws + o_trace);
-    b.st_prev = b.st;
-    b.pt_prev = b.pt_scal;
-    b.set_out = (BaSetOut*)(ws + o_set); b.set_prev = b.set_out;
+    ba_bind(b, ws, L, d, ns, (int)n_ranks, rs_comm_active(ctx) ? ctx->rank : 0);
     BaState* const st_base = b.st;
     double* const pts_base = b.pt_scal;
     BaSetOut* const set_base = b.set_out;
-    b.dbg = (unsigned long long*)(ws + o_dbg);
 #if RS_STAMPS
     RS_HIP(ctx, hipMemsetAsync(b.dbg, 0, sizeof(unsigned long long) * 64, ctx->stream));
 #endif
@@ -918,8 +938,7 @@ static int ba_solve_batch_grid(rs_context* ctx, int B, const rs_ba_problem* Q, c
     size_t ws_total = align_up(sizeof(BaWin) * (size_t)B, 256), pin_total = 0;
     int max_P = 0, max_items = 0, max_n = 0, max_C = 0;
     size_t k5_lds = 0, k8_lds = 0;
-    struct Lay { size_t Xc, Xp, prep, slot, sc, sp, Vinv, gp, lamp, Vc, Ukeep, acc, pts, dc, st, set, trace, dbg, fre, grp, total, acc_count, cam_stride, pts_block; };
-    std::vector<Lay> lay((size_t)B);
+    std::vector<BaLayout> lay((size_t)B);
     for (int i = 0; i < B; i++) {
         const rs_ba_problem& q = Q[i];
         if (q.n_cameras <= 0 || q.n_points <= 0 || q.n_obs <= 0 || q.n_cameras > 64) return 1;
@@ -937,28 +956,11 @@ static int ba_solve_batch_grid(rs_context* ctx, int B, const rs_ba_problem* Q, c
         const bool use_mfma = d.Cf >= 1 && ba_schur_lds_bytes(d.C, d.Cf) <= 160 * 1024;
         if (!use_mfma || ba_backsub_lds_bytes(d.C, d.n) > 64 * 1024 || d.n < 6 || d.n > BA_MAX_LDS_N) return 1;
         w.free_mask = mask;
-        // the single-window layout (ba_solve_impl), one copy per window
-        const size_t n = (size_t)d.n, C = (size_t)d.C, P = (size_t)d.P, nb = (size_t)ns + 1;
-        Lay& L = lay[(size_t)i];
-        size_t off = 0;
-        auto carve = [&](size_t bytes) { size_t o = off; off += align_up(bytes, 256); return o; };
-        L.Xc = carve(sizeof(double) * nb * C * 6); L.Xp = carve(sizeof(double) * nb * P * 3);
-        L.prep = carve(sizeof(double) * nb * C * BA_PREP); L.slot = carve(sizeof(int32_t) * C);
-        L.sc = carve(sizeof(double) * (n + 1)); L.sp = carve(sizeof(double) * P * 3);
-        L.Vinv = carve(sizeof(double) * ns * P * 6); L.gp = carve(sizeof(double) * P * 3);
-        L.lamp = carve(sizeof(double) * ns * P * 3);
-        L.Vc = carve(sizeof(double) * P * 6); L.Ukeep = carve(sizeof(double) * ((size_t)d.Cf * 36 + n + 1));
-        L.cam_stride = (size_t)ns * n + (size_t)d.Cf * 36 + n;
-        L.acc_count = (size_t)ns * n * n + (size_t)BA_UREP * L.cam_stride + 2 * (size_t)BA_NSLOT * BA_SLOT_STRIDE;
-        L.acc = carve(sizeof(double) * L.acc_count);
-        L.pts_block = (size_t)ns * BA_NSLOT * BA_SLOT_STRIDE;
-        L.pts = carve(sizeof(double) * 2 * L.pts_block); L.dc = carve(sizeof(double) * ns * (n + 2));
-        L.st = carve(sizeof(BaState) * 2); L.set = carve(sizeof(BaSetOut) * 2 * BA_MAXSETS);
-        L.trace = carve(sizeof(BaTrace) * (size_t)(opt.max_iter + 1)); L.dbg = carve(sizeof(unsigned long long) * 64);
-        L.fre = carve(C); L.grp = carve(ba_group_bytes(d.P, d.Cf, d.M));
-        L.total = off;
+        const size_t C = (size_t)d.C;
+        lay[(size_t)i] = ba_layout(d, ns, opt.max_iter, 1, ba_group_bytes(d.P, d.Cf, d.M));   // the single solve's layout, one copy per window
+        const BaLayout& L = lay[(size_t)i];
         ws_off[(size_t)i] = ws_total;
-        ws_total += L.total;
+        ws_total += L.bytes;
         pin_off[(size_t)i] = pin_total;
         pin_total += align_up(sizeof(BaState), 64) + 64 + align_up(sizeof(BaTrace) * (size_t)(opt.max_iter + 1), 64) + align_up(sizeof(double) * 6 * C, 64);
         max_P = std::max(max_P, d.P); max_n = std::max(max_n, d.n); max_C = std::max(max_C, d.C);
@@ -977,26 +979,12 @@ static int ba_solve_batch_grid(rs_context* ctx, int B, const rs_ba_problem* Q, c
     for (int i = 0; i < B; i++) {
         const rs_ba_problem& q = Q[i];
         BaWin& w = wins[(size_t)i];
-        const Lay& L = lay[(size_t)i];
+        const BaLayout& L = lay[(size_t)i];
         char* base = ws + ws_off[(size_t)i];
         const BaDims& d = w.d;
-        const size_t n = (size_t)d.n;
         BaBufs& b = w.b;
-        b.ns = ns;
         b.obs_ptr = q.d_obs_ptr; b.obs_cam = q.d_obs_cam; b.obs_uv = (const float2*)q.d_obs_uv;
-        b.Xc = (double*)(base + L.Xc); b.Xp = (double*)(base + L.Xp); b.prep = (double*)(base + L.prep);
-        b.slot = (int32_t*)(base + L.slot); b.sc = (double*)(base + L.sc); b.sp = (double*)(base + L.sp);
-        b.Vinv = (double*)(base + L.Vinv); b.gp = (double*)(base + L.gp); b.lamp = (double*)(base + L.lamp);
-        b.Vc = (double*)(base + L.Vc); b.Ukeep = (double*)(base + L.Ukeep);
-        b.acc = (double*)(base + L.acc); b.acc_count = L.acc_count;
-        b.S = b.acc; b.rhs = b.S + (size_t)ns * n * n; b.U = b.rhs + (size_t)ns * n; b.gc = b.U + (size_t)d.Cf * 36;
-        b.cam_stride = L.cam_stride; b.scal = b.rhs + (size_t)BA_UREP * L.cam_stride;
-        b.gmax_all = b.scal + (size_t)BA_NSLOT * BA_SLOT_STRIDE; b.gmax_blocks = 1; b.gmax = b.gmax_all;
-        b.pt_scal = (double*)(base + L.pts); b.pt_prev = b.pt_scal; b.dc = (double*)(base + L.dc);
-        b.st = (BaState*)(base + L.st); b.st_prev = b.st;
-        b.trace = (BaTrace*)(base + L.trace);
-        b.set_out = (BaSetOut*)(base + L.set); b.set_prev = b.set_out;
-        b.dbg = (unsigned long long*)(base + L.dbg);
+        ba_bind(b, base, L, d, ns, 1, 0);
         ba_group_carve(base + L.grp, d.P, d.Cf, d.M, &w.g);
         ba_group_set_items(&w.g, d.P, true);
         b.obs_cs = w.g.obs_cs;

@@ -125,11 +125,17 @@ def default_options():
 
 
 def _dp(t):
-    """device pointer of a torch tensor (or None)"""
+    """device pointer of a torch tensor (or None).  Checked and boxed once per tensor object (cached on it: a
+    benchmark pass makes ~60 of these conversions, at ~1 us each they rival the kernels they feed); tensors handed to
+    the library must not be resized afterwards."""
     if t is None:
         return None
-    assert t.is_cuda and t.is_contiguous(), "device tensors must be contiguous CUDA/HIP tensors"
-    return C.c_void_p(t.data_ptr())
+    p = t.__dict__.get("_rs_ptr")
+    if p is None:
+        assert t.is_cuda and t.is_contiguous(), "device tensors must be contiguous CUDA/HIP tensors"
+        p = C.c_void_p(t.data_ptr())
+        t._rs_ptr = p
+    return p
 
 
 # ---- host-only helpers (no GPU needed) ---------------------------------------
