@@ -338,7 +338,20 @@ def build_pass(e):
              poses=ctx.dev(pair["poses"]), cams0=ctx.dev(window["cams"]), pts0=ctx.dev(window["points"]),
              optr=ctx.dev(window["obs_ptr"]), ocam=ctx.dev(window["obs_cam"]), ouv=ctx.dev(window["obs_uv"]),
              single0=ctx.dev(single_pos), single_frame=ctx.dev(single_frame), before=ctx.dev(poses_before))
-    d["cams"], d["pts"], d["single"] = d["cams0"].clone(), d["pts0"].clone(), d["single0"].clone()
+    # working copies of what a pass modifies (cameras, points, re-anchored points), reset by ONE device copy per pass:
+    # the reset is bookkeeping of the benchmark, not part of the path
+    nb_c, nb_p, nb_s = d["cams0"].numel() * 8, d["pts0"].numel() * 8, d["single0"].numel() * 4
+    off_p, off_s = (nb_c + 255) // 256 * 256, ((nb_c + 255) // 256 * 256) + (nb_p + 255) // 256 * 256
+    state0 = torch.zeros(off_s + nb_s, dtype=torch.uint8, device=d["cams0"].device)
+    state = torch.zeros_like(state0)
+
+    def views(buf):
+        return (buf[0:nb_c].view(torch.float64).view(d["cams0"].shape), buf[off_p:off_p + nb_p].view(torch.float64).view(d["pts0"].shape),
+                buf[off_s:off_s + nb_s].view(torch.float32).view(d["single0"].shape))
+    for dst, src in zip(views(state0), (d["cams0"], d["pts0"], d["single0"])):
+        dst.copy_(src)
+    d["cams"], d["pts"], d["single"] = views(state)
+    state.copy_(state0)
     d["after"] = d["before"].clone()
     h_cams_np = np.zeros((n_kf, 6), np.float64)
     h_after = torch.empty((n_kf, 16), dtype=torch.float32).pin_memory()
@@ -353,9 +366,7 @@ def build_pass(e):
         ctx.reproj_match(fv_b, mv_b, out=r_b)                   # match_map
         ctx.triangulate_matches(d["kp1"], d["kp2"], m_out["mt"], m_out["mq"], m_out["cnt"], nq, d["poses"], pair["K"], out=t_out)
         last["window"] = rs.build_local_window(*lw_args)        # host, overlaps the kernels enqueued above
-        d["cams"].copy_(d["cams0"])
-        d["pts"].copy_(d["pts0"])
-        d["single"].copy_(d["single0"])
+        state.copy_(state0)
         last["ba"] = ctx.bundle_adjust(d["cams"], window["cam_free"], d["pts"], d["optr"], d["ocam"], d["ouv"], window["K"])
         # poses are host-owned objects in the reference (Frame::set_pose): read back, unpack (f32), re-anchor
         ctx.ba_cameras(h_cams_np)
