@@ -731,7 +731,7 @@ static int ba_solve_impl(rs_context* ctx, int n_cameras, int n_points, int n_obs
     if (solve_lds && ba_prepare_reduced_solve_lds(d.n) != 0) return rs_fail(ctx, RS_ERR_HIP, "LDS attribute (K7)");
     const size_t k5_lds = sizeof(double) * (size_t)d.Cf * 42;
     if (!use_mfma && k5_lds > 48 * 1024)
-        RS_HIP(ctx, hipFuncSetAttribute((const void*)ba_linearize_schur, hipFuncAttributeMaxDynamicSharedMemorySize, (int)k5_lds));
+        RS_HIP(ctx, rs_lds_attr((const void*)ba_linearize_schur, k5_lds));
     if (use_mfma && ba_prepare_schur(d.C, d.Cf) != 0) return rs_fail(ctx, RS_ERR_HIP, "LDS attribute (K5)");
     BaGroup grp;
     memset(&grp, 0, sizeof grp);

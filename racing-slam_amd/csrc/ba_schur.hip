@@ -781,7 +781,7 @@ size_t ba_schur_lds_bytes(int C, int Cf)
 int ba_prepare_schur(int C, int Cf)
 {
     const void* fn = C <= SCH_MAXC_LDS ? (const void*)ba_schur_mfma : (const void*)ba_schur_mfma_big;
-    return (int)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ba_schur_lds_bytes(C, Cf));
+    return (int)rs_lds_attr(fn, ba_schur_lds_bytes(C, Cf));
 }
 
 void ba_launch_schur(hipStream_t s, const BaDims& d, const BaBufs& b, const BaOpt& opt, const BaGroup& g, int it)
@@ -804,7 +804,7 @@ void ba_launch_grouping_batch(hipStream_t s, const BaWin* d_wins, int B, int max
 
 int ba_prepare_schur_batch(size_t lds)
 {
-    return (int)hipFuncSetAttribute((const void*)ba_schur_mfma_batch, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    return (int)rs_lds_attr((const void*)ba_schur_mfma_batch, lds);
 }
 
 void ba_launch_schur_batch(hipStream_t s, const BaWin* d_wins, int B, const BaOpt& opt, int it, int max_items, int it_l, size_t lds)

@@ -539,12 +539,12 @@ void ba_launch_reduced_solve_lds(hipStream_t s, const BaDims& d, const BaBufs& b
 int ba_prepare_reduced_solve_lds(int n)
 {
     const size_t lds = ba_reduced_solve_lds_bytes(n);
-    return (int)hipFuncSetAttribute((const void*)ba_reduced_solve_lds, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    return (int)rs_lds_attr((const void*)ba_reduced_solve_lds, lds);
 }
 
 int ba_prepare_reduced_solve_lds_batch(int max_n)
 {
-    return (int)hipFuncSetAttribute((const void*)ba_reduced_solve_lds_batch, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ba_reduced_solve_lds_bytes(max_n));
+    return (int)rs_lds_attr((const void*)ba_reduced_solve_lds_batch, ba_reduced_solve_lds_bytes(max_n));
 }
 
 void ba_launch_reduced_solve_lds_batch(hipStream_t s, const BaWin* d_wins, int B, const BaOpt& opt, int it, int ns, int max_n)

@@ -601,9 +601,9 @@ int ba_launch_reduced_solve_big(rs_context* ctx, const BaDims& d, const BaBufs& 
     hipStream_t s = ctx->stream;
     const size_t lds_fin = sizeof(double) * (n + BB * BBS + 1024);       // y, diagonal block, backsub partial sums
     if (lds_fin > 48 * 1024)
-        RS_HIP(ctx, hipFuncSetAttribute((const void*)ba_big_finish, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_fin));
+        RS_HIP(ctx, rs_lds_attr((const void*)ba_big_finish, lds_fin));
     const size_t lds_upd = sizeof(double) * (6 * BB * BBS + 2 * BB * 17 + BB);
-    RS_HIP(ctx, hipFuncSetAttribute((const void*)ba_big_update, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_upd));
+    RS_HIP(ctx, rs_lds_attr((const void*)ba_big_update, lds_upd));
     hipLaunchKernelGGL(ba_big_prologue, dim3(1), dim3(1024), 0, s, d, b, opt, g);
     hipLaunchKernelGGL(ba_big_assemble, dim3(256), dim3(256), 0, s, d, b);
     big_launch_factor(s, d, b, g, lds_upd);
@@ -872,9 +872,9 @@ int ba_launch_reduced_solve_inertial(rs_context* ctx, const BaDims& d, const BaB
     hipStream_t s = ctx->stream;
     const size_t lds_fin = sizeof(double) * ((size_t)N + BB * BBS + 1024);
     if (lds_fin > 48 * 1024)
-        RS_HIP(ctx, hipFuncSetAttribute((const void*)ba_imu_finish, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_fin));
+        RS_HIP(ctx, rs_lds_attr((const void*)ba_imu_finish, lds_fin));
     const size_t lds_upd = sizeof(double) * (6 * BB * BBS + 2 * BB * 17 + BB);
-    RS_HIP(ctx, hipFuncSetAttribute((const void*)ba_big_update, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_upd));
+    RS_HIP(ctx, rs_lds_attr((const void*)ba_big_update, lds_upd));
     hipLaunchKernelGGL(ba_imu_prologue, dim3(1), dim3(512), 0, s, d, b, opt, g);
     hipLaunchKernelGGL(ba_imu_assemble, dim3(N), dim3(256), 0, s, d, b);
     // the factorisation runs on the N x N system: same kernels, their view of (n, matrix, right-hand side) swapped

@@ -167,6 +167,6 @@ void ba_launch_backsub(hipStream_t s, const BaDims& d, const BaBufs& b)
 
 void ba_launch_backsub_batch(hipStream_t s, const BaWin* d_wins, int B, int it, int ns, int max_P, size_t lds)
 {
-    if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void*)ba_backsub_cost4_batch, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (lds > 48 * 1024) (void)rs_lds_attr((const void*)ba_backsub_cost4_batch, lds);
     hipLaunchKernelGGL(ba_backsub_cost4_batch, dim3((max_P + 63) / 64, ns, B), dim3(K8_THREADS), lds, s, d_wins, it);
 }

@@ -85,6 +85,10 @@ int rs_fail(rs_context* ctx, int code, const char* fmt, ...);
 // workspace: returns a device pointer with at least `bytes` bytes, 256-B aligned.
 int rs_workspace(rs_context* ctx, size_t bytes, void** out);
 int rs_pinned(rs_context* ctx, size_t bytes, void** out);
+// hipFuncSetAttribute(fn, MaxDynamicSharedMemorySize, bytes), but only when `bytes` exceeds what was already set for
+// `fn` in this process: the attribute is sticky and the driver call costs microseconds of host time per launch.
+hipError_t rs_lds_attr(const void* fn, size_t bytes);
+
 
 // profiling brackets around a kernel launch
 void rs_prof_start(rs_context* ctx, const char* name);

@@ -480,3 +480,17 @@ int rs_allreduce_f64(rs_context* ctx, double* d_buf, size_t count, bool is_max)
     if (e != 0) return rs_fail(ctx, RS_ERR_RCCL, "ncclAllReduce: %s", g_rccl.errstr ? g_rccl.errstr(e) : "?");
     return RS_OK;
 }
+
+#include <mutex>
+#include <unordered_map>
+hipError_t rs_lds_attr(const void* fn, size_t bytes)
+{
+    static std::mutex mu;
+    static std::unordered_map<const void*, size_t> have;
+    std::lock_guard<std::mutex> lock(mu);
+    size_t& cur = have[fn];
+    if (bytes <= cur) return hipSuccess;
+    const hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    if (e == hipSuccess) cur = bytes;
+    return e;
+}

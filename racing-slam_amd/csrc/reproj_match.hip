@@ -469,7 +469,7 @@ extern "C" int rs_reproj_match(rs_context* ctx, const rs_frame_view* fr, const r
         const int tree_in_lds = N <= K2_MAX_LDS_NODES ? 1 : 0;
         const size_t lds = sizeof(int) * (K2_STACK + 2 * K2_MAXC) * K2_THREADS + (tree_in_lds ? sizeof(K2Node) * (size_t)N : 0);
         if (lds > 48 * 1024)
-            RS_HIP(ctx, hipFuncSetAttribute((const void*)k2_reproj_match, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            RS_HIP(ctx, rs_lds_attr((const void*)k2_reproj_match, lds));
         rs_prof_scope ps(ctx, "K2_reproj_match");
         hipLaunchKernelGGL(k2_reproj_match, dim3((P + K2_THREADS - 1) / K2_THREADS), dim3(K2_THREADS), lds,
                            ctx->stream, f, m, replace, max_distance, tree_in_lds, d_point_kp, d_point_dist, prop);
