@@ -602,9 +602,11 @@ void rs_unpack_poses(const double* h_cameras /*[n][6]*/, int n, const uint8_t* h
 /* optimization::build_local_window (src/LocalWindow.cpp:10-52).  Host only.
  * Keyframes are 0..n_key_frames-1 in Mapper order; new_frame is the index of
  * the new frame in that list, or -1 when it is not (yet) a keyframe.
- * The covisibility input is CSR: frame f (0..n_key_frames; entry n_key_frames
- * is the new frame when new_frame == -1) matches points
- * h_frame_pt[h_frame_ptr[f] .. h_frame_ptr[f+1]-1]; point p is observed by
+ * The covisibility input is CSR: frame f matches points
+ * h_frame_pt[h_frame_ptr[f] .. h_frame_ptr[f+1]-1]; rows 0..n_key_frames-1 are
+ * the key frames (h_frame_ptr has n_key_frames + 1 entries) and, only when
+ * new_frame == -1, row n_key_frames is the new frame (n_key_frames + 2
+ * entries); point p is observed by
  * keyframes h_pt_obs[h_pt_ptr[p] .. h_pt_ptr[p+1]-1].
  * Output (capacity n_key_frames+1): h_out_frame[i] (n_key_frames = the new
  * non-keyframe), h_out_optimize[i]; *h_out_count entries. */

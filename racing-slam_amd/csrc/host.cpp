@@ -169,11 +169,12 @@ extern "C" int rs_build_local_window(int n_key_frames, int new_frame, int window
     int outside = 0;
     for (int i = 0; i < n; i++) outside += role[i] == kOutside ? 1 : 0;
     if (outside > 0) {
+        const int n_rows = new_frame >= 0 ? n : n + 1;        // row n of the CSR exists only for a new non-key frame
         int n_pts = 0;
-        for (int f = 0; f <= n; f++)
+        for (int f = 0; f < n_rows; f++)
             for (int a = frame_ptr[f]; a < frame_ptr[f + 1]; a++) n_pts = frame_pt[a] >= n_pts ? frame_pt[a] + 1 : n_pts;
         std::vector<uint8_t> seen((size_t)n_pts, 0);
-        for (int f = 0; f <= n && outside > 0; f++) {
+        for (int f = 0; f < n_rows && outside > 0; f++) {
             if (role[f] != kWindow) continue;
             for (int a = frame_ptr[f]; a < frame_ptr[f + 1] && outside > 0; a++) {
                 const int p = frame_pt[a];

@@ -57,3 +57,19 @@ def test_host_mirror_selftest(rs, oracle):
     print(r.stdout[-3000:], r.stderr[-2000:])
     assert r.returncode == 0, r.stdout[-3000:]
     assert "all checks passed" in r.stdout
+
+
+def test_host_only_entry_points_under_address_sanitizer():
+    """csrc/host.cpp + csrc/pose_graph.cpp (no GPU code in them) built with g++ -fsanitize=address and driven with
+    exactly-sized heap buffers: out-of-bounds reads that only crash under another heap layout abort here."""
+    gxx = shutil.which("g++")
+    if not gxx:
+        pytest.skip("g++ not available")
+    exe = os.path.join(ROOT, "tests", "host_cpp", "asan_host.bin")
+    srcs = [os.path.join(ROOT, "tests", "host_cpp", "asan_host.cpp"), os.path.join(ROOT, "racing-slam_amd", "csrc", "host.cpp"),
+            os.path.join(ROOT, "racing-slam_amd", "csrc", "pose_graph.cpp")]
+    subprocess.check_call([gxx, "-O1", "-g", "-std=c++17", "-fsanitize=address,undefined", "-fno-omit-frame-pointer", "-ffp-contract=off",
+                           "-o", exe] + srcs + ["-lm"])
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=300, env=dict(os.environ, ASAN_OPTIONS="detect_leaks=1"))
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-4000:])
+    assert "asan host checks passed" in r.stdout
