@@ -1137,21 +1137,23 @@ extern "C" int rs_ba_get_stats(rs_context* ctx, int h_out[4])
 // a single workgroup (6 unknowns; <= 2000 residual pairs): per iteration a
 // block reduction of the 6x6 normal equations, a register Cholesky on lane 0
 // and a second reduction for the candidate cost.
-#define RP_THREADS 256
+#define RP_THREADS 512         // 2000 observations: four per thread; 256 VGPRs per thread keep the 28 accumulators in registers
 
-__device__ __forceinline__ void block_sum(double* vals, int count, double* scratch /*[4][32]*/)
+__device__ __forceinline__ void block_sum(double* vals, int count, double* scratch /*[RP_THREADS / 64 + 1][32]*/)
 {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     for (int k = 0; k < count; k++) {
-        const double v = wave_sum(vals[k]);
-        if (lane == 0) scratch[wave * 32 + k] = v;
+        const double v = wave_sum_lane63(vals[k]);
+        if (lane == 63) scratch[wave * 32 + k] = v;
     }
     __syncthreads();
-    for (int k = 0; k < count; k++) {
+    if ((int)threadIdx.x < count) {                 // thread k folds the waves' partial sums of value k (fixed order)
         double t = 0.0;
-        for (int w = 0; w < RP_THREADS / 64; w++) t += scratch[w * 32 + k];
-        vals[k] = t;
+        for (int w = 0; w < RP_THREADS / 64; w++) t += scratch[w * 32 + threadIdx.x];
+        scratch[(RP_THREADS / 64) * 32 + threadIdx.x] = t;
     }
+    __syncthreads();
+    for (int k = 0; k < count; k++) vals[k] = scratch[(RP_THREADS / 64) * 32 + k];
     __syncthreads();
 }
 
@@ -1159,7 +1161,7 @@ __global__ __launch_bounds__(RP_THREADS) void ba_refine_pose(BaDims d, BaOpt opt
                                                             const float2* __restrict__ uv, int n,
                                                             double* __restrict__ cam_io, BaState* __restrict__ st_out)
 {
-    __shared__ double x[6], xn[6], prep[BA_PREP], prepn[BA_PREP], scratch[4 * 32];
+    __shared__ double x[6], xn[6], prep[BA_PREP], prepn[BA_PREP], scratch[(RP_THREADS / 64 + 1) * 32];
     __shared__ BaState st;
     __shared__ double sc[6];
     const int tid = threadIdx.x;
@@ -1215,29 +1217,31 @@ __global__ __launch_bounds__(RP_THREADS) void ba_refine_pose(BaDims d, BaOpt opt
                     lam[a] = clampd(s2 * H[a][a], opt.dmin, opt.dmax) / (st.radius * s2);
                     H[a][a] += lam[a];
                 }
-                // Cholesky 6x6
+                // Cholesky 6x6 (one reciprocal per column instead of a division per entry: this is one lane's serial code)
+                double rdiag[6];
                 for (int j = 0; j < 6 && !fail; j++) {
                     double dj = H[j][j];
                     for (int k = 0; k < j; k++) dj -= H[j][k] * H[j][k];
                     if (!(dj > 0.0) || !isfinite(dj)) { fail = true; break; }
                     dj = sqrt(dj);
                     H[j][j] = dj;
+                    rdiag[j] = 1.0 / dj;
                     for (int i = j + 1; i < 6; i++) {
                         double s = H[i][j];
                         for (int k = 0; k < j; k++) s -= H[i][k] * H[j][k];
-                        H[i][j] = s / dj;
+                        H[i][j] = s * rdiag[j];
                     }
                 }
                 if (!fail) {
                     for (int i = 0; i < 6; i++) {
                         double s = g[i];
                         for (int k = 0; k < i; k++) s -= H[i][k] * dlt[k];
-                        dlt[i] = s / H[i][i];
+                        dlt[i] = s * rdiag[i];
                     }
                     for (int i = 5; i >= 0; i--) {
                         double s = dlt[i];
                         for (int k = i + 1; k < 6; k++) s -= H[k][i] * dlt[k];
-                        dlt[i] = s / H[i][i];
+                        dlt[i] = s * rdiag[i];
                     }
                     double mcc = 0.0, ssq = 0.0, xsq = 0.0;
                     for (int a = 0; a < 6; a++) {
@@ -1306,6 +1310,7 @@ __global__ __launch_bounds__(RP_THREADS) void ba_refine_pose(BaDims d, BaOpt opt
         if (st.usable)
             for (int k = 0; k < 6; k++) cam_io[k] = x[k];
         *st_out = st;
+        __threadfence_system();           // cam_io / st_out are pinned host memory
     }
 }
 
@@ -1334,8 +1339,7 @@ extern "C" int rs_refine_pose(rs_context* ctx, double h_camera[6], const double*
     void* wsv = nullptr;
     int rc = rs_workspace(ctx, 1024, &wsv);
     if (rc) return rc;
-    double* d_cam = (double*)wsv;
-    BaState* d_st = (BaState*)((char*)wsv + 256);
+    (void)wsv;
     void* pin = nullptr;
     rc = rs_pinned(ctx, 512, &pin);
     if (rc) return rc;
@@ -1346,13 +1350,12 @@ extern "C" int rs_refine_pose(rs_context* ctx, double h_camera[6], const double*
     BaState* h_st = (BaState*)((char*)pin + 256);
     memcpy(h_cam, h_camera, 6 * sizeof(double));
     hipStream_t s = ctx->stream;
-    RS_HIP(ctx, hipMemcpyAsync(d_cam, h_cam, 6 * sizeof(double), hipMemcpyHostToDevice, s));
     {
+        // the kernel reads the camera from and writes camera + state to the PINNED block itself: no copy launches around
+        // a 40 us kernel (three hipMemcpyAsync cost more than the solve)
         rs_prof_scope ps(ctx, "K11_refine_pose");
-        hipLaunchKernelGGL(ba_refine_pose, dim3(1), dim3(RP_THREADS), 0, s, d, opt, d_points, (const float2*)d_uv, n, d_cam, d_st);
+        hipLaunchKernelGGL(ba_refine_pose, dim3(1), dim3(RP_THREADS), 0, s, d, opt, d_points, (const float2*)d_uv, n, h_cam, h_st);
     }
-    RS_HIP(ctx, hipMemcpyAsync(h_cam, d_cam, 6 * sizeof(double), hipMemcpyDeviceToHost, s));
-    RS_HIP(ctx, hipMemcpyAsync(h_st, d_st, sizeof(BaState), hipMemcpyDeviceToHost, s));
     RS_HIP(ctx, hipStreamSynchronize(s));
     RS_HIP(ctx, hipGetLastError());
     if (h_st->usable) memcpy(h_camera, h_cam, 6 * sizeof(double));
@@ -1384,7 +1387,7 @@ __global__ __launch_bounds__(RP_THREADS) void ba_refine_pose_inertial(BaDims d, 
                                                                      double* __restrict__ cam_io /*[9]: pose, velocity*/,
                                                                      BaState* __restrict__ st_out)
 {
-    __shared__ double x[9], xn[9], prep[BA_PREP], prepn[BA_PREP], scratch[4 * 32];
+    __shared__ double x[9], xn[9], prep[BA_PREP], prepn[BA_PREP], scratch[(RP_THREADS / 64 + 1) * 32];
     __shared__ double s_extr[9], s_extJ[9][IMU_NP];
     __shared__ BaState st;
     __shared__ double sc[9];
@@ -1576,6 +1579,7 @@ __global__ __launch_bounds__(RP_THREADS) void ba_refine_pose_inertial(BaDims d, 
         if (st.usable)
             for (int k = 0; k < 9; k++) cam_io[k] = x[k];
         *st_out = st;
+        __threadfence_system();           // cam_io / st_out are pinned host memory
     }
 }
 
@@ -1615,8 +1619,6 @@ extern "C" int rs_refine_pose_inertial(rs_context* ctx, double h_camera[6], cons
     void* wsv = nullptr;
     int rc = rs_workspace(ctx, ws_bytes, &wsv);
     if (rc) return rc;
-    double* d_cam = (double*)wsv;
-    BaState* d_st = (BaState*)((char*)wsv + 256);
     RpInertial* d_ext = (RpInertial*)((char*)wsv + ext_off);
     void* pin = nullptr;
     rc = rs_pinned(ctx, 1024 + sizeof(RpInertial), &pin);
@@ -1643,15 +1645,12 @@ extern "C" int rs_refine_pose_inertial(rs_context* ctx, double h_camera[6], cons
     memcpy(h_cam, h_camera, 6 * sizeof(double));
     for (int k = 0; k < 3; k++) h_cam[6 + k] = (kind == 2) ? h_velocity[k] : 0.0;
     hipStream_t s = ctx->stream;
-    RS_HIP(ctx, hipMemcpyAsync(d_cam, h_cam, 9 * sizeof(double), hipMemcpyHostToDevice, s));
-    RS_HIP(ctx, hipMemcpyAsync(d_ext, h_ext, sizeof(RpInertial), hipMemcpyHostToDevice, s));
+    RS_HIP(ctx, hipMemcpyAsync(d_ext, h_ext, sizeof(RpInertial), hipMemcpyHostToDevice, s));   // read in the inner loops: device memory
     {
         rs_prof_scope ps(ctx, "K11_refine_pose_inertial");
         hipLaunchKernelGGL(ba_refine_pose_inertial, dim3(1), dim3(RP_THREADS), 0, s, d, opt, d_points, (const float2*)d_uv, n,
-                           (const RpInertial*)d_ext, d_cam, d_st);
+                           (const RpInertial*)d_ext, h_cam, h_st);                            // camera / state: the pinned block itself
     }
-    RS_HIP(ctx, hipMemcpyAsync(h_cam, d_cam, 9 * sizeof(double), hipMemcpyDeviceToHost, s));
-    RS_HIP(ctx, hipMemcpyAsync(h_st, d_st, sizeof(BaState), hipMemcpyDeviceToHost, s));
     RS_HIP(ctx, hipStreamSynchronize(s));
     RS_HIP(ctx, hipGetLastError());
     if (h_st->usable) {

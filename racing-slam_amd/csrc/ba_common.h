@@ -217,6 +217,26 @@ __device__ __forceinline__ double wave_sum(double v)
     return v;
 }
 
+// The same sum on the VALU's data-parallel-primitive path instead of the LDS crossbar (each __shfl of a double is two
+// ds_bpermute: a workgroup reducing 28 values per thread spent 17 us in them).  The total is valid in LANE 63 ONLY.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dpp_f64(double v)
+{
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, ROW_MASK, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, ROW_MASK, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double wave_sum_lane63(double v)
+{
+    v += dpp_f64<0xB1, 0xf>(v);        // quad_perm [1,0,3,2]: lane ^ 1
+    v += dpp_f64<0x4E, 0xf>(v);        // quad_perm [2,3,0,1]: lane ^ 2
+    v += dpp_f64<0x141, 0xf>(v);       // row_half_mirror: the other quad of the 8
+    v += dpp_f64<0x140, 0xf>(v);       // row_mirror: the other half of the row of 16 -> every lane holds its row's sum
+    v += dpp_f64<0x142, 0xa>(v);       // row_bcast:15 into rows 1 and 3
+    v += dpp_f64<0x143, 0xc>(v);       // row_bcast:31 into rows 2 and 3 -> lane 63 holds the wave's sum
+    return v;
+}
+
 // symmetric 3x3 inverse through Cholesky (InvertPSDMatrix<3>); false if not PD
 __device__ __forceinline__ bool inv3_psd(const double V[6], double I[6])
 {
