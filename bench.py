@@ -26,6 +26,7 @@ Prints ONE JSON line on rank 0 with `roofline` (dominant kernel, HIP-event timed
 beside it; median / p10 / p90 over the repetitions).
 """
 import argparse
+import gc
 import hashlib
 import importlib
 import json
@@ -145,12 +146,20 @@ def timed(e, fn, steps, warmup):
 
     for _ in range(warmup):
         fn()
+    # The interpreter's cyclic garbage collector is kept out of the timed region (as timeit does): a full collection
+    # over the ~10^6 objects a process that imported torch holds takes ~50 ms — 70 passes' worth — and fires once
+    # every few thousand small allocations (tools/pass_jitter.py: one 54 ms pass among 400).
+    gc.collect()
+    gc_was_on = gc.isenabled()
+    gc.disable()
     barrier()
     t0 = time.perf_counter()
     for _ in range(steps):
         fn()
     barrier()
     elapsed = time.perf_counter() - t0
+    if gc_was_on:
+        gc.enable()
     if e.world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=e.ctx.device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)

@@ -56,6 +56,7 @@ static __device__ __forceinline__ void ba_init_body(const BaDims& d, const BaBuf
     for (int i = tid; i < BA_NSLOT * BA_SLOT_STRIDE; i += nth) b.gmax[i] = 0.0;
     for (int i = tid; i < zero_n; i += nth) zero_i32[i] = 0;      // histogram of the landmark grouping
     if (tid == 0) {
+        b.dbg[62] = 0ull;         // workgroups of ba_finalize that have finished (completion flag for the host)
         BaState s;
         s.radius = opt.r0; s.decrease_factor = 2.0; s.x_cost = 0.0; s.initial_cost = 0.0;
         s.cam_scal[0] = s.cam_scal[1] = s.cam_scal[2] = s.cam_scal[3] = 0.0;
@@ -434,7 +435,8 @@ __global__ __launch_bounds__(BA_THREADS) void ba_backsub_cost(BaDims d, BaBufs b
 // -------------------------------------------------------------------- finalize
 static __device__ __forceinline__ void ba_finalize_body(const BaDims& d, const BaBufs& b, const BaOpt& opt, int it, double* __restrict__ cams_out,
                                                         const uint8_t* __restrict__ cam_free, double* __restrict__ pts_out, BaState* host_st,
-                                                        BaTrace* host_trace, double* __restrict__ host_cams, double* __restrict__ host_vb)
+                                                        BaTrace* host_trace, double* __restrict__ host_cams, double* __restrict__ host_vb,
+                                                        volatile int* host_done = nullptr)
 {
     __shared__ int usable, cur;
     __shared__ BaState st_fin;
@@ -469,17 +471,29 @@ static __device__ __forceinline__ void ba_finalize_body(const BaDims& d, const B
     for (int i = tid; i < d.C * 6; i += nth) host_cams[i] = (usable && cam_free[i / 6]) ? Xc[i] : cams_out[i];
     if (host_vb)        // inertial solve: velocity | bias of the accepted state (the host applies the write-back rule)
         for (int i = tid; i < d.C * 9; i += nth) host_vb[i] = b.imu.Xv[(size_t)cur * d.C * 9 + i];
-    if (!usable) return;
-    for (int i = tid; i < d.C * 6; i += nth)
-        if (cam_free[i / 6]) cams_out[i] = Xc[i];
-    for (int i = tid; i < d.P * 3; i += nth) pts_out[i] = Xp[i];
+    if (usable) {
+        for (int i = tid; i < d.C * 6; i += nth)
+            if (cam_free[i / 6]) cams_out[i] = Xc[i];
+        for (int i = tid; i < d.P * 3; i += nth) pts_out[i] = Xp[i];
+    }
+    // Completion flag in pinned host memory, raised by the last workgroup to get here: the host spins on it instead of
+    // calling hipStreamSynchronize (a blocking wait whose wake-up costs tens to hundreds of microseconds on a busy host —
+    // more than a kernel of this solve).  Every workgroup's writes to host memory are fenced before it counts itself.
+    if (host_done) {
+        __threadfence_system();
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const unsigned long long arrived = atomicAdd(&b.dbg[62], 1ull);
+            if (arrived == gridDim.x - 1) { __threadfence_system(); *host_done = it + 1; __threadfence_system(); }
+        }
+    }
 }
 
 __global__ void ba_finalize(BaDims d, BaBufs b, BaOpt opt, int it, double* __restrict__ cams_out,
                             const uint8_t* __restrict__ cam_free, double* __restrict__ pts_out, BaState* host_st,
-                            BaTrace* host_trace, double* __restrict__ host_cams, double* __restrict__ host_vb)
+                            BaTrace* host_trace, double* __restrict__ host_cams, double* __restrict__ host_vb, volatile int* host_done)
 {
-    ba_finalize_body(d, b, opt, it, cams_out, cam_free, pts_out, host_st, host_trace, host_cams, host_vb);
+    ba_finalize_body(d, b, opt, it, cams_out, cam_free, pts_out, host_st, host_trace, host_cams, host_vb, host_done);
 }
 __global__ void ba_finalize_batch(const BaWin* w, BaOpt opt, int it)
 {
@@ -853,10 +867,18 @@ static int ba_solve_impl(rs_context* ctx, int n_cameras, int n_points, int n_obs
         b.pt_prev = pts_base + (size_t)((itf + 1) & 1) * pts_block;
         b.set_prev = set_base + (size_t)((itf + 1) & 1) * BA_MAXSETS;
         b.prog = nullptr;
+        h_prog->pad = 0;
         hipLaunchKernelGGL(ba_finalize, dim3(32), dim3(256), 0, s, d, b, opt, itf, d_cameras, (const uint8_t*)d_cam_free, d_points, h_st, h_trace,
-                           (double*)((char*)pin + pin_cams), h_vb);
+                           (double*)((char*)pin + pin_cams), h_vb, &h_prog->pad);
+        RS_HIP(ctx, hipGetLastError());
+        // wait for the completion flag the last workgroup of ba_finalize raises in pinned memory (summary, trace, camera
+        // mirror are then all there); fall back to the stream if it drains without the flag (a failed launch)
+        long spins = 0;
+        while (h_prog->pad != itf + 1) {
+            if ((++spins & 0x3FFFF) == 0 && hipStreamQuery(s) != hipErrorNotReady) break;
+        }
+        if (h_prog->pad != itf + 1) RS_HIP(ctx, hipStreamSynchronize(s));
     }
-    RS_HIP(ctx, hipStreamSynchronize(s));        // ba_finalize wrote the state block into the pinned h_st
     RS_HIP(ctx, hipGetLastError());
     h_summary->termination = h_st->termination;
     h_summary->iterations = h_st->iter;

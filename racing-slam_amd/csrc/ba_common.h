@@ -210,31 +210,43 @@ __device__ __forceinline__ void obs_eval(const double* __restrict__ cp, const do
     }
 }
 
-__device__ __forceinline__ double wave_sum(double v)
-{
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
-    return v;
-}
-
-// The same sum on the VALU's data-parallel-primitive path instead of the LDS crossbar (each __shfl of a double is two
-// ds_bpermute: a workgroup reducing 28 values per thread spent 17 us in them).  The total is valid in LANE 63 ONLY.
+// Wave-wide reductions on the VALU's data-parallel-primitive path instead of the LDS crossbar: a __shfl of a double is two
+// ds_bpermute_b32 (~100 cycles of latency each, six dependent steps per reduction, and one LDS pipe per CU — a workgroup
+// reducing 28 values per thread spent 17 us in them).  DPP moves are ordinary VALU instructions.
 template <int CTRL, int ROW_MASK>
-__device__ __forceinline__ double dpp_f64(double v)
+__device__ __forceinline__ double dpp_f64(double v, double fill)
 {
-    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, ROW_MASK, 0xf, false);
-    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, ROW_MASK, 0xf, false);
+    const int lo = __builtin_amdgcn_update_dpp(__double2loint(fill), __double2loint(v), CTRL, ROW_MASK, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp(__double2hiint(fill), __double2hiint(v), CTRL, ROW_MASK, 0xf, false);
     return __hiloint2double(hi, lo);
 }
+__device__ __forceinline__ double lane63_f64(double v)
+{
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), 63), __builtin_amdgcn_readlane(__double2loint(v), 63));
+}
+// total valid in LANE 63 ONLY
 __device__ __forceinline__ double wave_sum_lane63(double v)
 {
-    v += dpp_f64<0xB1, 0xf>(v);        // quad_perm [1,0,3,2]: lane ^ 1
-    v += dpp_f64<0x4E, 0xf>(v);        // quad_perm [2,3,0,1]: lane ^ 2
-    v += dpp_f64<0x141, 0xf>(v);       // row_half_mirror: the other quad of the 8
-    v += dpp_f64<0x140, 0xf>(v);       // row_mirror: the other half of the row of 16 -> every lane holds its row's sum
-    v += dpp_f64<0x142, 0xa>(v);       // row_bcast:15 into rows 1 and 3
-    v += dpp_f64<0x143, 0xc>(v);       // row_bcast:31 into rows 2 and 3 -> lane 63 holds the wave's sum
+    v += dpp_f64<0xB1, 0xf>(v, 0.0);   // quad_perm [1,0,3,2]: lane ^ 1
+    v += dpp_f64<0x4E, 0xf>(v, 0.0);   // quad_perm [2,3,0,1]: lane ^ 2
+    v += dpp_f64<0x141, 0xf>(v, 0.0);  // row_half_mirror: the other quad of the 8
+    v += dpp_f64<0x140, 0xf>(v, 0.0);  // row_mirror: the other half of the row of 16 -> every lane holds its row's sum
+    v += dpp_f64<0x142, 0xa>(v, 0.0);  // row_bcast:15 into rows 1 and 3
+    v += dpp_f64<0x143, 0xc>(v, 0.0);  // row_bcast:31 into rows 2 and 3 -> lane 63 holds the wave's sum
     return v;
+}
+// total valid in EVERY lane
+__device__ __forceinline__ double wave_sum(double v) { return lane63_f64(wave_sum_lane63(v)); }
+// maximum of non-negative values (the fill of the masked rows is 0), valid in every lane
+__device__ __forceinline__ double wave_max_nonneg(double v)
+{
+    v = fmax(v, dpp_f64<0xB1, 0xf>(v, 0.0));
+    v = fmax(v, dpp_f64<0x4E, 0xf>(v, 0.0));
+    v = fmax(v, dpp_f64<0x141, 0xf>(v, 0.0));
+    v = fmax(v, dpp_f64<0x140, 0xf>(v, 0.0));
+    v = fmax(v, dpp_f64<0x142, 0xa>(v, 0.0));
+    v = fmax(v, dpp_f64<0x143, 0xc>(v, 0.0));
+    return lane63_f64(v);
 }
 
 // symmetric 3x3 inverse through Cholesky (InvertPSDMatrix<3>); false if not PD
@@ -331,10 +343,7 @@ __device__ __forceinline__ void ba_apply_decision(BaState& st, double cand, doub
 // fold the BA_NSLOT partial slots (one wave, lane = slot); result valid in every lane
 __device__ __forceinline__ double slot_sum(const double* base, int field)
 {
-    double v = base[(size_t)(threadIdx.x & 63) * BA_SLOT_STRIDE + field];
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
-    return v;
+    return wave_sum(base[(size_t)(threadIdx.x & 63) * BA_SLOT_STRIDE + field]);
 }
 __device__ __forceinline__ double slot_max_bits(const double* base);
 // maximum over the slot lines of every rank's block (called by the first wave)
@@ -346,10 +355,7 @@ __device__ __forceinline__ double slot_max_all(const BaBufs& b)
 }
 __device__ __forceinline__ double slot_max_bits(const double* base)
 {
-    double v = __longlong_as_double((long long)((const unsigned long long*)base)[(size_t)(threadIdx.x & 63) * BA_SLOT_STRIDE]);
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v = fmax(v, __shfl_xor(v, off, 64));
-    return v;
+    return wave_max_nonneg(__longlong_as_double((long long)((const unsigned long long*)base)[(size_t)(threadIdx.x & 63) * BA_SLOT_STRIDE]));
 }
 
 

@@ -573,8 +573,7 @@ static __device__ __forceinline__ void ba_schur_body(const BaDims& d, const BaBu
     cost = wave_sum(cost);
 #pragma unroll
     for (int k = 0; k < BA_MAXSETS; k++) fail[k] = wave_sum(fail[k]);
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) gmax = fmax(gmax, __shfl_down(gmax, off, 64));
+    gmax = wave_max_nonneg(gmax);
     __shared__ double redw[SCH_WAVES][2 + BA_MAXSETS];
     const int nwaves = (int)(blockDim.x >> 6);
     if (lane == 0) {

@@ -169,13 +169,10 @@ static __device__ __forceinline__ void ba_reduced_solve_lds_body(const BaDims& d
     const double fail_sum = wave_sum(pre_fail);          // only wave 0 holds real values
     if (st.fresh) {
         const double c = wave_sum(pre_cost);
-        double gslots = pre_gm;
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) gslots = fmax(gslots, __shfl_xor(gslots, off, 64));
+        const double gslots = wave_max_nonneg(pre_gm);
         double gm = 0.0;
         for (int i = tid; i < n; i += nt) gm = fmax(gm, fabs(gcs[i]));
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) gm = fmax(gm, __shfl_down(gm, off, 64));
+        gm = wave_max_nonneg(gm);
         if ((tid & 63) == 0) red[tid >> 6] = gm;
         __syncthreads();
         if (tid == 0) {
