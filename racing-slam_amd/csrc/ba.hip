@@ -1181,7 +1181,7 @@ __device__ __forceinline__ void block_sum(double* vals, int count, double* scrat
 
 __global__ __launch_bounds__(RP_THREADS) void ba_refine_pose(BaDims d, BaOpt opt, const double* __restrict__ pts,
                                                             const float2* __restrict__ uv, int n,
-                                                            double* __restrict__ cam_io, BaState* __restrict__ st_out)
+                                                            double* __restrict__ cam_io, BaState* __restrict__ st_out, volatile int* host_done)
 {
     __shared__ double x[6], xn[6], prep[BA_PREP], prepn[BA_PREP], scratch[(RP_THREADS / 64 + 1) * 32];
     __shared__ BaState st;
@@ -1333,6 +1333,8 @@ __global__ __launch_bounds__(RP_THREADS) void ba_refine_pose(BaDims d, BaOpt opt
             for (int k = 0; k < 6; k++) cam_io[k] = x[k];
         *st_out = st;
         __threadfence_system();           // cam_io / st_out are pinned host memory
+        *host_done = 1;                   // the host spins on this instead of synchronising the stream
+        __threadfence_system();
     }
 }
 
@@ -1376,9 +1378,15 @@ extern "C" int rs_refine_pose(rs_context* ctx, double h_camera[6], const double*
         // the kernel reads the camera from and writes camera + state to the PINNED block itself: no copy launches around
         // a 40 us kernel (three hipMemcpyAsync cost more than the solve)
         rs_prof_scope ps(ctx, "K11_refine_pose");
-        hipLaunchKernelGGL(ba_refine_pose, dim3(1), dim3(RP_THREADS), 0, s, d, opt, d_points, (const float2*)d_uv, n, h_cam, h_st);
+        volatile int* h_done = (volatile int*)((char*)pin + 448);
+        *h_done = 0;
+        hipLaunchKernelGGL(ba_refine_pose, dim3(1), dim3(RP_THREADS), 0, s, d, opt, d_points, (const float2*)d_uv, n, h_cam, h_st, h_done);
+        RS_HIP(ctx, hipGetLastError());
+        long spins = 0;
+        while (*h_done != 1)
+            if ((++spins & 0x3FFFF) == 0 && hipStreamQuery(s) != hipErrorNotReady) break;
+        if (*h_done != 1) RS_HIP(ctx, hipStreamSynchronize(s));
     }
-    RS_HIP(ctx, hipStreamSynchronize(s));
     RS_HIP(ctx, hipGetLastError());
     if (h_st->usable) memcpy(h_camera, h_cam, 6 * sizeof(double));
     h_summary->termination = h_st->termination;
@@ -1407,7 +1415,7 @@ __global__ __launch_bounds__(RP_THREADS) void ba_refine_pose_inertial(BaDims d, 
                                                                      const float2* __restrict__ uv, int n,
                                                                      const RpInertial* __restrict__ ext,
                                                                      double* __restrict__ cam_io /*[9]: pose, velocity*/,
-                                                                     BaState* __restrict__ st_out)
+                                                                     BaState* __restrict__ st_out, volatile int* host_done)
 {
     __shared__ double x[9], xn[9], prep[BA_PREP], prepn[BA_PREP], scratch[(RP_THREADS / 64 + 1) * 32];
     __shared__ double s_extr[9], s_extJ[9][IMU_NP];
@@ -1602,6 +1610,8 @@ __global__ __launch_bounds__(RP_THREADS) void ba_refine_pose_inertial(BaDims d, 
             for (int k = 0; k < 9; k++) cam_io[k] = x[k];
         *st_out = st;
         __threadfence_system();           // cam_io / st_out are pinned host memory
+        *host_done = 1;                   // the host spins on this instead of synchronising the stream
+        __threadfence_system();
     }
 }
 
@@ -1670,10 +1680,16 @@ extern "C" int rs_refine_pose_inertial(rs_context* ctx, double h_camera[6], cons
     RS_HIP(ctx, hipMemcpyAsync(d_ext, h_ext, sizeof(RpInertial), hipMemcpyHostToDevice, s));   // read in the inner loops: device memory
     {
         rs_prof_scope ps(ctx, "K11_refine_pose_inertial");
+        volatile int* h_done = (volatile int*)((char*)pin + 448);
+        *h_done = 0;
         hipLaunchKernelGGL(ba_refine_pose_inertial, dim3(1), dim3(RP_THREADS), 0, s, d, opt, d_points, (const float2*)d_uv, n,
-                           (const RpInertial*)d_ext, h_cam, h_st);                            // camera / state: the pinned block itself
+                           (const RpInertial*)d_ext, h_cam, h_st, h_done);                    // camera / state: the pinned block itself
+        RS_HIP(ctx, hipGetLastError());
+        long spins = 0;
+        while (*h_done != 1)
+            if ((++spins & 0x3FFFF) == 0 && hipStreamQuery(s) != hipErrorNotReady) break;
+        if (*h_done != 1) RS_HIP(ctx, hipStreamSynchronize(s));
     }
-    RS_HIP(ctx, hipStreamSynchronize(s));
     RS_HIP(ctx, hipGetLastError());
     if (h_st->usable) {
         memcpy(h_camera, h_cam, 6 * sizeof(double));
