@@ -25,6 +25,7 @@ SOURCES = [
     ("ba.hip", ["-munsafe-fp-atomics"]),
     ("ba_solve.hip", ["-munsafe-fp-atomics"]),
     ("ba_solve_big.hip", ["-munsafe-fp-atomics"]),
+    ("ba_imu.hip", ["-munsafe-fp-atomics"]),
     ("ba_schur.hip", ["-munsafe-fp-atomics"]),
     ("ba_update.hip", ["-munsafe-fp-atomics"]),
     ("map.hip", []),

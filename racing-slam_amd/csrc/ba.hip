@@ -684,6 +684,11 @@ static int ba_solve_impl(rs_context* ctx, int n_cameras, int n_points, int n_obs
         for (int c = 0; c < n_cameras; c++) if (touched[c]) inert[c] = Ci++;
     }
     const int N_in = d.n + 9 * Ci;
+    // inertial solve on the local-window kernels (ba_imu.hip): the velocity / bias blocks are eliminated around the LDS
+    // K7.  Needs the factors to join consecutive inertial cameras (what the reference builds: block-tridiagonal H_zz).
+    bool imu_lds = in && use_mfma && k8_lds && solve_lds && Ci >= 2 && Ci <= ba_imu_lds_path_max_ci() && ctx->ba_imu_mode == 0;
+    if (imu_lds)
+        for (int f = 0; f < in->n_factors && imu_lds; f++) imu_lds = inert[in->factors[f].cam_j] == inert[in->factors[f].cam_i] + 1;
     int ns = 1;
     if (use_mfma && k8_lds && solve_lds && !in) {
         ns = ctx->ba_sets > 0 ? ctx->ba_sets : BA_DEFAULT_SETS;
@@ -811,7 +816,11 @@ static int ba_solve_impl(rs_context* ctx, int n_cameras, int n_points, int n_obs
             int rc2 = rs_allreduce_f64(ctx, b.acc, b.acc_count, false);
             if (rc2) return rc2;
         }
-        if (in) {
+        if (in && imu_lds) {
+            { rs_prof_scope ps(ctx, "K6i_imu_eliminate"); ba_launch_imu_eliminate(s, d, b, opt); }
+            { rs_prof_scope ps(ctx, "K7_ba_reduced_solve"); ba_launch_reduced_solve_lds(s, d, b, opt); }
+            { rs_prof_scope ps(ctx, "K7i_imu_expand"); ba_launch_imu_expand(s, d, b, opt); }
+        } else if (in) {
             rs_prof_scope ps(ctx, "K7_ba_reduced_solve_inertial");
             int rc2 = ba_launch_reduced_solve_inertial(ctx, d, b, opt, ws + o_big);
             if (rc2) return rc2;

@@ -518,6 +518,10 @@ int ba_launch_reduced_solve_big(rs_context* ctx, const BaDims& d, const BaBufs& 
 size_t ba_inertial_bytes(int N, int n_fac, int C);
 void ba_inertial_carve(char* ws, int N, int n_fac, int C, BaImu* imu, ImuFactorDev** d_fac, int32_t** d_inert);
 int ba_launch_reduced_solve_inertial(rs_context* ctx, const BaDims& d, const BaBufs& b, const BaOpt& opt, char* ws);
+// ---- inertial blocks eliminated around the LDS reduced solve (ba_imu.hip)
+void ba_launch_imu_eliminate(hipStream_t s, const BaDims& d, const BaBufs& b, const BaOpt& opt);
+void ba_launch_imu_expand(hipStream_t s, const BaDims& d, const BaBufs& b, const BaOpt& opt);
+int ba_imu_lds_path_max_ci();
 // ---- LDS-resident reduced solve (ba_solve.hip), n = 6*Cf <= BA_MAX_LDS_N
 size_t ba_reduced_solve_lds_bytes(int n);
 int ba_prepare_reduced_solve_lds(int n);

@@ -85,6 +85,11 @@ extern "C" int rs_context_set_int(rs_context* ctx, const char* name, int value)
         ctx->ba_sets = value;
         return RS_OK;
     }
+    if (strcmp(name, "ba_imu_mode") == 0) {
+        if (value < 0 || value > 1) return rs_fail(ctx, RS_ERR_INVALID, "ba_imu_mode must be 0 (eliminate around the LDS solve) or 1 (blocked N x N solve)");
+        ctx->ba_imu_mode = value;
+        return RS_OK;
+    }
     if (strcmp(name, "ba_batch_mode") == 0) {
         if (value < 0 || value > 1) return rs_fail(ctx, RS_ERR_INVALID, "ba_batch_mode must be 0 (grid where possible) or 1 (lanes)");
         ctx->ba_batch_mode = value;

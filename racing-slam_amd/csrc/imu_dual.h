@@ -118,16 +118,33 @@ __device__ inline void d_matrix_to_aa(const D R[9], D aa[3])
         q[2] = (DRM(R, 0, 2) - DRM(R, 2, 0)) * t;
         q[3] = (DRM(R, 1, 0) - DRM(R, 0, 1)) * t;
     } else {
+        // i = index of the largest diagonal entry, (j, k) = the cyclic successors; written out per case so that R and q
+        // stay in registers (a run-time index sends both arrays to scratch memory)
         int i = 0;
         if (DRM(R, 1, 1).a > DRM(R, 0, 0).a) i = 1;
-        if (DRM(R, 2, 2).a > DRM(R, i, i).a) i = 2;
-        const int j = (i + 1) % 3, k = (j + 1) % 3;
-        D t = dsqrt(DRM(R, i, i) - DRM(R, j, j) - DRM(R, k, k) + D::constant(1.0));
-        q[i + 1] = t * 0.5;
-        t = D::constant(0.5) / t;
-        q[0] = (DRM(R, k, j) - DRM(R, j, k)) * t;
-        q[j + 1] = (DRM(R, j, i) + DRM(R, i, j)) * t;
-        q[k + 1] = (DRM(R, k, i) + DRM(R, i, k)) * t;
+        if ((i == 0 ? DRM(R, 0, 0).a : DRM(R, 1, 1).a) < DRM(R, 2, 2).a) i = 2;
+        if (i == 0) {
+            D t = dsqrt(DRM(R, 0, 0) - DRM(R, 1, 1) - DRM(R, 2, 2) + D::constant(1.0));
+            q[1] = t * 0.5;
+            t = D::constant(0.5) / t;
+            q[0] = (DRM(R, 2, 1) - DRM(R, 1, 2)) * t;
+            q[2] = (DRM(R, 1, 0) + DRM(R, 0, 1)) * t;
+            q[3] = (DRM(R, 2, 0) + DRM(R, 0, 2)) * t;
+        } else if (i == 1) {
+            D t = dsqrt(DRM(R, 1, 1) - DRM(R, 2, 2) - DRM(R, 0, 0) + D::constant(1.0));
+            q[2] = t * 0.5;
+            t = D::constant(0.5) / t;
+            q[0] = (DRM(R, 0, 2) - DRM(R, 2, 0)) * t;
+            q[3] = (DRM(R, 2, 1) + DRM(R, 1, 2)) * t;
+            q[1] = (DRM(R, 0, 1) + DRM(R, 1, 0)) * t;
+        } else {
+            D t = dsqrt(DRM(R, 2, 2) - DRM(R, 0, 0) - DRM(R, 1, 1) + D::constant(1.0));
+            q[3] = t * 0.5;
+            t = D::constant(0.5) / t;
+            q[0] = (DRM(R, 1, 0) - DRM(R, 0, 1)) * t;
+            q[1] = (DRM(R, 0, 2) + DRM(R, 2, 0)) * t;
+            q[2] = (DRM(R, 1, 2) + DRM(R, 2, 1)) * t;
+        }
     }
     const D s2 = q[1] * q[1] + q[2] * q[2] + q[3] * q[3];
     if (s2.a > 0.0) {

@@ -717,12 +717,15 @@ def test_bundle_adjust_landmark_shards_in_process_group(rs, synth, n_shards, kw)
 @pytest.mark.parametrize("kw,skip", [(dict(n_kf=7, n_points=150, run_max=5, config_id=62, outlier_frac=0.08, rot_noise_deg=1.5), {(4, 5)}),
                                      (dict(n_kf=8, n_points=400, run_max=6, config_id=61), set()),
                                      (dict(), set())])
-def test_bundle_adjust_inertial(ctx, oracle, synth, kw, skip):
-    """§8(f) rank 2 / a15: bundle_adjust with IMU factor pairs (preintegration 9 + bias walk 6 residuals per pair,
+@pytest.mark.parametrize("imu_mode", [0, 1])
+def test_bundle_adjust_inertial(ctx, oracle, synth, kw, skip, imu_mode):
+    """imu_mode 0: velocity / bias blocks eliminated around the LDS reduced solve (ba_imu.hip); 1: the N x N blocked solve.
+    §8(f) rank 2 / a15: bundle_adjust with IMU factor pairs (preintegration 9 + bias walk 6 residuals per pair,
     velocity 3 + bias 6 unknowns per frame; reference src/Optimization.cpp:317-346, src/ImuFactor.cpp:19-118) through
     rs_bundle_adjust_inertial against the oracle: identical schedule per iteration, poses / velocities / biases / cost to
     f64 reformulation noise.  Cases: a gap in the factor chain, a full chain of 5, and the 20-key-frame benchmark window
     with 17 factor pairs (N = 108 + 162 = 270 camera-side unknowns on the blocked solve)."""
+    ctx.set_int("ba_imu_mode", imu_mode)
     w = synth.make_ba_window(**kw)
     imu = synth.make_imu(w, skip=skip)
     args = (w["cams"], w["cam_free"], w["points"], w["obs_ptr"], w["obs_cam"], w["obs_uv"], w["K"])
@@ -756,6 +759,7 @@ def test_bundle_adjust_inertial(ctx, oracle, synth, kw, skip):
     assert (s2["iterations"], s2["successful_steps"]) == (s3["iterations"], s3["successful_steps"])
     assert np.allclose(to_np(dc2), to_np(dc3), rtol=1e-9, atol=1e-11)
     assert np.array_equal(v2, imu["cam_velocity"]) and np.array_equal(b2, imu["cam_bias"])
+    ctx.set_int("ba_imu_mode", 0)
 
 
 def test_bundle_adjust_inertial_rejects_bad_factors(ctx, rs, synth):
