@@ -769,6 +769,12 @@ static int ba_solve_impl(rs_context* ctx, int n_cameras, int n_points, int n_obs
         int32_t* d_inert = nullptr;
         ba_inertial_carve(ws + o_big, N_in, in->n_factors, d.C, &b.imu, &d_fac, &d_inert);
         b.imu.n_fac = in->n_factors; b.imu.Ci = Ci; b.imu.N = N_in;
+        if (imu_lds) {          // the elimination's accumulators live in the N x N matrix of the blocked path (not used then)
+            if (ba_imu_lds_total_doubles(Ci, d.n) > (size_t)N_in * N_in) return rs_fail(ctx, RS_ERR_UNSUPPORTED, "inertial accumulators");
+            b.imu.zacc = b.imu.A;
+            b.imu.zacc_n = (int)ba_imu_lds_zacc_doubles(Ci, d.n);
+            RS_HIP(ctx, hipMemsetAsync(b.imu.zacc, 0, sizeof(double) * (size_t)b.imu.zacc_n, s));
+        }
         for (int k = 0; k < 3; k++) b.imu.gravity[k] = in->gravity[k];
         fac_host.resize((size_t)in->n_factors);
         for (int f = 0; f < in->n_factors; f++) { fac_host[(size_t)f].f = in->factors[f]; imu_whitener(in->factors[f].covariance, fac_host[(size_t)f].W); }

@@ -77,6 +77,8 @@ struct BaImu {
     double* sc;                    // [N] Jacobi scale
     double* gtot;                  // [N] camera-side gradient incl. the inertial blocks
     double* Jf;                    // [n_fac][9][24] preintegration Jacobians of this round
+    double* zacc;                  // local-window path (ba_imu.hip): accumulators the factor kernel adds into, cleared by K8
+    int zacc_n;                    //   [W | H_zz diagonal blocks | H_zz sub-diagonal blocks | g_z], zacc_n doubles (0 = path not in use)
     double gravity[3];
 };
 
@@ -522,6 +524,8 @@ int ba_launch_reduced_solve_inertial(rs_context* ctx, const BaDims& d, const BaB
 void ba_launch_imu_eliminate(hipStream_t s, const BaDims& d, const BaBufs& b, const BaOpt& opt);
 void ba_launch_imu_expand(hipStream_t s, const BaDims& d, const BaBufs& b, const BaOpt& opt);
 int ba_imu_lds_path_max_ci();
+size_t ba_imu_lds_zacc_doubles(int Ci, int n);
+size_t ba_imu_lds_total_doubles(int Ci, int n);
 // ---- LDS-resident reduced solve (ba_solve.hip), n = 6*Cf <= BA_MAX_LDS_N
 size_t ba_reduced_solve_lds_bytes(int n);
 int ba_prepare_reduced_solve_lds(int n);

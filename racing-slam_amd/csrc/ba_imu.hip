@@ -1,22 +1,20 @@
 // ba_imu.hip — inertial bundle adjustment on the LOCAL-WINDOW kernels (K5 MFMA Schur, LDS K7, K8): the velocity / bias
-// blocks of the IMU factors (reference src/Optimization.cpp:317-346, src/ImuFactor.cpp:19-118) are eliminated in one
-// workgroup between K5 and K7, so that K7 still solves the 6 Cf x 6 Cf pose system it was built for.
+// blocks of the IMU factors (reference src/Optimization.cpp:317-346, src/ImuFactor.cpp:19-118) are eliminated between
+// K5 and K7, so that K7 still solves the 6 Cf x 6 Cf pose system it was built for.
 //
 //   unknowns      poses p (6 per optimised camera), z_c = (velocity 3 | bias 6) per inertial camera, landmarks
 //   K5            eliminates the landmarks as always:  S_pp (vision), rhs, U, gc
-//   K6i (here)    linearises the IMU factor pairs (one 32-lane group per pair, one dual partial per lane, imu_dual.h):
-//                   H_pp  -> U (same camera) / S (pose_i x pose_j),  g_p -> gc
-//                   H_zz  block tridiagonal (a factor joins consecutive inertial cameras) in LDS,  H_zp, g_z -> G
-//                 damps z like every Ceres parameter (Jacobi scale from the first linearisation, clamp, / radius),
-//                 factors A_zz = L D L^T block by block, solves  Y = A_zz^-1 [H_zp | g_z]  and adds the Schur terms
-//                   S -= H_pz Y_p,   rhs -= H_pz y_g
-//                 The cost / gradient-maximum of the inertial blocks go into K5's slot lines, so K7 sees totals.
+//   K6a (here)    one workgroup per IMU factor pair, lane = local parameter (one dual partial per lane, imu_dual.h):
+//                   H_pp -> U (same camera) / S (pose_i x pose_j),  g_p -> gc,  cost -> K5's slot lines
+//                   H_zz (block tridiagonal: a factor joins consecutive inertial cameras), H_zp, g_z -> accumulators
+//   K6b (here)    one workgroup: damps z like every Ceres parameter (Jacobi scale from the first linearisation, clamp,
+//                 / radius), factors A_zz = L D L^T block by block, forward-substitutes  W = L^-1 [H_zp | g_z]  and adds
+//                 the Schur terms  S -= W_p^T D^-1 W_p,  rhs -= W_p^T D^-1 w_g  as an LDS-tiled product
 //   K7            unchanged: (U + Lambda_p + S) x_p = gc + rhs, candidate cameras, pose part of the step scalars
-//   K7i (here)    x_z = y_g - Y_p x_p: candidate velocities / biases, their part of the model cost change / step norm /
-//                 x norm, and the inertial blocks' cost at the candidate  -> BaState::cam_scal
-//   K8            unchanged.
-// Same LM schedule as the N x N blocked solve (ba_solve_big.hip) it replaces for windows of at most 21 optimised
-// cameras: 14 launches per round become 5.
+//   K7i (here)    x_z = L^-T D^-1 (w_g - W_p x_p): candidate velocities / biases, their part of the model cost change /
+//                 step norm / x norm, and the inertial blocks' cost at the candidate  -> BaState::cam_scal
+//   K8            unchanged (and clears the inertial accumulators with the others).
+// Same LM schedule as the N x N blocked solve (ba_solve_big.hip) it replaces for windows of at most 21 optimised cameras.
 #include "ba_common.h"
 #include "imu_dual.h"
 
@@ -35,102 +33,119 @@ __device__ __forceinline__ double imu_rcp(double p)
     return r;
 }
 
-// G [9 Ci][n + 1] (row z: H_zp | g_z, becomes Y) and G0 [9 Ci][n] (H_zp kept) live in the N x N buffer of the blocked path
-__device__ __forceinline__ double* imu_G(const BaBufs& b) { return b.imu.A; }
-__device__ __forceinline__ double* imu_G0(const BaBufs& b, int n) { return b.imu.A + (size_t)9 * b.imu.Ci * (n + 1); }
+// Layout of the inertial accumulators (BaImu::zacc, zeroed before every round): W [9 Ci][n + 1] (row z: H_zp | g_z, then
+// L^-1 of it), the diagonal blocks of H_zz [Ci][81], the sub-diagonal blocks (q + 1, q) [Ci][81], g_z [9 Ci].
+// Behind them (not cleared): the factor L [Ci][81] | [Ci][81] and D^-1 [9 Ci] that K7i needs.
+struct ImuView { double *W, *Hd, *Ho, *gz, *Ld, *Lo, *dinv; };
+__host__ __device__ inline size_t imu_zacc_count(int Ci, int n) { return (size_t)9 * Ci * (n + 1) + 162 * (size_t)Ci + 9 * (size_t)Ci; }
+__device__ __forceinline__ ImuView imu_view(const BaBufs& b, int n)
+{
+    const int Ci = b.imu.Ci;
+    ImuView v;
+    v.W = b.imu.zacc; v.Hd = v.W + (size_t)9 * Ci * (n + 1); v.Ho = v.Hd + 81 * Ci; v.gz = v.Ho + 81 * Ci;
+    v.Ld = v.gz + 9 * Ci; v.Lo = v.Ld + 81 * Ci; v.dinv = v.Lo + 81 * Ci;
+    return v;
+}
 
+// ---------------------------------------------------------------------------------------------- K6a
+// local parameter k of the pair (lane k): 0-5 pose_i | 6-8 velocity_i | 9-14 bias_i | 15-20 pose_j | 21-23 velocity_j
+__global__ __launch_bounds__(64) void ba_imu_factors(BaDims d, BaBufs b)
+{
+    const BaState st = *b.st;
+    if (st.done || threadIdx.x >= 32) return;
+    const int n = d.n, lk = threadIdx.x, fi = blockIdx.x;
+    const ImuView V = imu_view(b, n);
+    const double* Xc = b.Xc + (size_t)st.cur * d.C * 6;
+    const double* Xv = b.imu.Xv + (size_t)st.cur * d.C * 9;
+    const ImuFactorDev& F = b.imu.fac[fi];
+    const int ci = F.f.cam_i, cj = F.f.cam_j;
+    const int si = b.slot[ci], sj = b.slot[cj], qi = b.imu.inert_slot[ci], qj = b.imu.inert_slot[cj];   // qj == qi + 1 (host)
+    double r[9], jl[9], rw[6], is[2];
+    imu_preintegration_lanes(F, b.imu.gravity, Xc + 6 * ci, Xv + 9 * ci, Xv + 9 * ci + 3, Xc + 6 * cj, Xv + 9 * cj, r, jl);
+    imu_bias_walk(F.f, Xv + 9 * ci + 3, Xv + 9 * cj + 3, rw, is);
+    const bool isP = lk < 6 || (lk >= 15 && lk < 21), live = lk < IMU_NP;
+    const bool mine_i = lk < 15;                                  // parameter belongs to camera i
+    const int pc = lk < 6 ? 6 * si + lk : 6 * sj + (lk - 15);
+    const int zc = lk < 15 ? lk - 6 : lk - 21;                    // component inside the 9-block
+    const int zr = lk < 15 ? 9 * qi + zc : 9 * qj + zc;
+    // the other lanes' columns through LDS (a __shfl of a double is two ds_bpermute; these are broadcast reads; the 32
+    // lanes are one wave: no barrier needed beyond the LDS write -> read dependency the compiler tracks)
+    __shared__ double Jc[9][32];
+#pragma unroll
+    for (int a = 0; a < 9; a++) Jc[a][lk] = jl[a];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    double gk = 0.0;
+#pragma unroll
+    for (int a = 0; a < 9; a++) gk += jl[a] * r[a];
+    if (live) {
+        if (isP) { if (st.fresh) atomicAdd(&b.gc[pc], gk); }
+        else atomicAdd(&V.gz[zr], gk);
+    }
+#pragma unroll
+    for (int l = 0; l < IMU_NP; l++) {
+        double h = 0.0;
+#pragma unroll
+        for (int a = 0; a < 9; a++) h += jl[a] * Jc[a][l];
+        const bool oP = l < 6 || (l >= 15 && l < 21), o_i = l < 15;           // compile-time per l
+        const int opc = l < 6 ? 6 * si + l : 6 * sj + (l - 15);
+        const int ozc = l < 15 ? l - 6 : l - 21;
+        if (!live) continue;
+        if (isP && oP) {
+            if (mine_i == o_i) {                                  // same camera: its 6 x 6 diagonal block lives in U
+                if (st.fresh) atomicAdd(&b.U[(pc / 6) * 36 + (pc % 6) * 6 + (opc % 6)], h);
+            } else if (pc < opc) {
+                atomicAdd(&b.S[(size_t)pc * n + opc], h);         // K7 reads S's upper triangle
+            }
+        } else if (!isP && oP) {
+            atomicAdd(&V.W[(size_t)zr * (n + 1) + opc], h);
+        } else if (!isP && !oP) {
+            if (mine_i == o_i) atomicAdd(&V.Hd[(mine_i ? qi : qj) * 81 + zc * 9 + ozc], h);
+            else if (!mine_i) atomicAdd(&V.Ho[qi * 81 + zc * 9 + ozc], h);      // rows z_j, columns z_i
+        }
+    }
+    if (lk < 6) {                                   // bias walk: -1/sigma on bias_i[a], +1/sigma on bias_j[a]
+        const int a = lk;
+        const double sg = a < 3 ? is[0] : is[1], s2 = sg * sg;
+        double rwa = rw[0];                          // rw[a] without a run-time index (scratch)
+#pragma unroll
+        for (int q = 1; q < 6; q++) rwa = (a == q) ? rw[q] : rwa;
+        atomicAdd(&V.gz[9 * qi + 3 + a], -sg * rwa);
+        atomicAdd(&V.gz[9 * qj + 3 + a], sg * rwa);
+        atomicAdd(&V.Hd[qi * 81 + (3 + a) * 10], s2);
+        atomicAdd(&V.Hd[qj * 81 + (3 + a) * 10], s2);
+        atomicAdd(&V.Ho[qi * 81 + (3 + a) * 10], -s2);
+    }
+    if (lk == 0 && st.fresh) {                      // cost at x: into one of K5's slot lines (K7 sums them)
+        double c = 0.0;
+        for (int a = 0; a < 9; a++) c += 0.5 * r[a] * r[a];
+        for (int a = 0; a < 6; a++) c += 0.5 * rw[a] * rw[a];
+        atomicAdd(&b.scal[(size_t)(fi & (BA_NSLOT - 1)) * BA_SLOT_STRIDE], c);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------- K6b
+#define KCH 84                  // z rows per staged chunk (a multiple of 4: MFMA k-steps): two passes for 18 cameras
+#define KLD 116                 // row stride of a staged chunk (>= 16 * tiles per side; n + 1 <= 112)
+#define KTW 4                   // output tiles per wave (28 upper-triangular tiles of 16 x 16 over 8 waves)
 __global__ __launch_bounds__(KI_THREADS) void ba_imu_eliminate(BaDims d, BaBufs b, BaOpt opt)
 {
+    extern __shared__ __attribute__((aligned(16))) double dyn[];      // [KCH][KLD]: chunk of W
     __shared__ double Hd[IMU_MAXCI * 81];       // diagonal blocks of A_zz, then their L (unit lower) / D
     __shared__ double Ho[IMU_MAXCI * 81];       // block (q + 1, q), then L_{q+1,q}
     __shared__ double gz[IMU_MAXCI * 9], dinv[IMU_MAXCI * 9];
     __shared__ BaState st;
-    __shared__ double s_cost, s_red[KI_THREADS / 64];
+    __shared__ double s_red[KI_THREADS / 64];
     __shared__ int s_fail;
-    __shared__ int q_of_slot[IMU_MAXCI + 1];    // inertial slot of the camera that owns pose slot s, or -1
     const int n = d.n, Ci = b.imu.Ci, NZ = 9 * Ci, tid = threadIdx.x, nt = KI_THREADS;
     const int lane = tid & 63, wave = tid >> 6;
-    double* G = imu_G(b);
-    double* G0 = imu_G0(b, n);
-    if (tid == 0) { st = *b.st; s_cost = 0.0; s_fail = 0; }
-    for (int i = tid; i < Ci * 81; i += nt) { Hd[i] = 0.0; Ho[i] = 0.0; }
-    for (int i = tid; i < NZ; i += nt) gz[i] = 0.0;
-    if (tid <= IMU_MAXCI) q_of_slot[tid] = -1;
-    for (int i = tid; i < NZ * (n + 1); i += nt) G[i] = 0.0;
-    for (int i = tid; i < NZ * n; i += nt) G0[i] = 0.0;
+    const ImuView V = imu_view(b, n);
+    if (tid == 0) { st = *b.st; s_fail = 0; }
+    for (int i = tid; i < Ci * 81; i += nt) { Hd[i] = V.Hd[i]; Ho[i] = V.Ho[i]; }
+    for (int i = tid; i < NZ; i += nt) gz[i] = V.gz[i];
     __syncthreads();
     if (st.done) return;
-    for (int c = tid; c < d.C; c += nt) { const int s = b.slot[c]; if (s >= 0 && s <= IMU_MAXCI) q_of_slot[s] = b.imu.inert_slot[c]; }
-    const double* Xc = b.Xc + (size_t)st.cur * d.C * 6;
-    const double* Xv = b.imu.Xv + (size_t)st.cur * d.C * 9;
-    // ---- (1) the factor pairs: local parameter k of the pair (lane k of its 32-lane group) is
-    //   0-5 pose_i | 6-8 velocity_i | 9-14 bias_i | 15-20 pose_j | 21-23 velocity_j
-    {
-        const int grp = tid >> 5, lk = tid & 31;
-        for (int fi = grp; fi < b.imu.n_fac; fi += nt >> 5) {
-            const ImuFactorDev& F = b.imu.fac[fi];
-            const int ci = F.f.cam_i, cj = F.f.cam_j;
-            const int si = b.slot[ci], sj = b.slot[cj], qi = b.imu.inert_slot[ci], qj = b.imu.inert_slot[cj];   // qj == qi + 1 (host)
-            double r[9], jl[9], rw[6], is[2];
-            imu_preintegration_lanes(F, b.imu.gravity, Xc + 6 * ci, Xv + 9 * ci, Xv + 9 * ci + 3, Xc + 6 * cj, Xv + 9 * cj, r, jl);
-            imu_bias_walk(F.f, Xv + 9 * ci + 3, Xv + 9 * cj + 3, rw, is);
-            // this lane's parameter: a pose column (pc >= 0) or a z row (zr >= 0)
-            const bool isP = lk < 6 || (lk >= 15 && lk < 21), live = lk < IMU_NP;
-            const bool mine_i = lk < 15;                                  // parameter belongs to camera i
-            const int pc = lk < 6 ? 6 * si + lk : 6 * sj + (lk - 15);
-            const int zc = lk < 15 ? lk - 6 : lk - 21;                    // component inside the 9-block
-            const int zr = lk < 15 ? 9 * qi + zc : 9 * qj + zc;
-            double gk = 0.0;
-#pragma unroll
-            for (int a = 0; a < 9; a++) gk += jl[a] * r[a];
-            if (live) {
-                if (isP) { if (st.fresh) atomicAdd(&b.gc[pc], gk); }
-                else atomicAdd(&gz[zr], gk);
-            }
-#pragma unroll
-            for (int l = 0; l < IMU_NP; l++) {
-                double h = 0.0;
-#pragma unroll
-                for (int a = 0; a < 9; a++) h += jl[a] * __shfl(jl[a], l, 32);
-                const bool oP = l < 6 || (l >= 15 && l < 21), o_i = l < 15;           // compile-time per l
-                const int opc = l < 6 ? 6 * si + l : 6 * sj + (l - 15);
-                const int ozc = l < 15 ? l - 6 : l - 21;
-                if (!live) continue;
-                if (isP && oP) {
-                    if (mine_i == o_i) {                                  // same camera: its 6 x 6 diagonal block lives in U
-                        if (st.fresh) atomicAdd(&b.U[(pc / 6) * 36 + (pc % 6) * 6 + (opc % 6)], h);
-                    } else if (pc < opc) {
-                        atomicAdd(&b.S[(size_t)pc * n + opc], h);         // K7 reads S's upper triangle
-                    }
-                } else if (!isP && oP) {
-                    atomicAdd(&G[(size_t)zr * (n + 1) + opc], h);
-                    atomicAdd(&G0[(size_t)zr * n + opc], h);
-                } else if (!isP && !oP) {
-                    if (mine_i == o_i) atomicAdd(&Hd[(mine_i ? qi : qj) * 81 + zc * 9 + ozc], h);
-                    else if (!mine_i) atomicAdd(&Ho[qi * 81 + zc * 9 + ozc], h);      // rows z_j, columns z_i
-                }
-            }
-            if (lk < 6) {                                   // bias walk: -1/sigma on bias_i[a], +1/sigma on bias_j[a]
-                const int a = lk;
-                const double sg = a < 3 ? is[0] : is[1], s2 = sg * sg;
-                double rwa = rw[0];                          // rw[a] without a run-time index (scratch)
-#pragma unroll
-                for (int q = 1; q < 6; q++) rwa = (a == q) ? rw[q] : rwa;
-                atomicAdd(&gz[9 * qi + 3 + a], -sg * rwa);
-                atomicAdd(&gz[9 * qj + 3 + a], sg * rwa);
-                atomicAdd(&Hd[qi * 81 + (3 + a) * 10], s2);
-                atomicAdd(&Hd[qj * 81 + (3 + a) * 10], s2);
-                atomicAdd(&Ho[qi * 81 + (3 + a) * 10], -s2);
-            }
-            if (lk == 0) {
-                double c = 0.0;
-                for (int a = 0; a < 9; a++) c += 0.5 * r[a] * r[a];
-                for (int a = 0; a < 6; a++) c += 0.5 * rw[a] * rw[a];
-                atomicAdd(&s_cost, c);
-            }
-        }
-    }
-    __syncthreads();
     // ---- (2) Jacobi scale (first linearisation) and damping of the z parameters; their gradient and maximum
     double gm = 0.0;
     for (int t = tid; t < NZ; t += nt) {
@@ -141,16 +156,15 @@ __global__ __launch_bounds__(KI_THREADS) void ba_imu_eliminate(BaDims d, BaBufs 
         Hd[(t / 9) * 81 + (t % 9) * 10] = h + lam;
         b.imu.lam[n + t] = lam;
         b.imu.gtot[n + t] = gz[t];
-        G[(size_t)t * (n + 1) + n] = gz[t];
+        V.W[(size_t)t * (n + 1) + n] = gz[t];
         gm = fmax(gm, fabs(gz[t]));
     }
     gm = wave_max_nonneg(gm);
     if (lane == 0) s_red[wave] = gm;
     __syncthreads();
-    if (tid == 0 && st.fresh) {                             // totals for K7: cost at x and gradient maximum ride in slot 0
+    if (tid == 0 && st.fresh) {                             // gradient maximum of the z blocks rides in K5's slot 0
         double g = 0.0;
         for (int w = 0; w < nt / 64; w++) g = fmax(g, s_red[w]);
-        b.scal[0] += s_cost;
         if (g > 0.0) atomic_max_nonneg(&b.gmax[0], g);
     }
     // ---- (3) A_zz = L D L^T, block tridiagonal: one wave, lane = row of the 18 x 18 window [A_qq . ; A_q+1,q A_q+1,q+1],
@@ -194,83 +208,107 @@ __global__ __launch_bounds__(KI_THREADS) void ba_imu_eliminate(BaDims d, BaBufs 
         if (tid == 0) b.scal[1] += 1.0;                     // K7's failure count of set 0: the step is invalid
         return;
     }
-    // ---- (4) Y = A_zz^-1 G, one thread per column (n pose columns + the gradient): forward L t = g block by block,
-    // scale by D^-1, backward L^T y = t; the next block's nine entries are fetched while the current block is solved
+    for (int i = tid; i < Ci * 81; i += nt) { V.Ld[i] = Hd[i]; V.Lo[i] = Ho[i]; }          // for K7i's backward substitution
+    for (int i = tid; i < NZ; i += nt) V.dinv[i] = dinv[i];
+    // ---- (4) W <- L^-1 W, one thread per column (n pose columns + the gradient), block by block; the next block's nine
+    // entries are fetched while the current block is solved
     for (int col = tid; col <= n; col += nt) {
-        double t[9], nx[9];
+        double t[9], nx[9], prev[9];
 #pragma unroll
-        for (int k = 0; k < 9; k++) nx[k] = G[(size_t)k * (n + 1) + col];
-        double prev[9];
-#pragma unroll
-        for (int k = 0; k < 9; k++) prev[k] = 0.0;
+        for (int k = 0; k < 9; k++) { nx[k] = V.W[(size_t)k * (n + 1) + col]; prev[k] = 0.0; }
         for (int q = 0; q < Ci; q++) {
 #pragma unroll
             for (int k = 0; k < 9; k++) t[k] = nx[k];
             if (q + 1 < Ci) {
 #pragma unroll
-                for (int k = 0; k < 9; k++) nx[k] = G[(size_t)(9 * (q + 1) + k) * (n + 1) + col];
+                for (int k = 0; k < 9; k++) nx[k] = V.W[(size_t)(9 * (q + 1) + k) * (n + 1) + col];
             }
             if (q > 0) {
 #pragma unroll
                 for (int r = 0; r < 9; r++)
 #pragma unroll
-                    for (int k = 0; k < 9; k++) t[r] -= Ho[(q - 1) * 81 + r * 9 + k] * prev[k];     // L_{q,q-1} D_{q-1} t'_{q-1}: prev holds D t'
+                    for (int k = 0; k < 9; k++) t[r] -= Ho[(q - 1) * 81 + r * 9 + k] * prev[k];     // L_{q,q-1} w_{q-1}
             }
 #pragma unroll
             for (int r = 1; r < 9; r++)
 #pragma unroll
                 for (int k = 0; k < r; k++) t[r] -= Hd[q * 81 + r * 9 + k] * t[k];
-            // t = L^-1 (...) ; the factor is L D L^T with UNIT L and multipliers l = a / d, so  A x = g  <=>  L w = g, x' = D^-1 w, L^T x = x'
 #pragma unroll
-            for (int k = 0; k < 9; k++) { prev[k] = t[k]; G[(size_t)(9 * q + k) * (n + 1) + col] = t[k] * dinv[q * 9 + k]; }
-        }
-        // backward
-        double nxt[9];
-#pragma unroll
-        for (int k = 0; k < 9; k++) nxt[k] = 0.0;
-        for (int q = Ci - 1; q >= 0; q--) {
-            double y[9];
-#pragma unroll
-            for (int k = 0; k < 9; k++) y[k] = G[(size_t)(9 * q + k) * (n + 1) + col];
-            if (q + 1 < Ci) {
-#pragma unroll
-                for (int k = 0; k < 9; k++)
-#pragma unroll
-                    for (int r = 0; r < 9; r++) y[k] -= Ho[q * 81 + r * 9 + k] * nxt[r];              // L_{q+1,q}^T y_{q+1}
-            }
-#pragma unroll
-            for (int k = 7; k >= 0; k--)
-#pragma unroll
-                for (int r = k + 1; r < 9; r++) y[k] -= Hd[q * 81 + r * 9 + k] * y[r];
-#pragma unroll
-            for (int k = 0; k < 9; k++) { nxt[k] = y[k]; G[(size_t)(9 * q + k) * (n + 1) + col] = y[k]; }
+            for (int k = 0; k < 9; k++) { prev[k] = t[k]; V.W[(size_t)(9 * q + k) * (n + 1) + col] = t[k]; }
         }
     }
     __syncthreads();
-    // ---- (5) Schur terms onto the pose system: S[k][i] -= sum_z H_zp[z][k] Y[z][i] (k <= i), rhs[k] -= sum_z H_zp[z][k] y_g[z].
-    // H_zp's column k is non-zero only in the z blocks of camera(k)'s factors: its own and the two neighbours.
-    for (int idx = tid; idx < n * (n + 1); idx += nt) {
-        const int k = idx / (n + 1), i = idx % (n + 1);
-        if (i < n && i < k) continue;
-        const int q0 = q_of_slot[k / 6];                    // inertial slot of the camera that owns pose column k
-        if (q0 < 0) continue;
-        // 27 rows, all 54 loads in flight together (rows outside [0, Ci) are clamped and weighted 0)
-        double u[27], y[27];
+    // ---- (5) Schur terms onto the pose system: S[k][i] -= sum_z W[z][k] W[z][i] / d_z (k <= i < n), rhs[k] -= ... (i = n),
+    // as a product on the f64 matrix cores: 16 x 16 output tiles (the upper-triangular ones, dealt round-robin to the eight
+    // waves), K = the z rows, staged KCH at a time as W and D^-1 W (k-major, so an MFMA operand is one ds_read_b64)
+    {
+        typedef __attribute__((ext_vector_type(4))) double d4;
+        double* Wc = dyn;
+        const int lr = lane & 15, lq = lane >> 4;
+        const int nt16 = (n + 1 + 15) / 16;                 // tiles per side (n = 108: 7)
+        // this wave's tiles: t = wave, wave + 8, ... over the (tr <= tc) list
+        int tr[KTW], tc[KTW];
+        bool tv[KTW];
+        d4 acc[KTW];
 #pragma unroll
-        for (int e = 0; e < 27; e++) {
-            const int z = 9 * (q0 - 1) + e, zc = min(max(z, 0), NZ - 1);
-            u[e] = G0[(size_t)zc * n + k];
-            y[e] = G[(size_t)zc * (n + 1) + i];
+        for (int e = 0; e < KTW; e++) {
+            int t = wave + 8 * e, r = 0;
+            while (r < nt16 && t >= nt16 - r) { t -= nt16 - r; r++; }       // row r holds nt16 - r tiles (tc = r .. nt16 - 1)
+            tv[e] = r < nt16;
+            tr[e] = tv[e] ? r : 0;
+            tc[e] = tv[e] ? r + t : 0;
+            acc[e] = d4{0.0, 0.0, 0.0, 0.0};
         }
-        double acc = 0.0;
+        for (int z0 = 0; z0 < NZ; z0 += KCH) {
+            const int rows = min(KCH, NZ - z0);
+            {
+                // thread -> (column c = tid & 127, rows rg, rg + 4, ...): coalesced rows, seven loads of a thread in flight
+                const int c = tid & 127, rg = tid >> 7;
+                for (int e0 = 0; e0 < KCH / 4; e0 += 7) {
+                    double v[7];
 #pragma unroll
-        for (int e = 0; e < 27; e++) { const int z = 9 * (q0 - 1) + e; acc += (z >= 0 && z < NZ) ? u[e] * y[e] : 0.0; }
-        if (i < n) b.S[(size_t)k * n + i] -= acc;
-        else b.rhs[k] -= acc;
+                    for (int e = 0; e < 7; e++) {
+                        const int zz = rg + 4 * (e0 + e);
+                        v[e] = (zz < rows && c <= n) ? V.W[(size_t)(z0 + zz) * (n + 1) + c] : 0.0;
+                    }
+#pragma unroll
+                    for (int e = 0; e < 7; e++) {
+                        const int zz = rg + 4 * (e0 + e);
+                        if (c < KLD && zz < KCH) Wc[zz * KLD + c] = v[e];
+                    }
+                }
+            }
+            __syncthreads();
+            const int ksteps = (rows + 3) / 4;              // rows beyond `rows` are zero
+            for (int kc = 0; kc < ksteps; kc++) {
+                const double dz = (4 * kc + lq) < rows ? dinv[z0 + 4 * kc + lq] : 0.0;
+#pragma unroll
+                for (int e = 0; e < KTW; e++) {
+                    if (!tv[e]) continue;                   // wave-uniform
+                    const double av = Wc[(4 * kc + lq) * KLD + 16 * tr[e] + lr];
+                    const double bv = Wc[(4 * kc + lq) * KLD + 16 * tc[e] + lr] * dz;
+                    acc[e] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc[e], 0, 0, 0);
+                }
+            }
+            __syncthreads();
+        }
+#pragma unroll
+        for (int e = 0; e < KTW; e++) {
+            if (!tv[e]) continue;
+#pragma unroll
+            for (int reg = 0; reg < 4; reg++) {
+                const int k = 16 * tr[e] + lq + 4 * reg, i = 16 * tc[e] + lr;       // C[row = lq + 4 reg][col = lr]
+                if (k < n) {
+                    if (i < n) { if (k <= i) b.S[(size_t)k * n + i] -= acc[e][reg]; }
+                    else if (i == n) b.rhs[k] -= acc[e][reg];
+                }
+            }
+        }
     }
 }
 
-// K7i: the z step from the pose step, candidates, step scalars, candidate cost of the inertial blocks
+// ---------------------------------------------------------------------------------------------- K7i
+// the z step from the pose step, candidates, step scalars, candidate cost of the inertial blocks
 __global__ __launch_bounds__(KI_THREADS) void ba_imu_expand(BaDims d, BaBufs b, BaOpt opt)
 {
     __shared__ BaState st;
@@ -278,26 +316,50 @@ __global__ __launch_bounds__(KI_THREADS) void ba_imu_expand(BaDims d, BaBufs b, 
     __shared__ double s_cand;
     __shared__ int s_bad;
     __shared__ int cam_of_q[IMU_MAXCI + 1];
+    __shared__ double u[IMU_MAXCI * 9];                     // D^-1 (w_g - W_p x_p), then x_z
     const int n = d.n, Ci = b.imu.Ci, NZ = 9 * Ci, tid = threadIdx.x, nt = KI_THREADS;
     if (tid == 0) { st = *b.st; s_cand = 0.0; s_bad = 0; }
     for (int c = tid; c < d.C; c += nt) { const int q = b.imu.inert_slot[c]; if (q >= 0 && q <= IMU_MAXCI) cam_of_q[q] = c; }
     __syncthreads();
     if (st.done || st.solver_failed) return;
-    const double* G = imu_G(b);
+    const ImuView V = imu_view(b, n);
     const int cand = (st.cur + 1) % (b.ns + 1);
     const double* Xv = b.imu.Xv + (size_t)st.cur * d.C * 9;
     double* Xvn = b.imu.Xv + (size_t)cand * d.C * 9;
     const double* Xn = b.Xc + (size_t)cand * d.C * 6;
     for (int i = tid; i < d.C * 9; i += nt) Xvn[i] = Xv[i];              // cameras without an inertial block keep their state
+    // x_p = -delta_p (K7 left delta_p in dc): u = D^-1 (w_g + W_p delta_p)
+    for (int t = tid; t < NZ; t += nt) {
+        double acc = V.W[(size_t)t * (n + 1) + n];
+#pragma unroll 18
+        for (int k = 0; k < n; k++) acc += V.W[(size_t)t * (n + 1) + k] * b.dc[k];       // n is a multiple of 6
+        u[t] = acc * V.dinv[t];
+    }
+    __syncthreads();
+    // L^T x = u from the last block: nine lanes, lane k = component k of the block
+    if (tid < 64) {
+        const int k = tid < 9 ? tid : 0;
+        double ynext = 0.0;                                 // this lane's component of x_{q+1}
+        for (int q = Ci - 1; q >= 0; q--) {
+            double y = u[9 * q + k];
+            if (q + 1 < Ci) {
+#pragma unroll
+                for (int r = 0; r < 9; r++) y -= V.Lo[q * 81 + r * 9 + k] * imu_rl64(ynext, r);       // L_{q+1,q}^T x_{q+1}
+            }
+#pragma unroll
+            for (int r = 8; r >= 1; r--) {                  // unit upper-triangular solve: x_r is final when step r runs
+                const double xr = imu_rl64(y, r);
+                y -= (k < r) ? V.Ld[q * 81 + r * 9 + k] * xr : 0.0;
+            }
+            ynext = y;
+            if (tid < 9) u[9 * q + k] = y;
+        }
+    }
     __syncthreads();
     double mcc = 0.0, ssq = 0.0, xsq = 0.0;
     bool bad = false;
     for (int t = tid; t < NZ; t += nt) {
-        // x_z = y_g - Y_p x_p with x_p = -delta_p (K7 left delta_p in dc);  delta_z = -x_z
-        double xz = G[(size_t)t * (n + 1) + n];
-#pragma unroll 18
-        for (int k = 0; k < n; k++) xz += G[(size_t)t * (n + 1) + k] * b.dc[k];       // n is a multiple of 6
-        const double dlt = -xz;
+        const double dlt = -u[t];
         if (!isfinite(dlt)) bad = true;
         const int cam = cam_of_q[t / 9];
         const double x = Xv[9 * cam + t % 9], xn = x + dlt;
@@ -330,9 +392,16 @@ __global__ __launch_bounds__(KI_THREADS) void ba_imu_expand(BaDims d, BaBufs b, 
     }
 }
 
+// ---------------------------------------------------------------------------------------------- host glue
+size_t ba_imu_lds_zacc_doubles(int Ci, int n) { return imu_zacc_count(Ci, n); }
+size_t ba_imu_lds_total_doubles(int Ci, int n) { return imu_zacc_count(Ci, n) + 162 * (size_t)Ci + 9 * (size_t)Ci; }
+
 void ba_launch_imu_eliminate(hipStream_t s, const BaDims& d, const BaBufs& b, const BaOpt& opt)
 {
-    hipLaunchKernelGGL(ba_imu_eliminate, dim3(1), dim3(KI_THREADS), 0, s, d, b, opt);
+    hipLaunchKernelGGL(ba_imu_factors, dim3(b.imu.n_fac), dim3(64), 0, s, d, b);
+    const size_t lds = sizeof(double) * KCH * KLD;
+    (void)rs_lds_attr((const void*)ba_imu_eliminate, lds);
+    hipLaunchKernelGGL(ba_imu_eliminate, dim3(1), dim3(KI_THREADS), lds, s, d, b, opt);
 }
 void ba_launch_imu_expand(hipStream_t s, const BaDims& d, const BaBufs& b, const BaOpt& opt)
 {

@@ -51,6 +51,7 @@ static __device__ __forceinline__ void ba_backsub_cost4_body(const BaDims& d, co
     const size_t gnth = (size_t)gridDim.y * gridDim.x * blockDim.x;
     for (size_t i = gtid; i < b.acc_count; i += gnth) b.acc[i] = 0.0;
     for (size_t i = gtid; i < BA_NSLOT * BA_SLOT_STRIDE; i += gnth) b.gmax[i] = 0.0;
+    for (size_t i = gtid; i < (size_t)b.imu.zacc_n; i += gnth) b.imu.zacc[i] = 0.0;      // inertial accumulators (ba_imu.hip)
     if (set_failed || set >= st.nact) return;
     double* cprep = lds;                                    // [C][BA_PREP] current
     double* cprepn = lds + (size_t)d.C * BA_PREP;           // [C][BA_PREP] candidate
