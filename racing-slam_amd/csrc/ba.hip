@@ -690,7 +690,7 @@ static int ba_solve_impl(rs_context* ctx, int n_cameras, int n_points, int n_obs
     if (imu_lds)
         for (int f = 0; f < in->n_factors && imu_lds; f++) imu_lds = inert[in->factors[f].cam_j] == inert[in->factors[f].cam_i] + 1;
     int ns = 1;
-    if (use_mfma && k8_lds && solve_lds && !in) {
+    if (use_mfma && k8_lds && solve_lds && (!in || imu_lds)) {
         ns = ctx->ba_sets > 0 ? ctx->ba_sets : BA_DEFAULT_SETS;
         if (ns > BA_MAXSETS) ns = BA_MAXSETS;
         if (ns > opt.max_iter) ns = opt.max_iter > 0 ? opt.max_iter : 1;
@@ -700,7 +700,9 @@ static int ba_solve_impl(rs_context* ctx, int n_cameras, int n_points, int n_obs
     const BaLayout L = ba_layout(d, ns, opt.max_iter, n_ranks, use_mfma ? ba_group_bytes(d.P, d.Cf, d.M) : 16);
     const size_t o_grp = L.grp, o_free = L.fre, pts_block = L.pts_block;
     const size_t o_big = L.bytes;
-    const size_t ws_bytes = L.bytes + align_up(in ? ba_inertial_bytes(N_in, in->n_factors, d.C) : (solve_big ? ba_big_bytes(d.n) : 16), 256);
+    const size_t big_bytes = align_up(in ? ba_inertial_bytes(N_in, in->n_factors, d.C) : (solve_big ? ba_big_bytes(d.n) : 16), 256);
+    const size_t o_zacc = o_big + big_bytes;
+    const size_t ws_bytes = o_zacc + (imu_lds ? align_up(sizeof(double) * ba_imu_lds_total_doubles(Ci, d.n, ns), 256) : 0);
     void* wsv = nullptr;
     int rc = rs_workspace(ctx, ws_bytes, &wsv);
     if (rc) return rc;
@@ -769,9 +771,8 @@ static int ba_solve_impl(rs_context* ctx, int n_cameras, int n_points, int n_obs
         int32_t* d_inert = nullptr;
         ba_inertial_carve(ws + o_big, N_in, in->n_factors, d.C, &b.imu, &d_fac, &d_inert);
         b.imu.n_fac = in->n_factors; b.imu.Ci = Ci; b.imu.N = N_in;
-        if (imu_lds) {          // the elimination's accumulators live in the N x N matrix of the blocked path (not used then)
-            if (ba_imu_lds_total_doubles(Ci, d.n) > (size_t)N_in * N_in) return rs_fail(ctx, RS_ERR_UNSUPPORTED, "inertial accumulators");
-            b.imu.zacc = b.imu.A;
+        if (imu_lds) {
+            b.imu.zacc = (double*)(ws + o_zacc);
             b.imu.zacc_n = (int)ba_imu_lds_zacc_doubles(Ci, d.n);
             RS_HIP(ctx, hipMemsetAsync(b.imu.zacc, 0, sizeof(double) * (size_t)b.imu.zacc_n, s));
         }

@@ -525,7 +525,7 @@ void ba_launch_imu_eliminate(hipStream_t s, const BaDims& d, const BaBufs& b, co
 void ba_launch_imu_expand(hipStream_t s, const BaDims& d, const BaBufs& b, const BaOpt& opt);
 int ba_imu_lds_path_max_ci();
 size_t ba_imu_lds_zacc_doubles(int Ci, int n);
-size_t ba_imu_lds_total_doubles(int Ci, int n);
+size_t ba_imu_lds_total_doubles(int Ci, int n, int ns);
 // ---- LDS-resident reduced solve (ba_solve.hip), n = 6*Cf <= BA_MAX_LDS_N
 size_t ba_reduced_solve_lds_bytes(int n);
 int ba_prepare_reduced_solve_lds(int n);

@@ -33,17 +33,20 @@ __device__ __forceinline__ double imu_rcp(double p)
     return r;
 }
 
-// Layout of the inertial accumulators (BaImu::zacc, zeroed before every round): W [9 Ci][n + 1] (row z: H_zp | g_z, then
-// L^-1 of it), the diagonal blocks of H_zz [Ci][81], the sub-diagonal blocks (q + 1, q) [Ci][81], g_z [9 Ci].
-// Behind them (not cleared): the factor L [Ci][81] | [Ci][81] and D^-1 [9 Ci] that K7i needs.
-struct ImuView { double *W, *Hd, *Ho, *gz, *Ld, *Lo, *dinv; };
+// Layout behind BaImu::zacc.  SHARED by the speculative sets, zeroed before every round (K8): H [9 Ci][n + 1] (row z:
+// H_zp | g_z), the diagonal blocks of H_zz [Ci][81], the sub-diagonal blocks (q + 1, q) [Ci][81], g_z [9 Ci].
+// Then PER SET (its radius damps z differently): W = L^-1 H [9 Ci][n + 1], the factor L [Ci][81] | [Ci][81], D^-1 [9 Ci]
+// and the damping [9 Ci].
+struct ImuView { double *H, *Hd, *Ho, *gz, *W, *Ld, *Lo, *dinv, *lam; };
 __host__ __device__ inline size_t imu_zacc_count(int Ci, int n) { return (size_t)9 * Ci * (n + 1) + 162 * (size_t)Ci + 9 * (size_t)Ci; }
-__device__ __forceinline__ ImuView imu_view(const BaBufs& b, int n)
+__host__ __device__ inline size_t imu_set_count(int Ci, int n) { return (size_t)9 * Ci * (n + 1) + 162 * (size_t)Ci + 18 * (size_t)Ci; }
+__device__ __forceinline__ ImuView imu_view(const BaBufs& b, int n, int set)
 {
     const int Ci = b.imu.Ci;
     ImuView v;
-    v.W = b.imu.zacc; v.Hd = v.W + (size_t)9 * Ci * (n + 1); v.Ho = v.Hd + 81 * Ci; v.gz = v.Ho + 81 * Ci;
-    v.Ld = v.gz + 9 * Ci; v.Lo = v.Ld + 81 * Ci; v.dinv = v.Lo + 81 * Ci;
+    v.H = b.imu.zacc; v.Hd = v.H + (size_t)9 * Ci * (n + 1); v.Ho = v.Hd + 81 * Ci; v.gz = v.Ho + 81 * Ci;
+    v.W = b.imu.zacc + imu_zacc_count(Ci, n) + (size_t)set * imu_set_count(Ci, n);
+    v.Ld = v.W + (size_t)9 * Ci * (n + 1); v.Lo = v.Ld + 81 * Ci; v.dinv = v.Lo + 81 * Ci; v.lam = v.dinv + 9 * Ci;
     return v;
 }
 
@@ -54,7 +57,7 @@ __global__ __launch_bounds__(64) void ba_imu_factors(BaDims d, BaBufs b)
     const BaState st = *b.st;
     if (st.done || threadIdx.x >= 32) return;
     const int n = d.n, lk = threadIdx.x, fi = blockIdx.x;
-    const ImuView V = imu_view(b, n);
+    const ImuView V = imu_view(b, n, 0);
     const double* Xc = b.Xc + (size_t)st.cur * d.C * 6;
     const double* Xv = b.imu.Xv + (size_t)st.cur * d.C * 9;
     const ImuFactorDev& F = b.imu.fac[fi];
@@ -96,10 +99,10 @@ __global__ __launch_bounds__(64) void ba_imu_factors(BaDims d, BaBufs b)
             if (mine_i == o_i) {                                  // same camera: its 6 x 6 diagonal block lives in U
                 if (st.fresh) atomicAdd(&b.U[(pc / 6) * 36 + (pc % 6) * 6 + (opc % 6)], h);
             } else if (pc < opc) {
-                atomicAdd(&b.S[(size_t)pc * n + opc], h);         // K7 reads S's upper triangle
+                for (int q = 0; q < st.nact; q++) atomicAdd(&b.S[(size_t)q * n * n + (size_t)pc * n + opc], h);   // every set's S; K7 reads the upper triangle
             }
         } else if (!isP && oP) {
-            atomicAdd(&V.W[(size_t)zr * (n + 1) + opc], h);
+            atomicAdd(&V.H[(size_t)zr * (n + 1) + opc], h);
         } else if (!isP && !oP) {
             if (mine_i == o_i) atomicAdd(&V.Hd[(mine_i ? qi : qj) * 81 + zc * 9 + ozc], h);
             else if (!mine_i) atomicAdd(&V.Ho[qi * 81 + zc * 9 + ozc], h);      // rows z_j, columns z_i
@@ -140,29 +143,30 @@ __global__ __launch_bounds__(KI_THREADS) void ba_imu_eliminate(BaDims d, BaBufs 
     __shared__ int s_fail;
     const int n = d.n, Ci = b.imu.Ci, NZ = 9 * Ci, tid = threadIdx.x, nt = KI_THREADS;
     const int lane = tid & 63, wave = tid >> 6;
-    const ImuView V = imu_view(b, n);
+    const int set = blockIdx.x;                 // speculative radius evaluated by this workgroup (ba_common.h)
+    const ImuView V = imu_view(b, n, set);
     if (tid == 0) { st = *b.st; s_fail = 0; }
     for (int i = tid; i < Ci * 81; i += nt) { Hd[i] = V.Hd[i]; Ho[i] = V.Ho[i]; }
     for (int i = tid; i < NZ; i += nt) gz[i] = V.gz[i];
     __syncthreads();
-    if (st.done) return;
+    if (st.done || set >= st.nact) return;
+    const double radius = ba_set_radius(st, set);
     // ---- (2) Jacobi scale (first linearisation) and damping of the z parameters; their gradient and maximum
     double gm = 0.0;
     for (int t = tid; t < NZ; t += nt) {
         const double h = Hd[(t / 9) * 81 + (t % 9) * 10];
         double sc = b.imu.sc[n + t];
-        if (!st.have_scale) { sc = opt.jacobi ? 1.0 / (1.0 + sqrt(h)) : 1.0; b.imu.sc[n + t] = sc; }
-        const double s2 = sc * sc, lam = clampd(s2 * h, opt.dmin, opt.dmax) / (st.radius * s2);
+        if (!st.have_scale) { sc = opt.jacobi ? 1.0 / (1.0 + sqrt(h)) : 1.0; b.imu.sc[n + t] = sc; }      // first round: one set
+        const double s2 = sc * sc, lam = clampd(s2 * h, opt.dmin, opt.dmax) / (radius * s2);
         Hd[(t / 9) * 81 + (t % 9) * 10] = h + lam;
-        b.imu.lam[n + t] = lam;
-        b.imu.gtot[n + t] = gz[t];
-        V.W[(size_t)t * (n + 1) + n] = gz[t];
+        V.lam[t] = lam;
+        if (set == 0) b.imu.gtot[n + t] = gz[t];
         gm = fmax(gm, fabs(gz[t]));
     }
     gm = wave_max_nonneg(gm);
     if (lane == 0) s_red[wave] = gm;
     __syncthreads();
-    if (tid == 0 && st.fresh) {                             // gradient maximum of the z blocks rides in K5's slot 0
+    if (tid == 0 && st.fresh && set == 0) {                 // gradient maximum of the z blocks rides in K5's slot 0
         double g = 0.0;
         for (int w = 0; w < nt / 64; w++) g = fmax(g, s_red[w]);
         if (g > 0.0) atomic_max_nonneg(&b.gmax[0], g);
@@ -205,7 +209,7 @@ __global__ __launch_bounds__(KI_THREADS) void ba_imu_eliminate(BaDims d, BaBufs 
     }
     __syncthreads();
     if (s_fail) {
-        if (tid == 0) b.scal[1] += 1.0;                     // K7's failure count of set 0: the step is invalid
+        if (tid == 0) b.scal[1 + set] += 1.0;               // K7's failure count of this set: the step is invalid
         return;
     }
     for (int i = tid; i < Ci * 81; i += nt) { V.Ld[i] = Hd[i]; V.Lo[i] = Ho[i]; }          // for K7i's backward substitution
@@ -215,13 +219,13 @@ __global__ __launch_bounds__(KI_THREADS) void ba_imu_eliminate(BaDims d, BaBufs 
     for (int col = tid; col <= n; col += nt) {
         double t[9], nx[9], prev[9];
 #pragma unroll
-        for (int k = 0; k < 9; k++) { nx[k] = V.W[(size_t)k * (n + 1) + col]; prev[k] = 0.0; }
+        for (int k = 0; k < 9; k++) { nx[k] = col < n ? V.H[(size_t)k * (n + 1) + col] : gz[k]; prev[k] = 0.0; }
         for (int q = 0; q < Ci; q++) {
 #pragma unroll
             for (int k = 0; k < 9; k++) t[k] = nx[k];
             if (q + 1 < Ci) {
 #pragma unroll
-                for (int k = 0; k < 9; k++) nx[k] = V.W[(size_t)(9 * (q + 1) + k) * (n + 1) + col];
+                for (int k = 0; k < 9; k++) nx[k] = col < n ? V.H[(size_t)(9 * (q + 1) + k) * (n + 1) + col] : gz[9 * (q + 1) + k];
             }
             if (q > 0) {
 #pragma unroll
@@ -299,8 +303,8 @@ __global__ __launch_bounds__(KI_THREADS) void ba_imu_eliminate(BaDims d, BaBufs 
             for (int reg = 0; reg < 4; reg++) {
                 const int k = 16 * tr[e] + lq + 4 * reg, i = 16 * tc[e] + lr;       // C[row = lq + 4 reg][col = lr]
                 if (k < n) {
-                    if (i < n) { if (k <= i) b.S[(size_t)k * n + i] -= acc[e][reg]; }
-                    else if (i == n) b.rhs[k] -= acc[e][reg];
+                    if (i < n) { if (k <= i) b.S[(size_t)set * n * n + (size_t)k * n + i] -= acc[e][reg]; }
+                    else if (i == n) b.rhs[(size_t)set * n + k] -= acc[e][reg];
                 }
             }
         }
@@ -318,12 +322,15 @@ __global__ __launch_bounds__(KI_THREADS) void ba_imu_expand(BaDims d, BaBufs b, 
     __shared__ int cam_of_q[IMU_MAXCI + 1];
     __shared__ double u[IMU_MAXCI * 9];                     // D^-1 (w_g - W_p x_p), then x_z
     const int n = d.n, Ci = b.imu.Ci, NZ = 9 * Ci, tid = threadIdx.x, nt = KI_THREADS;
+    const int set = blockIdx.x;
     if (tid == 0) { st = *b.st; s_cand = 0.0; s_bad = 0; }
     for (int c = tid; c < d.C; c += nt) { const int q = b.imu.inert_slot[c]; if (q >= 0 && q <= IMU_MAXCI) cam_of_q[q] = c; }
     __syncthreads();
-    if (st.done || st.solver_failed) return;
-    const ImuView V = imu_view(b, n);
-    const int cand = (st.cur + 1) % (b.ns + 1);
+    if (st.done || set >= st.nact) return;
+    if (set == 0 ? st.solver_failed : b.set_out[set].solver_failed) return;
+    const ImuView V = imu_view(b, n, set);
+    const double* dcs = b.dc + (size_t)set * (n + 2);
+    const int cand = (st.cur + 1 + set) % (b.ns + 1);
     const double* Xv = b.imu.Xv + (size_t)st.cur * d.C * 9;
     double* Xvn = b.imu.Xv + (size_t)cand * d.C * 9;
     const double* Xn = b.Xc + (size_t)cand * d.C * 6;
@@ -332,7 +339,7 @@ __global__ __launch_bounds__(KI_THREADS) void ba_imu_expand(BaDims d, BaBufs b, 
     for (int t = tid; t < NZ; t += nt) {
         double acc = V.W[(size_t)t * (n + 1) + n];
 #pragma unroll 18
-        for (int k = 0; k < n; k++) acc += V.W[(size_t)t * (n + 1) + k] * b.dc[k];       // n is a multiple of 6
+        for (int k = 0; k < n; k++) acc += V.W[(size_t)t * (n + 1) + k] * dcs[k];        // n is a multiple of 6
         u[t] = acc * V.dinv[t];
     }
     __syncthreads();
@@ -363,7 +370,7 @@ __global__ __launch_bounds__(KI_THREADS) void ba_imu_expand(BaDims d, BaBufs b, 
         if (!isfinite(dlt)) bad = true;
         const int cam = cam_of_q[t / 9];
         const double x = Xv[9 * cam + t % 9], xn = x + dlt;
-        mcc += 0.5 * (dlt * dlt * b.imu.lam[n + t] - dlt * b.imu.gtot[n + t]);
+        mcc += 0.5 * (dlt * dlt * V.lam[t] - dlt * b.imu.gtot[n + t]);
         ssq += (x - xn) * (x - xn);
         xsq += x * x;
         Xvn[9 * cam + t % 9] = xn;
@@ -386,25 +393,32 @@ __global__ __launch_bounds__(KI_THREADS) void ba_imu_expand(BaDims d, BaBufs b, 
     if (tid == 0) {
         double a0 = 0, a1 = 0, a2 = 0;
         for (int w = 0; w < nt / 64; w++) { a0 += red[w][0]; a1 += red[w][1]; a2 += red[w][2]; }
-        st.cam_scal[0] += a0; st.cam_scal[1] += a1; st.cam_scal[2] += a2; st.cam_scal[3] = s_cand;
-        if (s_bad) st.solver_failed = 1;
-        *b.st = st;
+        if (set == 0) {
+            st.cam_scal[0] += a0; st.cam_scal[1] += a1; st.cam_scal[2] += a2; st.cam_scal[3] = s_cand;
+            if (s_bad) st.solver_failed = 1;
+            *b.st = st;
+        } else {
+            BaSetOut so = b.set_out[set];
+            so.cam_scal[0] += a0; so.cam_scal[1] += a1; so.cam_scal[2] += a2; so.cam_scal[3] = s_cand;
+            if (s_bad) so.solver_failed = 1;
+            b.set_out[set] = so;
+        }
     }
 }
 
 // ---------------------------------------------------------------------------------------------- host glue
 size_t ba_imu_lds_zacc_doubles(int Ci, int n) { return imu_zacc_count(Ci, n); }
-size_t ba_imu_lds_total_doubles(int Ci, int n) { return imu_zacc_count(Ci, n) + 162 * (size_t)Ci + 9 * (size_t)Ci; }
+size_t ba_imu_lds_total_doubles(int Ci, int n, int ns) { return imu_zacc_count(Ci, n) + (size_t)ns * imu_set_count(Ci, n); }
 
 void ba_launch_imu_eliminate(hipStream_t s, const BaDims& d, const BaBufs& b, const BaOpt& opt)
 {
     hipLaunchKernelGGL(ba_imu_factors, dim3(b.imu.n_fac), dim3(64), 0, s, d, b);
     const size_t lds = sizeof(double) * KCH * KLD;
     (void)rs_lds_attr((const void*)ba_imu_eliminate, lds);
-    hipLaunchKernelGGL(ba_imu_eliminate, dim3(1), dim3(KI_THREADS), lds, s, d, b, opt);
+    hipLaunchKernelGGL(ba_imu_eliminate, dim3(b.ns), dim3(KI_THREADS), lds, s, d, b, opt);
 }
 void ba_launch_imu_expand(hipStream_t s, const BaDims& d, const BaBufs& b, const BaOpt& opt)
 {
-    hipLaunchKernelGGL(ba_imu_expand, dim3(1), dim3(KI_THREADS), 0, s, d, b, opt);
+    hipLaunchKernelGGL(ba_imu_expand, dim3(b.ns), dim3(KI_THREADS), 0, s, d, b, opt);
 }
 int ba_imu_lds_path_max_ci() { return IMU_MAXCI; }

@@ -842,7 +842,7 @@ size_t ba_inertial_bytes(int N, int n_fac, int C)
     auto al = [](size_t v) { return (v + 255) & ~(size_t)255; };
     return ba_big_bytes(N) + al(sizeof(double) * (size_t)N * N) + 4 * al(sizeof(double) * ((size_t)N + 1)) +
            al(sizeof(double) * (size_t)(n_fac + 1) * 9 * IMU_NP) + al(sizeof(ImuFactorDev) * (size_t)(n_fac + 1)) +
-           al(sizeof(int32_t) * (size_t)(C + 1)) + al(sizeof(double) * 2 * 9 * (size_t)(C + 1)) + 256;
+           al(sizeof(int32_t) * (size_t)(C + 1)) + al(sizeof(double) * (BA_MAXSETS + 1) * 9 * (size_t)(C + 1)) + 256;      // Xv: one buffer per state slot
 }
 
 // carves the inertial buffers out of `ws` (after the BigBufs region); returns the device addresses the host uploads to
