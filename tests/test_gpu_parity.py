@@ -762,6 +762,34 @@ def test_bundle_adjust_inertial(ctx, oracle, synth, kw, skip, imu_mode):
     ctx.set_int("ba_imu_mode", 0)
 
 
+@pytest.mark.parametrize("ns", [1, 2, 3])
+def test_bundle_adjust_inertial_speculative_radii_do_not_change_the_schedule(ctx, oracle, synth, ns):
+    """The inertial solve on the local-window kernels evaluates 1 .. 3 trust-region radii per round like the vision-only one
+    (one elimination workgroup per radius): on a window that rejects steps the per-iteration record must equal the
+    oracle's whatever the number of sets, only the number of rounds changes."""
+    w = synth.make_ba_window(n_kf=8, n_points=150, run_max=5, config_id=36, outlier_frac=0.1, rot_noise_deg=2.0)
+    imu = synth.make_imu(w)
+    args = (w["cams"], w["cam_free"], w["points"], w["obs_ptr"], w["obs_cam"], w["obs_uv"], w["K"])
+    rc, rp, rv, rb, rs_, otr = oracle.bundle_adjust_inertial(*args, imu, trace=True)
+    assert 0 in [t["outcome"] for t in otr]                        # the window rejects steps
+    ctx.set_int("ba_speculative_sets", ns)
+    try:
+        dc, dp = ctx.dev(w["cams"]), ctx.dev(w["points"])
+        s, v, b = ctx.bundle_adjust_inertial(dc, w["cam_free"], dp, ctx.dev(w["obs_ptr"]), ctx.dev(w["obs_cam"]), ctx.dev(w["obs_uv"]), w["K"], imu)
+        tr = ctx.ba_trace()
+        stats = ctx.ba_stats()
+    finally:
+        ctx.set_int("ba_speculative_sets", 0)
+    assert [t["outcome"] for t in tr] == [t["outcome"] for t in otr]
+    assert np.allclose([t["radius"] for t in tr], [t["radius"] for t in otr], rtol=1e-7)
+    assert np.allclose([t["cost"] for t in tr], [t["cost"] for t in otr], rtol=1e-9)
+    assert np.allclose(to_np(dc), rc, rtol=1e-7, atol=1e-9) and np.allclose(v, rv, rtol=1e-7, atol=1e-9)
+    if ns == 1:
+        assert stats["rounds"] == s["iterations"]
+    else:
+        assert stats["rounds"] < s["iterations"]
+
+
 def test_bundle_adjust_inertial_rejects_bad_factors(ctx, rs, synth):
     w = synth.make_ba_window(n_kf=5, n_points=80, run_max=4)
     imu = synth.make_imu(w)
