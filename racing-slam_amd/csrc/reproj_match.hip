@@ -6,7 +6,8 @@
 // MapPoint::avg_viewing_normal / observed_distance_range (src/MapPoint.cpp:24-45)
 // and KDTree2D::radius_search (src/KDTree.cpp:45-82).
 //
-// K2: one lane per map point.  Projection and the three f32 gates, then the
+// K2: eight lanes per map point when the frame's KD-tree fits in LDS (k2_reproj_match_grouped below, the default),
+// one lane per point otherwise (k2_reproj_match).  Projection and the three f32 gates, then the
 // KD-tree radius search walked with an explicit stack kept in LDS, visiting
 // nodes in exactly the reference's recursion order (node, near child, far
 // child) so that "first candidate wins ties" is preserved.  Every accepted
@@ -411,6 +412,284 @@ __global__ __launch_bounds__(K2_THREADS) void k2_reproj_match(K2Frame f, K2Map m
     }
 }
 
+// K2g: the same search with EIGHT lanes per map point (trees that fit in LDS).  With one lane per point a 64-wide
+// wave walks 64 trees in lock step and then compares every candidate against the point's descriptors one after the
+// other; here a wave holds 8 points, lane 0 of a group walks the tree and queues the candidates, and the group's lanes
+// each own ONE observation of the point: its keyframe centre (viewing-normal gate) and its descriptor row (loaded
+// before the tree is staged), so a candidate costs one 256-bit compare per lane and a 3-step DPP minimum.
+// Observation order of the normal's f32 sum, visiting order of the candidates and the strict '<' rules are those of
+// k2_reproj_match above — the outputs are bit-identical (tests/test_gpu_parity.py runs both).
+#define K2G 8
+
+#ifndef RS_STAMPS
+#define RS_STAMPS 0
+#endif
+#if RS_STAMPS
+// diagnostic build (RS_STAMPS=1 python build.py): phase ends of the first wave of the middle workgroup, 10 ns ticks
+__device__ unsigned long long k2_stamps[8];
+#define K2_STAMP(i) do { if (threadIdx.x == 0 && blockIdx.x == gridDim.x / 2) k2_stamps[i] = wall_clock64(); } while (0)
+#define K2_STAMP0() K2_STAMP(0)
+extern "C" int rs_k2_stamps(unsigned long long* h_out, int reset)
+{
+    if (hipMemcpyFromSymbol(h_out, HIP_SYMBOL(k2_stamps), sizeof(unsigned long long) * 8) != hipSuccess) return RS_ERR_HIP;
+    if (reset) {
+        unsigned long long z[8] = {~0ull, 0, 0, 0, 0, 0, 0, 0};
+        if (hipMemcpyToSymbol(HIP_SYMBOL(k2_stamps), z, sizeof z) != hipSuccess) return RS_ERR_HIP;
+    }
+    return RS_OK;
+}
+#else
+#define K2_STAMP(i) do { } while (0)
+#define K2_STAMP0() do { } while (0)
+#endif
+
+__device__ __forceinline__ int group8_min(int v)
+{
+    v = min(v, __builtin_amdgcn_mov_dpp(v, 0xB1, 0xf, 0xf, true));     // quad_perm [1,0,3,2]
+    v = min(v, __builtin_amdgcn_mov_dpp(v, 0x4E, 0xf, 0xf, true));     // quad_perm [2,3,0,1]
+    v = min(v, __builtin_amdgcn_mov_dpp(v, 0x141, 0xf, 0xf, true));    // row_half_mirror: the other quad of the eight
+#if K2G == 16
+    v = min(v, __builtin_amdgcn_mov_dpp(v, 0x140, 0xf, 0xf, true));    // row_mirror: the other eight of the sixteen
+#endif
+    return v;
+}
+
+template <int K2G_THREADS_T>
+__global__ __launch_bounds__(K2G_THREADS_T) void k2_reproj_match_grouped(K2Frame f, K2Map m, int replace, int max_distance,
+                                                                       int32_t* __restrict__ point_kp,
+                                                                       int32_t* __restrict__ point_dist,
+                                                                       unsigned long long* __restrict__ prop)
+{
+    // dynamic LDS: [K2_STACK][K2G_PTS] traversal stacks, [K2_MAXC][K2G_PTS] candidate queue and minima, then the tree
+    constexpr int K2G_PTS = K2G_THREADS_T / K2G;
+    extern __shared__ __attribute__((aligned(16))) int k2_lds[];
+    int (*stack)[K2G_PTS] = (int (*)[K2G_PTS])k2_lds;
+    int (*queue)[K2G_PTS] = (int (*)[K2G_PTS])(k2_lds + K2_STACK * K2G_PTS);
+    int (*qmin)[K2G_PTS] = (int (*)[K2G_PTS])(k2_lds + (K2_STACK + K2_MAXC) * K2G_PTS);
+    K2Node* tree = (K2Node*)(k2_lds + (K2_STACK + 2 * K2_MAXC) * K2G_PTS);
+    K2_STAMP0();
+    const int g = threadIdx.x / K2G, sub = threadIdx.x % K2G;
+    const int p = blockIdx.x * K2G_PTS + g;
+    const bool have = p < m.n_points;
+    const int pc = have ? p : 0;
+    const bool elig = have && m.eligible[pc] != 0;
+    const int o0 = m.obs_ptr[pc], o1 = m.obs_ptr[pc + 1];
+    const int nobs = elig ? o1 - o0 : 0;
+    const float X[3] = {m.pos[3 * (size_t)pc], m.pos[3 * (size_t)pc + 1], m.pos[3 * (size_t)pc + 2]};
+    // this lane's observations of the first sixteen (sub and sub + 8): keyframe centre and descriptor row, in flight
+    // while the tree is staged; later ones are fetched inside the passes below
+    float C0[3] = {0.f, 0.f, 0.f}, C1[3] = {0.f, 0.f, 0.f};
+    uint4 b0 = make_uint4(0, 0, 0, 0), b1 = b0, b2 = b0, b3 = b0;
+    {
+        const bool h0 = sub < nobs, h1 = K2G + sub < nobs;
+        const int kf0 = h0 ? m.obs_kf[o0 + sub] : 0, kf1 = h1 ? m.obs_kf[o0 + K2G + sub] : 0;
+        const size_t row0 = h0 ? (size_t)m.obs_desc[o0 + sub] : 0, row1 = h1 ? (size_t)m.obs_desc[o0 + K2G + sub] : 0;
+        if (h0) {
+            const float* C = m.kf_centers + 3 * (size_t)kf0;
+            C0[0] = C[0]; C0[1] = C[1]; C0[2] = C[2];
+            b0 = m.pool[2 * row0]; b1 = m.pool[2 * row0 + 1];
+        }
+        if (h1) {
+            const float* C = m.kf_centers + 3 * (size_t)kf1;
+            C1[0] = C[0]; C1[1] = C[1]; C1[2] = C[2];
+            b2 = m.pool[2 * row1]; b3 = m.pool[2 * row1 + 1];
+        }
+    }
+    for (int base = threadIdx.x; base < f.n_keypoints; base += 8 * K2G_THREADS_T) {
+        int kpi[8], l[8], r[8];
+        float x[8], y[8];
+        bool taken[8];
+#pragma unroll
+        for (int q = 0; q < 8; q++) {
+            const int i = base + q * K2G_THREADS_T;
+            kpi[q] = 0; l[q] = -1; r[q] = -1; x[q] = 0.f; y[q] = 0.f;
+            if (i < f.n_keypoints) {
+                if (f.packed) {
+                    const float4 nd = f.packed[i];
+                    kpi[q] = ((const int*)(f.packed + f.n_keypoints))[i];
+                    x[q] = nd.x; y[q] = nd.y; l[q] = __float_as_int(nd.z); r[q] = __float_as_int(nd.w);
+                } else {
+                    kpi[q] = f.kd_node_kp[i]; l[q] = f.kd_left[i]; r[q] = f.kd_right[i];
+                }
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < 8; q++) {
+            const bool in = base + q * K2G_THREADS_T < f.n_keypoints;
+            taken[q] = in && !replace && f.kp_matched[kpi[q]] != 0;
+            if (in && !f.packed) { const float2 k = f.kp[kpi[q]]; x[q] = k.x; y[q] = k.y; }
+        }
+#pragma unroll
+        for (int q = 0; q < 8; q++) {
+            const int i = base + q * K2G_THREADS_T;
+            if (i < f.n_keypoints) {
+                K2Node nd;
+                nd.x = x[q]; nd.y = y[q];
+                nd.lr = (unsigned)(l[q] & 0xFFFF) | ((unsigned)(r[q] & 0xFFFF) << 16);
+                nd.kp = kpi[q] | (taken[q] ? (int)0x80000000 : 0);
+                tree[i] = nd;
+            }
+        }
+    }
+    K2_STAMP(1);
+    __syncthreads();
+    K2_STAMP(2);
+    // everything below is uniform within a group of eight lanes except where `sub` appears
+    int out_kp = -1, out_d = max_distance;
+    if (have) do {
+        if (!elig) break;
+        const float* T = f.T;
+        float uvw[3];                                                    // Camera::project (src/Camera.cpp:25-32)
+        {
+            float KP[12];
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                KP[0 * 4 + j] = (f.fx * T[0 * 4 + j] + 0.0f * T[1 * 4 + j]) + f.cx * T[2 * 4 + j];
+                KP[1 * 4 + j] = (0.0f * T[0 * 4 + j] + f.fy * T[1 * 4 + j]) + f.cy * T[2 * 4 + j];
+                KP[2 * 4 + j] = (0.0f * T[0 * 4 + j] + 0.0f * T[1 * 4 + j]) + 1.0f * T[2 * 4 + j];
+            }
+#pragma unroll
+            for (int i = 0; i < 3; i++)
+                uvw[i] = (KP[4 * i] * X[0] + KP[4 * i + 1] * X[1]) + (KP[4 * i + 2] * X[2] + KP[4 * i + 3] * 1.0f);
+        }
+        float u, v;
+        if (uvw[2] < 0.0f) { u = -1.0f; v = -1.0f; }
+        else { u = uvw[0] / uvw[2]; v = uvw[1] / uvw[2]; }
+        if (!(u >= 0.0f && u < (float)f.width && v >= 0.0f && v < (float)f.height)) break;   // :58
+
+        float center[3];                                                 // Frame::camera_center (src/Frame.cpp:39-42)
+#pragma unroll
+        for (int i = 0; i < 3; i++) {
+            const float a[3] = {-T[0 * 4 + i], -T[1 * 4 + i], -T[2 * 4 + i]};
+            const float t[3] = {T[3], T[7], T[11]};
+            center[i] = dot3f(a, t);
+        }
+        const float ray[3] = {X[0] - center[0], X[1] - center[1], X[2] - center[2]};
+        float normal[3] = {0.0f, 0.0f, 0.0f};
+        float nearest = 3.402823466e+38f, furthest = 0.0f;
+        for (int ob = 0; ob < nobs; ob += K2G) {                          // src/MapPoint.cpp:24-45, eight observations per pass
+            float Cx[3] = {ob == 0 ? C0[0] : C1[0], ob == 0 ? C0[1] : C1[1], ob == 0 ? C0[2] : C1[2]};
+            if (ob > K2G && ob + sub < nobs) {
+                const float* C = m.kf_centers + 3 * (size_t)m.obs_kf[o0 + ob + sub];
+                Cx[0] = C[0]; Cx[1] = C[1]; Cx[2] = C[2];
+            }
+            float d[3] = {X[0] - Cx[0], X[1] - Cx[1], X[2] - Cx[2]};
+            const float dist = sqrtf(dot3f(d, d));
+            normalize3f(d);
+            normalize3f(d);
+#pragma unroll
+            for (int j = 0; j < K2G; j++) {                               // summed in observation order by every lane
+                const float dj0 = __shfl(d[0], j, K2G), dj1 = __shfl(d[1], j, K2G), dj2 = __shfl(d[2], j, K2G);
+                const float distj = __shfl(dist, j, K2G);
+                if (ob + j < nobs) {
+                    nearest = distj < nearest ? distj : nearest;
+                    furthest = furthest < distj ? distj : furthest;
+                    normal[0] += dj0; normal[1] += dj1; normal[2] += dj2;
+                }
+            }
+        }
+        normalize3f(normal);
+        float rn[3] = {ray[0], ray[1], ray[2]};
+        normalize3f(rn);
+        if (dot3f(normal, rn) < 0.5f) break;                             // :62-66
+        const float distance = sqrtf(dot3f(ray, ray));
+        if (distance < nearest / 2.0f || distance > furthest * 1.25f) break;   // :69-73
+
+        K2_STAMP(3);
+        // KDTree2D::radius_search (src/MapMatcher.cpp:75, src/KDTree.cpp:45-82) by lane 0 of the group
+        const float r2 = 20.0f * 20.0f;
+        int nc = 0, over_kp = 0, over_d = max_distance;
+        if (sub == 0) {
+            int sp = 0;
+            int cur = f.kd_root, odd = 0;
+            K2Node nd;
+            if (cur >= 0) nd = tree[cur];
+            while (cur >= 0) {
+                int l = (int)(nd.lr & 0xFFFFu), r = (int)(nd.lr >> 16);
+                l = l == 0xFFFF ? -1 : l; r = r == 0xFFFF ? -1 : r;
+                const K2Node ndl = tree[l >= 0 ? l : 0], ndr = tree[r >= 0 ? r : 0];
+                const float dx = nd.x - u, dy = nd.y - v;
+                const float d2 = dx * dx + dy * dy;
+                if (d2 <= r2 && nd.kp >= 0) {                               // in range and open (:65, :81)
+                    const int kp = nd.kp;
+                    if (nc < K2_MAXC) queue[nc++][g] = kp;
+                    else {                                                  // crowded neighbourhoods: on the spot, after every queued one
+                        const uint4 a0 = f.desc[2 * (size_t)kp], a1 = f.desc[2 * (size_t)kp + 1];
+                        int d = 0x7fffffff;
+                        for (int o = o0; o < o1; o++) {
+                            const size_t row = (size_t)m.obs_desc[o];
+                            d = min(d, hamming256(a0, a1, m.pool[2 * row], m.pool[2 * row + 1]));
+                        }
+                        if (d < over_d) { over_d = d; over_kp = kp; }
+                    }
+                }
+                const float delta = odd ? dy : dx;
+                const bool left_near = delta > 0;
+                const int near_child = left_near ? l : r;
+                const int far_child = left_near ? r : l;
+                odd ^= 1;
+                if (delta * delta <= r2 && far_child >= 0 && sp < K2_STACK) stack[sp++][g] = far_child | (odd << 30);
+                if (near_child >= 0) { cur = near_child; nd = left_near ? ndl : ndr; }
+                else if (sp > 0) { const int e = stack[--sp][g]; cur = e & 0x3FFFFFFF; odd = (e >> 30) & 1; nd = tree[cur]; }
+                else cur = -1;
+            }
+        }
+        K2_STAMP(4);
+        nc = __shfl(nc, 0, K2G);
+        over_d = __shfl(over_d, 0, K2G);
+        over_kp = __shfl(over_kp, 0, K2G);
+        // the queued candidates (visiting order), four per round trip; each lane compares its observation's row
+        int best_kp = 0, best_d = max_distance;
+        if (nc > 0 && nobs > 0) {
+            for (int ob = 0; ob < nobs; ob += K2G) {
+                uint4 r0 = ob == 0 ? b0 : b2, r1 = ob == 0 ? b1 : b3;
+                const bool mine = ob + sub < nobs;
+                if (ob > K2G && mine) {
+                    const size_t row = (size_t)m.obs_desc[o0 + ob + sub];
+                    r0 = m.pool[2 * row]; r1 = m.pool[2 * row + 1];
+                }
+                for (int c = 0; c < nc; c += 4) {
+                    int kq[4];
+                    uint4 a0[4], a1[4];
+#pragma unroll
+                    for (int q = 0; q < 4; q++) {
+                        kq[q] = queue[min(c + q, nc - 1)][g];
+                        a0[q] = f.desc[2 * (size_t)kq[q]]; a1[q] = f.desc[2 * (size_t)kq[q] + 1];
+                    }
+#pragma unroll
+                    for (int q = 0; q < 4; q++) {
+                        const int d = group8_min(mine ? hamming256(a0[q], a1[q], r0, r1) : 0x7fffffff);
+                        if (c + q < nc) {
+                            if (ob == 0) { if (d < best_d) { best_d = d; best_kp = kq[q]; } }   // :88-91, visiting order
+                            if (nobs > K2G) qmin[c + q][g] = ob == 0 ? d : min(d, qmin[c + q][g]);
+                        }
+                    }
+                }
+            }
+            if (nobs > K2G) {                                             // more than eight observations: minima over all passes
+                best_kp = 0; best_d = max_distance;
+                for (int c = 0; c < nc; c++) {
+                    const int d = qmin[c][g];
+                    if (d < best_d) { best_d = d; best_kp = queue[c][g]; }
+                }
+            }
+        }
+        K2_STAMP(5);
+        if (over_d < best_d) { best_d = over_d; best_kp = over_kp; }
+        if (best_d < max_distance) {
+            out_kp = best_kp;
+            out_d = best_d;
+            // :95-97 sequential strict-'<' over map order == atomicMin of (dist, map order)
+            if (sub == 0) atomicMin(&prop[best_kp], ((unsigned long long)(unsigned)best_d << 32) | (unsigned)p);
+        }
+    } while (0);
+    if (have && sub == 0) {
+        point_kp[p] = out_kp;
+        point_dist[p] = out_d;
+    }
+    K2_STAMP(6);
+}
+
 // K3: one workgroup decodes the proposal table, compacts the accepted matches in order and resets the table
 // (tried as a tail of K2's last workgroup: no cheaper than this launch)
 __global__ __launch_bounds__(1024) void k3_accept(unsigned long long* __restrict__ prop, int n,
@@ -467,12 +746,22 @@ extern "C" int rs_reproj_match(rs_context* ctx, const rs_frame_view* fr, const r
         m.obs_kf = mp->d_obs_kf; m.obs_desc = mp->d_obs_desc; m.kf_centers = mp->d_kf_centers;
         m.pool = (const uint4*)mp->d_desc_pool;
         const int tree_in_lds = N <= K2_MAX_LDS_NODES ? 1 : 0;
-        const size_t lds = sizeof(int) * (K2_STACK + 2 * K2_MAXC) * K2_THREADS + (tree_in_lds ? sizeof(K2Node) * (size_t)N : 0);
-        if (lds > 48 * 1024)
-            RS_HIP(ctx, rs_lds_attr((const void*)k2_reproj_match, lds));
         rs_prof_scope ps(ctx, "K2_reproj_match");
-        hipLaunchKernelGGL(k2_reproj_match, dim3((P + K2_THREADS - 1) / K2_THREADS), dim3(K2_THREADS), lds,
-                           ctx->stream, f, m, replace, max_distance, tree_in_lds, d_point_kp, d_point_dist, prop);
+        if (tree_in_lds && ctx->k2_mode == 0) {                           // eight lanes per map point
+            const int th = 512, pts = th / K2G;                           // 64 map points per workgroup (256 / 1024 threads: slower)
+            const size_t lds = sizeof(int) * (K2_STACK + 2 * K2_MAXC) * pts + sizeof(K2Node) * (size_t)N;
+            auto kern = k2_reproj_match_grouped<512>;
+            if (lds > 48 * 1024)
+                RS_HIP(ctx, rs_lds_attr((const void*)kern, lds));
+            hipLaunchKernelGGL(kern, dim3((P + pts - 1) / pts), dim3(th), lds,
+                               ctx->stream, f, m, replace, max_distance, d_point_kp, d_point_dist, prop);
+        } else {
+            const size_t lds = sizeof(int) * (K2_STACK + 2 * K2_MAXC) * K2_THREADS + (tree_in_lds ? sizeof(K2Node) * (size_t)N : 0);
+            if (lds > 48 * 1024)
+                RS_HIP(ctx, rs_lds_attr((const void*)k2_reproj_match, lds));
+            hipLaunchKernelGGL(k2_reproj_match, dim3((P + K2_THREADS - 1) / K2_THREADS), dim3(K2_THREADS), lds,
+                               ctx->stream, f, m, replace, max_distance, tree_in_lds, d_point_kp, d_point_dist, prop);
+        }
     }
     {
         rs_prof_scope ps(ctx, "K3_accept");

@@ -247,6 +247,16 @@ def _reproj_case(ctx, oracle, rs, frame, mp, replace):
     for k in ("point_kp", "point_dist", "prop_point", "prop_dist"):
         assert np.array_equal(to_np(outp[k]), to_np(out[k])), k
     assert int(to_np(outp["count"])[0]) == cnt and np.array_equal(to_np(outp["match_point"])[:cnt], ref["match_point"])
+    # one lane per map point (the kernel that also serves KD-trees too large for LDS) instead of eight: identical outputs
+    ctx.set_int("k2_mode", 1)
+    try:
+        out1 = ctx.reproj_match(fv, mv, replace=replace)
+        for k in ("point_kp", "point_dist", "prop_point", "prop_dist"):
+            assert np.array_equal(to_np(out1[k]), to_np(out[k])), k
+        assert int(to_np(out1["count"])[0]) == cnt and np.array_equal(to_np(out1["match_kp"])[:cnt], ref["match_kp"])
+        assert np.array_equal(to_np(out1["match_point"])[:cnt], ref["match_point"])
+    finally:
+        ctx.set_int("k2_mode", 0)
     return cnt
 
 

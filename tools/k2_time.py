@@ -15,14 +15,16 @@ w = synth.make_ba_window()
 frame, mp = synth.make_match_scene(w, n_keypoints=2000, kdtree_build=rs.kdtree_build)
 fv, keep_f = ctx.make_frame_view(frame, pack=True)
 mv, keep_m = ctx.make_map_view(mp)
-out = ctx.reproj_match(fv, mv)
-for _ in range(20):
-    ctx.reproj_match(fv, mv, out=out)
-ctx.synchronize()
-ctx.prof_begin()
-for _ in range(200):
-    ctx.reproj_match(fv, mv, out=out)
-ctx.synchronize()
-p = ctx.prof_end()
-print(os.environ.get("RS_K2_STOP", "0"), {k: round(1e3 * v[1] / v[0], 2) for k, v in p.items()}, "matches", int(out["match_count"].item()) if "match_count" in out else None)
+for mode in (0, 1):                                  # eight lanes per map point / one lane per point
+    ctx.set_int("k2_mode", mode)
+    out = ctx.reproj_match(fv, mv)
+    for _ in range(20):
+        ctx.reproj_match(fv, mv, out=out)
+    ctx.synchronize()
+    ctx.prof_begin()
+    for _ in range(200):
+        ctx.reproj_match(fv, mv, out=out)
+    ctx.synchronize()
+    p = ctx.prof_end()
+    print("k2_mode", mode, {k: round(1e3 * v[1] / v[0], 2) for k, v in p.items()}, "matches", int(out["count"].item()))
 ctx.close()
