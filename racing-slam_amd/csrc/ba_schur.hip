@@ -212,11 +212,88 @@ __device__ __forceinline__ void tile_rc(int t, int NT, int& r, int& c)
     c = r + rem;
 }
 
-// SYRK of the compact item on the matrix cores + scatter into S / rhs.  Each wave owns the
-// tiles  wave, wave + 4, ...  of the upper triangle and runs over ALL K-chunks of the tile.
+// The K loop of NM tiles of one wave, software-pipelined: the operands of chunk kc + 1 are requested before the
+// MFMAs of chunk kc are issued (straight-line code per NM, so that the compiler's lgkmcnt waits are exact: with the
+// loads inside wave-uniform branches every MFMA waited for its own ds_read — 230 cycles per MFMA instead of 64).
+template <int NM, int STRIDE>
+__device__ __forceinline__ void syrk_tiles(const double* yt, int nchunks, const int* tr, const int* tc, d4* acc, int lr, int lk)
+{
+    double a0[NM], b0[NM], a1[NM], b1[NM];
+    const double* col = yt + (size_t)lk * STRIDE + lr;
+#pragma unroll
+    for (int t = 0; t < NM; t++) { a0[t] = col[16 * tr[t]]; b0[t] = col[16 * tc[t]]; }
+    for (int kc = 0; kc < nchunks; kc += 2) {
+        const double* c1 = col + (size_t)(4 * min(kc + 1, nchunks - 1)) * STRIDE;
+#pragma unroll
+        for (int t = 0; t < NM; t++) { a1[t] = c1[16 * tr[t]]; b1[t] = c1[16 * tc[t]]; }
+#pragma unroll
+        for (int t = 0; t < NM; t++) acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[t], b0[t], acc[t], 0, 0, 0);
+        const double* c2 = col + (size_t)(4 * min(kc + 2, nchunks - 1)) * STRIDE;
+#pragma unroll
+        for (int t = 0; t < NM; t++) { a0[t] = c2[16 * tr[t]]; b0[t] = c2[16 * tc[t]]; }
+        if (kc + 1 < nchunks) {
+#pragma unroll
+            for (int t = 0; t < NM; t++) acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1[t], b1[t], acc[t], 0, 0, 0);
+        }
+    }
+}
+
+// SYRK of the compact item on the matrix cores + scatter into S / rhs.  Only the tiles of the upper triangle that
+// carry data are enumerated, and they are dealt to SIMDs (wave w runs on SIMD w % 4), not to waves: SIMD 1, 2, 3, 0,
+// 1, ... in turn, then round-robin over the waves of the workgroup on that SIMD.  (f64 MFMA throughput is per SIMD:
+// with 5 waves, "tile t to wave t % 5" put 4 of 10 tiles on SIMD 0, which holds waves 0 and 4.)  Every wave runs
+// over ALL K-chunks of its tiles.
 //   yt : LDS tile, column-major [col][STRIDE]; rows [0, 6*ns] used (row 6*ns = rhs row)
 template <int NT, int TPW, int STRIDE>
 __device__ __forceinline__ void syrk_scatter(const double* yt, int nchunks, int ns, const int* gslot, int n,
+                                             int wave, int nw, double* __restrict__ S, double* __restrict__ rhs)
+{
+    const int lane = threadIdx.x & 63;
+    const int lr = lane & 15, lk = lane >> 4;
+    const int nrow = 6 * ns;                 // rhs row index
+    const int nt_used = (nrow + 16) / 16;    // tile rows that carry data (incl. the rhs row), <= NT
+    const int ntiles = nt_used * (nt_used + 1) / 2;
+    const int simd = wave & 3, pos = (simd + 3) & 3;
+    const int nws = (nw - simd + 3) >> 2;    // waves of this workgroup on my SIMD; I am number wave >> 2 of them
+    d4 acc[TPW];
+    int tr[TPW], tc[TPW];
+    int nmine = 0;
+#pragma unroll
+    for (int t = 0; t < TPW; t++) {
+        acc[t] = (d4){0.0, 0.0, 0.0, 0.0};
+        tr[t] = 0; tc[t] = 0;
+        const int tile = pos + 4 * ((wave >> 2) + nws * t);
+        if (tile < ntiles) { tile_rc(tile, nt_used, tr[t], tc[t]); nmine = t + 1; }
+    }
+    static_assert(TPW >= 1 && TPW <= 3, "tiles per wave");
+    switch (nmine) {                          // wave-uniform
+    case 1: syrk_tiles<1, STRIDE>(yt, nchunks, tr, tc, acc, lr, lk); break;
+    case 2: if (TPW >= 2) syrk_tiles<(TPW >= 2 ? 2 : 1), STRIDE>(yt, nchunks, tr, tc, acc, lr, lk); break;
+    case 3: if (TPW >= 3) syrk_tiles<(TPW >= 3 ? 3 : 1), STRIDE>(yt, nchunks, tr, tc, acc, lr, lk); break;
+    default: break;
+    }
+    // C/D layout of v_mfma_f64_16x16x4_f64: col = lane & 15, row = (lane >> 4) + 4 * reg
+#pragma unroll
+    for (int t = 0; t < TPW; t++) {
+        if (t >= nmine) continue;
+#pragma unroll
+        for (int reg = 0; reg < 4; reg++) {
+            const int R = 16 * tr[t] + lk + 4 * reg, Cc = 16 * tc[t] + lr;
+            const double v = acc[t][reg];
+            if (R >= nrow || Cc > nrow || R > Cc) continue;
+            const int gr = 6 * gslot[R / 6] + R % 6;
+            if (Cc == nrow) atomicAdd(&rhs[gr], -v);
+            else atomicAdd(&S[(size_t)gr * n + 6 * gslot[Cc / 6] + Cc % 6], -v);
+        }
+    }
+}
+
+// The 8x8-tile class (unions of 11 .. 21 cameras; rare in a local window): up to 8 accumulator tiles per wave leave no
+// registers for operand double buffering, so this class keeps the plain loop.  Each wave owns the
+// tiles  wave, wave + 4, ...  of the upper triangle and runs over ALL K-chunks of the tile.
+//   yt : LDS tile, column-major [col][STRIDE]; rows [0, 6*ns] used (row 6*ns = rhs row)
+template <int NT, int TPW, int STRIDE>
+__device__ __forceinline__ void syrk_scatter_plain(const double* yt, int nchunks, int ns, const int* gslot, int n,
                                              int wave, int nw, double* __restrict__ S, double* __restrict__ rhs)
 {
     const int lane = threadIdx.x & 63;
@@ -476,7 +553,7 @@ static __device__ __forceinline__ void ba_schur_body(const BaDims& d, const BaBu
             }
             prev_all_ok = __syncthreads_or((p >= 0 && !ok) ? 1 : 0) == 0;
             const int nw = (int)(blockDim.x >> 6);
-            syrk_scatter<4, 2, YT_STRIDE4>(yt, ncol / 4, ns, gslot, d.n, wave, nw, S_set, rhs_set);
+            syrk_scatter<4, 3, YT_STRIDE4>(yt, ncol / 4, ns, gslot, d.n, wave, nw, S_set, rhs_set);
         } else
         for (int bt = 0; bt < nbatch; bt++) {
             const int ncol = 3 * lb_n;
@@ -522,10 +599,10 @@ static __device__ __forceinline__ void ba_schur_body(const BaDims& d, const BaBu
             BA_STAMP(b, 4);
             const int nw = (int)(blockDim.x >> 6);            // 8 (64 landmarks) or 5 (40 landmarks)
             if (big) {
-                if (nw >= 8) syrk_scatter<8, 5, YT_STRIDE8>(yt, ncol / 4, ns, gslot, d.n, wave, nw, S_set, rhs_set);
-                else syrk_scatter<8, 8, YT_STRIDE8>(yt, ncol / 4, ns, gslot, d.n, wave, nw, S_set, rhs_set);
+                if (nw >= 8) syrk_scatter_plain<8, 5, YT_STRIDE8>(yt, ncol / 4, ns, gslot, d.n, wave, nw, S_set, rhs_set);
+                else syrk_scatter_plain<8, 8, YT_STRIDE8>(yt, ncol / 4, ns, gslot, d.n, wave, nw, S_set, rhs_set);
             } else {
-                syrk_scatter<4, 2, YT_STRIDE4>(yt, ncol / 4, ns, gslot, d.n, wave, nw, S_set, rhs_set);
+                syrk_scatter<4, 3, YT_STRIDE4>(yt, ncol / 4, ns, gslot, d.n, wave, nw, S_set, rhs_set);
             }
         }
     } else if (ns > 21) {
