@@ -32,6 +32,7 @@
 #include <stdlib.h>
 
 #include "ba_common.h"
+#include "ba_backsub_body.h"
 #include "imu_dual.h"
 
 // ---------------------------------------------------------------------- K0
@@ -57,6 +58,7 @@ static __device__ __forceinline__ void ba_init_body(const BaDims& d, const BaBuf
     for (int i = tid; i < zero_n; i += nth) zero_i32[i] = 0;      // histogram of the landmark grouping
     if (tid == 0) {
         b.dbg[62] = 0ull;         // workgroups of ba_finalize that have finished (completion flag for the host)
+        for (int k = BA_HAND; k <= BA_HAND_ERR; k++) b.dbg[k] = 0ull;     // K7 -> K8 hand-off words and their error counter (ba_backsub_body.h)
         BaState s;
         s.radius = opt.r0; s.decrease_factor = 2.0; s.x_cost = 0.0; s.initial_cost = 0.0;
         s.cam_scal[0] = s.cam_scal[1] = s.cam_scal[2] = s.cam_scal[3] = 0.0;
@@ -446,6 +448,7 @@ static __device__ __forceinline__ void ba_finalize_body(const BaDims& d, const B
     if (threadIdx.x == 0) {
         BaState st = st_fin;
         // after a successful step the cost at the new point is K5's value if it ran, else the candidate cost
+        if (b.dbg[BA_HAND_ERR] != 0ull) st.termination = RS_BA_FAILURE;     // a K8 workgroup of the fused launch never saw its K7 publish
         const bool ok = st.termination != RS_BA_FAILURE && isfinite(st.x_cost) && st.x_cost <= st.initial_cost;
         usable = ok ? 1 : 0;
         cur = st.cur;
@@ -804,6 +807,8 @@ static int ba_solve_impl(rs_context* ctx, int n_cameras, int n_points, int n_obs
     // minimum the host follows the state machine through the progress word the first kernel of every round publishes
     // in pinned memory: when round r starts with `iter` iterations done, at most max_iter - iter rounds (r included)
     // can still do work.  The host stays one round ahead of the GPU, so the stream never drains.
+    // K7 + K8 as one launch (ba_solve.hip): the plain local window only — vision-only, one rank, both LDS kernels
+    const bool fuse78 = ctx->ba_fuse_mode == 0 && solve_lds && k8_lds && !in && !rs_comm_active(ctx);
     auto enqueue_round = [&](int it) -> int {
         // double-buffered state / step-scalar blocks: round `it` works on [it & 1] and reads [(it + 1) & 1]
         b.st = st_base + (it & 1); b.st_prev = st_base + ((it + 1) & 1);
@@ -831,6 +836,9 @@ static int ba_solve_impl(rs_context* ctx, int n_cameras, int n_points, int n_obs
             rs_prof_scope ps(ctx, "K7_ba_reduced_solve_inertial");
             int rc2 = ba_launch_reduced_solve_inertial(ctx, d, b, opt, ws + o_big);
             if (rc2) return rc2;
+        } else if (solve_lds && fuse78) {
+            rs_prof_scope ps(ctx, "K78_ba_solve_backsub");
+            ba_launch_solve_backsub(s, d, b, opt);
         } else if (solve_lds) {
             rs_prof_scope ps(ctx, "K7_ba_reduced_solve");
             ba_launch_reduced_solve_lds(s, d, b, opt);
@@ -842,7 +850,9 @@ static int ba_solve_impl(rs_context* ctx, int n_cameras, int n_points, int n_obs
             rs_prof_scope ps(ctx, "K7_ba_reduced_solve_global");
             hipLaunchKernelGGL(ba_reduced_solve, dim3(1), dim3(256), 0, s, d, b, opt, 0);
         }
-        if (k8_lds) {
+        if (fuse78) {
+            // K8 ran inside the K7 launch
+        } else if (k8_lds) {
             rs_prof_scope ps(ctx, "K8_ba_backsub_cost");
             ba_launch_backsub(s, d, b);
         } else {

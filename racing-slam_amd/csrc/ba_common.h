@@ -6,6 +6,9 @@
 #include "common.h"
 
 #define BA_PREP 24            // doubles per camera: R[9] Jl[9] c[3] small pad pad
+#define BA_PREP_LDS 25        // row stride of the camera blocks when they are staged in LDS: 24 doubles = 48 banks puts every
+                              // camera on one of TWO bank offsets (48 c mod 32), and the lanes of a wave read the same entry of
+                              // DIFFERENT cameras; 50 banks give 16 cameras 16 disjoint bank pairs
 #define BA_THREADS 64
 #define BA_NSLOT 64            // partial-sum slots (one 64-B line each) for the scalar reductions:
                               // device-scope atomics on ONE line serialise at ~12 ns each
@@ -162,6 +165,24 @@ __device__ __forceinline__ void cam_prepare(const double* cam, double* out)
     out[21] = small; out[22] = 0.0; out[23] = 0.0;
 }
 
+// 1 / p and 1 / sqrt(x) to within an ulp or two: v_rcp_f64 / v_rsq_f64 + two Newton steps.  The IEEE sequences the
+// compiler emits for `/` and sqrt() are ~40 instructions each with a long dependent tail.
+__device__ __forceinline__ double rcp_nr(double p)
+{
+    double r = __builtin_amdgcn_rcp(p);
+    r = fma(fma(-p, r, 1.0), r, r);
+    r = fma(fma(-p, r, 1.0), r, r);
+    return r;
+}
+__device__ __forceinline__ double rsqrt_nr(double x)
+{
+    double y = __builtin_amdgcn_rsq(x);
+    const double h = 0.5 * x;
+    y = y * (1.5 - h * y * y);
+    y = y * (1.5 - h * y * y);
+    return y;
+}
+
 struct ObsLin {
     double r0, r1, w, rho;
     double jc[12];   // 2x6  [d/d aa | d/d centre]
@@ -177,20 +198,23 @@ __device__ __forceinline__ void obs_eval(const double* __restrict__ cp, const do
     const double p1 = cp[3] * q0 + cp[4] * q1 + cp[5] * q2;
     const double p2 = cp[6] * q0 + cp[7] * q1 + cp[8] * q2;
     const double fx = (double)d.fx, fy = (double)d.fy;
-    o.r0 = fx * p0 / p2 + (double)d.cx - (double)uv.x;     // src/Optimization.cpp:48-49
-    o.r1 = fy * p1 / p2 + (double)d.cy - (double)uv.y;
+    // one reciprocal of the depth for the residual and the Jacobians, one reciprocal square root for the loss (instead of
+    // three IEEE divisions and a square root per observation; the results differ from those by an ulp or two, nine orders
+    // below the tolerances this solve is held to)
+    const double iz = rcp_nr(p2);
+    o.r0 = fx * p0 * iz + (double)d.cx - (double)uv.x;     // src/Optimization.cpp:48-49
+    o.r1 = fy * p1 * iz + (double)d.cy - (double)uv.y;
     const double s = o.r0 * o.r0 + o.r1 * o.r1;
     const double b2 = d.huber_a * d.huber_a;
-    if (s > b2) {   // ceres::HuberLoss
-        const double r = sqrt(s);
-        o.rho = 2.0 * d.huber_a * r - b2;
-        o.w = d.huber_a / r;
+    if (s > b2) {   // ceres::HuberLoss: rho = 2 a sqrt(s) - a^2, weight a / sqrt(s)
+        const double irs = rsqrt_nr(s);
+        o.rho = 2.0 * d.huber_a * (s * irs) - b2;
+        o.w = d.huber_a * irs;
     } else {
         o.rho = s;
         o.w = 1.0;
     }
     if (JAC) {
-        const double iz = 1.0 / p2;
         const double a = fx * iz, b = fy * iz;
         const double ax = -a * p0 * iz, bx = -b * p1 * iz;
 #pragma unroll
@@ -530,6 +554,7 @@ size_t ba_imu_lds_total_doubles(int Ci, int n, int ns);
 size_t ba_reduced_solve_lds_bytes(int n);
 int ba_prepare_reduced_solve_lds(int n);
 void ba_launch_reduced_solve_lds(hipStream_t s, const BaDims& d, const BaBufs& b, const BaOpt& opt);
+void ba_launch_solve_backsub(hipStream_t s, const BaDims& d, const BaBufs& b, const BaOpt& opt);   // K7 + K8 in one launch (ba_solve.hip)
 // ---- back-substitution + candidate cost (ba_update.hip)
 size_t ba_backsub_lds_bytes(int C, int n);
 void ba_launch_backsub(hipStream_t s, const BaDims& d, const BaBufs& b);

@@ -164,16 +164,7 @@ __device__ __forceinline__ int nth_set_bit(uint64_t m0, uint64_t m1, int r)
 }
 
 // cholesky of the damped point block; Li = L^-1 (lower, row-major 6 entries: 00 10 11 20 21 22)
-// 1/sqrt(x) from v_rsq_f64 + two Newton steps (no f64 sqrt / divide sequences on the chain)
-__device__ __forceinline__ double rsqrt_nr(double x)
-{
-    double y = __builtin_amdgcn_rsq(x);
-    const double h = 0.5 * x;
-    y = y * (1.5 - h * y * y);
-    y = y * (1.5 - h * y * y);
-    return y;
-}
-
+// (rsqrt_nr: ba_common.h — no f64 sqrt / divide sequences on the chain)
 // L[6] (same order as Li) also returns the factor itself: sqrt(x) = x * rsqrt(x)
 __device__ __forceinline__ bool chol3_inv(const double V[6], double Li[6], double I[6], double L[6])
 {
@@ -353,8 +344,8 @@ static __device__ __forceinline__ void ba_schur_body(const BaDims& d, const BaBu
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     double* yt = lds;                                            // WG tile
     double* ulds = lds + YT_DOUBLES;                             // [SCH_UCAP][42], by rank in the item's camera union
-    double* cprep = ulds + SCH_UCAP * 42;                        // [C][BA_PREP] camera blocks (PREP_LDS only)
-    int* gslot = (int*)(cprep + (PREP_LDS ? (size_t)d.C * BA_PREP : 0));   // [24]
+    double* cprep = ulds + SCH_UCAP * 42;                        // [C][BA_PREP_LDS] camera blocks (PREP_LDS only)
+    int* gslot = (int*)(cprep + (PREP_LDS ? (size_t)d.C * BA_PREP_LDS : 0));   // [24]
     const int nlds = SCH_UCAP * 42;
     // ---- everything that does not depend on the LM state goes out before the state barrier: the item's
     // camera mask, this lane's landmark record {landmark, first observation, count} (one 16-byte load
@@ -373,8 +364,9 @@ static __device__ __forceinline__ void ba_schur_body(const BaDims& d, const BaBu
     // ---- one more round trip: camera blocks -> LDS, the landmark, the first observation of every lane
     const double* gprep = b.prep + (size_t)st.cur * d.C * BA_PREP;
     if (PREP_LDS)
-        for (int i = threadIdx.x; i < d.C * BA_PREP; i += blockDim.x) cprep[i] = gprep[i];
+        for (int i = threadIdx.x; i < d.C * BA_PREP; i += blockDim.x) cprep[(i / BA_PREP) * BA_PREP_LDS + i % BA_PREP] = gprep[i];
     const double* prep = PREP_LDS ? (const double*)cprep : gprep;       // pure LDS or pure global pointer per instantiation
+    constexpr int PSTR = PREP_LDS ? BA_PREP_LDS : BA_PREP;              // its row stride
     const double* Xp = b.Xp + (size_t)st.cur * d.P * 3;
     double X[3] = {0, 0, 0};
     if (p >= 0) { X[0] = Xp[3 * (size_t)p]; X[1] = Xp[3 * (size_t)p + 1]; X[2] = Xp[3 * (size_t)p + 2]; }
@@ -410,7 +402,7 @@ static __device__ __forceinline__ void ba_schur_body(const BaDims& d, const BaBu
             uvv = b.obs_uv[o0 + jj];
         }
         const int c = cs & 0xFFFF;
-        obs_eval<true>(prep + (size_t)c * BA_PREP, X, uvv, d, o);
+        obs_eval<true>(prep + (size_t)c * PSTR, X, uvv, d, o);
         cost += 0.5 * o.rho;
         const double w = o.w;
         V[0] += w * (o.jp[0] * o.jp[0] + o.jp[3] * o.jp[3]);
@@ -576,7 +568,7 @@ static __device__ __forceinline__ void ba_schur_body(const BaDims& d, const BaBu
                     const int c = cs & 0xFFFF;
                     const int s = (cs >> 16) - 1;
                     if (s < 0) continue;
-                    obs_eval<true>(prep + (size_t)c * BA_PREP, X, uvv, d, o);
+                    obs_eval<true>(prep + (size_t)c * PSTR, X, uvv, d, o);
                     const int pos = rank_in_mask(um0, um1, s);
                     double* dst = yt + (size_t)(3 * lb) * stride + 6 * pos;
 #pragma unroll
@@ -611,7 +603,7 @@ static __device__ __forceinline__ void ba_schur_body(const BaDims& d, const BaBu
             for (int oi = o0; oi < o0 + nobs; oi++) {
                 const int si = b.slot[b.obs_cam[oi]];
                 if (si < 0) continue;
-                obs_eval<true>(prep + (size_t)b.obs_cam[oi] * BA_PREP, X, b.obs_uv[oi], d, o);
+                obs_eval<true>(prep + (size_t)b.obs_cam[oi] * PSTR, X, b.obs_uv[oi], d, o);
                 double Y[18];
 #pragma unroll
                 for (int a = 0; a < 6; a++) {
@@ -627,7 +619,7 @@ static __device__ __forceinline__ void ba_schur_body(const BaDims& d, const BaBu
                 for (int ojx = o0; ojx < o0 + nobs; ojx++) {
                     const int sj = b.slot[b.obs_cam[ojx]];
                     if (sj < si) continue;      // upper block triangle only
-                    obs_eval<true>(prep + (size_t)b.obs_cam[ojx] * BA_PREP, X, b.obs_uv[ojx], d, oj);
+                    obs_eval<true>(prep + (size_t)b.obs_cam[ojx] * PSTR, X, b.obs_uv[ojx], d, oj);
                     double* Sblk = S_set + (size_t)(6 * si) * d.n + 6 * sj;
 #pragma unroll
                     for (int e = 0; e < 6; e++) {
@@ -850,7 +842,7 @@ int ba_launch_grouping(rs_context* ctx, const BaDims& d, const BaBufs& b, const 
 size_t ba_schur_lds_bytes(int C, int Cf)
 {
     (void)Cf;
-    const size_t prep = C <= SCH_MAXC_LDS ? (size_t)C * BA_PREP : 0;
+    const size_t prep = C <= SCH_MAXC_LDS ? (size_t)C * BA_PREP_LDS : 0;
     return sizeof(double) * ((size_t)YT_DOUBLES + (size_t)SCH_UCAP * 42 + prep + 6 * IT_L) + sizeof(int) * 32;   // + Mt
 }
 

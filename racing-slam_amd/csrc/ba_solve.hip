@@ -25,6 +25,7 @@
 // Then a backward substitution in one wave with y in registers, and the camera
 // step / candidate cameras / step scalars.  Measurements: DESIGN.md 4.2.
 #include "ba_common.h"
+#include "ba_backsub_body.h"
 
 #define K7_THREADS 512
 #define K7_TPW 6       // tiles per tile wave: 6 tile waves x 6 = the 36 lower-triangle tiles of a 128 x 128 matrix
@@ -48,6 +49,11 @@ __device__ __forceinline__ double fast_rcp(double x)
 }
 
 
+// HANDOFF: this workgroup is a producer of the fused launch (ba_solve_backsub below).  It publishes two words per set
+// (ba_backsub_body.h): BA_HAND_TAKEN once the accumulators are in registers / LDS and the gradient test is done (K8 clears
+// them while the factorisation runs), and BA_HAND when delta_c — stored write-through (sc1) — is complete, or the solver
+// has failed.  Every exit past the common early-out publishes what the consumers wait for.
+template <bool HANDOFF>
 static __device__ __forceinline__ void ba_reduced_solve_lds_body(const BaDims& d, const BaBufs& b, const BaOpt& opt)
 {
     extern __shared__ __attribute__((aligned(16))) double sm[];
@@ -132,10 +138,31 @@ static __device__ __forceinline__ void ba_reduced_solve_lds_body(const BaDims& d
         }
     }
     __syncthreads();
-    if (st.done || set >= st.nact) return;
+    if (st.done || set >= st.nact) return;        // (the consumers of the fused launch take the same exit on the same state)
+#if RS_STAMPS
+    if (HANDOFF && tid == 0 && set == 0) b.dbg[42] = wall_clock64();
+#endif
+    const unsigned long long epoch = (unsigned long long)(unsigned)st.n_rounds << 2;
+    auto publish = [&](int word, unsigned long long code) {   // reached by every thread of the workgroup
+        if (HANDOFF) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // this wave's loads have arrived, its stores are done
+            __syncthreads();
+            if (tid == 0) {
+#if RS_STAMPS
+                if (set == 0) b.dbg[word == BA_HAND ? 40 : 43] = wall_clock64();
+#endif
+                __hip_atomic_store(b.dbg + word + set, epoch | code, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+    };
     BA_STAMP(b, 2);
-    for (int i = tid; i < BA_NSLOT * BA_SLOT_STRIDE; i += nt)                         // K8 of this round accumulates here
-        b.pt_scal[(size_t)set * BA_NSLOT * BA_SLOT_STRIDE + i] = 0.0;
+    for (int i = tid; i < BA_NSLOT * BA_SLOT_STRIDE; i += nt) {                       // K8 of this round accumulates here
+        double* z = b.pt_scal + (size_t)set * BA_NSLOT * BA_SLOT_STRIDE + i;
+        // fused launch: K8's atomics execute at the memory side within this launch; a plain store would sit in this
+        // XCD's L2 until the kernel ends and then overwrite their sums.  Written through, and complete before publish().
+        if (HANDOFF) ba_store_sc1(z, 0.0);
+        else *z = 0.0;
+    }
     for (int i = tid; i < 2 * 8 * 128; i += nt) Pd[i] = 0.0;
     // fold the replicas of the camera-side accumulators (replica layout: rhs[n] U[Cf*36] gc[n])
 #pragma unroll
@@ -184,10 +211,11 @@ static __device__ __forceinline__ void ba_reduced_solve_lds_body(const BaDims& d
             else if (g <= opt.gtol) { st.done = 1; st.termination = RS_BA_CONVERGENCE_GRADIENT; }
         }
         __syncthreads();
-        if (st.done) { if (tid == 0 && set == 0) *b.st = st; return; }      // every set reaches the same verdict
+        if (st.done) { if (tid == 0 && set == 0) *b.st = st; publish(BA_HAND_TAKEN, 2ull); return; }      // every set reaches the same verdict
     } else {
         __syncthreads();
     }
+    publish(BA_HAND_TAKEN, 0ull);      // the accumulators are in registers / LDS from here on: K8 may clear them
     if (tid == 0 && fail_sum > 0.0) s_fail = 1;          // K5 saw a non-finite landmark block
     BA_STAMP(b, 0);
 
@@ -409,6 +437,7 @@ static __device__ __forceinline__ void ba_reduced_solve_lds_body(const BaDims& d
             if (set == 0) { st.solver_failed = 1; *b.st = st; }
             else b.set_out[set].solver_failed = 1;
         }
+        publish(BA_HAND, 1ull);
         return;
     }
     // (4) backward substitution L^T x = y in ONE wave without block barriers: y (row n of the panels)
@@ -460,13 +489,24 @@ static __device__ __forceinline__ void ba_reduced_solve_lds_body(const BaDims& d
     }
     __syncthreads();
     BA_STAMP(b, 6);
+    double* dc_set = b.dc + (size_t)set * (n + 2);
+    if (HANDOFF) {
+        // delta_c leaves first, written through, and the set's word is published: K8's workgroups derive the candidate
+        // cameras and their blocks themselves (the same arithmetic as below) while this workgroup finishes its epilogue
+        int badi = 0;
+        for (int i = tid; i < n; i += nt) {
+            const double dlt = -xs[i];
+            if (!isfinite(dlt)) badi = 1;
+            ba_store_sc1(&dc_set[i], dlt);
+        }
+        publish(BA_HAND, __syncthreads_or(badi) ? 1ull : 0ull);
+    }
     // (5) delta_c = -x, candidate cameras, camera part of the step scalars
     double mcc = 0.0, ssq = 0.0, xsq = 0.0;
     bool bad = false;
     const double* Xc = b.Xc + (size_t)st.cur * d.C * 6;
     const int cand = (st.cur + 1 + set) % (b.ns + 1);       // this set's candidate buffer
     double* Xn = b.Xc + (size_t)cand * d.C * 6;
-    double* dc_set = b.dc + (size_t)set * (n + 2);
     for (int c = tid; c < d.C; c += nt) {
         const int s = b.slot[c];
         bool active = false;
@@ -481,12 +521,12 @@ static __device__ __forceinline__ void ba_reduced_solve_lds_body(const BaDims& d
                 const double xn = x + dlt;
                 if (active) { ssq += (x - xn) * (x - xn); xsq += x * x; }
                 Xn[6 * c + k] = xn;
-                dc_set[6 * s + k] = dlt;
+                if (!HANDOFF) dc_set[6 * s + k] = dlt;
             } else {
                 Xn[6 * c + k] = x;
             }
         }
-        cam_prepare(Xn + 6 * c, b.prep + ((size_t)cand * d.C + c) * BA_PREP);
+        cam_prepare(Xn + 6 * c, b.prep + ((size_t)cand * d.C + c) * BA_PREP);      // (for the next round's K5)
     }
     mcc = wave_sum(mcc); ssq = wave_sum(ssq); xsq = wave_sum(xsq);
     if (__any(bad) && (tid & 63) == 0) s_fail = 1;
@@ -512,19 +552,44 @@ static __device__ __forceinline__ void ba_reduced_solve_lds_body(const BaDims& d
     BA_STAMP_FLUSH(b, 0);
 }
 
-__global__ __launch_bounds__(K7_THREADS) void ba_reduced_solve_lds(BaDims d, BaBufs b, BaOpt opt) { ba_reduced_solve_lds_body(d, b, opt); }
+__global__ __launch_bounds__(K7_THREADS) void ba_reduced_solve_lds(BaDims d, BaBufs b, BaOpt opt) { ba_reduced_solve_lds_body<false>(d, b, opt); }
+
+// K7 + K8 in ONE launch (single local window, vision only, one rank): workgroups [0, ns) are K7, one per speculative
+// set; the others are K8's, `nblk` landmark blocks of K7_THREADS / 4 landmarks per set, and wait for their set's
+// hand-off word.  A K8 launch behind K7 costs the launch gap plus K8's own prologue (state, landmark records, Jacobi
+// scale, V^-1, the first observations: two dependent round trips) AFTER the solve; here all of that is in flight
+// while K7 is solving, and what remains behind the hand-off is one round trip for delta_c / the candidate's camera
+// blocks and the arithmetic.  Producers never wait for consumers and are dispatched first, and a consumer's wait
+// is bounded (ba_hand_wait), so the grid always drains.
+__global__ __launch_bounds__(K7_THREADS) void ba_solve_backsub(BaDims d, BaBufs b, BaOpt opt, int nblk)
+{
+    if ((int)blockIdx.x < b.ns) {
+        ba_reduced_solve_lds_body<true>(d, b, opt);
+    } else {
+        const int v = (int)blockIdx.x - b.ns;
+        ba_backsub_cost4_body<true>(d, b, v % nblk, v / nblk, (size_t)v, (size_t)gridDim.x - b.ns);
+    }
+}
 // batched: blockIdx.x = speculative set, blockIdx.z = window
 __global__ __launch_bounds__(K7_THREADS) void ba_reduced_solve_lds_batch(const BaWin* w, BaOpt opt, int it)
 {
     const BaWin& x = w[blockIdx.z];
     const BaBufs b = ba_win_round(x, it, false);
-    ba_reduced_solve_lds_body(x.d, b, opt);
+    ba_reduced_solve_lds_body<false>(x.d, b, opt);
 }
 
 size_t ba_reduced_solve_lds_bytes(int n)
 {
     const int LD = n + 1 + ((n & 1) ? 1 : 0);
     return sizeof(double) * ((size_t)(n + 1) * LD + 2 * (size_t)n + 6 * (size_t)n + 6 * (size_t)n + 3 * (size_t)n + 8 + 2 * 8 * 128);
+}
+
+void ba_launch_solve_backsub(hipStream_t s, const BaDims& d, const BaBufs& b, const BaOpt& opt)
+{
+    const size_t lds = max(ba_reduced_solve_lds_bytes(d.n), ba_backsub_lds_bytes(d.C, d.n));
+    (void)rs_lds_attr((const void*)ba_solve_backsub, lds);
+    const int per = K7_THREADS / 4, nblk = (d.P + per - 1) / per;
+    hipLaunchKernelGGL(ba_solve_backsub, dim3(b.ns + nblk * b.ns), dim3(K7_THREADS), lds, s, d, b, opt, nblk);
 }
 
 void ba_launch_reduced_solve_lds(hipStream_t s, const BaDims& d, const BaBufs& b, const BaOpt& opt)

@@ -123,16 +123,7 @@ __global__ __launch_bounds__(256) void ba_big_assemble(BaDims d, BaBufs b)
 }
 
 // ------------------------------------------------------------------ diagonal block
-// 1 / p to within an ulp or two: v_rcp_f64 + two Newton steps (the pivot reciprocal only scales a column of
-// multipliers; a full IEEE division is 40 instructions on the critical path of every column)
-__device__ __forceinline__ double rcp_nr(double p)
-{
-    double r = __builtin_amdgcn_rcp(p);
-    r = fma(fma(-p, r, 1.0), r, r);
-    r = fma(fma(-p, r, 1.0), r, r);
-    return r;
-}
-
+// (rcp_nr: ba_common.h — a full IEEE division is 40 instructions on the critical path of every column)
 __global__ __launch_bounds__(256) void ba_big_diag(BaDims d, BaBufs b, BigBufs g, int J)
 {
     if (b.st->done) return;
@@ -266,6 +257,29 @@ typedef __attribute__((ext_vector_type(4))) double d4;
 // v_mfma_f64_16x16x4_f64 takes A[lane&15][lane>>4] and B[lane&15][lane>>4] of a 16x4 slice, and returns
 // C[row = (lane>>4) + 4 reg][col = lane & 15].  The 9 output tiles are dealt round-robin to the 4 waves;
 // `store(R, C, v)` is called for every element this lane owns.
+// K loop of NTL tiles of one wave, straight-line per tile count so that the operands of chunk kc + 1 are requested
+// before the MFMAs of chunk kc issue (inside `if (ti < ntile)` branches every MFMA waited for its own ds_read)
+template <int NTL>
+__device__ __forceinline__ void gemm_nt_tiles(const double* const* xa, const double* const* zb, int nchunk, d4* acc)
+{
+    double a0[NTL], b0[NTL], a1[NTL], b1[NTL];
+#pragma unroll
+    for (int ti = 0; ti < NTL; ti++) { a0[ti] = xa[ti][0]; b0[ti] = zb[ti][0]; }
+    for (int kc = 0; kc < nchunk; kc += 2) {
+        const int k1 = 4 * min(kc + 1, nchunk - 1), k2 = 4 * min(kc + 2, nchunk - 1);
+#pragma unroll
+        for (int ti = 0; ti < NTL; ti++) { a1[ti] = xa[ti][k1]; b1[ti] = zb[ti][k1]; }
+#pragma unroll
+        for (int ti = 0; ti < NTL; ti++) acc[ti] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[ti], b0[ti], acc[ti], 0, 0, 0);
+#pragma unroll
+        for (int ti = 0; ti < NTL; ti++) { a0[ti] = xa[ti][k2]; b0[ti] = zb[ti][k2]; }
+        if (kc + 1 < nchunk) {
+#pragma unroll
+            for (int ti = 0; ti < NTL; ti++) acc[ti] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1[ti], b1[ti], acc[ti], 0, 0, 0);
+        }
+    }
+}
+
 template <typename F>
 __device__ __forceinline__ void gemm_nt_48(const double* X, const double* Z, int nchunk, F store)
 {
@@ -285,10 +299,9 @@ __device__ __forceinline__ void gemm_nt_48(const double* X, const double* Z, int
         zb[ti] = Z + (16 * (tt % 3) + lr) * BBS + lk;
         if (t < 9) ntile = ti + 1;
     }
-    for (int kc = 0; kc < nchunk; kc++) {
-#pragma unroll
-        for (int ti = 0; ti < 3; ti++)
-            if (ti < ntile) acc[ti] = __builtin_amdgcn_mfma_f64_16x16x4f64(xa[ti][4 * kc], zb[ti][4 * kc], acc[ti], 0, 0, 0);
+    if (nchunk > 0) {
+        if (ntile == 3) gemm_nt_tiles<3>(xa, zb, nchunk, acc);       // wave-uniform
+        else gemm_nt_tiles<2>(xa, zb, nchunk, acc);
     }
 #pragma unroll
     for (int ti = 0; ti < 3; ti++) {

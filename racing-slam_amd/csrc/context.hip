@@ -90,6 +90,11 @@ extern "C" int rs_context_set_int(rs_context* ctx, const char* name, int value)
         ctx->ba_imu_mode = value;
         return RS_OK;
     }
+    if (strcmp(name, "ba_fuse_mode") == 0) {
+        if (value < 0 || value > 1) return rs_fail(ctx, RS_ERR_INVALID, "ba_fuse_mode must be 0 (solve + back-substitution in one launch where possible) or 1 (separate launches)");
+        ctx->ba_fuse_mode = value;
+        return RS_OK;
+    }
     if (strcmp(name, "k2_mode") == 0) {
         if (value < 0 || value > 1) return rs_fail(ctx, RS_ERR_INVALID, "k2_mode must be 0 (eight lanes per map point where possible) or 1 (one lane per point)");
         ctx->k2_mode = value;

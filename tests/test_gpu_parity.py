@@ -626,6 +626,34 @@ def test_bundle_adjust_speculative_radii_do_not_change_the_schedule(ctx, rs, ora
     del args
 
 
+@pytest.mark.parametrize("kw", [dict(), dict(n_kf=8, n_points=150, run_max=5, config_id=36, outlier_frac=0.1, rot_noise_deg=2.0),
+                                dict(n_kf=12, n_points=3000, run_max=8, config_id=19, outlier_frac=0.06)])
+def test_bundle_adjust_fused_solve_and_backsubstitution(ctx, oracle, synth, kw):
+    """K7 + K8 in one launch (the default on the plain local window: K8's workgroups wait for their set's hand-off word
+    inside the launch) against the two separate launches: the same per-iteration record as the oracle either way, the
+    results equal to summation-order level, and a second run of the fused form reproduces the first (a stale read of
+    delta_c or of the candidate camera blocks would not)."""
+    w = synth.make_ba_window(**kw)
+    _, _, os_, otr = oracle.bundle_adjust_trace(w["cams"], w["cam_free"], w["points"], w["obs_ptr"], w["obs_cam"], w["obs_uv"], w["K"])
+    runs = []
+    try:
+        for mode in (1, 0, 0):
+            ctx.set_int("ba_fuse_mode", mode)
+            dc, dp = ctx.dev(w["cams"]), ctx.dev(w["points"])
+            s = ctx.bundle_adjust(dc, w["cam_free"], dp, ctx.dev(w["obs_ptr"]), ctx.dev(w["obs_cam"]), ctx.dev(w["obs_uv"]), w["K"])
+            runs.append((s, ctx.ba_trace(), to_np(dc), to_np(dp)))
+    finally:
+        ctx.set_int("ba_fuse_mode", 0)
+    s1, t1, c1, p1 = runs[0]
+    for s, tr, c, p in runs:
+        assert (s["iterations"], s["successful_steps"], s["termination"], s["usable"]) == \
+               (os_["iterations"], os_["successful_steps"], os_["termination"], os_["usable"])
+        assert [t["outcome"] for t in tr] == [t["outcome"] for t in otr]
+        assert np.allclose([t["cost"] for t in tr], [t["cost"] for t in otr], rtol=1e-9)
+        assert np.isclose(s["final_cost"], s1["final_cost"], rtol=1e-10)
+        assert np.allclose(c, c1, rtol=1e-9, atol=1e-11) and np.allclose(p, p1, rtol=1e-9, atol=1e-10)
+
+
 def test_reanchor_points(ctx, oracle, rs, synth):
     """rs_reanchor_points (K13, the tail of Mapper::bundle_adjust, src/Mapper.cpp:380-393) bit for bit against the oracle."""
     rng = np.random.default_rng(6)
