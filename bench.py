@@ -46,7 +46,7 @@ HBM_PEAK_GBS = 8000.0     # /opt/skills/guides/MI355X_MICROARCH.md
 VALU_INT_PEAK_TOPS = 39.3  # 256 CU x 64 lanes x 2.4 GHz 32-bit integer ops (K1's real ceiling)
 METRIC = "match+triangulate+local-BA passes/sec @ 2k kpts/frame, 20-KF x 10k-pt window"
 
-PMC_NAMES = {"K5_ba_schur_mfma": "ba_schur_mfma", "K7_ba_reduced_solve": "ba_reduced_solve_lds",
+PMC_NAMES = {"K5_ba_schur_mfma": "ba_schur_mfma", "K7_ba_reduced_solve": "ba_reduced_solve_lds", "K78_ba_solve_backsub": "ba_solve_backsub",
              "K8_ba_backsub_cost": "ba_backsub_cost4", "K1_hamming_knn2": "k1_hamming_knn2",
              "K1b_merge_filter": "k1_merge_filter", "K2_reproj_match": "k2_reproj_match",
              "K4_triangulate_dlt": "k4_triangulate", "K7_ba_reduced_solve_blocked": "ba_big_update"}
@@ -95,7 +95,7 @@ def algorithmic_work(w, n_free):
     n = 6.0 * n_free
     return dict(M=M, P=P, C=C, n=n, lin_flops=500.0 * M,
                 schur_flops=float(np.sum(50 + 108 * k + 216 * k * (k + 1) / 2 + 72 * k)),
-                solve_flops=n ** 3 / 3, lin_bytes=16 * M + 2 * 24 * P + 2 * 48 * C + 8 * n * n,
+                solve_flops=n ** 3 / 3, backsub_flops=410.0 * M + 50.0 * P, lin_bytes=16 * M + 2 * 24 * P + 2 * 48 * C + 8 * n * n,
                 cost_bytes=16 * M + 24 * P + 48 * C)
 
 
@@ -416,6 +416,7 @@ def bench_pass(e, args):
     pmc, pmc_file, pmc_fresh = pmc_traffic("pass")
     # K5: linearisation flops only on the rounds that relinearise; the Schur term once per speculative set
     k5_flops = (stats["fresh_rounds"] * work["lin_flops"] + stats["set_evaluations"] * work["schur_flops"]) / max(stats["rounds"], 1)
+    sets_per_round = stats["set_evaluations"] / max(stats["rounds"], 1)
     rl = {}
     for name, bound, amount, note in (
             ("K5_ba_schur_mfma", "mfma", k5_flops, "avg over the solve's rounds: 500*M linearisation flops on relinearising rounds, "
@@ -424,6 +425,10 @@ def bench_pass(e, args):
              "single-workgroup block LDL^T: an 18-step dependency chain, neither the MFMA nor the HBM roof applies "
              "(DESIGN.md 4.2); the number to watch is us_per_block_step"),
             ("K8_ba_backsub_cost", "hbm", work["cost_bytes"] + 16 * work["M"] + 2 * 24 * work["P"], None),
+            ("K78_ba_solve_backsub", "latency", sets_per_round * (work["solve_flops"] + work["backsub_flops"]),
+             "K7 + K8 of a round in ONE launch (one K7 workgroup per speculative radius; K8's workgroups wait inside the launch "
+             "for its hand-off): the 18-step block LDL^T chain sets the duration, neither the MFMA nor the HBM roof applies "
+             "(DESIGN.md 4.2); flops = (n^3/3 + 410 M + 50 P) per evaluated radius; the number to watch is us_per_block_step"),
             ("K1_hamming_knn2", "valu-int", 16.0 * nq * nt, "8 xor + 8 popcount-accumulate per descriptor pair; HBM side: "
                                                             "%.0f KB per launch" % ((32.0 * (nq + nt) + 12.0 * nq) / 1e3)),
             ("K4_triangulate_dlt", "mfma", 2500.0 * nq, "fp64 VALU (no matrix work), priced against the fp64 peak"),
@@ -431,9 +436,10 @@ def bench_pass(e, args):
         r = roofline_entry(name, bound, amount, per_kernel, pmc, note)
         if r:
             rl[name] = r
-    if "K7_ba_reduced_solve" in rl:
-        rl["K7_ba_reduced_solve"]["us_per_block_step"] = rl["K7_ba_reduced_solve"]["avg_launch_us"] / max(work["n"] / 6.0, 1.0)
-        rl["K7_ba_reduced_solve"]["workgroups_per_launch"] = "one per speculative radius (<= 3)"
+    for k7 in ("K7_ba_reduced_solve", "K78_ba_solve_backsub"):
+        if k7 in rl:
+            rl[k7]["us_per_block_step"] = rl[k7]["avg_launch_us"] / max(work["n"] / 6.0, 1.0)
+            rl[k7]["workgroups_per_launch"] = "one per speculative radius (<= 3)" + (" + K8's" if k7.startswith("K78") else "")
     dom = max(per_kernel, key=lambda k: per_kernel[k]["total_ms"]) if per_kernel else None
     roofline = rl.get(dom)
     if roofline is not None:
@@ -596,7 +602,9 @@ def bench_ba(e, args, cfg):
     pmc, pmc_file, pmc_fresh = pmc_traffic(cfg)
     k5_flops = (stats["fresh_rounds"] * work["lin_flops"] + stats["set_evaluations"] * work["schur_flops"]) / max(stats["rounds"], 1)
     rl = {}
+    sets_per_round = stats["set_evaluations"] / max(stats["rounds"], 1)
     for name, bound, amount in (("K5_ba_schur_mfma", "mfma", k5_flops), ("K7_ba_reduced_solve", "latency", work["solve_flops"]),
+                                ("K78_ba_solve_backsub", "latency", sets_per_round * (work["solve_flops"] + work["backsub_flops"])),
                                 ("K7_ba_reduced_solve_blocked", "mfma", work["solve_flops"]),
                                 ("K8_ba_backsub_cost", "hbm", work["cost_bytes"] + 16 * work["M"] + 2 * 24 * work["P"])):
         r = roofline_entry(name, bound, amount, per_kernel, pmc)
