@@ -808,7 +808,10 @@ static int ba_solve_impl(rs_context* ctx, int n_cameras, int n_points, int n_obs
     // in pinned memory: when round r starts with `iter` iterations done, at most max_iter - iter rounds (r included)
     // can still do work.  The host stays one round ahead of the GPU, so the stream never drains.
     // K7 + K8 as one launch (ba_solve.hip): the plain local window only — vision-only, one rank, both LDS kernels
-    const bool fuse78 = ctx->ba_fuse_mode == 0 && solve_lds && k8_lds && !in && !rs_comm_active(ctx);
+    // and only while all of its workgroups are resident at once (one per CU: the launch carries K7's LDS): beyond that
+    // K8's workgroups would run in several shifts behind the hand-off, and the launch of its own (many per CU) is faster
+    const bool fuse78 = ctx->ba_fuse_mode == 0 && solve_lds && k8_lds && !in && !rs_comm_active(ctx) &&
+                        ba_solve_backsub_workgroups(d, b) <= ctx->n_cu;
     auto enqueue_round = [&](int it) -> int {
         // double-buffered state / step-scalar blocks: round `it` works on [it & 1] and reads [(it + 1) & 1]
         b.st = st_base + (it & 1); b.st_prev = st_base + ((it + 1) & 1);

@@ -584,6 +584,12 @@ size_t ba_reduced_solve_lds_bytes(int n)
     return sizeof(double) * ((size_t)(n + 1) * LD + 2 * (size_t)n + 6 * (size_t)n + 6 * (size_t)n + 3 * (size_t)n + 8 + 2 * 8 * 128);
 }
 
+int ba_solve_backsub_workgroups(const BaDims& d, const BaBufs& b)
+{
+    const int per = K7_THREADS / 4;
+    return b.ns * (1 + (d.P + per - 1) / per);
+}
+
 void ba_launch_solve_backsub(hipStream_t s, const BaDims& d, const BaBufs& b, const BaOpt& opt)
 {
     const size_t lds = max(ba_reduced_solve_lds_bytes(d.n), ba_backsub_lds_bytes(d.C, d.n));

@@ -40,6 +40,7 @@ extern "C" int rs_context_create(int device_id, rs_context** out)
     }
     rs_context* c = new rs_context();
     c->device = device_id;
+    c->n_cu = prop.multiProcessorCount;
     if (const char* e = getenv("RS_BA_SETS")) { const int v = atoi(e); if (v >= 1 && v <= 3) c->ba_sets = v; }
     *out = c;
     return RS_OK;
