@@ -597,7 +597,7 @@ static BaLayout ba_layout(const BaDims& d, int ns, int max_iter, size_t n_ranks,
     L.acc_count = (size_t)ns * n * n + (size_t)BA_UREP * L.cam_stride + (1 + n_ranks) * (size_t)BA_NSLOT * BA_SLOT_STRIDE;
     L.acc = carve(sizeof(double) * L.acc_count);
     L.pts_block = (size_t)ns * BA_NSLOT * BA_SLOT_STRIDE;
-    L.pts = carve(sizeof(double) * 2 * L.pts_block); L.dc = carve(sizeof(double) * ns * (n + 2));
+    L.pts = carve(sizeof(double) * 2 * L.pts_block); L.dc = carve(sizeof(double) * ns * BA_DC_STRIDE(n));
     L.st = carve(sizeof(BaState) * 2);
     L.set = carve(sizeof(BaSetOut) * 2 * BA_MAXSETS);
     L.trace = carve(sizeof(BaTrace) * (size_t)(max_iter + 1));

@@ -129,7 +129,7 @@ static __device__ __forceinline__ void ba_backsub_cost4_body(const BaDims& d, co
             const int li = (i / BA_PREP) * BA_PREP_LDS + i % BA_PREP;
             cprep[li] = gprep[i]; cprepn[li] = gprepn[i];
         }
-        for (int i = threadIdx.x; i < d.n; i += blockDim.x) dcl[i] = b.dc[(size_t)set * (d.n + 2) + i];
+        for (int i = threadIdx.x; i < d.n; i += blockDim.x) dcl[i] = b.dc[(size_t)set * BA_DC_STRIDE(d.n) + i];
     } else {
         // everything above is in flight while this set's K7 (workgroup `set` of the same launch) is still solving
         double* xcl = dcl + d.n;                    // [C][6] current cameras
@@ -144,7 +144,7 @@ static __device__ __forceinline__ void ba_backsub_cost4_body(const BaDims& d, co
         const unsigned code = hand_code[set];
         if (code == 4u) { if (threadIdx.x == 0) atomicAdd(b.dbg + BA_HAND_ERR, 1ull); return; }
         if (code & 1u) return;                      // this set's solver failed
-        for (int i = threadIdx.x; i < d.n; i += blockDim.x) dcl[i] = ba_load_sc1(b.dc + (size_t)set * (d.n + 2) + i);
+        for (int i = threadIdx.x; i < d.n; i += blockDim.x) dcl[i] = ba_load_sc1(b.dc + (size_t)set * BA_DC_STRIDE(d.n) + i);
         __syncthreads();
         // the candidate's cameras and their blocks, exactly as K7's epilogue forms them for the next linearisation
         for (int c = threadIdx.x; c < d.C; c += blockDim.x) {

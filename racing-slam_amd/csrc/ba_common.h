@@ -6,6 +6,8 @@
 #include "common.h"
 
 #define BA_PREP 24            // doubles per camera: R[9] Jl[9] c[3] small pad pad
+#define BA_DC_STRIDE(n) ((((n) + 2 + 15) / 16) * 16)     // doubles per speculative set in b.dc: whole 128-byte lines, so that no
+                              // line holds the camera steps of two sets (each is published by its own K7 workgroup, ba_solve.hip)
 #define BA_PREP_LDS 25        // row stride of the camera blocks when they are staged in LDS: 24 doubles = 48 banks puts every
                               // camera on one of TWO bank offsets (48 c mod 32), and the lanes of a wave read the same entry of
                               // DIFFERENT cameras; 50 banks give 16 cameras 16 disjoint bank pairs
@@ -116,7 +118,7 @@ struct BaBufs {
     int gmax_blocks;    //   so that the SUM all-reduce of the accumulators also delivers every rank's maximum (no max collective)
     double* pt_scal; // [ns][BA_NSLOT][8] per slot, K8 of THIS round: cand_cost, mcc_p, step_sq_p, x_sq_p
     const double* pt_prev;   // the same block of the PREVIOUS round (read by the next linearisation's decision)
-    double* dc;      // [ns][n+2]
+    double* dc;      // [ns][BA_DC_STRIDE(n)]
     BaSetOut* set_out;            // [ns] K7 results of sets >= 1, THIS round
     const BaSetOut* set_prev;     // the previous round's
     BaProgress* prog;             // pinned host memory (null when the caller does not poll)

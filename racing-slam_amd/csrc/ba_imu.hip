@@ -329,7 +329,7 @@ __global__ __launch_bounds__(KI_THREADS) void ba_imu_expand(BaDims d, BaBufs b, 
     if (st.done || set >= st.nact) return;
     if (set == 0 ? st.solver_failed : b.set_out[set].solver_failed) return;
     const ImuView V = imu_view(b, n, set);
-    const double* dcs = b.dc + (size_t)set * (n + 2);
+    const double* dcs = b.dc + (size_t)set * BA_DC_STRIDE(n);
     const int cand = (st.cur + 1 + set) % (b.ns + 1);
     const double* Xv = b.imu.Xv + (size_t)st.cur * d.C * 9;
     double* Xvn = b.imu.Xv + (size_t)cand * d.C * 9;

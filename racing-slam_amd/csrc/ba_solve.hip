@@ -489,7 +489,7 @@ static __device__ __forceinline__ void ba_reduced_solve_lds_body(const BaDims& d
     }
     __syncthreads();
     BA_STAMP(b, 6);
-    double* dc_set = b.dc + (size_t)set * (n + 2);
+    double* dc_set = b.dc + (size_t)set * BA_DC_STRIDE(n);
     if (HANDOFF) {
         // delta_c leaves first, written through, and the set's word is published: K8's workgroups derive the candidate
         // cameras and their blocks themselves (the same arithmetic as below) while this workgroup finishes its epilogue
