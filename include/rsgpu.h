@@ -72,9 +72,11 @@ int rs_context_synchronize(rs_context* ctx);
  * results do not depend on it (tests/test_gpu_parity.py), only the number of launches does.
  * "ba_imu_mode": rs_bundle_adjust_inertial — 0 (default) the velocity / bias blocks are eliminated around the
  * local-window reduced solve where the window allows it, 1 always the blocked solve of the full camera-side system.
- * "ba_fuse_mode": rs_bundle_adjust on a single local window (vision only, one rank) — 0 (default) the reduced
- * solve and the back-substitution / candidate cost of a round run as ONE launch (the latter's workgroups wait for
- * the former's hand-off words inside the launch), 1 as two launches; same results.
+ * "ba_fuse_mode": rs_bundle_adjust on a single local window (vision only, one rank) — the reduced solve and the
+ * back-substitution / candidate cost of a round as ONE launch (the latter's workgroups wait for the former's hand-off
+ * words inside the launch, holding a CU each): 0 (default) when no other solve of this process is in flight (lower
+ * latency for one session; several sessions on one GPU get more aggregate throughput from two launches), 1 never,
+ * 2 wherever possible; same results.
  * "k2_mode": rs_reproj_match — 0 (default) eight lanes per map point where the frame's KD-tree fits in LDS
  * (<= 6144 keypoints), 1 always one lane per point; the outputs are identical.
  * "ba_batch_mode": how rs_bundle_adjust_batch runs its windows — 0 (default) one launch sequence for all of them

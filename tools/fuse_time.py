@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""cfg-3 bundle adjustment with K7 + K8 as one launch (ba_fuse_mode 0, the default) and as two (1): ms per solve and the
+"""cfg-3 bundle adjustment with K7 + K8 as one launch (ba_fuse_mode 2; the default 0 does so when no other solve is in
+flight) and as two (1): ms per solve and the
 per-scope averages."""
 import importlib
 import os
@@ -17,7 +18,7 @@ dev = [ctx.dev(w[k]) for k in ("obs_ptr", "obs_cam", "obs_uv")]
 c0, p0 = ctx.dev(w["cams"]), ctx.dev(w["points"])
 dc, dp = ctx.dev(w["cams"]), ctx.dev(w["points"])
 for rep in range(2):
-    for mode in (1, 0):
+    for mode in (1, 2):
         ctx.set_int("ba_fuse_mode", mode)
         for _ in range(10):
             dc.copy_(c0); dp.copy_(p0)
