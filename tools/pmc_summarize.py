@@ -3,6 +3,7 @@
 
     pmc_summarize.py pmc   <fetch_dir> <write_dir> <out.csv>     per-kernel HBM-side bytes per launch
     pmc_summarize.py stats <stats_dir> <out.csv>                  the *_kernel_stats.csv of a --stats run, copied
+    pmc_summarize.py mfma  <dir> <out.csv>                        matrix-core counters of one --pmc pass, per-dispatch averages
 
 FETCH_SIZE / WRITE_SIZE come from separate runs of the same command (they do not fit one pass: MI355X_MICROARCH.md,
 "rocprofv3 PMC slots").  rocprofv3 reports both in KB; on gfx950 FETCH_SIZE counts 64 B per 128-B request, so the
@@ -56,6 +57,17 @@ def main():
         if not files:
             raise SystemExit(f"no kernel_stats.csv under {d}")
         shutil.copy(files[0], out)
+    elif mode == "mfma":
+        d, out = sys.argv[2:4]
+        names = ("SQ_VALU_MFMA_BUSY_CYCLES", "SQ_BUSY_CYCLES", "SQ_WAVE_CYCLES", "SQ_INSTS_VALU_MFMA_MOPS_F64")
+        cols = [per_kernel(d, c) for c in names]
+        import bench
+        with open(out, "w") as fh:
+            fh.write(f"# kernel_source_hash={bench.kernel_source_hash()} rocprofv3 --pmc {' '.join(names)} (one pass, --kernel-trace only), per-dispatch averages\n")
+            fh.write("kernel,dispatches," + ",".join(names) + ",mfma_busy_over_sq_busy\n")
+            for k in sorted(cols[1], key=lambda k: -cols[1][k][0]):
+                avg = [c[k][0] / max(c[k][1], 1) if k in c else 0.0 for c in cols]
+                fh.write(f"{k},{cols[1][k][1]}," + ",".join(f"{v:.0f}" for v in avg) + f",{avg[0] / max(avg[1], 1.0):.4f}\n")
     else:
         raise SystemExit(__doc__)
 
