@@ -10,6 +10,7 @@ pkg = importlib.import_module("racing-slam_amd")
 rs, synth = pkg.rsgpu, pkg.synth
 
 ctx = rs.Context(0)
+ctx.set_int("ba_fuse_mode", 1)      # K7's stamps belong to the two-launch form (the fused launch: tools/k78_stamps.py)
 w = synth.make_ba_window()
 dev = [ctx.dev(w[k]) for k in ("obs_ptr", "obs_cam", "obs_uv")]
 for ns in (1, 3):
