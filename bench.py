@@ -11,6 +11,8 @@
         match_key_frame (points observed by the last key frame), then match_map (whole map, with the keypoints
         and points matched by the first call taken out)
     (3) two-view DLT triangulation + gates of the accepted pairs                       cfg 2, triangulate_points
+    (3b) Mapper::triangulate_tracks (src/Mapper.cpp:246-305): 2000 tracks, each triangulated from (first sighting,
+        key frame) with gates (1.0, 4.0), reprojection check into <= 100 sightings, parallax rule, top-up to 100
     (4) Mapper::bundle_adjust (src/Mapper.cpp:364-394): build_local_window (host), the 10-iteration local BA
         on 20 KF x 10k landmarks x ~60k observations (cfg 3), read-back + unpack of the refined poses, rigid
         re-anchoring of the single-observation points
@@ -46,10 +48,13 @@ HBM_PEAK_GBS = 8000.0     # /opt/skills/guides/MI355X_MICROARCH.md
 VALU_INT_PEAK_TOPS = 39.3  # 256 CU x 64 lanes x 2.4 GHz 32-bit integer ops (K1's real ceiling)
 METRIC = "match+triangulate+local-BA passes/sec @ 2k kpts/frame, 20-KF x 10k-pt window"
 
+# profile-scope name -> kernel name as rocprofv3 prints it (prefix match: template arguments and "void " are ignored)
 PMC_NAMES = {"K5_ba_schur_mfma": "ba_schur_mfma", "K7_ba_reduced_solve": "ba_reduced_solve_lds", "K78_ba_solve_backsub": "ba_solve_backsub",
              "K8_ba_backsub_cost": "ba_backsub_cost4", "K1_hamming_knn2": "k1_hamming_knn2",
-             "K1b_merge_filter": "k1_merge_filter", "K2_reproj_match": "k2_reproj_match",
-             "K4_triangulate_dlt": "k4_triangulate", "K7_ba_reduced_solve_blocked": "ba_big_update"}
+             "K1b_merge_filter": "k1_merge_filter", "K2_reproj_match": "k2_reproj_match_grouped",
+             "K4_triangulate_dlt": "k4_triangulate", "K7_ba_reduced_solve_blocked": "ba_big_update",
+             "K6_tracks": "k6_tracks", "K12_point_errors": "k12_point_errors", "K11_refine_pose": "ba_refine_pose"}
+PMC_ROUNDS = ("round3", "round2")      # newest committed counter file first
 
 
 def kernel_source_hash():
@@ -68,8 +73,15 @@ def pmc_traffic(config):
     WRITE_SIZE collected in separate runs, unit / gfx950 corrections as MI355X_MICROARCH.md prescribes; see
     profiles/README.md).  Counters cannot be collected from inside bench.py: the file is the record of the last
     collection, with the kernel-source hash it was taken at."""
-    path = os.path.join(ROOT, "profiles", f"round2_pmc_{config}.csv")
+    path = None
+    for rnd in PMC_ROUNDS:
+        cand = os.path.join(ROOT, "profiles", f"{rnd}_pmc_{config}.csv")
+        if os.path.exists(cand):
+            path = cand
+            break
     out, src_hash = {}, None
+    if path is None:
+        return {}, None, None
     try:
         with open(path) as fh:
             for line in fh:
@@ -79,8 +91,12 @@ def pmc_traffic(config):
                     continue
                 f = line.strip().rsplit(",", 4)          # kernel names may contain commas (template arguments)
                 if len(f) == 5 and f[0] != "kernel":
+                    name = f[0].strip().strip('"')
+                    if name.startswith("void "):
+                        name = name[5:]
+                    name = name.split("<")[0].split("(")[0].strip()
                     try:
-                        out[f[0]] = float(f[4])
+                        out.setdefault(name, float(f[4]))      # (rows are sorted by total traffic: the first instance of a template wins)
                     except ValueError:
                         pass
     except OSError:
@@ -113,13 +129,12 @@ def setup(args):
     e.world = int(os.environ.get("WORLD_SIZE", "1"))
     e.rank = int(os.environ.get("RANK", "0"))
     e.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus != e.world and e.world == 1 and args.gpus > 1:
-        raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run (one process per GPU)")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the product path has no CPU fallback")
     torch.cuda.set_device(e.local_rank)
     if e.world > 1:
         dist.init_process_group("nccl", device_id=torch.device("cuda", e.local_rank))
+    e.ndev = torch.cuda.device_count()
     e.ctx = e.rs.Context(e.local_rank)
     return e
 
@@ -133,6 +148,72 @@ def attach_comm(e):
             uid.copy_(torch.frombuffer(bytearray(e.rs.Context.comm_unique_id()), dtype=torch.uint8))
         dist.broadcast(uid, 0)
         e.ctx.comm_init(bytes(uid.cpu().numpy().tobytes()), e.world, e.rank)
+
+
+def comm_evidence(e, per_kernel):
+    """What the exchange step ran over, as the communicator itself reports it (ncclCommCount), and the HIP-event time
+    of the two collectives of a BA round on the library stream."""
+    n, kind = e.ctx.comm_count()
+    out = {"rccl_ranks": n if kind == 1 else None, "comm_kind": {0: "none", 1: "rccl", 2: "in-process group"}[kind],
+           "comm_ranks": n}
+    for k in ("C1_allreduce_system", "C2_allreduce_cost"):
+        if k in per_kernel:
+            out[k + "_us"] = round(per_kernel[k]["avg_us"], 2)
+            out[k + "_per_step"] = per_kernel[k]["launches"]
+    return out
+
+
+def in_process_shards(e, w_all, n_shards, reps=5):
+    """The landmark-sharded BA (the product's N > 1 path: rank-offset blocks, two all-reduces per round, redundant reduced
+    solves) on ONE GPU: n contexts of this process, each with its own stream and host thread, joined by
+    rs_comm_init_local (a deterministic on-device sum instead of RCCL).  Bounds the exchange-step overhead of the
+    sharded form; it is NOT a scaling curve (the shards share one GPU)."""
+    import threading
+    torch, rs, synth = e.torch, e.rs, e.synth
+    ctxs = [rs.Context(e.local_rank) for _ in range(n_shards)]
+    streams = [torch.cuda.Stream(device=ctxs[0].device) for _ in range(n_shards)]
+    for c, st in zip(ctxs, streams):
+        c.use_stream(st)
+    rs.Context.comm_init_local(ctxs)
+    shards = [synth.shard_ba_by_landmark(w_all, n_shards, r) for r in range(n_shards)]
+    res = [None] * n_shards
+    bar = threading.Barrier(n_shards)
+
+    def work(r):
+        try:
+            c, sh = ctxs[r], shards[r]
+            with torch.cuda.stream(streams[r]):
+                c0, p0 = c.dev(sh["cams"]), c.dev(sh["points"])
+                dc, dp = c0.clone(), p0.clone()
+                dev = [c.dev(sh[k]) for k in ("obs_ptr", "obs_cam", "obs_uv")]
+                times = []
+                for _ in range(reps + 1):
+                    dc.copy_(c0)
+                    dp.copy_(p0)
+                    streams[r].synchronize()
+                    bar.wait()
+                    t0 = time.perf_counter()
+                    s = c.bundle_adjust(dc, sh["cam_free"], dp, *dev, sh["K"])
+                    times.append(time.perf_counter() - t0)
+                res[r] = (min(times[1:]), s)
+        except Exception as ex:      # noqa: BLE001
+            res[r] = ex
+            bar.abort()
+
+    th = [threading.Thread(target=work, args=(r,)) for r in range(n_shards)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join(timeout=300)
+    alive = any(t.is_alive() for t in th)
+    for c in ctxs:
+        if not alive:
+            c.comm_destroy()
+            c.close()
+    if alive or any(isinstance(r, Exception) or r is None for r in res):
+        return {"error": repr([r for r in res if isinstance(r, Exception)][:1]) if not alive else "a rank is stuck"}
+    return {"ms_per_solve": 1e3 * max(r[0] for r in res), "iterations": res[0][1]["iterations"],
+            "final_cost": res[0][1]["final_cost"]}
 
 
 def timed(e, fn, steps, warmup):
@@ -199,13 +280,38 @@ def C_omp_set_threads(n):
     return True
 
 
+def cpu_quota():
+    """CPU share of this process: the cgroup quota (cpu.max / cfs_quota) where one is set, else the affinity mask."""
+    n_aff = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    src = "affinity mask"
+    quota = None
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as fh:                 # cgroup v2: "<quota|max> <period>"
+            q, p = fh.read().split()[:2]
+            if q != "max":
+                quota = float(q) / float(p)
+                src = "/sys/fs/cgroup/cpu.max"
+    except (OSError, ValueError):
+        try:
+            with open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us") as fq, open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as fp:
+                q, p = float(fq.read()), float(fp.read())
+                if q > 0:
+                    quota = q / p
+                    src = "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"
+        except (OSError, ValueError):
+            pass
+    n = n_aff if quota is None else max(1, min(n_aff, int(quota + 0.5)))
+    return n, src, n_aff
+
+
 def cpu_baseline(cpu_fn, units_per_call, unit, what, budget_s):
     """The oracle's sources rebuilt as a BASELINE (-O3 -march=native on this host; never the checker binary):
     1 thread, and all cores with OpenMP (mirrors Ceres' num_threads = hardware_concurrency, src/Optimization.cpp:122-132)."""
     import pyoracle as O
     model, ncpu, _ = O.cpu_model()
-    ncore = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else ncpu
-    ncore = max(1, min(ncore, 16))      # a one-GPU box's CPU share is 16 cores, whatever the affinity mask says
+    ncore, quota_src, n_aff = cpu_quota()
+    if quota_src == "affinity mask":
+        ncore = max(1, min(ncore, 32))   # no quota to read: more OpenMP threads than a box's share only contend (the ladder below tries fewer)
     out = {}
     try:
         O.use_baseline("fast")
@@ -220,6 +326,7 @@ def cpu_baseline(cpu_fn, units_per_call, unit, what, budget_s):
         os.environ["OMP_WAIT_POLICY"] = "passive"
         lib_omp = O.use_baseline("fast_omp")
         best = None
+        share = ncore
         for nt in sorted({ncore, max(1, ncore // 2), max(1, ncore // 4)}, reverse=True):
             try:
                 lib_omp_set = C_omp_set_threads(nt)
@@ -232,9 +339,9 @@ def cpu_baseline(cpu_fn, units_per_call, unit, what, budget_s):
         del lib_omp, lib_omp_set
         out["all"] = dict(value=units_per_call / m["median_s"], unit=unit, cores=ncore, kind="port",
                           p10=units_per_call / m["p90_s"], p90=units_per_call / m["p10_s"], repetitions=m["reps"],
-                          cpu_model=model, nproc=ncpu,
+                          cpu_model=model, nproc=ncpu, cpu_share=share, cpu_share_source=quota_src, affinity_cpus=n_aff,
                           sample=what + "; the same build + OpenMP over queries / map points / correspondences / "
-                                        "observations / landmark blocks")
+                                        "observations / landmark blocks; threads = best of {share, share/2, share/4}")
     finally:
         O.use_baseline(None)
     return out
@@ -374,13 +481,36 @@ def build_pass(e):
     h_after.copy_(torch.from_numpy(poses_before))
     m_out = ctx.match_descriptors(d["q"], d["t"], nq, nt)
     t_out = ctx.triangulate_matches(d["kp1"], d["kp2"], m_out["mt"], m_out["mq"], m_out["cnt"], nq, d["poses"], pair["K"])
+    # (3b) Mapper::triangulate_tracks (src/Mapper.cpp:246-305): 2000 tracks of the new key frame
+    tk = synth.make_tracks(n_tracks=2000, config_id=6 + 100 * rank)
+    tk_dev = (ctx.dev(tk["track_uv"]), ctx.dev(tk["sight_ptr"]), ctx.dev(tk["sight_pose"]), ctx.dev(tk["sight_uv"]), ctx.dev(tk["poses"]))
+    tk_skip = ctx.dev(tk["skip"])
+    k_out = ctx.triangulate_tracks(*tk_dev, tk["kf_pose"], tk["K"], d_skip=tk_skip)
+    # stages timed BESIDE the pass (not in `value`): Mapper::cull_points' arithmetic over the window's points after the BA
+    # (src/Mapper.cpp:396-431) and Tracker's per-frame refine_pose (src/Tracker.cpp:313) on the new frame's matched points
+    cull_in = dict(positions=window["points"].astype(np.float32), obs_ptr=window["obs_ptr"], obs_pose=window["obs_cam"],
+                   obs_uv=window["obs_uv"], poses=poses_before, K=window["K"])
+    cull_dev = [ctx.dev(cull_in[k]) for k in ("positions", "obs_ptr", "obs_pose", "obs_uv", "poses")]
+    c_out = ctx.point_errors(*cull_dev, window["K"])
+    sel = np.flatnonzero(window["obs_cam"] == n_kf - 1)[:2000]
+    ref_pts = window["points_true"][full_obs_pt[sel]] if world == 1 else window["points"][full_obs_pt[sel]]
+    refine_in = dict(cam=window["cams"][n_kf - 1].copy(), points=np.ascontiguousarray(ref_pts, np.float64),
+                     uv=np.ascontiguousarray(window["obs_uv"][sel]), K=window["K"])
+    refine_dev = (ctx.dev(refine_in["points"]), ctx.dev(refine_in["uv"]))
     last = {}
+
+    def cull_stage():
+        ctx.point_errors(*cull_dev, window["K"], out=c_out)
+
+    def refine_stage():
+        last["refine"] = ctx.refine_pose(refine_in["cam"], *refine_dev, window["K"])
 
     def one_pass():
         ctx.match_descriptors(d["q"], d["t"], nq, nt, out=m_out)
         ctx.reproj_match(fv_a, mv_a, out=r_a)                   # match_key_frame
         ctx.reproj_match(fv_b, mv_b, out=r_b)                   # match_map
         ctx.triangulate_matches(d["kp1"], d["kp2"], m_out["mt"], m_out["mq"], m_out["cnt"], nq, d["poses"], pair["K"], out=t_out)
+        ctx.triangulate_tracks(*tk_dev, tk["kf_pose"], tk["K"], d_skip=tk_skip, out=k_out)      # Mapper::triangulate_tracks
         last["window"] = rs.build_local_window(*lw_args)        # host, overlaps the kernels enqueued above
         state.copy_(state0)
         last["ba"] = ctx.bundle_adjust(d["cams"], window["cam_free"], d["pts"], d["optr"], d["ocam"], d["ouv"], window["K"])
@@ -390,23 +520,116 @@ def build_pass(e):
         d["after"].copy_(h_after, non_blocking=True)
         ctx.reanchor_points(None, d["single_frame"], d["before"], d["after"], d["single"])
 
-    def cpu_pass(O):
+    def cpu_pass(O, keep_results=None):
         mq, mt = O.match_descriptors(pair["desc2"], pair["desc1"])
-        O.reproj_match(frame, mp_a)
-        O.reproj_match(frame_b, mp_b)
-        O.triangulate(pair["kp1"][mt], pair["kp2"][mq], pair["poses"], pair["K"])
-        O.build_local_window(*lw_args)
+        ra = O.reproj_match(frame, mp_a)
+        rb = O.reproj_match(frame_b, mp_b)
+        tri = O.triangulate(pair["kp1"][mt], pair["kp2"][mq], pair["poses"], pair["K"])
+        trk = O.triangulate_tracks(tk["track_uv"], tk["sight_ptr"], tk["sight_pose"], tk["sight_uv"], tk["poses"], tk["kf_pose"],
+                                   tk["K"], skip=tk["skip"])
+        lw = O.build_local_window(*lw_args)
         cams, pts, s = O.bundle_adjust(window["cams"], window["cam_free"], window["points"], window["obs_ptr"],
                                        window["obs_cam"], window["obs_uv"], window["K"])
         after = poses_before.copy()
         for c in free_idx:
             after[c] = O.unpack_pose(cams[c]).reshape(16)
-        O.reanchor_points(None, single_frame, poses_before, after, single_pos)
+        single = O.reanchor_points(None, single_frame, poses_before, after, single_pos)
+        if keep_results is not None:
+            keep_results.update(mq=mq, mt=mt, ra=ra, rb=rb, tri=tri, trk=trk, lw=lw, cams=cams, pts=pts, ba=s, after=after, single=single)
+
+    def cpu_cull(O):
+        return O.point_errors(cull_in["positions"], cull_in["obs_ptr"], cull_in["obs_pose"], cull_in["obs_uv"], cull_in["poses"], cull_in["K"])
+
+    def cpu_refine(O):
+        return O.refine_pose(refine_in["cam"], refine_in["points"], refine_in["uv"], refine_in["K"])
+
+    def gpu_results():
+        """What the last GPU pass left behind (host copies), in the same keys as cpu_pass's keep_results."""
+        torch.cuda.synchronize()
+        ctx.synchronize()
+        g = lambda t: t.detach().cpu().numpy()      # noqa: E731
+        cnt = int(g(m_out["cnt"])[0])
+        na, nb_ = int(g(r_a["count"])[0]), int(g(r_b["count"])[0])
+        nt_ = int(g(t_out["count"])[0])
+        kc = g(k_out["counts"])
+        return dict(mq=g(m_out["mq"])[0, :cnt], mt=g(m_out["mt"])[0, :cnt],
+                    ra=dict(match_kp=g(r_a["match_kp"])[:na], match_point=g(r_a["match_point"])[:na]),
+                    rb=dict(match_kp=g(r_b["match_kp"])[:nb_], match_point=g(r_b["match_point"])[:nb_]),
+                    tri=dict(keep=g(t_out["keep"])[:cnt], xyz=g(t_out["xyz"])[:cnt], out_index=g(t_out["out_index"])[:nt_]),
+                    trk=dict(status=g(k_out["status"])[:2000], xyz=g(k_out["xyz"])[:2000], accepted=g(k_out["accepted"])[:kc[0]],
+                             inconsistent=g(k_out["inconsistent"])[:kc[2]], parallax_cos=g(k_out["parallax_cos"])[:2000],
+                             required_cos=g(k_out["required_cos"])[:2000]),
+                    lw=last.get("window"), cams=g(d["cams"]), pts=g(d["pts"]), ba=last.get("ba"), after=h_after.numpy().copy(),
+                    single=g(d["single"]), cull=dict(mean_err=g(c_out["mean_err"]), cull=g(c_out["cull"])),
+                    refine=last.get("refine"))
 
     keep = (keep_fa, keep_ma, keep_fb, keep_mb)
     meta = dict(pair=pair, window=window, window_all=window_all, nq=nq, nt=nt, mp=mp, keep=keep, last=last,
-                n_single=n_single, match_key_frame_points=int(mp_a["eligible"].sum()), match_map_points=int(elig_b.sum()))
+                n_single=n_single, match_key_frame_points=int(mp_a["eligible"].sum()), match_map_points=int(elig_b.sum()),
+                frame_a=frame, mp_a=mp_a, frame_b=frame_b, mp_b=mp_b, tracks=tk, cull_in=cull_in, refine_in=refine_in,
+                cull_stage=cull_stage, refine_stage=refine_stage, cpu_cull=cpu_cull, cpu_refine=cpu_refine,
+                gpu_results=gpu_results, n_track_sightings=int(tk["sight_ptr"][-1]))
     return one_pass, cpu_pass, meta
+
+
+def check_pass_parity(meta, cpu_pass, O):
+    """The CPU leg computes the oracle's answer on the very inputs of the timed pass: compare it with what the GPU's LAST
+    pass left behind.  Integer / index outputs, keep flags, triangulated and re-anchored positions: bit for bit (the
+    contract of tests/test_gpu_parity.py); the BA: identical LM schedule, cost to 1e-7, poses / points to 1e-6.
+    Returns (ok, report)."""
+    ref = {}
+    cpu_pass(O, ref)
+    got = meta["gpu_results"]()
+    rep, bad = {}, []
+
+    def eq(name, a, b):
+        ok = bool(np.array_equal(np.asarray(a), np.asarray(b)))
+        rep[name] = ok
+        if not ok:
+            bad.append(name)
+
+    def bits(name, a, b):
+        a, b = np.ascontiguousarray(a, np.float32), np.ascontiguousarray(b, np.float32)
+        eq(name, a.view(np.uint32), b.view(np.uint32))
+
+    eq("match_descriptors.query", got["mq"], ref["mq"])
+    eq("match_descriptors.train", got["mt"], ref["mt"])
+    for k, tag in (("ra", "match_key_frame"), ("rb", "match_map")):
+        eq(tag + ".keypoints", got[k]["match_kp"], ref[k]["match_kp"])
+        eq(tag + ".points", got[k]["match_point"], ref[k]["match_point"])
+    eq("triangulate.keep", got["tri"]["keep"], ref["tri"]["keep"])
+    bits("triangulate.xyz", got["tri"]["xyz"], ref["tri"]["xyz"])
+    eq("triangulate.out_index", got["tri"]["out_index"], ref["tri"]["out_index"])
+    eq("tracks.status", got["trk"]["status"], ref["trk"]["status"])
+    bits("tracks.xyz", got["trk"]["xyz"], ref["trk"]["xyz"])
+    eq("tracks.inconsistent", got["trk"]["inconsistent"], ref["trk"]["inconsistent"])
+    # accepted list: identical unless a candidate sits within device-libm ulps of its parallax requirement (acosf / cosf)
+    cand = ref["trk"]["status"] == 1
+    on_edge = cand & (np.abs(ref["trk"]["parallax_cos"] - ref["trk"]["required_cos"]) <= 3e-7)
+    if not on_edge.any():
+        eq("tracks.accepted", got["trk"]["accepted"], ref["trk"]["accepted"])
+    else:
+        rep["tracks.accepted"] = "boundary tracks present: %d" % int(on_edge.sum())
+    eq("build_local_window.frames", got["lw"][0], ref["lw"][0])
+    eq("build_local_window.optimize", got["lw"][1], ref["lw"][1])
+    s, r = got["ba"], ref["ba"]
+    sched = tuple(s[k] for k in ("iterations", "successful_steps", "termination", "usable")) == \
+        tuple(r[k] for k in ("iterations", "successful_steps", "termination", "usable"))
+    rep["bundle_adjust.schedule"] = bool(sched)
+    rep["bundle_adjust.final_cost_rel_err"] = abs(s["final_cost"] - r["final_cost"]) / max(abs(r["final_cost"]), 1e-300)
+    rep["bundle_adjust.cameras_max_abs_err"] = float(np.abs(got["cams"] - ref["cams"]).max())
+    rep["bundle_adjust.points_max_abs_err"] = float(np.abs(got["pts"] - ref["pts"]).max())
+    if not sched or rep["bundle_adjust.final_cost_rel_err"] > 1e-7 or \
+            not np.allclose(got["cams"], ref["cams"], rtol=1e-6, atol=1e-8) or not np.allclose(got["pts"], ref["pts"], rtol=1e-6, atol=1e-7):
+        bad.append("bundle_adjust")
+    # the f32 poses come from f64 cameras that agree to ~1e-9: an f32 rounding boundary may flip a last bit
+    rep["unpack_poses.max_abs_err"] = float(np.abs(got["after"] - ref["after"]).max())
+    if rep["unpack_poses.max_abs_err"] > 1e-5:
+        bad.append("unpack_poses")
+    rep["reanchor.max_abs_err"] = float(np.abs(got["single"] - ref["single"]).max())
+    if rep["reanchor.max_abs_err"] > 1e-3:
+        bad.append("reanchor")
+    return not bad, dict(rep, mismatches=bad)
 
 
 def bench_pass(e, args):
@@ -418,6 +641,22 @@ def bench_pass(e, args):
     value = e.world * args.steps / elapsed
     per_kernel = profiled(e, one_pass, args.steps)
     stats = ctx.ba_stats()
+    # in-run parity: the oracle on the very inputs of the timed pass against what the GPU's last pass left behind
+    parity = None
+    if e.rank == 0 and e.world == 1 and not args.no_cpu_baseline:
+        import pyoracle as O
+        ok, parity = check_pass_parity(meta, cpu_pass, O)
+        if not ok:
+            raise SystemExit("bench.py: the GPU pass differs from the oracle on the benchmark's own inputs: %s" % json.dumps(parity))
+    # stages beside the pass (Mapper::cull_points' arithmetic, Tracker's refine_pose): wall time per call + kernel time
+    stages = {}
+    for tag, fn in (("cull_stage", meta["cull_stage"]), ("refine_stage", meta["refine_stage"])):
+        dt = timed(e, fn, args.steps, args.warmup)
+        pk = profiled(e, fn, args.steps)
+        stages[tag] = dict(us_per_call=1e6 * dt / max(args.steps, 1), per_kernel_us={k: round(v["avg_us"], 2) for k, v in sorted(pk.items())})
+        per_kernel_side = pk
+        stages[tag]["_pk"] = per_kernel_side
+    empty_launch_us = ctx.empty_launch_us()
     window, nq, nt, mp = meta["window"], meta["nq"], meta["nt"], meta["mp"]
     work = algorithmic_work(window, int(np.sum(window["cam_free"])))
     pmc, pmc_file, pmc_fresh = pmc_traffic("pass")
@@ -439,10 +678,25 @@ def bench_pass(e, args):
             ("K1_hamming_knn2", "valu-int", 16.0 * nq * nt, "8 xor + 8 popcount-accumulate per descriptor pair; HBM side: "
                                                             "%.0f KB per launch" % ((32.0 * (nq + nt) + 12.0 * nq) / 1e3)),
             ("K4_triangulate_dlt", "mfma", 2500.0 * nq, "fp64 VALU (no matrix work), priced against the fp64 peak"),
+            ("K6_tracks", "mfma", 2500.0 * 2000 + 60.0 * meta["n_track_sightings"],
+             "Mapper::triangulate_tracks body: one DLT per track (2.5 kflop fp64 VALU) + an f32 reprojection per sighting; "
+             "a dependent fp64 chain per lane, priced against the fp64 peak"),
             ("K2_reproj_match", "hbm", 13.0 * len(mp["positions"]) + 40.0 * len(mp["obs_kf"]) + 48.0 * nq, None)):
         r = roofline_entry(name, bound, amount, per_kernel, pmc, note)
         if r:
             rl[name] = r
+    # roofline entries of the side stages: K12 streams the observation CSR (16 B per observation + 12 B per point in, 5 B out);
+    # K11 is one workgroup running the whole LM loop (latency)
+    M_w, P_w = float(len(window["obs_cam"])), float(len(window["points"]))
+    r = roofline_entry("K12_point_errors", "hbm", 16.0 * M_w + 17.0 * P_w, stages["cull_stage"]["_pk"], pmc)
+    if r:
+        rl["K12_point_errors"] = r
+    r = roofline_entry("K11_refine_pose", "latency", 2.0 * 400.0 * len(meta["refine_in"]["uv"]) * 4, stages["refine_stage"]["_pk"], pmc,
+                       "one workgroup, the whole LM loop in one launch: flops = (linearise + cost pass) x iterations, ~400 per observation and pass")
+    if r:
+        rl["K11_refine_pose"] = r
+    for st in stages.values():
+        st.pop("_pk", None)
     for k7 in ("K7_ba_reduced_solve", "K78_ba_solve_backsub"):
         if k7 in rl:
             rl[k7]["us_per_block_step"] = rl[k7]["avg_launch_us"] / max(work["n"] / 6.0, 1.0)
@@ -457,13 +711,22 @@ def bench_pass(e, args):
     cpu = None
     if e.rank == 0 and e.world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline(cpu_pass, 1.0, "passes/s", "full passes of the same workload (all stages incl. both "
-                           "reprojection matches, build_local_window, unpack, re-anchoring)", args.cpu_seconds)
+                           "reprojection matches, the 2000-track triangulation, build_local_window, unpack, re-anchoring)", args.cpu_seconds)
+        import pyoracle as O
+        O.use_baseline("fast")
+        try:
+            for tag, fn in (("cull_stage", meta["cpu_cull"]), ("refine_stage", meta["cpu_refine"])):
+                m = cpu_measure(lambda: fn(O), 2.0, min_reps=10)
+                stages[tag]["cpu_us_per_call_1_thread"] = 1e6 * m["median_s"]
+        finally:
+            O.use_baseline(None)
     line = {
         "metric": METRIC, "value": value, "unit": "passes/s", "n_gpus": e.world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "u8 Hamming (match), f64 (DLT SVD, BA), f32 (gates)", "data": "synthetic",
         "config": {"workload": "cfg2 pair (2000x2000 brute-force match + 2000-slot DLT triangulation) + two "
                                "reprojection-gated matches (match_key_frame, match_map; 2000 kp x 10k landmarks) + "
+                               "Mapper::triangulate_tracks (2000 tracks, per-track DLT + sighting checks + quota) + "
                                "Mapper::bundle_adjust on cfg3 (build_local_window, 20 KF x 10k landmarks x ~60k obs, "
                                "10 LM iterations, pose read-back, re-anchoring of 2000 single-observation points) per GPU",
                    "passes_per_step": e.world,
@@ -478,8 +741,15 @@ def bench_pass(e, args):
         "per_kernel_launches_per_pass": {k: v["launches"] / max(args.steps, 1) for k, v in sorted(per_kernel.items())},
         "ba_summary": meta["last"].get("ba"), "ba_rounds": stats,
         "roofline_all": rl,
+        "stages_beside_the_pass": dict(stages, note="not in `value`: Mapper::cull_points' arithmetic (rs_point_errors over the window's "
+                                       "10k points / ~60k observations) and Tracker's per-frame refine_pose (2000 observations); "
+                                       "wall time per call incl. the host hand-off, kernel time, CPU restatement 1 thread"),
+        "parity_checked_in_run": bool(parity is not None), "parity": parity,
+        "empty_launch_us": round(empty_launch_us, 3),
         "boundary": boundary,
     }
+    if e.world > 1:
+        line.update(comm_evidence(e, per_kernel))
     finish(e, args, line)
 
 
@@ -624,7 +894,8 @@ def bench_ba(e, args, cfg):
     # throughput mode (reported beside `value`, never instead of it): B independent windows per call on the library's
     # lanes (rs_bundle_adjust_batch) — what a server holding several sessions on one GPU gets
     batch = None
-    if e.world == 1 and cfg == "cfg3":
+    want = getattr(args, "in_process_shards", 0)
+    if e.world == 1 and cfg == "cfg3" and not want:
         batch = {}
         for mode, tag in ((0, "grid"), (1, "lanes")):
             ctx.set_int("ba_batch_mode", mode)
@@ -659,12 +930,29 @@ def bench_ba(e, args, cfg):
         batch["note"] = ("B copies of the same cfg-3 window solved by one rs_bundle_adjust_batch call, incl. the 2B state-reset "
                          "copies.  grid: ONE launch sequence for all windows (blockIdx.z = window; the library's default); "
                          "lanes: 8 child contexts with their own streams, one host thread each")
+    # the sharded form of the solve on this ONE GPU (in-process group): bounds what the exchange step costs
+    shards = None
+    if e.world == 1 and (want or not args.no_shard_rehearsal):
+        shards = {"unsharded_ms_per_solve": 1e3 * elapsed / max(args.steps, 1)}
+        for n_sh in ((want,) if want else (2, 4, 8)):
+            shards["shards_%d" % n_sh] = in_process_shards(e, w_all, n_sh, reps=3 if cfg == "cfg5" else 5)
+        shards["note"] = ("NOT a scaling curve: n landmark shards of the same window solved side by side on ONE GPU by n contexts of "
+                          "this process (rs_comm_init_local; own stream and host thread each; two on-device sum all-reduces per LM "
+                          "round instead of RCCL).  It executes the product's N > 1 code path and bounds the overhead of the exchange "
+                          "steps; the shards share the GPU's CUs, so no speed-up is expected")
     cpu = None
     if e.rank == 0 and e.world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline(cpu_step, 1.0, "solves/s", "the same window, whole 10-iteration solve", args.cpu_seconds)
     name = "20-KF local BA solves/sec, 10k landmarks / ~60k obs (BASELINE configs[2])" if cfg == "cfg3" else \
            "100-KF global BA solves/sec, 80k landmarks / ~480k obs (BASELINE configs[4])"
+    extra = comm_evidence(e, per_kernel) if e.world > 1 else {}
+    if want and shards and "ms_per_solve" in shards.get("shards_%d" % want, {}):
+        extra["requested_gpus"] = want
+        extra["note"] = ("--gpus %d on a box with %d GPU(s): the %d landmark shards ran in ONE process on ONE GPU (in_process_shards); "
+                         "`value` is the unsharded single-GPU figure, n_gpus = 1; no multi-GPU scaling was measured" % (want, e.ndev, want))
     finish(e, args, {
+        **extra,
+        "empty_launch_us": round(ctx.empty_launch_us(), 3),
         "metric": name, "value": args.steps / elapsed, "unit": "solves/s", "n_gpus": e.world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / max(args.steps, 1), "higher_is_better": True,
         "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
@@ -674,7 +962,8 @@ def bench_ba(e, args, cfg):
         "roofline": roofline, "cpu_baseline": cpu["one"] if cpu else None, "cpu_baseline_all_cores": cpu["all"] if cpu else None,
         "per_kernel_us": {k: round(v["avg_us"], 2) for k, v in sorted(per_kernel.items())},
         "per_kernel_launches_per_solve": {k: v["launches"] / max(args.steps, 1) for k, v in sorted(per_kernel.items())},
-        "ba_summary": last.get("ba"), "ba_rounds": stats, "roofline_all": rl, "batch_throughput": batch})
+        "ba_summary": last.get("ba"), "ba_rounds": stats, "roofline_all": rl, "batch_throughput": batch,
+        "in_process_shards": shards})
 
 
 def main():
@@ -687,7 +976,31 @@ def main():
     ap.add_argument("--no-boundary", dest="boundary", action="store_false",
                     help="skip the end-to-end interface timings (tests/host_cpp/bench_boundary.bin) of --config pass")
     ap.add_argument("--cpu-seconds", type=float, default=25.0, help="time budget of the CPU baseline leg")
+    ap.add_argument("--no-shard-rehearsal", action="store_true",
+                    help="cfg3 / cfg5 at N = 1: skip the in-process 2 / 4 / 8-shard solves reported beside `value`")
     args = ap.parse_args()
+    # --gpus N > 1 without a launcher: start one rank per GPU ourselves (python -m torch.distributed.run, rendezvous on
+    # 127.0.0.1) BEFORE this process touches a GPU, relay the ranks' output and exit with their status.  On a box with
+    # fewer GPUs than ranks the landmark shards run in ONE process on one GPU instead (rs_comm_init_local).
+    if args.gpus > 1 and int(os.environ.get("WORLD_SIZE", "1")) == 1:
+        import torch
+        ndev = torch.cuda.device_count()        # does not initialise the GPU
+        if ndev >= args.gpus:
+            import socket
+            import subprocess
+            with socket.socket() as sk:
+                sk.bind(("127.0.0.1", 0))
+                port = sk.getsockname()[1]
+            cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=%d" % args.gpus,
+                   "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+            env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+            sys.exit(subprocess.run(cmd, env=env).returncode)
+        args.in_process_shards = args.gpus
+        if args.config in ("cfg2", "cfg4"):
+            raise SystemExit("--gpus %d on a box with %d GPU(s): %s shards with no exchange step, there is nothing to rehearse "
+                             "in one process; run it with --gpus 1" % (args.gpus, ndev, args.config))
+        if args.config == "pass":
+            args.config = "cfg3"                 # the pass's only exchange step is the sharded local BA
     # The end-to-end interface timings run in a child process (tests/host_cpp/bench_boundary.bin).  It is started
     # BEFORE this process initialises the GPU: a process that holds a GPU context must not fork + exec on the box.
     if args.config == "pass" and args.boundary and int(os.environ.get("WORLD_SIZE", "1")) == 1:

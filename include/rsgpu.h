@@ -40,7 +40,7 @@
 extern "C" {
 #endif
 
-#define RSGPU_ABI_VERSION 2
+#define RSGPU_ABI_VERSION 3
 #define RS_DESC_BYTES 32
 
 typedef enum rs_status {
@@ -77,6 +77,9 @@ int rs_context_synchronize(rs_context* ctx);
  * words inside the launch, holding a CU each): 0 (default) when no other solve of this process is in flight (lower
  * latency for one session; several sessions on one GPU get more aggregate throughput from two launches), 1 never,
  * 2 wherever possible; same results.
+ * "ba_handoff_timeout_us": how long (1 .. 1000000, default 4000) a workgroup of that fused launch waits for a hand-off
+ * word before it gives up; a solve in which that happened is re-run once as separate launches from its untouched
+ * inputs (rs_ba_get_stats [4] counts them) — the caller sees the same result either way.
  * "k2_mode": rs_reproj_match — 0 (default) eight lanes per map point where the frame's KD-tree fits in LDS
  * (<= 6144 keypoints), 1 always one lane per point; the outputs are identical.
  * "ba_batch_mode": how rs_bundle_adjust_batch runs its windows — 0 (default) one launch sequence for all of them
@@ -247,8 +250,9 @@ int rs_map_get_positions(const rs_map* map, int first, int count, float* h_xyz /
  * map; results identical to rs_reproj_match on the flattened map.
  *   h_kp_matched [n] or NULL: Frame::is_matched(keypoint) (:81);  h_matched_points: slots of the points the frame already
  *   matches (:53);  required_observer_kf >= 0: match_key_frame (:169);  n_only >= 0: match_for_fuse — only the listed
- *   slots take part (they compete for a keypoint in MAP order; the reference's list order comes from an unordered_set,
- *   src/Mapper.cpp:208, i.e. is unspecified);  replace as rs_reproj_match.
+ *   slots take part, and they compete for a keypoint in LIST order, as the reference's loop over its vector does
+ *   (:120-126) and as the flattened path does when the shim flattens that vector in order: ONE rule on both paths
+ *   (dead slots in the list are skipped like the reference's null pointers);  replace as rs_reproj_match.
  * Outputs (host, capacity n each): the accepted matches in ascending keypoint order as (keypoint, point slot). */
 int rs_map_match(rs_context* ctx, rs_map* map, rs_frame* frame, const float h_pose[16], const float h_intrinsics[4],
                  int width, int height, const uint8_t* h_kp_matched, const int32_t* h_matched_points, int n_matched_points,
@@ -490,8 +494,11 @@ int rs_ba_get_trace(rs_context* ctx, rs_ba_iteration* h_out, int capacity, int* 
 int rs_ba_get_cameras(rs_context* ctx, double* h_cameras /*[n_cameras][6]*/, int n_cameras);
 /* Launch accounting of the last rs_bundle_adjust: h_out[0] = rounds that did work (one K5 + K7 + K8 each),
  * [1] = rounds that relinearised (the others only re-damped after a rejected step), [2] = speculative sets
- * evaluated in total (= LM steps solved for, >= iterations), [3] = rounds enqueued by the host. */
-int rs_ba_get_stats(rs_context* ctx, int h_out[4]);
+ * evaluated in total (= LM steps solved for, >= iterations), [3] = rounds enqueued by the host, [4] = solves of this
+ * context (since it was created) that were run a second time as separate launches because a workgroup of the fused
+ * solve + back-substitution launch timed out waiting for its hand-off word ("ba_handoff_timeout_us", default 4000:
+ * a scheduling event — queue preemption, another process on the GPU — not a solver failure), [5..7] reserved (0). */
+int rs_ba_get_stats(rs_context* ctx, int h_out[8]);
 
 /* optimization::refine_pose (src/Optimization.cpp:194-267), vision-only:
  * the same residual with the points held constant, 6 unknowns.
@@ -641,6 +648,9 @@ int rs_comm_destroy(rs_context* ctx);
  * rs_bundle_adjust calls, each from its own thread.  Used to run landmark shards side by side on one GPU and to
  * test the N > 1 path on a one-GPU box.  rs_comm_destroy on every member releases the group. */
 int rs_comm_init_local(rs_context** ctxs, int n);
+/* Evidence of what the exchange step runs over: *h_ranks = number of ranks of the attached communicator as RCCL
+ * itself reports it (ncclCommCount) or the size of the in-process group; *h_kind = 0 none, 1 RCCL, 2 in-process. */
+int rs_comm_count(rs_context* ctx, int* h_ranks, int* h_kind);
 
 /* ------------------------------------------------------------- profiling */
 
@@ -660,6 +670,10 @@ int rs_prof_end(rs_context* ctx, rs_prof_entry* h_entries /*[RS_PROF_MAX]*/, int
  * call (thread 0 of workgroup 0 stamps s_memtime at phase boundaries; slots 0-6
  * K7, 8-14 K5).  n <= 64. */
 int rs_prof_counters(rs_context* ctx, uint64_t* h_out, int n);
+/* Launch latency of this device as the library's own launches see it ("state the measured empty-launch
+ * latency next to the numbers"): n back-to-back launches of an empty one-workgroup kernel on the context stream
+ * between two HIP events; *h_us = microseconds per launch. */
+int rs_prof_empty_launch(rs_context* ctx, int n, double* h_us);
 
 #ifdef __cplusplus
 }

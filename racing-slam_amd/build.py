@@ -54,7 +54,9 @@ def build(force=False, verbose=False):
     cc = hipcc()
     objdir = os.path.join(HERE, "build")
     os.makedirs(objdir, exist_ok=True)
-    headers = [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "tri_core.h"), os.path.join(CSRC, "ba_common.h"), os.path.join(CSRC, "imu_dual.h"), os.path.join(HERE, "..", "include", "rsgpu.h"), __file__]
+    # every header of csrc/ is a dependency of every object: a stale .so must never ship
+    headers = sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h"))
+    headers += [os.path.join(HERE, "..", "include", "rsgpu.h"), __file__]
     objs = []
     rebuilt = False
     for src, extra in SOURCES:

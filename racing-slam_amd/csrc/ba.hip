@@ -66,7 +66,7 @@ static __device__ __forceinline__ void ba_init_body(const BaDims& d, const BaBuf
         s.iter = 0; s.successful = 0; s.invalid_steps = 0; s.done = 0;
         s.termination = 0; s.cur = 0; s.have_scale = 0; s.solver_failed = 0;
         s.fresh = 1; s.usable = 0; s.consec_accepts = 0; s.nact = 1;
-        s.n_rounds = 0; s.n_fresh = 0; s.n_sets = 0; s.pad = 0;
+        s.n_rounds = 0; s.n_fresh = 0; s.n_sets = 0; s.hand_lost = 0;
         b.st[1] = s;      // the state iteration 0 starts from (st[(0 + 1) & 1])
     }
 }
@@ -449,7 +449,10 @@ static __device__ __forceinline__ void ba_finalize_body(const BaDims& d, const B
     if (threadIdx.x == 0) {
         BaState st = st_fin;
         // after a successful step the cost at the new point is K5's value if it ran, else the candidate cost
-        if (b.dbg[BA_HAND_ERR] != 0ull) st.termination = RS_BA_FAILURE;     // a K8 workgroup of the fused launch never saw its K7 publish
+        // a K8 workgroup of the fused launch never saw its K7 publish: the result is unusable — not because the solver failed
+        // but because of scheduling (queue preemption, another process on the GPU, counter collection): the host re-runs the
+        // solve as separate launches from the untouched inputs (ba_solve_impl)
+        if (b.dbg[BA_HAND_ERR] != 0ull) { st.termination = RS_BA_FAILURE; st.hand_lost = 1; }
         const bool ok = st.termination != RS_BA_FAILURE && isfinite(st.x_cost) && st.x_cost <= st.initial_cost;
         usable = ok ? 1 : 0;
         cur = st.cur;
@@ -627,6 +630,7 @@ static void ba_bind(BaBufs& b, char* ws, const BaLayout& L, const BaDims& d, int
     b.trace = (BaTrace*)(ws + L.trace);
     b.set_out = (BaSetOut*)(ws + L.set); b.set_prev = b.set_out;
     b.dbg = (unsigned long long*)(ws + L.dbg);
+    b.hand_timeout = BA_HAND_TIMEOUT_TICKS;
 }
 
 // Solves of this process that are between entry and return right now (any context, any thread).  A solve that has the
@@ -640,23 +644,27 @@ struct BaInFlight {
     ~BaInFlight() { g_ba_in_flight.fetch_sub(1); }
 };
 
-static int ba_solve_impl(rs_context* ctx, int n_cameras, int n_points, int n_obs, double* d_cameras,
+static int ba_solve_once(rs_context* ctx, int n_cameras, int n_points, int n_obs, double* d_cameras,
                          const uint8_t* h_cam_free, double* d_points, const int32_t* d_obs_ptr,
                          const int32_t* d_obs_cam, const float* d_obs_uv, const float h_intrinsics[4],
-                         const rs_ba_options* options, rs_ba_summary* h_summary, const BaInertialArgs* in)
+                         const rs_ba_options* options, rs_ba_summary* h_summary, const BaInertialArgs* in,
+                         bool allow_fuse, bool* hand_lost)
 {
+    *hand_lost = false;
     if (!ctx || !h_summary) return RS_ERR_INVALID;
     const BaInFlight in_flight;
     memset(h_summary, 0, sizeof *h_summary);
     if (n_cameras < 0 || n_points < 0 || n_obs < 0) return rs_fail(ctx, RS_ERR_INVALID, "negative size");
-    if (in && rs_comm_active(ctx)) return rs_fail(ctx, RS_ERR_UNSUPPORTED, "inertial factors in a landmark-sharded solve");
-    if (n_cameras == 0 || n_points == 0 || n_obs == 0) {   // nothing to optimise
-        if (ctx->n_ranks > 1) return rs_fail(ctx, RS_ERR_UNSUPPORTED, "empty shard in a multi-rank solve");
+    // A landmark shard may be EMPTY (more ranks than landmarks, or a rank whose range holds none): the rank still takes
+    // part in every exchange step with zero contributions and solves the reduced system like the others.  Cameras are
+    // replicated, so n_cameras == 0 is the same on every rank and ends the call everywhere.
+    const bool sharded = rs_comm_active(ctx) && ctx->n_ranks > 1;
+    if (n_cameras == 0 || ((n_points == 0 || n_obs == 0) && !sharded)) {   // nothing to optimise
         h_summary->usable = 0;
         h_summary->termination = RS_BA_FAILURE;
         return RS_OK;
     }
-    if (!d_cameras || !h_cam_free || !d_points || !d_obs_ptr || !d_obs_cam || !d_obs_uv || !h_intrinsics)
+    if (!d_cameras || !h_cam_free || !d_obs_ptr || !h_intrinsics || (n_points > 0 && !d_points) || (n_obs > 0 && (!d_obs_cam || !d_obs_uv)))
         return rs_fail(ctx, RS_ERR_INVALID, "null pointer");
     rs_ba_options def;
     if (!options) { rs_ba_default_options(&def); options = &def; }
@@ -678,7 +686,9 @@ static int ba_solve_impl(rs_context* ctx, int n_cameras, int n_points, int n_obs
     opt.dmax = options->max_lm_diagonal; opt.ftol = options->function_tolerance;
     opt.gtol = options->gradient_tolerance; opt.ptol = options->parameter_tolerance;
     if (opt.max_iter < 0 || opt.max_iter > 1000) return rs_fail(ctx, RS_ERR_INVALID, "max_num_iterations out of range");
-    if (d.Cf * 42 * sizeof(double) > 60 * 1024) return rs_fail(ctx, RS_ERR_UNSUPPORTED, "more than 182 free cameras");
+    // beyond 128 free cameras K5 is the generic kernel with its U / gc partial sums in LDS: 42 doubles per free camera of
+    // the 160 KB a workgroup may hold
+    if ((size_t)d.Cf * 42 * sizeof(double) > 159 * 1024) return rs_fail(ctx, RS_ERR_UNSUPPORTED, "more than 484 free cameras");
 
     // which kernels: the MFMA Schur path + LDS reduced solve + LDS back-substitution form the fast path of a local
     // window; only that path evaluates speculative radii (ns > 1)
@@ -775,7 +785,7 @@ static int ba_solve_impl(rs_context* ctx, int n_cameras, int n_points, int n_obs
     if (use_mfma) ba_group_carve(ws + o_grp, d.P, d.Cf, d.M, &grp);
     b.obs_cs = use_mfma ? grp.obs_cs : nullptr;
 
-    const int pblocks = (d.P + BA_THREADS - 1) / BA_THREADS;
+    const int pblocks = d.P > 0 ? (d.P + BA_THREADS - 1) / BA_THREADS : 1;      // (an empty shard still runs the round's decision)
     int32_t* zero_ptr = nullptr;
     int zero_n = 0;
     if (use_mfma) ba_group_zero_range(grp, &zero_ptr, &zero_n);
@@ -823,7 +833,8 @@ static int ba_solve_impl(rs_context* ctx, int n_cameras, int n_points, int n_obs
     // K7 + K8 as one launch (ba_solve.hip): the plain local window only — vision-only, one rank, both LDS kernels
     // and only while all of its workgroups are resident at once (one per CU: the launch carries K7's LDS): beyond that
     // K8's workgroups would run in several shifts behind the hand-off, and the launch of its own (many per CU) is faster
-    const bool fuse78 = (ctx->ba_fuse_mode == 2 || (ctx->ba_fuse_mode == 0 && in_flight.others == 0)) &&
+    b.hand_timeout = 100ull * (unsigned long long)ctx->ba_handoff_timeout_us;
+    const bool fuse78 = allow_fuse && (ctx->ba_fuse_mode == 2 || (ctx->ba_fuse_mode == 0 && in_flight.others == 0)) &&
                         solve_lds && k8_lds && !in && !rs_comm_active(ctx) &&
                         ba_solve_backsub_workgroups(d, b) <= ctx->n_cu;
     auto enqueue_round = [&](int it) -> int {
@@ -934,6 +945,7 @@ static int ba_solve_impl(rs_context* ctx, int n_cameras, int n_points, int n_obs
     ctx->ba_trace_n = h_st->iter;
     ctx->ba_stats[0] = h_st->n_rounds; ctx->ba_stats[1] = h_st->n_fresh; ctx->ba_stats[2] = h_st->n_sets;
     ctx->ba_stats[3] = rounds;
+    *hand_lost = h_st->hand_lost != 0;
     ctx->ba_cams = (const double*)((char*)pin + pin_cams);
     ctx->ba_cams_n = n_cameras;
     if (in && h_st->usable)                                  // unpack_inertial for the optimised frames, src/Optimization.cpp:363-368
@@ -943,6 +955,25 @@ static int ba_solve_impl(rs_context* ctx, int n_cameras, int n_points, int n_obs
             for (int k = 0; k < 6; k++) in->h_bias[6 * c + k] = h_vb[9 * c + 3 + k];
         }
     return RS_OK;
+}
+
+// A lost hand-off inside the fused K7 + K8 launch (ba_backsub_body.h) says something about scheduling, not about the
+// data: the inputs are untouched (nothing is written back from an unusable solve), so the solve runs once more as
+// separate launches, which need no hand-off.  Counted in rs_ba_get_stats [4].
+static int ba_solve_impl(rs_context* ctx, int n_cameras, int n_points, int n_obs, double* d_cameras,
+                         const uint8_t* h_cam_free, double* d_points, const int32_t* d_obs_ptr,
+                         const int32_t* d_obs_cam, const float* d_obs_uv, const float h_intrinsics[4],
+                         const rs_ba_options* options, rs_ba_summary* h_summary, const BaInertialArgs* in)
+{
+    bool lost = false;
+    int rc = ba_solve_once(ctx, n_cameras, n_points, n_obs, d_cameras, h_cam_free, d_points, d_obs_ptr, d_obs_cam, d_obs_uv,
+                           h_intrinsics, options, h_summary, in, true, &lost);
+    if (rc == RS_OK && lost) {
+        ctx->ba_stats[4]++;
+        rc = ba_solve_once(ctx, n_cameras, n_points, n_obs, d_cameras, h_cam_free, d_points, d_obs_ptr, d_obs_cam, d_obs_uv,
+                           h_intrinsics, options, h_summary, in, false, &lost);
+    }
+    return rc;
 }
 
 extern "C" int rs_bundle_adjust(rs_context* ctx, int n_cameras, int n_points, int n_obs, double* d_cameras,
@@ -1189,10 +1220,10 @@ extern "C" int rs_ba_get_cameras(rs_context* ctx, double* h_cameras, int n_camer
     return RS_OK;
 }
 
-extern "C" int rs_ba_get_stats(rs_context* ctx, int h_out[4])
+extern "C" int rs_ba_get_stats(rs_context* ctx, int h_out[8])
 {
     if (!ctx || !h_out) return RS_ERR_INVALID;
-    for (int i = 0; i < 4; i++) h_out[i] = ctx->ba_stats[i];
+    for (int i = 0; i < 8; i++) h_out[i] = ctx->ba_stats[i];
     return RS_OK;
 }
 
@@ -1236,7 +1267,7 @@ __global__ __launch_bounds__(RP_THREADS) void ba_refine_pose(BaDims d, BaOpt opt
         st.radius = opt.r0; st.decrease_factor = 2.0; st.x_cost = 0.0; st.initial_cost = 0.0;
         st.iter = 0; st.successful = 0; st.invalid_steps = 0; st.done = 0; st.termination = 0; st.cur = 0;
         st.have_scale = 0; st.solver_failed = 0; st.fresh = 1; st.usable = 0; st.consec_accepts = 0; st.nact = 1;
-        st.n_rounds = 0; st.n_fresh = 0; st.n_sets = 0; st.pad = 0;
+        st.n_rounds = 0; st.n_fresh = 0; st.n_sets = 0; st.hand_lost = 0;
     }
     __syncthreads();
     double acc[28];
@@ -1472,7 +1503,7 @@ __global__ __launch_bounds__(RP_THREADS) void ba_refine_pose_inertial(BaDims d, 
         st.radius = opt.r0; st.decrease_factor = 2.0; st.x_cost = 0.0; st.initial_cost = 0.0;
         st.iter = 0; st.successful = 0; st.invalid_steps = 0; st.done = 0; st.termination = 0; st.cur = 0;
         st.have_scale = 0; st.solver_failed = 0; st.fresh = 1; st.usable = 0; st.consec_accepts = 0; st.nact = 1;
-        st.n_rounds = 0; st.n_fresh = 0; st.n_sets = 0; st.pad = 0;
+        st.n_rounds = 0; st.n_fresh = 0; st.n_sets = 0; st.hand_lost = 0;
     }
     __syncthreads();
     double acc[28];

@@ -16,19 +16,20 @@
 #define BA_HAND 48
 #define BA_HAND_TAKEN 52
 #define BA_HAND_ERR 56
-#define BA_HAND_TIMEOUT_TICKS 400000ull      // 4 ms of the 100 MHz wall clock: a lost producer must not hang the GPU
+#define BA_HAND_TIMEOUT_TICKS 400000ull      // default: 4 ms of the 100 MHz wall clock (BaBufs::hand_timeout; rs_context_set_int
+                                             // "ba_handoff_timeout_us"): a lost producer must not hang the GPU
 
 __device__ __forceinline__ double ba_load_sc1(const double* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void ba_store_sc1(double* p, double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
 // one lane: waits until set k's producer of round `want` has published the word; returns its code, or 4 after the time-out
-__device__ __forceinline__ unsigned ba_hand_wait(const unsigned long long* hand, int k, unsigned want)
+__device__ __forceinline__ unsigned ba_hand_wait(const unsigned long long* hand, int k, unsigned want, unsigned long long timeout_ticks)
 {
     const unsigned long long t0 = wall_clock64();
     for (;;) {
         const unsigned long long v = __hip_atomic_load(hand + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if ((unsigned)(v >> 2) == want) return (unsigned)(v & 3ull);
-        if (wall_clock64() - t0 > BA_HAND_TIMEOUT_TICKS) return 4u;
+        if (wall_clock64() - t0 > timeout_ticks) return 4u;
         __builtin_amdgcn_s_sleep(2);
     }
 }
@@ -93,7 +94,7 @@ static __device__ __forceinline__ void ba_backsub_cost4_body(const BaDims& d, co
         if (set_failed || set >= st.nact) return;
     } else {
         // every active set's K7 has taken the accumulators: clear them now, under the factorisation
-        if ((int)threadIdx.x < st.nact) hand_code[threadIdx.x] = ba_hand_wait(b.dbg + BA_HAND_TAKEN, (int)threadIdx.x, (unsigned)st.n_rounds);
+        if ((int)threadIdx.x < st.nact) hand_code[threadIdx.x] = ba_hand_wait(b.dbg + BA_HAND_TAKEN, (int)threadIdx.x, (unsigned)st.n_rounds, b.hand_timeout);
         __syncthreads();
         bool lost = false, conv = false;
         for (int k = 0; k < st.nact; k++) { lost = lost || hand_code[k] == 4u; conv = conv || (hand_code[k] & 2u); }
@@ -138,7 +139,7 @@ static __device__ __forceinline__ void ba_backsub_cost4_body(const BaDims& d, co
         for (int i = threadIdx.x; i < d.C * 6; i += blockDim.x) xcl[i] = b.Xc[(size_t)st.cur * d.C * 6 + i];
         for (int i = threadIdx.x; i < d.C; i += blockDim.x) sll[i] = b.slot[i];
         K78_STAMP(b, 1);
-        if (threadIdx.x == 0) hand_code[set] = ba_hand_wait(b.dbg + BA_HAND, set, (unsigned)st.n_rounds);
+        if (threadIdx.x == 0) hand_code[set] = ba_hand_wait(b.dbg + BA_HAND, set, (unsigned)st.n_rounds, b.hand_timeout);
         K78_STAMP(b, 2);
         __syncthreads();
         const unsigned code = hand_code[set];

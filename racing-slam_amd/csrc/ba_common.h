@@ -29,7 +29,8 @@ struct BaState {
     int fresh, usable;
     int consec_accepts;       // successful steps in a row (drives how many radii the next round speculates on)
     int nact;                 // sets evaluated by THIS round (1 .. ns)
-    int n_rounds, n_fresh, n_sets, pad;   // accounting: rounds that did work, of those relinearised, sets evaluated
+    int n_rounds, n_fresh, n_sets;        // accounting: rounds that did work, of those relinearised, sets evaluated
+    int hand_lost;                        // set by ba_finalize: a consumer of the fused K7 + K8 launch gave up waiting (the host re-runs the solve)
 };
 
 // Speculative radii.  After a REJECTED step Ceres does not relinearise: x stays, the radius becomes
@@ -123,6 +124,7 @@ struct BaBufs {
     const BaSetOut* set_prev;     // the previous round's
     BaProgress* prog;             // pinned host memory (null when the caller does not poll)
     unsigned long long* dbg;   // [64] in-kernel phase cycle counters (diagnostic; rs_prof_counters)
+    unsigned long long hand_timeout;   // fused K7 + K8 launch: ticks of the 100 MHz wall clock a consumer waits for a hand-off word
     BaTrace* trace;          // [max_iter] per-iteration record (rs_ba_get_trace)
     BaState* st;             // state of THIS iteration (st[it & 1])
     const BaState* st_prev;  // state the previous iteration ended with (st[(it + 1) & 1])

@@ -750,7 +750,7 @@ __global__ __launch_bounds__(64 * SCH_WAVES) void ba_schur_mfma_batch(const BaWi
 size_t ba_group_bytes(int P, int Cf, int M)
 {
     const size_t nb = ((size_t)Cf * Cf + 2) * GRP_REP;
-    const size_t ni = ((size_t)P + IT_L_SMALL - 1) / IT_L_SMALL;
+    const size_t ni = ((size_t)P + IT_L_SMALL - 1) / IT_L_SMALL + 1;
     return 256 * 10 + sizeof(int32_t) * (2 * (size_t)P + 2 * nb + (size_t)M) + sizeof(int4) * (size_t)P +
            sizeof(uint64_t) * (2 * (size_t)P + 2 * ni);
 }
@@ -844,10 +844,10 @@ static size_t al256(size_t v) { return (v + 255) & ~(size_t)255; }
 void ba_group_carve(char* base, int P, int Cf, int M, BaGroup* g)
 {
     const size_t nb = ((size_t)Cf * Cf + 2) * GRP_REP;
-    const size_t ni_max = ((size_t)P + IT_L_SMALL - 1) / IT_L_SMALL;
+    const size_t ni_max = ((size_t)P + IT_L_SMALL - 1) / IT_L_SMALL + 1;
     g->it_l = P <= 256 * IT_L_SMALL ? IT_L_SMALL : IT_L;
-    const size_t ni = ((size_t)P + g->it_l - 1) / g->it_l;
-    size_t off = 0;
+    const size_t ni = P > 0 ? ((size_t)P + g->it_l - 1) / g->it_l : 1;     // an empty landmark shard keeps one (empty) item:
+    size_t off = 0;                                                            // its workgroup runs the round's decision
     g->sorted = (int32_t*)(base + off); off += al256(sizeof(int32_t) * P);
     g->bucket = (int32_t*)(base + off); off += al256(sizeof(int32_t) * P);
     g->hist = (int32_t*)(base + off); off += al256(sizeof(int32_t) * nb);
@@ -925,5 +925,5 @@ void ba_launch_schur_batch(hipStream_t s, const BaWin* d_wins, int B, const BaOp
 void ba_group_set_items(BaGroup* g, int P, bool throughput)
 {
     g->it_l = throughput ? IT_L : (P <= 256 * IT_L_SMALL ? IT_L_SMALL : IT_L);
-    g->n_items = (P + g->it_l - 1) / g->it_l;
+    g->n_items = P > 0 ? (P + g->it_l - 1) / g->it_l : 1;
 }

@@ -30,7 +30,7 @@ size_t ba_backsub_lds_bytes(int C, int n)
 
 void ba_launch_backsub(hipStream_t s, const BaDims& d, const BaBufs& b)
 {
-    hipLaunchKernelGGL(ba_backsub_cost4, dim3((d.P + 63) / 64, b.ns), dim3(K8_THREADS), ba_backsub_lds_bytes(d.C, d.n), s, d, b);
+    hipLaunchKernelGGL(ba_backsub_cost4, dim3(d.P > 0 ? (d.P + 63) / 64 : 1, b.ns), dim3(K8_THREADS), ba_backsub_lds_bytes(d.C, d.n), s, d, b);
 }
 
 void ba_launch_backsub_batch(hipStream_t s, const BaWin* d_wins, int B, int it, int ns, int max_P, size_t lds)

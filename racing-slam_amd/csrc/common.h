@@ -56,7 +56,8 @@ struct rs_context {
     // per-iteration record of the last rs_bundle_adjust (points into the pinned block; rs_ba_get_trace)
     const void* ba_trace = nullptr;
     int ba_trace_n = 0;
-    int ba_stats[4] = {0, 0, 0, 0};     // rs_ba_get_stats
+    int ba_stats[8] = {0, 0, 0, 0, 0, 0, 0, 0};     // rs_ba_get_stats
+    int ba_handoff_timeout_us = 4000;   // fused K7 + K8 launch: how long a K8 workgroup waits for its hand-off word ("ba_handoff_timeout_us")
     const double* ba_cams = nullptr;    // cameras after the last rs_bundle_adjust, mirrored in the pinned block
     int ba_cams_n = 0;
     // speculative trust-region radii per BA round (0 = library default; rs_context_set_int "ba_speculative_sets")

@@ -96,6 +96,11 @@ extern "C" int rs_context_set_int(rs_context* ctx, const char* name, int value)
         ctx->ba_fuse_mode = value;
         return RS_OK;
     }
+    if (strcmp(name, "ba_handoff_timeout_us") == 0) {
+        if (value < 1 || value > 1000000) return rs_fail(ctx, RS_ERR_INVALID, "ba_handoff_timeout_us must be 1 .. 1000000");
+        ctx->ba_handoff_timeout_us = value;
+        return RS_OK;
+    }
     if (strcmp(name, "k2_mode") == 0) {
         if (value < 0 || value > 1) return rs_fail(ctx, RS_ERR_INVALID, "k2_mode must be 0 (eight lanes per map point where possible) or 1 (one lane per point)");
         ctx->k2_mode = value;
@@ -318,6 +323,7 @@ typedef int (*fn_init_rank)(void**, int, rs_nccl_uid, int);
 typedef int (*fn_destroy)(void*);
 typedef int (*fn_allreduce)(const void*, void*, size_t, int, int, void*, hipStream_t);
 typedef const char* (*fn_errstr)(int);
+typedef int (*fn_count)(const void*, int*);
 
 static struct {
     void* h = nullptr;
@@ -326,6 +332,7 @@ static struct {
     fn_destroy destroy = nullptr;
     fn_allreduce allreduce = nullptr;
     fn_errstr errstr = nullptr;
+    fn_count count = nullptr;
 } g_rccl;
 
 static int rccl_load(rs_context* ctx)
@@ -342,6 +349,7 @@ static int rccl_load(rs_context* ctx)
     g_rccl.destroy = (fn_destroy)dlsym(g_rccl.h, "ncclCommDestroy");
     g_rccl.allreduce = (fn_allreduce)dlsym(g_rccl.h, "ncclAllReduce");
     g_rccl.errstr = (fn_errstr)dlsym(g_rccl.h, "ncclGetErrorString");
+    g_rccl.count = (fn_count)dlsym(g_rccl.h, "ncclCommCount");
     if (!g_rccl.get_uid || !g_rccl.init_rank || !g_rccl.destroy || !g_rccl.allreduce)
         return rs_fail(ctx, RS_ERR_RCCL, "librccl lacks the expected symbols");
     return RS_OK;
@@ -484,6 +492,44 @@ extern "C" int rs_comm_destroy(rs_context* ctx)
     }
     ctx->n_ranks = 1;
     ctx->rank = 0;
+    return RS_OK;
+}
+
+extern "C" int rs_comm_count(rs_context* ctx, int* h_ranks, int* h_kind)
+{
+    if (!ctx || !h_ranks || !h_kind) return RS_ERR_INVALID;
+    *h_ranks = 1;
+    *h_kind = 0;
+    if (ctx->local) { *h_ranks = ctx->local->n; *h_kind = 2; return RS_OK; }
+    if (!ctx->comm) return RS_OK;
+    *h_kind = 1;
+    if (!g_rccl.count) return rs_fail(ctx, RS_ERR_RCCL, "librccl lacks ncclCommCount");
+    int n = 0;
+    const int e = g_rccl.count(ctx->comm, &n);
+    if (e != 0) return rs_fail(ctx, RS_ERR_RCCL, "ncclCommCount: %s", g_rccl.errstr ? g_rccl.errstr(e) : "?");
+    *h_ranks = n;
+    return RS_OK;
+}
+
+__global__ void rs_empty_kernel() {}
+
+extern "C" int rs_prof_empty_launch(rs_context* ctx, int n, double* h_us)
+{
+    if (!ctx || !h_us || n < 1 || n > 100000) return RS_ERR_INVALID;
+    RS_HIP(ctx, hipSetDevice(ctx->device));
+    hipEvent_t a, b;
+    RS_HIP(ctx, hipEventCreate(&a));
+    RS_HIP(ctx, hipEventCreate(&b));
+    for (int i = 0; i < 8; i++) hipLaunchKernelGGL(rs_empty_kernel, dim3(1), dim3(64), 0, ctx->stream);
+    RS_HIP(ctx, hipEventRecord(a, ctx->stream));
+    for (int i = 0; i < n; i++) hipLaunchKernelGGL(rs_empty_kernel, dim3(1), dim3(64), 0, ctx->stream);
+    RS_HIP(ctx, hipEventRecord(b, ctx->stream));
+    RS_HIP(ctx, hipEventSynchronize(b));
+    float ms = 0.f;
+    RS_HIP(ctx, hipEventElapsedTime(&ms, a, b));
+    (void)hipEventDestroy(a);
+    (void)hipEventDestroy(b);
+    *h_us = 1e3 * (double)ms / n;
     return RS_OK;
 }
 

@@ -352,7 +352,7 @@ static int map_sync_device(rs_map* m)
 
 // per-call eligibility (src/MapMatcher.cpp:53, :169): alive, not already matched by the frame, and — for
 // match_key_frame — observed by the required key frame
-// flag table [P], all zero between calls: bit 0 = the frame already matches the point, bit 1 = listed (match_for_fuse)
+// flag table [P], all zero between calls: bit 0 = the frame already matches the point
 __global__ __launch_bounds__(256) void k_map_flag(const int32_t* __restrict__ idx, int n, uint8_t* __restrict__ flag, uint8_t bit, int set)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -383,8 +383,12 @@ __global__ __launch_bounds__(256) void k_map_eligible(int P, const uint8_t* __re
 //   h_matched_points       the point slots the frame already matches      (:53)
 //   required_observer_kf   >= 0: only points observed by that key frame (:169); -1: none
 //   h_only_points          match_for_fuse (:117-127): only these slots take part (n_only < 0: the whole map).  They
-//                          compete for a keypoint in MAP order, not list order (the reference's list comes out of an
-//                          unordered_set, src/Mapper.cpp:208: unspecified order upstream)
+//                          compete for a keypoint in LIST order, as the reference's loop over its vector does (:120-126)
+//                          and as the flattened path does (the shim flattens the vector in order): the listed points are
+//                          gathered from the mirror into a small view of their own, point i of it = h_only_points[i].
+//                          Dead slots in the list are skipped like the reference's null pointers (:121-123).
+// Every host list is validated and every buffer is grown BEFORE the first launch, and the flag table is cleared by the
+// same launches that follow the eligibility kernel whatever happens later: it is all-zero between calls.
 extern "C" int rs_map_match(rs_context* ctx, rs_map* m, rs_frame* f, const float h_pose[16], const float h_intrinsics[4],
                             int width, int height, const uint8_t* h_kp_matched, const int32_t* h_matched_points,
                             int n_matched_points, int required_observer_kf, const int32_t* h_only_points, int n_only,
@@ -397,9 +401,22 @@ extern "C" int rs_map_match(rs_context* ctx, rs_map* m, rs_frame* f, const float
     const int N = f->n, P = (int)m->alive.size();
     if (N == 0 || P == 0) return RS_OK;
     if (!h_match_kp || !h_match_point) return rs_fail(ctx, RS_ERR_INVALID, "null output");
+    if (n_only > 0 && !h_only_points) return rs_fail(ctx, RS_ERR_INVALID, "null point list");
+    for (int i = 0; i < n_matched_points; i++)
+        if (h_matched_points[i] < 0 || h_matched_points[i] >= P) return rs_fail(ctx, RS_ERR_INVALID, "matched point %d out of range", i);
+    for (int i = 0; i < n_only; i++)
+        if (h_only_points[i] < 0 || h_only_points[i] >= P) return rs_fail(ctx, RS_ERR_INVALID, "listed point %d out of range", i);
+    if (n_only == 0) return RS_OK;                       // an empty list: nothing takes part
     RS_HIP(ctx, hipSetDevice(ctx->device));
     int rc = map_sync_device(m);
     if (rc) return rc;
+    const bool listed = n_only > 0;
+    const int Pv = listed ? n_only : P;                  // points of the view the matcher runs on
+    const size_t need = 2 * (size_t)Pv + 4 * (size_t)N + 1;
+    size_t co = m->cap_out;
+    rc = grow(ctx, &m->d_out, &co, need, 0);
+    if (rc) return rc;
+    m->cap_out = co;
     rc = rs_stage_begin(ctx);
     if (rc) return rc;
     hipStream_t s = ctx->stream;
@@ -407,38 +424,52 @@ extern "C" int rs_map_match(rs_context* ctx, rs_map* m, rs_frame* f, const float
     uint8_t* d_matched = nullptr;
     if (h_kp_matched) { rc = rs_stage_upload(ctx, h_kp_matched, (size_t)N, (void**)&d_matched); if (rc) return rc; }
     else { rc = rs_stage_alloc(ctx, (size_t)N, (void**)&d_matched); if (rc) return rc; RS_HIP(ctx, hipMemsetAsync(d_matched, 0, (size_t)N, s)); }
-    int32_t* d_mp = nullptr;
-    if (n_matched_points > 0) {
-        for (int i = 0; i < n_matched_points; i++)
-            if (h_matched_points[i] < 0 || h_matched_points[i] >= P) return rs_fail(ctx, RS_ERR_INVALID, "matched point %d out of range", i);
-        rc = rs_stage_upload(ctx, h_matched_points, sizeof(int32_t) * (size_t)n_matched_points, (void**)&d_mp);
-        if (rc) return rc;
-        hipLaunchKernelGGL(k_map_flag, dim3((n_matched_points + 255) / 256), dim3(256), 0, s, d_mp, n_matched_points, m->d_flag, (uint8_t)1, 1);
+    rs_map_view mv{P, m->d_pos, m->d_elig, m->d_obs_ptr, m->d_obs_kf, m->d_obs_desc, m->d_centres, m->d_pool};
+    if (listed) {
+        // the listed points as a view of their own, in list order, from the mirror (map_sync_device has just rebuilt the
+        // observation tables): a fuse list is a few hundred points
+        std::vector<uint8_t> taken((size_t)P, 0), elig((size_t)n_only);
+        for (int i = 0; i < n_matched_points; i++) taken[(size_t)h_matched_points[i]] = 1;
+        std::vector<float> pos(3 * (size_t)n_only);
+        std::vector<int32_t> optr((size_t)n_only + 1), okf, odesc;
+        for (int i = 0; i < n_only; i++) {
+            const size_t p = (size_t)h_only_points[i];
+            memcpy(&pos[3 * (size_t)i], &m->pos[3 * p], sizeof(float) * 3);
+            optr[(size_t)i] = (int32_t)okf.size();
+            bool e = m->alive[p] != 0 && !taken[p];
+            bool seen = required_observer_kf < 0;
+            for (int32_t o = m->h_obs_ptr[p]; o < m->h_obs_ptr[p + 1]; o++) {
+                okf.push_back(m->h_obs_kf[(size_t)o]);
+                odesc.push_back(m->h_obs_desc[(size_t)o]);
+                seen = seen || m->h_obs_kf[(size_t)o] == required_observer_kf;
+            }
+            elig[(size_t)i] = (e && seen) ? 1 : 0;
+        }
+        optr[(size_t)n_only] = (int32_t)okf.size();
+        if (okf.empty()) { okf.push_back(0); odesc.push_back(0); }
+        float* d_p = nullptr; uint8_t* d_e = nullptr; int32_t *d_op = nullptr, *d_ok = nullptr, *d_od = nullptr;
+        if ((rc = rs_stage_upload(ctx, pos.data(), sizeof(float) * pos.size(), (void**)&d_p))) return rc;
+        if ((rc = rs_stage_upload(ctx, elig.data(), elig.size(), (void**)&d_e))) return rc;
+        if ((rc = rs_stage_upload(ctx, optr.data(), sizeof(int32_t) * optr.size(), (void**)&d_op))) return rc;
+        if ((rc = rs_stage_upload(ctx, okf.data(), sizeof(int32_t) * okf.size(), (void**)&d_ok))) return rc;
+        if ((rc = rs_stage_upload(ctx, odesc.data(), sizeof(int32_t) * odesc.size(), (void**)&d_od))) return rc;
+        mv = rs_map_view{n_only, d_p, d_e, d_op, d_ok, d_od, m->d_centres, m->d_pool};
+    } else {
+        int32_t* d_mp = nullptr;
+        if (n_matched_points > 0) {
+            rc = rs_stage_upload(ctx, h_matched_points, sizeof(int32_t) * (size_t)n_matched_points, (void**)&d_mp);
+            if (rc) return rc;
+            hipLaunchKernelGGL(k_map_flag, dim3((n_matched_points + 255) / 256), dim3(256), 0, s, d_mp, n_matched_points, m->d_flag, (uint8_t)1, 1);
+        }
+        {
+            rs_prof_scope ps(ctx, "K2p_map_eligible");
+            hipLaunchKernelGGL(k_map_eligible, dim3((P + 255) / 256), dim3(256), 0, s, P, m->d_alive, m->d_flag, m->d_obs_ptr, m->d_obs_kf,
+                               required_observer_kf, 0, m->d_elig);
+        }
+        if (n_matched_points > 0)       // leave the flag table all-zero for the next call (enqueued before anything below can fail)
+            hipLaunchKernelGGL(k_map_flag, dim3((n_matched_points + 255) / 256), dim3(256), 0, s, d_mp, n_matched_points, m->d_flag, (uint8_t)1, 0);
     }
-    int32_t* d_only = nullptr;
-    if (n_only > 0) {
-        if (!h_only_points) return rs_fail(ctx, RS_ERR_INVALID, "null point list");
-        for (int i = 0; i < n_only; i++)
-            if (h_only_points[i] < 0 || h_only_points[i] >= P) return rs_fail(ctx, RS_ERR_INVALID, "listed point %d out of range", i);
-        rc = rs_stage_upload(ctx, h_only_points, sizeof(int32_t) * (size_t)n_only, (void**)&d_only);
-        if (rc) return rc;
-        hipLaunchKernelGGL(k_map_flag, dim3((n_only + 255) / 256), dim3(256), 0, s, d_only, n_only, m->d_flag, (uint8_t)2, 1);
-    }
-    {
-        rs_prof_scope ps(ctx, "K2p_map_eligible");
-        hipLaunchKernelGGL(k_map_eligible, dim3((P + 255) / 256), dim3(256), 0, s, P, m->d_alive, m->d_flag, m->d_obs_ptr, m->d_obs_kf,
-                           required_observer_kf, n_only >= 0 ? 1 : 0, m->d_elig);
-    }
-    if (n_matched_points > 0)       // leave the flag table all-zero for the next call
-        hipLaunchKernelGGL(k_map_flag, dim3((n_matched_points + 255) / 256), dim3(256), 0, s, d_mp, n_matched_points, m->d_flag, (uint8_t)1, 0);
-    if (n_only > 0)
-        hipLaunchKernelGGL(k_map_flag, dim3((n_only + 255) / 256), dim3(256), 0, s, d_only, n_only, m->d_flag, (uint8_t)2, 0);
-    const size_t need = 2 * (size_t)P + 4 * (size_t)N + 1;
-    size_t co = m->cap_out;
-    rc = grow(ctx, &m->d_out, &co, need, 0);
-    if (rc) return rc;
-    m->cap_out = co;
-    int32_t* pk = m->d_out, *pd = pk + P, *pp = pd + P, *pdist = pp + N, *mkp = pdist + N, *mpt = mkp + N, *cnt = mpt + N;
+    int32_t* pk = m->d_out, *pd = pk + Pv, *pp = pd + Pv, *pdist = pp + N, *mkp = pdist + N, *mpt = mkp + N, *cnt = mpt + N;
     rs_frame_view fv{};
     memcpy(fv.pose, h_pose, sizeof fv.pose);
     fv.fx = h_intrinsics[0]; fv.fy = h_intrinsics[1]; fv.cx = h_intrinsics[2]; fv.cy = h_intrinsics[3];
@@ -446,7 +477,6 @@ extern "C" int rs_map_match(rs_context* ctx, rs_map* m, rs_frame* f, const float
     fv.d_keypoints = f->d_kp; fv.d_descriptors = f->d_desc; fv.d_kp_matched = d_matched;
     fv.d_kd_node_kp = f->d_kd; fv.d_kd_left = f->d_kd + N; fv.d_kd_right = f->d_kd + 2 * (size_t)N; fv.kd_root = f->kd_root;
     fv.d_kd_packed = f->d_packed;
-    rs_map_view mv{P, m->d_pos, m->d_elig, m->d_obs_ptr, m->d_obs_kf, m->d_obs_desc, m->d_centres, m->d_pool};
     rc = rs_reproj_match(ctx, &fv, &mv, replace, max_distance, pk, pd, pp, pdist, mkp, mpt, cnt);
     if (rc) return rc;
     int32_t n_out = 0;
@@ -458,6 +488,8 @@ extern "C" int rs_map_match(rs_context* ctx, rs_map* m, rs_frame* f, const float
     if (rc) return rc;
     rc = rs_stage_sync(ctx);
     if (rc) return rc;
+    if (listed)
+        for (int i = 0; i < n_out; i++) h_match_point[i] = h_only_points[h_match_point[i]];      // view index -> map slot
     *h_count = n_out;
     return RS_OK;
 }

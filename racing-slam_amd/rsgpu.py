@@ -19,7 +19,7 @@ EXPORTS = [
     "rs_map_add_keyframe", "rs_map_set_keyframe_pose", "rs_map_add_point", "rs_map_set_position", "rs_map_remove_point",
     "rs_map_add_observation", "rs_map_remove_observation", "rs_map_counts", "rs_map_get_positions", "rs_map_match", "rs_map_pose_graph", "rs_pose_graph", "rs_pose_relative", "rs_transform_points", "rs_map_bundle_adjust", "rs_triangulate", "rs_triangulate_matches", "rs_triangulate_matches_batch", "rs_triangulate_tracks", "rs_point_errors", "rs_ba_default_options",
     "rs_bundle_adjust", "rs_bundle_adjust_batch", "rs_ba_get_trace", "rs_ba_get_stats", "rs_ba_get_cameras", "rs_reanchor_points", "rs_refine_pose", "rs_bundle_adjust_inertial", "rs_refine_pose_inertial", "rs_pack_pose", "rs_unpack_pose", "rs_pack_poses", "rs_unpack_poses", "rs_build_local_window",
-    "rs_comm_get_unique_id", "rs_comm_init_rank", "rs_comm_destroy", "rs_comm_init_local", "rs_prof_begin", "rs_prof_end", "rs_prof_counters",
+    "rs_comm_get_unique_id", "rs_comm_init_rank", "rs_comm_destroy", "rs_comm_init_local", "rs_comm_count", "rs_prof_begin", "rs_prof_end", "rs_prof_counters", "rs_prof_empty_launch",
 ]
 
 _lib = None
@@ -518,9 +518,9 @@ class Context:
         return out
 
     def ba_stats(self):
-        buf = (C.c_int * 4)()
+        buf = (C.c_int * 8)()
         self._check(self.lib.rs_ba_get_stats(self.h, buf), "rs_ba_get_stats")
-        return dict(rounds=buf[0], fresh_rounds=buf[1], set_evaluations=buf[2], rounds_enqueued=buf[3])
+        return dict(rounds=buf[0], fresh_rounds=buf[1], set_evaluations=buf[2], rounds_enqueued=buf[3], handoff_retries=buf[4])
 
     def reanchor_points(self, d_point_idx, d_frame_idx, d_before, d_after, d_positions):
         """Mapper::bundle_adjust's tail (src/Mapper.cpp:380-393); d_positions [P][3] f32 is updated in place."""
@@ -568,6 +568,12 @@ class Context:
     def comm_destroy(self):
         self._check(self.lib.rs_comm_destroy(self.h), "rs_comm_destroy")
 
+    def comm_count(self):
+        """(ranks as the communicator itself reports them, kind: 0 none / 1 RCCL / 2 in-process group)"""
+        n, k = C.c_int(0), C.c_int(0)
+        self._check(self.lib.rs_comm_count(self.h, C.byref(n), C.byref(k)), "rs_comm_count")
+        return n.value, k.value
+
     # -- profiling
     def prof_begin(self):
         self._check(self.lib.rs_prof_begin(self.h), "rs_prof_begin")
@@ -582,6 +588,11 @@ class Context:
         buf = (C.c_uint64 * n)()
         self._check(self.lib.rs_prof_counters(self.h, buf, n), "rs_prof_counters")
         return list(buf)
+
+    def empty_launch_us(self, n=2000):
+        us = C.c_double(0.0)
+        self._check(self.lib.rs_prof_empty_launch(self.h, int(n), C.byref(us)), "rs_prof_empty_launch")
+        return us.value
 
     def synchronize(self):
         self._check(self.lib.rs_context_synchronize(self.h), "rs_context_synchronize")

@@ -245,12 +245,13 @@ def make_imu(window, seed=11, duration=0.5, sigma_rot=2e-3, sigma_vel=2e-2, sigm
     return out
 
 
-def shard_ba_by_landmark(prob, n_shards, shard):
+def shard_ba_by_landmark(prob, n_shards, shard, bounds=None):
     """Landmark shard `shard` of `n_shards` (contiguous blocks of landmarks;
-    cameras replicated) — SURVEY.md §8(e)."""
+    cameras replicated) — SURVEY.md §8(e).  bounds: explicit split points [n_shards + 1]
+    (equal bounds give an empty shard)."""
     P = len(prob["points"])
-    lo = (P * shard) // n_shards
-    hi = (P * (shard + 1)) // n_shards
+    lo = (P * shard) // n_shards if bounds is None else int(bounds[shard])
+    hi = (P * (shard + 1)) // n_shards if bounds is None else int(bounds[shard + 1])
     o0, o1 = int(prob["obs_ptr"][lo]), int(prob["obs_ptr"][hi])
     out = dict(prob)
     out["points"] = prob["points"][lo:hi].copy()

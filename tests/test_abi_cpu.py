@@ -22,7 +22,7 @@ def test_library_exports_every_declared_symbol(rs):
     missing = [s for s in syms if not hasattr(lib, s)]
     assert not missing, missing
     assert sorted(rs.EXPORTS) == syms
-    assert lib.rs_abi_version() == 2
+    assert lib.rs_abi_version() == 3
 
 
 def test_no_cpu_fallback(rs):

@@ -1,0 +1,305 @@
+"""GPU parity tests added in round 3 (VERDICT r2 "next round" items 1, 2, 4, 7): the benchmark pass's OWN inputs against
+the oracle, cfg 5 at full size value by value, one order rule for match_for_fuse on both product paths, the lost
+hand-off retry of the fused solve launch, and the envelope holes of the multi-rank / many-camera BA.
+PARITY UNPINNED against the reference itself (it ships no fixtures): the oracle is the restatement in oracle/*.c.
+"""
+import threading
+
+import numpy as np
+import pytest
+
+from conftest import to_np
+from test_gpu_parity import _reproj_case
+
+pytestmark = pytest.mark.gpu
+
+
+class _Env:
+    pass
+
+
+def _bench_env(ctx, rs, synth):
+    import torch
+    e = _Env()
+    e.ctx, e.rs, e.synth, e.torch = ctx, rs, synth, torch
+    e.world, e.rank, e.local_rank = 1, 0, 0
+    return e
+
+
+def test_bench_pass_inputs_against_oracle(ctx, rs, oracle, synth):
+    """the reprojection matcher was never compared with the oracle at the size the metric runs it
+    (2000 keypoints x 10 000 points; 621 / 8 884 eligible).  This builds bench.py's pass inputs (build_pass) and checks
+    both K2 calls — eight-lane kernel, packed tree, one-lane kernel — the cfg-2 match + triangulation, the track stage and
+    the whole pass's outputs against the oracle on exactly those inputs.  Reference: src/MapMatcher.cpp:45-98,165-175."""
+    import bench
+    one_pass, cpu_pass, meta = bench.build_pass(_bench_env(ctx, rs, synth))
+    assert len(meta["frame_a"]["keypoints"]) == 2000 and len(meta["mp_a"]["positions"]) == 10000
+    n_a = _reproj_case(ctx, oracle, rs, meta["frame_a"], meta["mp_a"], 0)          # match_key_frame
+    n_b = _reproj_case(ctx, oracle, rs, meta["frame_b"], meta["mp_b"], 0)          # match_map (first call's matches taken out)
+    assert n_a > 100 and n_b > 100
+    assert int(meta["mp_a"]["eligible"].sum()) == meta["match_key_frame_points"] < meta["match_map_points"]
+    for _ in range(3):
+        one_pass()
+    ok, report = bench.check_pass_parity(meta, cpu_pass, oracle)
+    assert ok, report
+    for k in ("match_descriptors.query", "match_key_frame.points", "match_map.points", "triangulate.xyz", "tracks.status",
+              "build_local_window.frames", "bundle_adjust.schedule"):
+        assert report[k] is True, (k, report)
+    # the side stages the bench line reports beside the pass
+    meta["cull_stage"]()
+    meta["refine_stage"]()
+    got = meta["gpu_results"]()
+    ref_c = meta["cpu_cull"](oracle)
+    n = len(meta["cull_in"]["positions"])
+    assert np.array_equal(got["cull"]["mean_err"][:n].view(np.uint32), ref_c["mean_err"].view(np.uint32))
+    assert np.array_equal(got["cull"]["cull"][:n], ref_c["cull"])
+    ref_cam, ref_s = meta["cpu_refine"](oracle)
+    cam, s = got["refine"]
+    assert (s["iterations"], s["successful_steps"], s["termination"]) == (ref_s["iterations"], ref_s["successful_steps"], ref_s["termination"])
+    assert np.allclose(cam, ref_cam, rtol=1e-7, atol=1e-9)
+
+
+def test_bundle_adjust_cfg5_full_size_against_oracle(ctx, oracle, synth):
+    """BASELINE.json configs[4] at FULL size — 100 key frames, 80 k landmarks, ~480 k observations, reduced system n = 588
+    (window-size-independent MFMA Schur kernel + the blocked reduced solve) — value by value against the oracle, with the
+    per-iteration trace (the oracle solves it in ~8 s).  Reference: src/Optimization.cpp:269-374.
+    Tolerances: identical schedule; costs 1e-9 / 1e-7; poses and points 1e-6 relative (f64 summation order; the reference
+    rounds its results to f32 on write-back)."""
+    w = synth.make_ba_window(n_kf=100, n_points=80000, config_id=5)
+    dc, dp = ctx.dev(w["cams"]), ctx.dev(w["points"])
+    args = (ctx.dev(w["obs_ptr"]), ctx.dev(w["obs_cam"]), ctx.dev(w["obs_uv"]))
+    s = ctx.bundle_adjust(dc, w["cam_free"], dp, *args, w["K"])
+    tr = ctx.ba_trace()
+    rc, rp, rs_, otr = oracle.bundle_adjust_trace(w["cams"], w["cam_free"], w["points"], w["obs_ptr"], w["obs_cam"], w["obs_uv"], w["K"])
+    assert s["usable"] == rs_["usable"] == 1
+    assert (s["iterations"], s["successful_steps"], s["termination"]) == (rs_["iterations"], rs_["successful_steps"], rs_["termination"])
+    assert [t["outcome"] for t in tr] == [t["outcome"] for t in otr]
+    for k, tol in (("radius", 1e-7), ("cost", 1e-9), ("candidate_cost", 1e-7), ("model_cost_change", 1e-6), ("x_norm", 1e-9)):
+        assert np.allclose([t[k] for t in tr], [t[k] for t in otr], rtol=tol), k
+    assert np.isclose(s["initial_cost"], rs_["initial_cost"], rtol=1e-12) and np.isclose(s["final_cost"], rs_["final_cost"], rtol=1e-7)
+    c1, p1 = to_np(dc), to_np(dp)
+    assert np.allclose(c1, rc, rtol=1e-6, atol=1e-8)
+    assert np.allclose(p1, rp, rtol=1e-6, atol=1e-7)
+    fixed = ~np.asarray(w["cam_free"]).astype(bool)
+    assert fixed.sum() == 2 and np.array_equal(c1[fixed], w["cams"][fixed])
+    assert s["final_cost"] < 0.15 * s["initial_cost"]
+    # size-independent property kept from round 2: a second solve started from the result finds (almost) nothing left
+    s2 = ctx.bundle_adjust(dc, w["cam_free"], dp, *args, w["K"])
+    assert s2["initial_cost"] == pytest.approx(s["final_cost"], rel=1e-9)
+    assert s2["final_cost"] <= s2["initial_cost"] and s2["final_cost"] > 0.5 * s2["initial_cost"]
+
+
+def test_match_for_fuse_shuffled_list_one_order_rule(ctx, rs, oracle, synth):
+    """match_for_fuse (src/MapMatcher.cpp:117-127) loops over its vector, so points that tie for a
+    keypoint are decided by LIST order.  The flattened path (the shim flattens the vector in order) and the resident path
+    (rs_map_match with only_points) must both follow that one rule: same result for the same shuffled list, equal to the
+    oracle on the list-ordered arrays.  Duplicated descriptors force distance ties between listed points."""
+    from test_resident_map import Scene
+    sc = Scene(ctx, rs, synth, n_kf=6, n_points=600, seed=9, dup_pairs=True)
+    rng = np.random.default_rng(5)
+    # crowd the points: many of them share positions' projections and identical descriptors -> ties for one keypoint
+    for p in range(0, 600, 2):
+        sc.set_position(p + 1, sc.pos[p] + np.float32(1e-4))
+    kpm = (rng.random(len(sc.frame["keypoints"])) < 0.3).astype(np.uint8)
+    matched = rng.choice(600, 40, replace=False)
+    for trial in range(3):
+        only = rng.permutation(600)[:300].astype(np.int32)                       # shuffled: NOT map order
+        fr = dict(sc.frame, kp_matched=kpm)
+        full = sc.flat(matched_points=matched)
+        # the listed points as their own arrays IN LIST ORDER (what the shim builds from the caller's vector)
+        optr = [0]
+        okf, odesc = [], []
+        for p in only:
+            a, b = full["obs_ptr"][p], full["obs_ptr"][p + 1]
+            okf += list(full["obs_kf"][a:b]); odesc += list(full["obs_desc"][a:b])
+            optr.append(len(okf))
+        sub = dict(full, positions=full["positions"][only], eligible=full["eligible"][only], obs_ptr=np.array(optr, np.int32),
+                   obs_kf=np.array(okf, np.int32), obs_desc=np.array(odesc, np.int32))
+        ref = oracle.reproj_match(fr, sub, replace=1)
+        fv, k1 = ctx.make_frame_view(fr)
+        mv, k2 = ctx.make_map_view(sub)
+        flat = ctx.reproj_match(fv, mv, replace=1)
+        n = int(to_np(flat["count"])[0])
+        assert n == len(ref["match_kp"]) > 20
+        assert np.array_equal(to_np(flat["match_kp"])[:n], ref["match_kp"]) and np.array_equal(to_np(flat["match_point"])[:n], ref["match_point"])
+        mk, mpt = sc.map.match(sc.rframe, fr["pose"], sc.K, fr["width"], fr["height"], kp_matched=kpm, matched_points=matched,
+                               only_points=only, replace=1)
+        assert np.array_equal(mk, ref["match_kp"])
+        assert np.array_equal(mpt, only[ref["match_point"]])                      # map slots of the list-order winners
+        # the rule matters on this scene: map order would have decided at least one keypoint differently
+        if trial == 0:
+            srt = np.sort(only)
+            mk2, mpt2 = sc.map.match(sc.rframe, fr["pose"], sc.K, fr["width"], fr["height"], kp_matched=kpm, matched_points=matched,
+                                     only_points=srt, replace=1)
+            assert np.array_equal(mk2, mk)
+            assert not np.array_equal(mpt2, mpt), "scene has no ties between listed points: the test would not see the order rule"
+    # an empty list, and a list holding a dead slot (the reference skips null pointers)
+    mk, mpt = sc.map.match(sc.rframe, sc.frame["pose"], sc.K, sc.frame["width"], sc.frame["height"], only_points=np.zeros(0, np.int32), replace=1)
+    assert len(mk) == 0
+    sc.remove_point(int(only[0]))
+    mk, mpt = sc.map.match(sc.rframe, sc.frame["pose"], sc.K, sc.frame["width"], sc.frame["height"], only_points=only, replace=1)
+    assert int(only[0]) not in set(mpt.tolist())
+    sc.check(oracle)                                                              # the flag table was left clean
+    sc.map.close()
+
+
+def test_bundle_adjust_lost_handoff_is_rerun_as_two_launches(ctx, oracle, synth):
+    """ADVICE r2 (medium) / VERDICT r2 #7a: in the fused K7 + K8 launch a K8 workgroup that does not see its hand-off word
+    in time used to turn the solve into RS_BA_FAILURE.  That is a scheduling event, not a solver failure: the solve is now
+    re-run once as separate launches from its untouched inputs.  The hook: "ba_handoff_timeout_us" = 1 makes every K8
+    workgroup give up (K7 needs ~30 us).  The result must be the two-launch result and the oracle's schedule, and
+    rs_ba_get_stats must count the retry."""
+    w = synth.make_ba_window()
+    _, _, os_, otr = oracle.bundle_adjust_trace(w["cams"], w["cam_free"], w["points"], w["obs_ptr"], w["obs_cam"], w["obs_uv"], w["K"])
+    args = (ctx.dev(w["obs_ptr"]), ctx.dev(w["obs_cam"]), ctx.dev(w["obs_uv"]))
+
+    def run():
+        dc, dp = ctx.dev(w["cams"]), ctx.dev(w["points"])
+        s = ctx.bundle_adjust(dc, w["cam_free"], dp, *args, w["K"])
+        return s, ctx.ba_trace(), to_np(dc), to_np(dp), ctx.ba_stats()
+
+    try:
+        ctx.set_int("ba_fuse_mode", 1)
+        s1, t1, c1, p1, st1 = run()                       # two launches: the reference result of this test
+        ctx.set_int("ba_fuse_mode", 2)
+        s2, t2, c2, p2, st2 = run()                       # fused, default timeout: no retry
+        assert st2["handoff_retries"] == st1["handoff_retries"]
+        ctx.set_int("ba_handoff_timeout_us", 1)
+        s3, t3, c3, p3, st3 = run()                       # fused, every consumer times out -> re-run in two-launch form
+    finally:
+        ctx.set_int("ba_handoff_timeout_us", 4000)
+        ctx.set_int("ba_fuse_mode", 0)
+    assert st3["handoff_retries"] == st2["handoff_retries"] + 1
+    for s, tr in ((s1, t1), (s2, t2), (s3, t3)):
+        assert s["usable"] == 1
+        assert (s["iterations"], s["successful_steps"], s["termination"]) == (os_["iterations"], os_["successful_steps"], os_["termination"])
+        assert [t["outcome"] for t in tr] == [t["outcome"] for t in otr]
+    assert np.isclose(s3["final_cost"], s1["final_cost"], rtol=1e-10)
+    assert np.allclose(c3, c1, rtol=1e-9, atol=1e-11) and np.allclose(p3, p1, rtol=1e-9, atol=1e-10)
+    # and the default path afterwards is healthy
+    s4, t4, c4, p4, st4 = run()
+    assert s4["usable"] == 1 and st4["handoff_retries"] == st3["handoff_retries"]
+
+
+def _sharded_solve(rs, synth, w, shards, inertial=None, knobs=()):
+    """n contexts on device 0 joined by rs_comm_init_local, one landmark shard each (see test_gpu_parity)."""
+    import torch
+    n = len(shards)
+    ctxs = [rs.Context(0) for _ in range(n)]
+    for c in ctxs:
+        for name, value in knobs:
+            c.set_int(name, value)
+    streams = [torch.cuda.Stream(device=ctxs[0].device) for _ in range(n)]
+    for c, st in zip(ctxs, streams):
+        c.use_stream(st)
+    rs.Context.comm_init_local(ctxs)
+    out = [None] * n
+
+    def work(r):
+        try:
+            c, sh = ctxs[r], shards[r]
+            with torch.cuda.stream(streams[r]):
+                dcr, dpr = c.dev(sh["cams"]), c.dev(sh["points"])
+                args = (c.dev(sh["obs_ptr"]), c.dev(sh["obs_cam"]), c.dev(sh["obs_uv"]))
+                streams[r].synchronize()
+                if inertial is None:
+                    s = c.bundle_adjust(dcr, sh["cam_free"], dpr, *args, sh["K"])
+                    out[r] = (s, c.ba_trace(), to_np(dcr), to_np(dpr))
+                else:
+                    s, v, b = c.bundle_adjust_inertial(dcr, sh["cam_free"], dpr, *args, sh["K"], inertial)
+                    out[r] = (s, c.ba_trace(), to_np(dcr), to_np(dpr), v, b)
+        except Exception as ex:      # noqa: BLE001
+            out[r] = ex
+
+    threads = [threading.Thread(target=work, args=(r,)) for r in range(n)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=180)
+    assert not any(t.is_alive() for t in threads), "a rank is stuck in the exchange step"
+    for c in ctxs:
+        c.comm_destroy()
+        c.close()
+    for o in out:
+        assert not isinstance(o, Exception), o
+    return out
+
+
+def test_bundle_adjust_empty_landmark_shard(rs, synth):
+    """VERDICT r2 missing #4: an empty shard in a multi-rank solve was refused.  Eight ranks on a small window meet it.
+    Three shards, the middle one EMPTY: it must take part in every exchange step with zero contributions and end with
+    the same cameras as the others and as the unsharded solve."""
+    w = synth.make_ba_window(n_kf=8, n_points=900, run_max=5, config_id=36, outlier_frac=0.1, rot_noise_deg=2.0)
+    single = rs.Context(0)
+    dc, dp = single.dev(w["cams"]), single.dev(w["points"])
+    s0 = single.bundle_adjust(dc, w["cam_free"], dp, single.dev(w["obs_ptr"]), single.dev(w["obs_cam"]), single.dev(w["obs_uv"]), w["K"])
+    tr0, c0, p0 = single.ba_trace(), to_np(dc), to_np(dp)
+    single.close()
+    bounds = [0, 500, 500, 900]
+    shards = [synth.shard_ba_by_landmark(w, 3, r, bounds=bounds) for r in range(3)]
+    assert len(shards[1]["points"]) == 0 and len(shards[1]["obs_cam"]) == 0
+    out = _sharded_solve(rs, synth, w, shards)
+    for r in range(3):
+        s, tr, cr, pr = out[r]
+        assert (s["iterations"], s["successful_steps"], s["termination"], s["usable"]) == \
+               (s0["iterations"], s0["successful_steps"], s0["termination"], s0["usable"])
+        assert [t["outcome"] for t in tr] == [t["outcome"] for t in tr0]
+        assert np.isclose(s["final_cost"], s0["final_cost"], rtol=1e-6)
+        assert np.allclose(cr, c0, rtol=1e-6, atol=1e-8)
+        lo, hi = shards[r]["point_range"]
+        assert np.allclose(pr, p0[lo:hi], rtol=1e-6, atol=1e-7)
+        assert np.array_equal(cr, out[0][2]), "ranks must end with bit-identical cameras"
+
+
+@pytest.mark.parametrize("imu_mode", [0, 1])
+def test_bundle_adjust_inertial_landmark_sharded(rs, oracle, synth, imu_mode):
+    """VERDICT r2 missing #4: inertial factors in a landmark-sharded solve were refused.  The IMU blocks are camera-side:
+    every rank adds them to the (already all-reduced) camera system redundantly, like it solves redundantly.  Two shards
+    against the oracle's inertial solve: schedule, poses, velocities, biases."""
+    w = synth.make_ba_window(n_kf=8, n_points=400, run_max=6, config_id=61)
+    imu = synth.make_imu(w)
+    rc, rp, rv, rb, rs_, otr = oracle.bundle_adjust_inertial(w["cams"], w["cam_free"], w["points"], w["obs_ptr"], w["obs_cam"],
+                                                             w["obs_uv"], w["K"], imu, trace=True)
+    shards = [synth.shard_ba_by_landmark(w, 2, r) for r in range(2)]
+    out = _sharded_solve(rs, synth, w, shards, inertial=imu, knobs=(("ba_imu_mode", imu_mode),))
+    for r in range(2):
+        s, tr, cr, pr, v, b = out[r]
+        assert (s["iterations"], s["successful_steps"], s["termination"], s["usable"]) == \
+               (rs_["iterations"], rs_["successful_steps"], rs_["termination"], rs_["usable"])
+        assert [t["outcome"] for t in tr] == [t["outcome"] for t in otr]
+        assert np.isclose(s["final_cost"], rs_["final_cost"], rtol=1e-7)
+        assert np.allclose(cr, rc, rtol=1e-6, atol=1e-8)
+        lo, hi = shards[r]["point_range"]
+        assert np.allclose(pr, rp[lo:hi], rtol=1e-6, atol=1e-7)
+        assert np.allclose(v, rv, rtol=1e-6, atol=1e-8) and np.allclose(b, rb, rtol=1e-5, atol=1e-8)
+
+
+def test_bundle_adjust_two_hundred_free_cameras(ctx, rs, oracle, synth):
+    """VERDICT r2 missing #4: more than 182 free cameras were refused (the reference has no such limit,
+    src/Optimization.cpp:269-374).  240 key frames, 238 free: the generic K5 with its camera partial sums in 80 KB of LDS,
+    the blocked reduced solve at n = 1428; against the oracle."""
+    w = synth.make_ba_window(n_kf=240, n_points=2500, run_min=2, run_max=8, config_id=55)
+    assert int(np.sum(w["cam_free"])) == 238
+    o = oracle.default_options(); o.max_num_iterations = 4
+    go = rs.default_options(); go.max_num_iterations = 4
+    rc, rp, rs_ = oracle.bundle_adjust(w["cams"], w["cam_free"], w["points"], w["obs_ptr"], w["obs_cam"], w["obs_uv"], w["K"], o)
+    dc, dp = ctx.dev(w["cams"]), ctx.dev(w["points"])
+    s = ctx.bundle_adjust(dc, w["cam_free"], dp, ctx.dev(w["obs_ptr"]), ctx.dev(w["obs_cam"]), ctx.dev(w["obs_uv"]), w["K"], go)
+    assert s["usable"] == rs_["usable"] == 1
+    assert (s["iterations"], s["successful_steps"], s["termination"]) == (rs_["iterations"], rs_["successful_steps"], rs_["termination"])
+    assert np.isclose(s["final_cost"], rs_["final_cost"], rtol=1e-7)
+    assert np.allclose(to_np(dc), rc, rtol=1e-6, atol=1e-8)
+    assert np.allclose(to_np(dp), rp, rtol=1e-6, atol=1e-7)
+
+
+def test_comm_count_and_empty_launch(ctx, rs):
+    """rs_comm_count reports what the exchange step runs over (ncclCommCount for RCCL); rs_prof_empty_launch the launch
+    latency bench.py prints next to its numbers."""
+    assert ctx.comm_count() == (1, 0)
+    ctx.comm_init(rs.Context.comm_unique_id(), 1, 0)
+    try:
+        assert ctx.comm_count() == (1, 1)
+    finally:
+        ctx.comm_destroy()
+    us = ctx.empty_launch_us(500)
+    assert 0.5 < us < 100.0

@@ -20,7 +20,7 @@ class Scene:
     """Host-side model of the reference's objects: key frames with their own descriptor matrices, points with ordered
     observation lists; builds the resident map incrementally and the flat arrays from scratch."""
 
-    def __init__(self, ctx, rs, synth, n_kf=6, n_points=600, seed=3):
+    def __init__(self, ctx, rs, synth, n_kf=6, n_points=600, seed=3, dup_pairs=False):
         self.ctx, self.rs = ctx, rs
         w = synth.make_ba_window(n_kf=n_kf, n_points=n_points, run_max=5, config_id=70 + seed)
         frame, mp = synth.make_match_scene(w, n_keypoints=500, kdtree_build=rs.kdtree_build, config_id=70 + seed)
@@ -29,6 +29,14 @@ class Scene:
         self.kf_pose, self.kf_desc, self.kf_kp, self.kf_handle = [], [], [], []
         obs_pt = np.repeat(np.arange(n_points), np.diff(w["obs_ptr"]))
         pool_of_obs = mp["desc_pool"][mp["obs_desc"]]                 # descriptor of every observation, CSR order
+        if dup_pairs:      # points 2k and 2k + 1 carry the SAME descriptors: they tie for every keypoint they both reach
+            for p in range(0, n_points - 1, 2):
+                a0, a1, b0, b1 = w["obs_ptr"][p], w["obs_ptr"][p + 1], w["obs_ptr"][p + 1], w["obs_ptr"][p + 2]
+                for j in range(b0, b1):
+                    pool_of_obs[j] = pool_of_obs[a0 + (j - b0) % (a1 - a0)]
+                if a1 - a0 > b1 - b0:      # same descriptor SET on both sides: cut the longer one down to the shorter's rows
+                    for j in range(a0, a1):
+                        pool_of_obs[j] = pool_of_obs[a0 + (j - a0) % (b1 - b0)]
         kp_index = np.zeros(len(obs_pt), np.int64)
         for k in range(n_kf):
             sel = np.flatnonzero(w["obs_cam"] == k)
