@@ -585,7 +585,7 @@ struct BaLayout {
     size_t bytes;                       // end of the common part (callers may carve more behind it)
     size_t acc_count, cam_stride, pts_block;
 };
-static BaLayout ba_layout(const BaDims& d, int ns, int max_iter, size_t n_ranks, size_t grp_bytes)
+static BaLayout ba_layout(const BaDims& d, int ns, int max_iter, size_t n_ranks, size_t grp_bytes, int srep = 1)
 {
     BaLayout L;
     const size_t n = (size_t)d.n, C = (size_t)d.C, P = (size_t)d.P, nb = (size_t)ns + 1;
@@ -598,7 +598,7 @@ static BaLayout ba_layout(const BaDims& d, int ns, int max_iter, size_t n_ranks,
     L.lamp = carve(sizeof(double) * ns * P * 3);
     L.Vc = carve(sizeof(double) * P * 6); L.Ukeep = carve(sizeof(double) * ((size_t)d.Cf * 36 + n + 1));
     L.cam_stride = (size_t)ns * n + (size_t)d.Cf * 36 + n;
-    L.acc_count = (size_t)ns * n * n + (size_t)BA_UREP * L.cam_stride + (1 + n_ranks) * (size_t)BA_NSLOT * BA_SLOT_STRIDE;
+    L.acc_count = (size_t)srep * ns * n * n + (size_t)BA_UREP * L.cam_stride + (1 + n_ranks) * (size_t)BA_NSLOT * BA_SLOT_STRIDE;
     L.acc = carve(sizeof(double) * L.acc_count);
     L.pts_block = (size_t)ns * BA_NSLOT * BA_SLOT_STRIDE;
     L.pts = carve(sizeof(double) * 2 * L.pts_block); L.dc = carve(sizeof(double) * ns * BA_DC_STRIDE(n));
@@ -612,16 +612,17 @@ static BaLayout ba_layout(const BaDims& d, int ns, int max_iter, size_t n_ranks,
     return L;
 }
 // pointers of round parity 0 (the double-buffered blocks are re-pointed per round); rank = this rank's gradient-max block
-static void ba_bind(BaBufs& b, char* ws, const BaLayout& L, const BaDims& d, int ns, int n_ranks, int rank)
+static void ba_bind(BaBufs& b, char* ws, const BaLayout& L, const BaDims& d, int ns, int n_ranks, int rank, int srep = 1)
 {
     const size_t n = (size_t)d.n;
     b.ns = ns;
+    b.srep = srep; b.s_rep_stride = (size_t)ns * n * n;
     b.Xc = (double*)(ws + L.Xc); b.Xp = (double*)(ws + L.Xp); b.prep = (double*)(ws + L.prep);
     b.slot = (int32_t*)(ws + L.slot); b.sc = (double*)(ws + L.sc); b.sp = (double*)(ws + L.sp);
     b.Vinv = (double*)(ws + L.Vinv); b.gp = (double*)(ws + L.gp); b.lamp = (double*)(ws + L.lamp);
     b.Vc = (double*)(ws + L.Vc); b.Ukeep = (double*)(ws + L.Ukeep);
     b.acc = (double*)(ws + L.acc); b.acc_count = L.acc_count;
-    b.S = b.acc; b.rhs = b.S + (size_t)ns * n * n; b.U = b.rhs + (size_t)ns * n; b.gc = b.U + (size_t)d.Cf * 36;
+    b.S = b.acc; b.rhs = b.S + (size_t)srep * ns * n * n; b.U = b.rhs + (size_t)ns * n; b.gc = b.U + (size_t)d.Cf * 36;
     b.cam_stride = L.cam_stride; b.scal = b.rhs + (size_t)BA_UREP * L.cam_stride;
     b.gmax_all = b.scal + (size_t)BA_NSLOT * BA_SLOT_STRIDE; b.gmax_blocks = n_ranks;
     b.gmax = b.gmax_all + (size_t)rank * BA_NSLOT * BA_SLOT_STRIDE;
@@ -723,7 +724,10 @@ static int ba_solve_once(rs_context* ctx, int n_cameras, int n_points, int n_obs
     }
     const size_t C = (size_t)d.C;
     const size_t n_ranks = rs_comm_active(ctx) ? (size_t)ctx->n_ranks : 1;
-    const BaLayout L = ba_layout(d, ns, opt.max_iter, n_ranks, use_mfma ? ba_group_bytes(d.P, d.Cf, d.M) : 16);
+    // replicas of S for K5's scatter: the plain local window only (MFMA K5 + LDS K7, one rank, vision only)
+    int srep = 1;
+    if (use_mfma && solve_lds && !in && !rs_comm_active(ctx)) srep = ctx->ba_s_replicas > 0 ? ctx->ba_s_replicas : BA_DEFAULT_SREP;
+    const BaLayout L = ba_layout(d, ns, opt.max_iter, n_ranks, use_mfma ? ba_group_bytes(d.P, d.Cf, d.M) : 16, srep);
     const size_t o_grp = L.grp, o_free = L.fre, pts_block = L.pts_block;
     const size_t o_big = L.bytes;
     const size_t big_bytes = align_up(in ? ba_inertial_bytes(N_in, in->n_factors, d.C) : (solve_big ? ba_big_bytes(d.n) : 16), 256);
@@ -736,7 +740,7 @@ static int ba_solve_once(rs_context* ctx, int n_cameras, int n_points, int n_obs
     BaBufs b;
     memset(&b.imu, 0, sizeof b.imu);
     b.obs_ptr = d_obs_ptr; b.obs_cam = d_obs_cam; b.obs_uv = (const float2*)d_obs_uv;
-    ba_bind(b, ws, L, d, ns, (int)n_ranks, rs_comm_active(ctx) ? ctx->rank : 0);
+    ba_bind(b, ws, L, d, ns, (int)n_ranks, rs_comm_active(ctx) ? ctx->rank : 0, srep);
     BaState* const st_base = b.st;
     double* const pts_base = b.pt_scal;
     BaSetOut* const set_base = b.set_out;

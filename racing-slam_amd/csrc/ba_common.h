@@ -18,6 +18,7 @@
 #define BA_UREP 8             // replicas of the camera-side accumulators (U, gc, rhs): workgroup w adds
                               // into replica w % 8, K7 folds them; cuts same-line atomic traffic 8x
 #define BA_MAX_LDS_N 126      // largest reduced system kept in LDS by K7
+#define BA_DEFAULT_SREP 1      // replicas of S on the local-window path (BaBufs::srep)
 #define BA_DEFAULT_SETS 3      // default number of speculative radii per round on the local-window path
 #define BA_MAXSETS 3          // speculative trust-region radii evaluated per round (see "Speculative radii" below)
 
@@ -94,6 +95,9 @@ struct BaBufs {
     const int32_t* obs_cam;   // [M]
     const float2* obs_uv;     // [M]
     const int32_t* obs_cs;    // [M] cam | (slot + 1) << 16, built by the landmark grouping (null on the generic path)
+    int srep;        // replicas of S that K5's workgroups scatter into (workgroup w adds into replica w % srep, K7 folds them):
+                     // the f64 atomics of ~250 workgroups into the ~730 lines of one S run at a fraction of the chip's atomic rate
+    size_t s_rep_stride;   // doubles per replica of S = ns * n * n
     int ns;          // speculative sets (1 .. BA_MAXSETS); state buffers rotate over ns + 1 slots:
                      // x lives in slot st.cur, the candidate of set s in slot (st.cur + 1 + s) % (ns + 1)
     double* Xc;      // [ns+1][C][6]
@@ -105,7 +109,7 @@ struct BaBufs {
     double* Vinv;    // [ns][P][6]  (xx xy xz yy yz zz)
     double* gp;      // [P][3]
     double* lamp;    // [ns][P][3]
-    // accumulators, contiguous for one all-reduce: S[ns][n*n] | BA_UREP x { rhs[ns][n] U[Cf*36] gc[n] } | scal | gmax
+    // accumulators, contiguous for one all-reduce: S[srep][ns][n*n] | BA_UREP x { rhs[ns][n] U[Cf*36] gc[n] } | scal | gmax
     double* acc;
     size_t acc_count;
     double* S; double* rhs; double* U; double* gc;   // S: set 0, set s at + s*n*n; rhs/U/gc: replica 0 (rhs of set s at

@@ -482,7 +482,7 @@ static __device__ __forceinline__ void ba_schur_body(const BaDims& d, const BaBu
     double* Mt = (double*)(gslot + 32);                       // [it_l][6] behind the slot table
     for (int set = 0; set < st.nact; set++) {
     const double radius = ba_set_radius(st, set);
-    double* const S_set = b.S + (size_t)set * d.n * d.n;
+    double* const S_set = b.S + (size_t)(blockIdx.x % (unsigned)b.srep) * b.s_rep_stride + (size_t)set * d.n * d.n;
     double* const rhs_set = rhs_rep + (size_t)set * d.n;
     double Li[6] = {0, 0, 0, 0, 0, 0}, I[6] = {0, 0, 0, 0, 0, 0}, Lc[6] = {0, 0, 0, 0, 0, 0};
     bool ok = false;

@@ -134,7 +134,10 @@ static __device__ __forceinline__ void ba_reduced_solve_lds_body(const BaDims& d
 #pragma unroll
         for (int q = 0; q < 4; q++) {
             const int ic = min(16 * tr[s] + lq + 4 * q, n - 1);
-            sv[s][q] = b.S[((size_t)set * n + kc) * n + ic];           // only k <= i is used: (k, i) is S's upper triangle
+            const double* sp = b.S + ((size_t)set * n + kc) * n + ic;   // only k <= i is used: (k, i) is S's upper triangle
+            double v = sp[0];
+            for (int r = 1; r < b.srep; r++) v += sp[(size_t)r * b.s_rep_stride];      // K5 scattered into srep replicas
+            sv[s][q] = v;
         }
     }
     __syncthreads();
