@@ -76,7 +76,8 @@ int rs_context_synchronize(rs_context* ctx);
  * back-substitution / candidate cost of a round as ONE launch (the latter's workgroups wait for the former's hand-off
  * words inside the launch, holding a CU each): 0 (default) when no other solve of this process is in flight (lower
  * latency for one session; several sessions on one GPU get more aggregate throughput from two launches), 1 never,
- * 2 wherever possible; same results.
+ * 2 wherever possible, 3 the WHOLE round — linearisation, reduced solve, back-substitution — as one launch wherever the
+ * window allows it (every workgroup resident at once: one item of landmarks per compute unit); same results.
  * "ba_handoff_timeout_us": how long (1 .. 1000000, default 4000) a workgroup of that fused launch waits for a hand-off
  * word before it gives up; a solve in which that happened is re-run once as separate launches from its untouched
  * inputs (rs_ba_get_stats [4] counts them) — the caller sees the same result either way.

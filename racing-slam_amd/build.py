@@ -28,6 +28,7 @@ SOURCES = [
     ("ba_imu.hip", ["-munsafe-fp-atomics"]),
     ("ba_schur.hip", ["-munsafe-fp-atomics"]),
     ("ba_update.hip", ["-munsafe-fp-atomics"]),
+    ("ba_round.hip", ["-munsafe-fp-atomics"]),
     ("map.hip", []),
     ("host.cpp", ["-ffp-contract=off"]),
     ("pose_graph.cpp", ["-ffp-contract=off"]),

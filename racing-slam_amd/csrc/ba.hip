@@ -60,6 +60,8 @@ static __device__ __forceinline__ void ba_init_body(const BaDims& d, const BaBuf
     if (tid == 0) {
         b.dbg[62] = 0ull;         // workgroups of ba_finalize that have finished (completion flag for the host)
         for (int k = BA_HAND; k <= BA_HAND_ERR; k++) b.dbg[k] = 0ull;     // K7 -> K8 hand-off words and their error counter (ba_backsub_body.h)
+        b.dbg[BA_SDONE] = 0ull;
+        b.dbg[37] = 0ull; b.dbg[38] = 0ull; b.dbg[26] = 0ull; b.dbg[27] = ~0ull; b.dbg[28] = 0ull; b.dbg[29] = ~0ull;
         BaState s;
         s.radius = opt.r0; s.decrease_factor = 2.0; s.x_cost = 0.0; s.initial_cost = 0.0;
         s.cam_scal[0] = s.cam_scal[1] = s.cam_scal[2] = s.cam_scal[3] = 0.0;
@@ -838,15 +840,28 @@ static int ba_solve_once(rs_context* ctx, int n_cameras, int n_points, int n_obs
     // and only while all of its workgroups are resident at once (one per CU: the launch carries K7's LDS): beyond that
     // K8's workgroups would run in several shifts behind the hand-off, and the launch of its own (many per CU) is faster
     b.hand_timeout = 100ull * (unsigned long long)ctx->ba_handoff_timeout_us;
-    const bool fuse78 = allow_fuse && (ctx->ba_fuse_mode == 2 || (ctx->ba_fuse_mode == 0 && in_flight.others == 0)) &&
-                        solve_lds && k8_lds && !in && !rs_comm_active(ctx) &&
+    // The whole round as ONE launch (ba_round.hip: K5's item workgroups become K8's after they have counted themselves for
+    // K7): the same conditions plus the MFMA K5 with its camera blocks in LDS, and again every workgroup resident at once.
+    const bool plain_window = allow_fuse && solve_lds && k8_lds && !in && !rs_comm_active(ctx);
+    // Measured (tools/round_stamps.py): 86 us per round against 43 + 45 as two launches — the round is a strict
+    // chain (linearise -> solve -> back-substitute), so keeping the workgroups resident buys the boundary and little else.
+    // It is therefore opt-in ("ba_fuse_mode" 3); the default stays K5, then K7 + K8 in one launch.
+    const bool fuse_round = plain_window && use_mfma && ctx->ba_fuse_mode == 3 &&
+                            ba_round_eligible(d) && ba_round_workgroups(d, b, grp) <= ctx->n_cu;
+    const bool fuse78 = !fuse_round && plain_window && (ctx->ba_fuse_mode >= 2 || (ctx->ba_fuse_mode == 0 && in_flight.others == 0)) &&
                         ba_solve_backsub_workgroups(d, b) <= ctx->n_cu;
+    if (fuse_round && ba_prepare_round(d) != 0) return rs_fail(ctx, RS_ERR_HIP, "LDS attribute (round)");
     auto enqueue_round = [&](int it) -> int {
         // double-buffered state / step-scalar blocks: round `it` works on [it & 1] and reads [(it + 1) & 1]
         b.st = st_base + (it & 1); b.st_prev = st_base + ((it + 1) & 1);
         b.pt_scal = pts_base + (size_t)(it & 1) * pts_block;
         b.pt_prev = pts_base + (size_t)((it + 1) & 1) * pts_block;
         b.set_out = set_base + (size_t)(it & 1) * BA_MAXSETS; b.set_prev = set_base + (size_t)((it + 1) & 1) * BA_MAXSETS;
+        if (fuse_round) {
+            rs_prof_scope ps(ctx, "K578_ba_round");
+            ba_launch_round(s, d, b, opt, grp, it);
+            return RS_OK;
+        }
         if (use_mfma) {
             rs_prof_scope ps(ctx, "K5_ba_schur_mfma");
             ba_launch_schur(s, d, b, opt, grp, it);

@@ -16,6 +16,10 @@
 #define BA_HAND 48
 #define BA_HAND_TAKEN 52
 #define BA_HAND_ERR 56
+// One launch per LM round (ba_round, ba_solve.hip): the item workgroups count themselves here when their part of the
+// linearisation — S, rhs, U, gc, cost and failure slots, all accumulated by memory-side atomics — is complete; the K7
+// workgroups wait for n_rounds * n_items.  A line of its own (the stamps use 0 - 15 and 32 - 43).
+#define BA_SDONE 24
 #define BA_HAND_TIMEOUT_TICKS 400000ull      // default: 4 ms of the 100 MHz wall clock (BaBufs::hand_timeout; rs_context_set_int
                                              // "ba_handoff_timeout_us"): a lost producer must not hang the GPU
 
@@ -46,8 +50,10 @@ __device__ __forceinline__ unsigned ba_hand_wait(const unsigned long long* hand,
 // taken them (BA_HAND_TAKEN); delta_c is read behind the set's BA_HAND word with L1-bypassing loads, and the candidate
 // cameras' blocks are formed here (K7 forms the same for the next round after it has published).
 template <bool FUSED>
+// st_in: the round's state where the caller holds it already (ba_round: the state block is being written by another
+// workgroup of the same launch); nullptr = read the state block.
 static __device__ __forceinline__ void ba_backsub_cost4_body(const BaDims& d, const BaBufs& b, const int vb, const int set,
-                                                            const size_t wg_index, const size_t wg_count)
+                                                            const size_t wg_index, const size_t wg_count, const BaState* st_in = nullptr)
 {
     extern __shared__ __attribute__((aligned(16))) double lds[];
     // ---- loads that depend on nothing but the landmark index go out first, together with the state block
@@ -77,7 +83,7 @@ static __device__ __forceinline__ void ba_backsub_cost4_body(const BaDims& d, co
         for (int k = 0; k < 6; k++) I[k] = b.Vinv[((size_t)set * d.P + p) * 6 + k];
     }
     K78_STAMP(b, 0);
-    const BaState st = *b.st;
+    const BaState st = st_in ? *st_in : *b.st;
     if (st.done) return;
     // K7 has consumed the accumulators: clear them for the next linearisation (no separate launch)
     const size_t gtid = wg_index * blockDim.x + threadIdx.x;

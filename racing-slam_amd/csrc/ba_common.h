@@ -437,12 +437,14 @@ __device__ __forceinline__ void ba_decide(const BaBufs& b, const BaOpt& opt, int
     }
 }
 
-// state of round `it` (called by all threads of the first kernel of the round; one barrier)
-__device__ __forceinline__ BaState ba_state_for_iteration(const BaBufs& b, const BaOpt& opt, int it, BaState* sh)
+// state of round `it` (called by all threads of a workgroup; one barrier).  Every workgroup recomputes the decision
+// from the previous round's (immutable) blocks; the OWNER also stores it as this round's state block, writes the trace
+// entries and tells the host.
+__device__ __forceinline__ BaState ba_round_state(const BaBufs& b, const BaOpt& opt, int it, BaState* sh, bool owner)
 {
     if (threadIdx.x < 64) {
-        ba_decide(b, opt, it, blockIdx.x == 0 ? b.trace : nullptr, sh);
-        if (threadIdx.x == 0 && blockIdx.x == 0) {
+        ba_decide(b, opt, it, owner ? b.trace : nullptr, sh);
+        if (threadIdx.x == 0 && owner) {
             *b.st = *sh;
             if (b.prog) {            // tell the host where the state machine is (pinned memory)
                 b.prog->iter = sh->iter;
@@ -454,6 +456,10 @@ __device__ __forceinline__ BaState ba_state_for_iteration(const BaBufs& b, const
     }
     __syncthreads();
     return *sh;
+}
+__device__ __forceinline__ BaState ba_state_for_iteration(const BaBufs& b, const BaOpt& opt, int it, BaState* sh)
+{
+    return ba_round_state(b, opt, it, sh, blockIdx.x == 0);
 }
 
 // radius and decrease factor of speculative set k, given the state's (set 0)
@@ -564,6 +570,11 @@ int ba_prepare_reduced_solve_lds(int n);
 void ba_launch_reduced_solve_lds(hipStream_t s, const BaDims& d, const BaBufs& b, const BaOpt& opt);
 int ba_solve_backsub_workgroups(const BaDims& d, const BaBufs& b);
 void ba_launch_solve_backsub(hipStream_t s, const BaDims& d, const BaBufs& b, const BaOpt& opt);   // K7 + K8 in one launch (ba_solve.hip)
+// ---- K5 + K7 + K8 of a round in one launch (ba_round.hip)
+bool ba_round_eligible(const BaDims& d);
+int ba_round_workgroups(const BaDims& d, const BaBufs& b, const BaGroup& g);
+int ba_prepare_round(const BaDims& d);
+void ba_launch_round(hipStream_t s, const BaDims& d, const BaBufs& b, const BaOpt& opt, const BaGroup& g, int it);
 // ---- back-substitution + candidate cost (ba_update.hip)
 size_t ba_backsub_lds_bytes(int C, int n);
 void ba_launch_backsub(hipStream_t s, const BaDims& d, const BaBufs& b);

@@ -1,0 +1,580 @@
+// ba_solve_body.h — the body of K7 (the reduced camera system of the local-window BA in one workgroup; see ba_solve.hip
+// for the layout and the roles), shared by the K7 / K7 + K8 kernels (ba_solve.hip) and by the one-launch-per-round kernel
+// (ba_round.hip).
+#pragma once
+#include "ba_common.h"
+#include "ba_backsub_body.h"
+
+#define K7_THREADS 512
+#define K7_TPW 6       // tiles per tile wave: 6 tile waves x 6 = the 36 lower-triangle tiles of a 128 x 128 matrix
+
+typedef __attribute__((ext_vector_type(4))) double d4;
+
+// broadcast one lane's double to the wave (lane is wave-uniform)
+__device__ __forceinline__ double readlane_f64(double v, int lane)
+{
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), lane);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
+    return __hiloint2double(hi, lo);
+}
+
+// 1/x from v_rcp_f64 + one Newton step
+__device__ __forceinline__ double fast_rcp(double x)
+{
+    double r = __builtin_amdgcn_rcp(x);
+    const double e = fma(-x, r, 1.0);
+    return fma(r, e, r);
+}
+
+
+// HANDOFF: this workgroup is a producer of the fused launch (ba_solve_backsub below).  It publishes two words per set
+// (ba_backsub_body.h): BA_HAND_TAKEN once the accumulators are in registers / LDS and the gradient test is done (K8 clears
+// them while the factorisation runs), and BA_HAND when delta_c — stored write-through (sc1) — is complete, or the solver
+// has failed.  Every exit past the common early-out publishes what the consumers wait for.
+// ROUND (implies HANDOFF): the workgroup is a K7 workgroup of ba_round (ba_round.hip, one launch per LM round).  It owns the
+// state block (set 0 decides the round and stores the state), waits until all `n_items` item workgroups of the launch have
+// counted themselves on BA_SDONE — their atomics into the accumulators are then performed — and reads the accumulators with
+// L1-bypassing loads (they were produced inside this launch).
+template <bool HANDOFF, bool ROUND = false>
+static __device__ __forceinline__ void ba_reduced_solve_lds_body(const BaDims& d, const BaBufs& b, const BaOpt& opt, const int it = 0,
+                                                                 const int n_items = 0)
+{
+    extern __shared__ __attribute__((aligned(16))) double sm[];
+    const int n = d.n, tid = threadIdx.x, nt = K7_THREADS;
+    const int set = blockIdx.x;                    // speculative radius evaluated by this workgroup (ba_common.h)
+    const int LD = n + 1 + ((n & 1) ? 1 : 0);     // odd row stride (n is a multiple of 6)
+    double* A = sm;                                // (n+1) x LD: published panels + rhs row n
+    double* lam = A + (size_t)(n + 1) * LD;        // [n] camera damping
+    double* xs = lam + n;                          // [n] solution
+    double* Minv = xs + n;                         // [n/6][36] inverses of the diagonal blocks of L
+    double* Us = Minv + 6 * n;                     // [Cf*36] U folded over the BA_UREP replicas
+    double* gcs = Us + 6 * n;                      // [n] gc folded
+    double* grs = gcs + n;                         // [n] gc + rhs folded: the reduced right-hand side
+    // MFMA operand panels of the current step, k-major: Pd[e][i] = F[i][e] d_e, Nf[e][i] = -F[i][e];
+    // rows e = 6, 7 stay zero (K = 6 padded to 8).  16-byte aligned.
+    double* Pd = sm + (((size_t)(n + 1) * LD + 17 * (size_t)n + 1) & ~(size_t)1);
+    double* Nf = Pd + 8 * 128;
+    __shared__ BaState st;
+    __shared__ int s_fail;
+    __shared__ double red[K7_THREADS / 64];
+    __shared__ double red3[K7_THREADS / 64][3];
+    BA_STAMP_DECL;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lr = lane & 15, lq = lane >> 4;
+    const int NTL = (n + 1 + 15) / 16;             // tile rows/cols
+    // Roles.  f64 MFMA and f64 VALU share one datapath per SIMD (measured: they do not overlap, neither
+    // within a wave nor between two waves of one SIMD), and waves w, w+4 of a workgroup land on the same
+    // SIMD.  So the latency chain of the factorisation (diagonal block -> panel -> next diagonal block)
+    // gets a SIMD of its own: waves 0 and 4 are the CHAIN waves (one matrix row per lane, 128 >= n+1-6
+    // rows), waves 1,2,3,5,6,7 are the TILE waves that keep the trailing matrix in MFMA accumulators.
+    const bool chain = (wave & 3) == 0;            // waves 0 and 4
+    const int tw = chain ? 0 : wave - 1 - (wave >> 2);     // tile wave index 0..5
+    // slot s of tile wave tw holds lower-triangle tile number t = 6 s + tw, tiles numbered row by row
+    int tr[K7_TPW], tc[K7_TPW];
+    bool tv[K7_TPW];
+#pragma unroll
+    for (int s = 0; s < K7_TPW; s++) {
+        const int t = 6 * s + tw;
+        int r = 0;
+#pragma unroll
+        for (int q = 1; q < 8; q++) r += (t >= q * (q + 1) / 2) ? 1 : 0;
+        tr[s] = r;
+        tc[s] = t - r * (r + 1) / 2;
+        tv[s] = !chain && r < NTL;
+    }
+
+    // accumulators: plain loads behind a kernel boundary, L1-bypassing ones when they were produced inside this launch
+    auto acc_ld = [&](const double* p) -> double { return ROUND ? ba_load_sc1(p) : *p; };
+    if (ROUND) {
+        // the round's decision (every workgroup of the launch computes the same; set 0 owns the state block), then the
+        // wait for the item workgroups: one lane polls, the others follow behind the barrier
+#if RS_STAMPS
+        if (tid == 0 && set == 0) b.dbg[45] = wall_clock64();
+#endif
+        if (tid == 0) s_fail = 0;
+        const BaState s0 = ba_round_state(b, opt, it, &st, set == 0);
+        if (s0.done || set >= s0.nact) return;
+        __shared__ unsigned s_lost;
+        if (tid == 0) {
+            const unsigned long long want = (unsigned long long)(unsigned)s0.n_rounds * (unsigned long long)n_items;
+            const unsigned long long t0 = wall_clock64();
+            unsigned lost = 0;
+            while (__hip_atomic_load(b.dbg + BA_SDONE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want) {
+                if (wall_clock64() - t0 > b.hand_timeout) { lost = 1; break; }
+                __builtin_amdgcn_s_sleep(2);
+            }
+            s_lost = lost;
+#if RS_STAMPS
+            if (set == 0) b.dbg[44] = wall_clock64();
+#endif
+        }
+        __syncthreads();
+        if (s_lost) {
+            // an item workgroup never arrived (not resident, or preempted): nothing can be solved.  Release the consumers
+            // ("solve over") and flag the launch; the host re-runs the solve as separate launches.
+            if (tid == 0) {
+                atomicAdd(b.dbg + BA_HAND_ERR, 1ull);
+                const unsigned long long w = ((unsigned long long)(unsigned)s0.n_rounds << 2) | 2ull;
+                __hip_atomic_store(b.dbg + BA_HAND_TAKEN + set, w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            return;
+        }
+    }
+    // ---- every global load of the prologue is issued here, up front, so that the ~1 us latencies of the
+    // state block, K5's slot sums, the Jacobi scale, the accumulator replicas and S overlap
+    if (!ROUND && tid == 0) { st = *b.st; s_fail = 0; }
+    double pre_cost = 0.0, pre_fail = 0.0, pre_gm = 0.0;
+    if (tid < 64) {
+        pre_cost = acc_ld(&b.scal[(size_t)tid * BA_SLOT_STRIDE + 0]);
+        pre_fail = acc_ld(&b.scal[(size_t)tid * BA_SLOT_STRIDE + 1 + set]);
+        for (int r = 0; r < b.gmax_blocks; r++)      // every rank's block (they arrive through the SUM all-reduce)
+            pre_gm = fmax(pre_gm, acc_ld(&b.gmax_all[((size_t)r * BA_NSLOT + tid) * BA_SLOT_STRIDE]));
+    }
+    const double pre_sc = tid < n ? b.sc[tid] : 1.0;                   // n <= 126: one entry per thread
+    double fold[2] = {0.0, 0.0}, keep[2] = {0.0, 0.0};                 // 8 n <= 1008 entries: two per thread
+    // replica layout: rhs[ns][n] U[Cf*36] gc[n]; this set's view of it is entry i < n -> its rhs, i >= n -> U | gc
+#pragma unroll
+    for (int h = 0; h < 2; h++) {
+        const int i = tid + h * nt;
+        if (i < 8 * n) {
+            const size_t addr = i < n ? (size_t)set * n + i : (size_t)(b.ns - 1) * n + i;
+#pragma unroll
+            for (int r = 0; r < BA_UREP; r++) fold[h] += acc_ld(&b.rhs[(size_t)r * b.cam_stride + addr]);
+            if (i >= n) keep[h] = b.Ukeep[i - n];                      // U | gc of the last fresh linearisation
+        }
+    }
+    // (Tried: S through LDS — all threads read the needed half of S with consecutive lanes on consecutive entries of a row
+    // into the panel area, the tile waves gather from there — 23 dependent-looking iterations and two more barriers: K7
+    // 37.9 -> 47.5 us.  The gather below keeps 24 independent loads per lane in flight.)
+    double sv[K7_TPW][4];                                              // tile waves: their entries of S
+#pragma unroll
+    for (int s = 0; s < K7_TPW; s++) {
+#pragma unroll
+        for (int q = 0; q < 4; q++) sv[s][q] = 0.0;
+        if (!tv[s]) continue;                                          // wave-uniform
+        const int kc = min(16 * tc[s] + lr, n - 1);
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const int ic = min(16 * tr[s] + lq + 4 * q, n - 1);
+            const double* sp = b.S + ((size_t)set * n + kc) * n + ic;   // only k <= i is used: (k, i) is S's upper triangle
+            double v = acc_ld(sp);
+            for (int r = 1; r < b.srep; r++) v += acc_ld(sp + (size_t)r * b.s_rep_stride);      // K5 scattered into srep replicas
+            sv[s][q] = v;
+        }
+    }
+    __syncthreads();
+    if (st.done || set >= st.nact) return;        // (the consumers of the fused launch take the same exit on the same state)
+#if RS_STAMPS
+    if (HANDOFF && tid == 0 && set == 0) b.dbg[42] = wall_clock64();
+#endif
+    const unsigned long long epoch = (unsigned long long)(unsigned)st.n_rounds << 2;
+    auto publish = [&](int word, unsigned long long code) {   // reached by every thread of the workgroup
+        if (HANDOFF) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // this wave's loads have arrived, its stores are done
+            __syncthreads();
+            if (tid == 0) {
+#if RS_STAMPS
+                if (set == 0) b.dbg[word == BA_HAND ? 40 : 43] = wall_clock64();
+#endif
+                __hip_atomic_store(b.dbg + word + set, epoch | code, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+    };
+    BA_STAMP(b, 2);
+    for (int i = tid; i < BA_NSLOT * BA_SLOT_STRIDE; i += nt) {                       // K8 of this round accumulates here
+        double* z = b.pt_scal + (size_t)set * BA_NSLOT * BA_SLOT_STRIDE + i;
+        // fused launch: K8's atomics execute at the memory side within this launch; a plain store would sit in this
+        // XCD's L2 until the kernel ends and then overwrite their sums.  Written through, and complete before publish().
+        if (HANDOFF) ba_store_sc1(z, 0.0);
+        else *z = 0.0;
+    }
+    for (int i = tid; i < 2 * 8 * 128; i += nt) Pd[i] = 0.0;
+    // fold the replicas of the camera-side accumulators (replica layout: rhs[n] U[Cf*36] gc[n])
+#pragma unroll
+    for (int h = 0; h < 2; h++) {
+        const int i = tid + h * nt;
+        if (i < 8 * n) {
+            // U and gc are only accumulated on fresh iterations (K5 skips its first pass after a rejected step)
+            const double v = (i < n || st.fresh) ? fold[h] : keep[h];
+            if (i >= n && st.fresh && set == 0) b.Ukeep[i - n] = v;
+            if (i < n) grs[i] = v;                         // rhs part
+            else if (i < n + 6 * n) Us[i - n] = v;
+            else gcs[i - 7 * n] = v;
+        }
+    }
+    __syncthreads();
+    for (int i = tid; i < n; i += nt) grs[i] += gcs[i];
+    // Jacobi scaling of the camera blocks (first iteration) and the LM damping
+    if (tid < n) {
+        const double h = Us[(tid / 6) * 36 + (tid % 6) * 7];
+        double sc = pre_sc;
+        if (!st.have_scale) {
+            sc = opt.jacobi ? 1.0 / (1.0 + sqrt(h)) : 1.0;
+            if (set == 0) b.sc[tid] = sc;
+        }
+        const double s2 = sc * sc;
+        lam[tid] = clampd(s2 * h, opt.dmin, opt.dmax) / (ba_set_radius(st, set) * s2);
+    }
+    BA_STAMP(b, 3);
+
+    // (1) fresh linearisation: cost at x, gradient test
+    const double fail_sum = wave_sum(pre_fail);          // only wave 0 holds real values
+    if (st.fresh) {
+        const double c = wave_sum(pre_cost);
+        const double gslots = wave_max_nonneg(pre_gm);
+        double gm = 0.0;
+        for (int i = tid; i < n; i += nt) gm = fmax(gm, fabs(gcs[i]));
+        gm = wave_max_nonneg(gm);
+        if ((tid & 63) == 0) red[tid >> 6] = gm;
+        __syncthreads();
+        if (tid == 0) {
+            st.x_cost = c;
+            if (st.iter == 0) st.initial_cost = st.x_cost;
+            double g = gslots;
+            for (int w = 0; w < nt / 64; w++) g = fmax(g, red[w]);
+            if (!isfinite(st.x_cost)) { st.done = 1; st.termination = RS_BA_FAILURE; }
+            else if (g <= opt.gtol) { st.done = 1; st.termination = RS_BA_CONVERGENCE_GRADIENT; }
+        }
+        __syncthreads();
+        if (st.done) { if (tid == 0 && set == 0) *b.st = st; publish(BA_HAND_TAKEN, 2ull); return; }      // every set reaches the same verdict
+    } else {
+        __syncthreads();
+    }
+    publish(BA_HAND_TAKEN, 0ull);      // the accumulators are in registers / LDS from here on: K8 may clear them
+    if (tid == 0 && fail_sum > 0.0) s_fail = 1;          // K5 saw a non-finite landmark block
+    BA_STAMP(b, 0);
+
+    const int NB = n / 6;
+    // (3) block L D L^T, one camera (6 columns) per step, two barriers per step.  The two roles run
+    // DIFFERENT loops with the same barrier count (s_barrier only counts arrivals), so neither role's
+    // registers are live in the other's code:
+    //   phase 1 (after barrier A: block column J is final in LDS)
+    //       chain: (a) factor + invert the 6x6 diagonal block (per lane, redundantly: no cross-lane traffic)
+    //              (b) one lane per row: F_i = row_i L^-T D^-1 -> LDS (factor panel + the MFMA operand panels)
+    //       tiles: rank-6 trailing update of step J-1 (operands in registers) on the live tiles, then
+    //              publish block column J+1 RAW (it has the updates of steps <= J-1)
+    //   phase 2 (after barrier B)
+    //       chain: apply step J's update to the 6 entries of block column J+1 of its row (36 FMAs), so
+    //              the next diagonal block never waits for the matrix cores
+    //       tiles: load the MFMA operands of step J
+    if (chain) {
+        BA_STAMP(b, 1);
+        const int crow = (wave >> 2) * 64 + lane;  // row slot 0..127 (n + 1 - 6 <= 121 rows)
+        __syncthreads();                           // block column 0 published by the tile waves
+        for (int J = 0; J < NB; J++) {
+            const int c0 = 6 * J, r0 = c0 + 6;
+            const int irow = r0 + crow;
+            const bool has_row = irow <= n;
+            if (wave != 0 && r0 + 64 > n) {        // wave 4 has no rows left: leave the SIMD to wave 0
+                __syncthreads();
+                __syncthreads();
+                continue;
+            }
+            double* row = A + min(irow, n) * LD + c0;
+            // loads first: the diagonal block and this lane's panel row (clamped address, no branch)
+            double L[6][6], rr[6];
+#pragma unroll
+            for (int a = 0; a < 6; a++)
+#pragma unroll
+                for (int e = 0; e <= a; e++) L[a][e] = A[(c0 + a) * LD + c0 + e];
+#pragma unroll
+            for (int e = 0; e < 6; e++) rr[e] = row[e];
+            // (a) L D L^T of the diagonal block
+            double dinv[6], dpiv[6], F[6];
+            bool fbad = false;
+#pragma unroll
+            for (int c = 0; c < 6; c++) {
+                const double piv = L[c][c];
+                if (!(piv > 0.0) || !isfinite(piv)) fbad = true;
+                const double rd = fast_rcp(piv);
+                dinv[c] = rd;
+                dpiv[c] = piv;
+                double lc[6];
+#pragma unroll
+                for (int a = c + 1; a < 6; a++) lc[a] = L[a][c] * rd;              // l_ac; L[a][c] still holds l_ac * d_c
+#pragma unroll
+                for (int a = c + 1; a < 6; a++)
+#pragma unroll
+                    for (int e = c + 1; e <= a; e++) L[a][e] -= lc[a] * L[e][c];   // a_ae -= l_ac d_c l_ec
+#pragma unroll
+                for (int a = c + 1; a < 6; a++) L[a][c] = lc[a];
+            }
+            // (b) panel row: t = row L^-T by forward substitution (unit lower L), F = t D^-1
+            {
+                double t[6];
+#pragma unroll
+                for (int r = 0; r < 6; r++) {
+                    double sacc = rr[r];
+#pragma unroll
+                    for (int e = 0; e < r; e++) sacc -= t[e] * L[r][e];
+                    t[r] = sacc;
+                }
+#pragma unroll
+                for (int r = 0; r < 6; r++) F[r] = t[r] * dinv[r];
+            }
+            if (has_row) {
+#pragma unroll
+                for (int r = 0; r < 6; r++) {
+                    row[r] = F[r];
+                    Nf[r * 128 + irow] = -F[r];
+                    Pd[r * 128 + irow] = F[r] * dpiv[r];
+                }
+            }
+            __syncthreads();                                               // barrier B
+            if (J + 1 < NB) {
+                // step J's update of block column J+1: A[i][r0+k] -= sum_e F_i[e] d_e F[r0+k][c0+e]
+                double* nxt = row + 6;
+                double x[6];
+#pragma unroll
+                for (int k = 0; k < 6; k++) x[k] = nxt[k];
+#pragma unroll
+                for (int e = 0; e < 6; e++) {
+                    const double2* g2 = reinterpret_cast<const double2*>(Pd + e * 128 + r0);
+                    const double2 g01 = g2[0], g23 = g2[1], g45 = g2[2];
+                    x[0] -= F[e] * g01.x; x[1] -= F[e] * g01.y;
+                    x[2] -= F[e] * g23.x; x[3] -= F[e] * g23.y;
+                    x[4] -= F[e] * g45.x; x[5] -= F[e] * g45.y;
+                }
+                if (has_row) {
+#pragma unroll
+                    for (int k = 0; k < 6; k++) nxt[k] = x[k];
+                }
+            }
+            if (tid == 63) {         // the unit-lower diagonal blocks, for the backward substitution
+#pragma unroll
+                for (int a = 1; a < 6; a++)
+#pragma unroll
+                    for (int e = 0; e < a; e++) Minv[J * 36 + a * 6 + e] = L[a][e];
+                if (fbad) s_fail = 1;
+            }
+            __syncthreads();                                               // barrier A of step J+1
+        }
+    } else {
+        // (2) the lower triangle + rhs row in the accumulator tiles: S (prefetched) + U + damping
+        d4 acc[K7_TPW];
+        double opA[K7_TPW][2], opB[K7_TPW][2];
+#pragma unroll
+        for (int s = 0; s < K7_TPW; s++) {
+            acc[s] = d4{0.0, 0.0, 0.0, 0.0};
+            opA[s][0] = opA[s][1] = opB[s][0] = opB[s][1] = 0.0;
+            if (!tv[s]) continue;                       // wave-uniform
+            const int k = 16 * tc[s] + lr;
+            if (tr[s] >= tc[s] + 2 && 16 * tr[s] + 15 < n) {
+                // a tile at least two tile rows below the diagonal and above the rhs row: |i - k| >= 17, so no
+                // camera block and no diagonal entry falls into it — it is S alone (wave-uniform shortcut)
+#pragma unroll
+                for (int q = 0; q < 4; q++) acc[s][q] = (k < n) ? sv[s][q] : 0.0;
+                continue;
+            }
+            const int kc = min(k, n - 1), kb = kc / 6;
+            const double gv = grs[kc];
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const int i = 16 * tr[s] + lq + 4 * q;
+                const int ic = min(i, n - 1);
+                const double uv = Us[kb * 36 + (kc - 6 * kb) * 6 + ic % 6];
+                double val = sv[s][q] + ((kb == ic / 6) ? uv : 0.0) + ((i == k) ? lam[ic] : 0.0);
+                val = (k < n && i < n && k <= i) ? val : ((i == n && k < n) ? gv : 0.0);
+                acc[s][q] = val;
+            }
+        }
+        // publish block column 0 (raw == final)
+#pragma unroll
+        for (int s = 0; s < K7_TPW; s++) {
+            if (!tv[s] || tc[s] != 0) continue;
+            const int k = lr;
+            if (k >= 6) continue;
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const int i = 16 * tr[s] + lq + 4 * q;
+                if (i >= k && i <= n) A[i * LD + k] = acc[s][q];
+            }
+        }
+        // loop-invariant publish addressing: LDS index of this lane's first entry of slot s and the
+        // mask of its 4 rows that lie in the stored lower triangle
+        int paddr[K7_TPW];
+        unsigned pmask[K7_TPW];
+#pragma unroll
+        for (int s = 0; s < K7_TPW; s++) {
+            const int k = 16 * tc[s] + lr;
+            paddr[s] = (16 * tr[s] + lq) * LD + k;
+            unsigned m = 0;
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const int i = 16 * tr[s] + lq + 4 * q;
+                m |= (i >= k && i <= n) ? (1u << q) : 0u;
+            }
+            pmask[s] = m;
+        }
+        const int LD4 = 4 * LD;
+        __syncthreads();
+        for (int J = 0; J < NB; J++) {
+            const int c0 = 6 * J, r0 = c0 + 6;
+            // phase 1: the odd slots' half of the trailing update of step J-1 (the even slots' half ran
+            // in phase 2 of step J-1, while the chain did its fix-up); live region: rows/cols >= c0
+            if (J > 0) {
+#pragma unroll
+                for (int s = 1; s < K7_TPW; s += 2) {
+                    if (!tv[s] || 16 * tc[s] + 15 < c0) continue;                  // wave-uniform
+                    acc[s] = __builtin_amdgcn_mfma_f64_16x16x4f64(opA[s][0], opB[s][0], acc[s], 0, 0, 0);
+                    acc[s] = __builtin_amdgcn_mfma_f64_16x16x4f64(opA[s][1], opB[s][1], acc[s], 0, 0, 0);
+                }
+            }
+            // publish block column J+1 raw (k in [r0, r0+6), rows i >= k) from the owning tiles
+            if (J + 1 < NB) {
+#pragma unroll
+                for (int s = 0; s < K7_TPW; s++) {
+                    if (!tv[s] || 16 * tc[s] + 15 < r0 || 16 * tc[s] >= r0 + 6) continue;   // wave-uniform
+                    const int k = 16 * tc[s] + lr;
+                    if (k < r0 || k >= r0 + 6) continue;
+#pragma unroll
+                    for (int q = 0; q < 4; q++)
+                        if (pmask[s] >> q & 1) A[paddr[s] + q * LD4] = acc[s][q];
+                }
+            }
+            __syncthreads();                                               // barrier B
+            if (J + 1 < NB) {
+                // operands of step J for the matrix cores.  No masks: rows that are already factored only
+                // put garbage into accumulator entries that are never read again.
+#pragma unroll
+                for (int s = 0; s < K7_TPW; s++) {
+                    if (!tv[s] || 16 * tc[s] + 15 < r0) continue;                  // wave-uniform
+#pragma unroll
+                    for (int kc = 0; kc < 2; kc++) {
+                        opA[s][kc] = Nf[(4 * kc + lq) * 128 + 16 * tr[s] + lr];
+                        opB[s][kc] = Pd[(4 * kc + lq) * 128 + 16 * tc[s] + lr];
+                    }
+                }
+                // phase 2: the even slots' half of the trailing update of step J
+#pragma unroll
+                for (int s = 0; s < K7_TPW; s += 2) {
+                    if (!tv[s] || 16 * tc[s] + 15 < r0) continue;                  // wave-uniform
+                    acc[s] = __builtin_amdgcn_mfma_f64_16x16x4f64(opA[s][0], opB[s][0], acc[s], 0, 0, 0);
+                    acc[s] = __builtin_amdgcn_mfma_f64_16x16x4f64(opA[s][1], opB[s][1], acc[s], 0, 0, 0);
+                }
+            }
+            __syncthreads();                                               // barrier A of step J+1
+        }
+    }
+    __syncthreads();
+    if (s_fail) {
+        if (tid == 0) {
+            if (set == 0) { st.solver_failed = 1; *b.st = st; }
+            else b.set_out[set].solver_failed = 1;
+        }
+        publish(BA_HAND, 1ull);
+        return;
+    }
+    // (4) backward substitution L^T x = y in ONE wave without block barriers: y (row n of the panels)
+    // lives in registers, two entries per lane; per block column the 6 entries of y_J are broadcast with
+    // v_readlane, every lane solves the 6x6 unit-lower block redundantly, and each lane updates its own
+    // entries with the panel column loaded ahead of the dependency chain.
+    if (wave == 0) {
+        const double* yrow = A + (size_t)n * LD;
+        double y0 = yrow[min(lane, n)], y1 = yrow[min(64 + lane, n)];
+        const int i0 = min(lane, n), i1 = min(64 + lane, n);
+        // One step.  Operands (the unit-lower diagonal block and this lane's two entries of the panel
+        // column) do not depend on the chain: the caller loads them one step ahead into the other register
+        // set (the loop is unrolled by two so that the sets never have to be copied).  The second entry
+        // (rows 64..) is only touched while the block column lies beyond row 64.
+#define K7_BS_LOAD(J_, L_, P0_, P1_)                                                                       \
+    {                                                                                                      \
+        const int jj_ = max((J_), 0), cc_ = 6 * jj_;                                                       \
+        _Pragma("unroll") for (int e = 1; e < 6; e++)                                                      \
+            _Pragma("unroll") for (int t = 0; t < e; t++) L_[e][t] = Minv[jj_ * 36 + e * 6 + t];           \
+        _Pragma("unroll") for (int e = 0; e < 6; e++) P0_[e] = A[(cc_ + e) * LD + i0];                     \
+        if (cc_ > 64) { _Pragma("unroll") for (int e = 0; e < 6; e++) P1_[e] = A[(cc_ + e) * LD + i1]; }   \
+    }
+#define K7_BS_STEP(J_, L_, P0_, P1_)                                                                       \
+    {                                                                                                      \
+        const int c0_ = 6 * (J_);                                                                          \
+        double x[6];                                                                                       \
+        _Pragma("unroll") for (int t = 5; t >= 0; t--) {                                                   \
+            const int idx = c0_ + t;                                                                       \
+            double sacc = readlane_f64(idx >= 64 ? y1 : y0, idx & 63);                                     \
+            _Pragma("unroll") for (int e = 5; e > t; e--) sacc -= L_[e][t] * x[e];                         \
+            x[t] = sacc;                                                                                   \
+        }                                                                                                  \
+        _Pragma("unroll") for (int e = 0; e < 6; e++) y0 -= P0_[e] * x[e];                                 \
+        if (c0_ > 64) { _Pragma("unroll") for (int e = 0; e < 6; e++) y1 -= P1_[e] * x[e]; }               \
+        if (lane == 0) { _Pragma("unroll") for (int t = 0; t < 6; t++) xs[c0_ + t] = x[t]; }               \
+    }
+        double La[6][6], Pa0[6], Pa1[6], Lb[6][6], Pb0[6], Pb1[6];
+        K7_BS_LOAD(NB - 1, La, Pa0, Pa1);
+        for (int J = NB - 1; J >= 0; J -= 2) {
+            K7_BS_LOAD(J - 1, Lb, Pb0, Pb1);
+            K7_BS_STEP(J, La, Pa0, Pa1);
+            if (J - 1 >= 0) {
+                K7_BS_LOAD(J - 2, La, Pa0, Pa1);
+                K7_BS_STEP(J - 1, Lb, Pb0, Pb1);
+            }
+        }
+#undef K7_BS_LOAD
+#undef K7_BS_STEP
+    }
+    __syncthreads();
+    BA_STAMP(b, 6);
+    double* dc_set = b.dc + (size_t)set * BA_DC_STRIDE(n);
+    if (HANDOFF) {
+        // delta_c leaves first, written through, and the set's word is published: K8's workgroups derive the candidate
+        // cameras and their blocks themselves (the same arithmetic as below) while this workgroup finishes its epilogue
+        int badi = 0;
+        for (int i = tid; i < n; i += nt) {
+            const double dlt = -xs[i];
+            if (!isfinite(dlt)) badi = 1;
+            ba_store_sc1(&dc_set[i], dlt);
+        }
+        publish(BA_HAND, __syncthreads_or(badi) ? 1ull : 0ull);
+    }
+    // (5) delta_c = -x, candidate cameras, camera part of the step scalars
+    double mcc = 0.0, ssq = 0.0, xsq = 0.0;
+    bool bad = false;
+    const double* Xc = b.Xc + (size_t)st.cur * d.C * 6;
+    const int cand = (st.cur + 1 + set) % (b.ns + 1);       // this set's candidate buffer
+    double* Xn = b.Xc + (size_t)cand * d.C * 6;
+    for (int c = tid; c < d.C; c += nt) {
+        const int s = b.slot[c];
+        bool active = false;
+        if (s >= 0)
+            for (int k = 0; k < 6; k++) active = active || Us[s * 36 + k * 7] > 0.0;
+        for (int k = 0; k < 6; k++) {
+            const double x = Xc[6 * c + k];
+            if (s >= 0) {
+                const double dlt = -xs[6 * s + k];
+                if (!isfinite(dlt)) bad = true;
+                mcc += 0.5 * (dlt * dlt * lam[6 * s + k] - dlt * gcs[6 * s + k]);
+                const double xn = x + dlt;
+                if (active) { ssq += (x - xn) * (x - xn); xsq += x * x; }
+                Xn[6 * c + k] = xn;
+                if (!HANDOFF) dc_set[6 * s + k] = dlt;
+            } else {
+                Xn[6 * c + k] = x;
+            }
+        }
+        cam_prepare(Xn + 6 * c, b.prep + ((size_t)cand * d.C + c) * BA_PREP);      // (for the next round's K5)
+    }
+    mcc = wave_sum(mcc); ssq = wave_sum(ssq); xsq = wave_sum(xsq);
+    if (__any(bad) && (tid & 63) == 0) s_fail = 1;
+    if ((tid & 63) == 0) { red3[tid >> 6][0] = mcc; red3[tid >> 6][1] = ssq; red3[tid >> 6][2] = xsq; }
+    __syncthreads();
+    if (tid == 0) {
+        double a0 = 0, a1 = 0, a2 = 0;
+        for (int w = 0; w < nt / 64; w++) { a0 += red3[w][0]; a1 += red3[w][1]; a2 += red3[w][2]; }
+        if (set == 0) {
+            st.cam_scal[0] = a0; st.cam_scal[1] = a1; st.cam_scal[2] = a2;
+            st.solver_failed = s_fail;
+            *b.st = st;
+        } else {
+            BaSetOut so;
+            so.cam_scal[0] = a0; so.cam_scal[1] = a1; so.cam_scal[2] = a2; so.cam_scal[3] = 0.0;
+            so.solver_failed = s_fail;
+#pragma unroll
+            for (int q = 0; q < 7; q++) so.pad[q] = 0;
+            b.set_out[set] = so;
+        }
+    }
+    BA_STAMP(b, 7);
+    BA_STAMP_FLUSH(b, 0);
+}
+

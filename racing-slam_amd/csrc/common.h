@@ -64,7 +64,8 @@ struct rs_context {
     // speculative trust-region radii per BA round (0 = library default; rs_context_set_int "ba_speculative_sets")
     int ba_sets = 0;
     int n_cu = 256;                     // compute units of the device
-    int ba_fuse_mode = 0;               // local-window BA: 0 = K7 + K8 in one launch when this is the only solve in flight, 1 = never, 2 = wherever possible
+    int ba_fuse_mode = 0;               // local-window BA: 0 = K7 + K8 in one launch when this is the only solve in flight, 1 = never,
+                                        // 2 = K7 + K8 in one launch wherever possible, 3 = the whole round (K5 + K7 + K8) wherever possible
     int k2_mode = 0;                    // rs_reproj_match: 0 = eight lanes per map point where the KD-tree fits in LDS, 1 = always one lane per point
     int ba_imu_mode = 0;                // inertial solves: 0 = z blocks eliminated around the LDS K7 where possible, 1 = always the N x N blocked solve
     int ba_batch_mode = 0;              // rs_bundle_adjust_batch: 0 = one grid for all windows where possible, 1 = lanes only

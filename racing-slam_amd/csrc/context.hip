@@ -92,7 +92,7 @@ extern "C" int rs_context_set_int(rs_context* ctx, const char* name, int value)
         return RS_OK;
     }
     if (strcmp(name, "ba_fuse_mode") == 0) {
-        if (value < 0 || value > 2) return rs_fail(ctx, RS_ERR_INVALID, "ba_fuse_mode must be 0 (solve + back-substitution in one launch when no other solve of the process is in flight), 1 (separate launches) or 2 (one launch wherever possible)");
+        if (value < 0 || value > 3) return rs_fail(ctx, RS_ERR_INVALID, "ba_fuse_mode must be 0 (solve + back-substitution in one launch when no other solve of the process is in flight), 1 (separate launches), 2 (solve + back-substitution in one launch wherever possible) or 3 (the whole round in one launch wherever possible)");
         ctx->ba_fuse_mode = value;
         return RS_OK;
     }

@@ -182,6 +182,41 @@ def test_bundle_adjust_lost_handoff_is_rerun_as_two_launches(ctx, oracle, synth)
     assert s4["usable"] == 1 and st4["handoff_retries"] == st3["handoff_retries"]
 
 
+@pytest.mark.parametrize("kw", [dict(), dict(n_kf=8, n_points=150, run_max=5, config_id=36, outlier_frac=0.1, rot_noise_deg=2.0),
+                                dict(n_kf=12, n_points=3000, run_max=8, config_id=19, outlier_frac=0.06),
+                                dict(n_kf=20, n_points=10120, config_id=3)])
+def test_bundle_adjust_round_in_one_launch(ctx, oracle, synth, kw):
+    """ba_fuse_mode 3: K5, K7 and K8 of a round as ONE launch (csrc/ba_round.hip) — the item workgroups count themselves for
+    K7 when their atomics are performed, K7 reads the accumulators with L1-bypassing loads, the same workgroups then
+    back-substitute their own landmarks behind K7's hand-off words.  Same per-iteration record as the oracle and as the
+    separate launches, results equal to summation-order level, and twelve runs all reproduce it (a stale read behind any
+    of the hand-offs would not).  The last case is the largest window that is resident at once (253 workgroups)."""
+    w = synth.make_ba_window(**kw)
+    _, _, os_, otr = oracle.bundle_adjust_trace(w["cams"], w["cam_free"], w["points"], w["obs_ptr"], w["obs_cam"], w["obs_uv"], w["K"])
+    runs = []
+    try:
+        for mode in (1,) + (3,) * 12:
+            ctx.set_int("ba_fuse_mode", mode)
+            dc, dp = ctx.dev(w["cams"]), ctx.dev(w["points"])
+            ctx.prof_begin()
+            s = ctx.bundle_adjust(dc, w["cam_free"], dp, ctx.dev(w["obs_ptr"]), ctx.dev(w["obs_cam"]), ctx.dev(w["obs_uv"]), w["K"])
+            prof = ctx.prof_end()
+            runs.append((s, ctx.ba_trace(), to_np(dc), to_np(dp), prof))
+    finally:
+        ctx.set_int("ba_fuse_mode", 0)
+    assert "K578_ba_round" in runs[1][4] and "K5_ba_schur_mfma" not in runs[1][4]
+    assert "K578_ba_round" not in runs[0][4]
+    s1, t1, c1, p1, _ = runs[0]
+    for s, tr, c, p, _ in runs:
+        assert (s["iterations"], s["successful_steps"], s["termination"], s["usable"]) == \
+               (os_["iterations"], os_["successful_steps"], os_["termination"], os_["usable"])
+        assert [t["outcome"] for t in tr] == [t["outcome"] for t in otr]
+        assert np.allclose([t["cost"] for t in tr], [t["cost"] for t in otr], rtol=1e-9)
+        assert np.isclose(s["final_cost"], s1["final_cost"], rtol=1e-10)
+        assert np.allclose(c, c1, rtol=1e-9, atol=1e-11) and np.allclose(p, p1, rtol=1e-9, atol=1e-10)
+    assert ctx.ba_stats()["handoff_retries"] == 0
+
+
 def _sharded_solve(rs, synth, w, shards, inertial=None, knobs=()):
     """n contexts on device 0 joined by rs_comm_init_local, one landmark shard each (see test_gpu_parity)."""
     import torch
