@@ -287,6 +287,18 @@ int rs_triangulate(rs_context* ctx,
                    float* d_xyz, uint8_t* d_keep,
                    int32_t* d_out_index, float* d_out_xyz, int32_t* d_out_count);
 
+/* The same function as the reference's callers see it — host vectors in, the TriangulatedPoint list out
+ * (src/Triangulation.h:24-37; called with ONE correspondence per call by Mapper::triangulate_tracks, src/Mapper.cpp:253,
+ * and with a handful by pose::recover_pose, src/PoseEstimation.cpp:48).  Up to 256 correspondences run as one launch of
+ * one workgroup whose inputs are kernel arguments / a pinned block and whose compacted result lands in pinned memory
+ * behind a completion flag: no staging copies, no stream synchronisation.  Larger n goes through the staging pool and
+ * rs_triangulate.  Results are bit-identical to rs_triangulate's.
+ *   h_uv1, h_uv2 [n][2];  h_out_index [n], h_out_xyz [n][3] (capacity n), *h_count = points kept. */
+int rs_triangulate_host(rs_context* ctx, const float* h_uv1, const float* h_uv2, int n,
+                        const float h_pose1[16], const float h_pose2[16], const float h_intrinsics[4],
+                        float min_parallax_cosine, float max_reprojection_error,
+                        int32_t* h_out_index, float* h_out_xyz, int* h_count);
+
 /* triangulate_points(frame1, frame2, matches, camera) (src/Triangulation.cpp:28-35) with
  * get_matching_points (:11-26) fused and the match list left on the device:
  * correspondence i = (d_kp1[d_match_train[i]], d_kp2[d_match_query[i]]) for

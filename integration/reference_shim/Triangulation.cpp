@@ -40,19 +40,16 @@ std::vector<TriangulatedPoint> triangulate_points(const std::vector<Eigen::Vecto
     pose_to_row_major(pose2, poses.data() + 16);
     float K[4];
     intrinsics(camera.get_intrinsic_matrix(), K);
-    Stage stage;
-    DevBuf<float> d1(uv1), d2(uv2), dp(poses), xyz(3 * n), oxyz(3 * n);
-    DevBuf<uint8_t> keep(n);
-    DevBuf<int32_t> oidx(n), cnt(1);
-    if (!ok(rs_triangulate(context(), d1.p, d2.p, (int)n, dp.p, 2, nullptr, nullptr, K, min_parallax_cosine, max_reprojection_error,
-                           xyz.p, keep.p, oidx.p, oxyz.p, cnt.p), "rs_triangulate"))
+    // host in, host out (rs_triangulate_host): up to 256 correspondences — Mapper::triangulate_tracks calls this with one —
+    // are a single launch whose result lands in pinned memory behind a completion flag
+    std::vector<int32_t> hi(n);
+    std::vector<float> hx(3 * n);
+    int m = 0;
+    if (!ok(rs_triangulate_host(context(), uv1.data(), uv2.data(), (int)n, poses.data(), poses.data() + 16, K, min_parallax_cosine,
+                                max_reprojection_error, hi.data(), hx.data(), &m), "rs_triangulate_host"))
         return {};
-    const auto hm = cnt.fetch(1);
-    const auto hi = oidx.fetch(n);
-    const auto hx = oxyz.fetch(3 * n);
-    stage.sync();
     std::vector<TriangulatedPoint> out;
-    for (int i = 0; i < hm[0]; i++) out.push_back(TriangulatedPoint{Eigen::Vector3f(hx[3 * i], hx[3 * i + 1], hx[3 * i + 2]), hi[i]});
+    for (int i = 0; i < m; i++) out.push_back(TriangulatedPoint{Eigen::Vector3f(hx[3 * i], hx[3 * i + 1], hx[3 * i + 2]), hi[i]});
     return out;
 }
 

@@ -75,6 +75,8 @@ struct rs_context {
     // proposal table of rs_reproj_match: persistent, always left at all-ones by the accept tail
     unsigned long long* prop = nullptr;
     size_t prop_cap = 0;
+    void* tri_pin = nullptr;            // pinned in / out block + completion flag of rs_triangulate_host's one-launch path
+    int tri_ticket = 0;
     void* k1_top = nullptr;             // [batch][nq] {best, second} packed keys of rs_match_descriptors; all-ones between calls
     size_t k1_top_cap = 0;
 };

@@ -65,6 +65,7 @@ extern "C" int rs_context_destroy(rs_context* ctx)
     if (ctx->prop) (void)hipFree(ctx->prop);
     if (ctx->k1_top) (void)hipFree(ctx->k1_top);
     if (ctx->pinned) (void)hipHostFree(ctx->pinned);
+    if (ctx->tri_pin) (void)hipHostFree(ctx->tri_pin);
     for (auto& s : ctx->prof)
         for (auto e : s.ev) (void)hipEventDestroy(e);
     delete ctx;

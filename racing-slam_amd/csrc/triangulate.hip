@@ -174,6 +174,113 @@ extern "C" int rs_triangulate(rs_context* ctx, const float* d_uv1, const float* 
                       d_out_xyz, d_out_count);
 }
 
+// ---------------------------------------------------------------------------------------- host in, host out
+// triangulate_points as the reference's callers see it: std::vectors in, std::vector out, and — in Mapper::triangulate_tracks
+// (src/Mapper.cpp:253) and pose::recover_pose (src/PoseEstimation.cpp:48) — a handful of correspondences per call.  Through
+// the staging pool such a call is 3 uploads + 2 launches + 3 downloads + a stream synchronisation (50 us for n = 1).  Up to
+// RS_TRI_SMALL correspondences take ONE launch of ONE workgroup instead: the two poses travel as kernel arguments, the
+// correspondences are read straight from a pinned host block, the kept points are written — compacted, in input order — into
+// that block, and the last instruction raises a completion flag the host spins on.  No copy launch, no hipStreamSynchronize.
+#define RS_TRI_SMALL 256
+struct TriPoses { float T1[16], T2[16]; };
+struct TriSmallOut { volatile int flag; int count; int pad[2]; int32_t index[RS_TRI_SMALL]; float xyz[RS_TRI_SMALL * 3]; };
+
+__global__ __launch_bounds__(RS_TRI_SMALL) void k4_small(const float2* __restrict__ uv /*pinned: [n] view 1, then [n] view 2*/, int n,
+                                                         float2 a0, float2 b0, TriPoses ps, TriParams prm, TriSmallOut* __restrict__ out, int ticket)
+{
+    const int i = threadIdx.x;
+    bool ok = false;
+    float X[3] = {0.f, 0.f, 0.f};
+    if (i < n) {
+        const float2 p1 = n == 1 ? a0 : uv[i], p2 = n == 1 ? b0 : uv[n + i];      // (a single correspondence is a kernel argument)
+        ok = dlt_one(p1, p2, ps.T1, ps.T2, prm, X);
+    }
+    int total;
+    const int off = rs_block_exclusive_scan(ok ? 1 : 0, &total);
+    if (ok) {
+        out->index[off] = i;
+        out->xyz[3 * off] = X[0]; out->xyz[3 * off + 1] = X[1]; out->xyz[3 * off + 2] = X[2];
+    }
+    if (i == 0) out->count = total;
+    __threadfence_system();
+    __syncthreads();
+    if (i == 0) out->flag = ticket;
+}
+
+extern "C" int rs_triangulate_host(rs_context* ctx, const float* h_uv1, const float* h_uv2, int n, const float h_pose1[16],
+                                   const float h_pose2[16], const float h_intrinsics[4], float min_parallax_cosine,
+                                   float max_reprojection_error, int32_t* h_out_index, float* h_out_xyz, int* h_count)
+{
+    if (!ctx || !h_count) return RS_ERR_INVALID;
+    *h_count = 0;
+    if (n < 0) return rs_fail(ctx, RS_ERR_INVALID, "negative n");
+    if (n == 0) return RS_OK;                                       // empty guard, src/Triangulation.cpp:46-48
+    if (!h_uv1 || !h_uv2 || !h_pose1 || !h_pose2 || !h_intrinsics || !h_out_index || !h_out_xyz) return rs_fail(ctx, RS_ERR_INVALID, "null pointer");
+    RS_HIP(ctx, hipSetDevice(ctx->device));
+    if (n > RS_TRI_SMALL) {
+        // a whole frame pair: staging pool + the grid kernels
+        int rc = rs_stage_begin(ctx);
+        if (rc) return rc;
+        float *d1 = nullptr, *d2 = nullptr, *dp = nullptr, *xyz = nullptr, *oxyz = nullptr;
+        uint8_t* keep = nullptr;
+        int32_t *oidx = nullptr, *cnt = nullptr;
+        float poses[32];
+        memcpy(poses, h_pose1, sizeof(float) * 16);
+        memcpy(poses + 16, h_pose2, sizeof(float) * 16);
+        const size_t N = (size_t)n;
+        if ((rc = rs_stage_upload(ctx, h_uv1, sizeof(float) * 2 * N, (void**)&d1))) return rc;
+        if ((rc = rs_stage_upload(ctx, h_uv2, sizeof(float) * 2 * N, (void**)&d2))) return rc;
+        if ((rc = rs_stage_upload(ctx, poses, sizeof poses, (void**)&dp))) return rc;
+        if ((rc = rs_stage_alloc(ctx, sizeof(float) * 3 * N, (void**)&xyz))) return rc;
+        if ((rc = rs_stage_alloc(ctx, sizeof(float) * 3 * N, (void**)&oxyz))) return rc;
+        if ((rc = rs_stage_alloc(ctx, N, (void**)&keep))) return rc;
+        if ((rc = rs_stage_alloc(ctx, sizeof(int32_t) * N, (void**)&oidx))) return rc;
+        if ((rc = rs_stage_alloc(ctx, sizeof(int32_t), (void**)&cnt))) return rc;
+        rc = rs_triangulate(ctx, d1, d2, n, dp, 2, nullptr, nullptr, h_intrinsics, min_parallax_cosine, max_reprojection_error, xyz, keep, oidx, oxyz, cnt);
+        if (rc) return rc;
+        int32_t m = 0;
+        if ((rc = rs_stage_download(ctx, cnt, sizeof(int32_t), &m))) return rc;
+        if ((rc = rs_stage_download(ctx, oidx, sizeof(int32_t) * N, h_out_index))) return rc;
+        if ((rc = rs_stage_download(ctx, oxyz, sizeof(float) * 3 * N, h_out_xyz))) return rc;
+        if ((rc = rs_stage_sync(ctx))) return rc;
+        *h_count = m;
+        return RS_OK;
+    }
+    if (!ctx->tri_pin) {
+        if (hipHostMalloc(&ctx->tri_pin, sizeof(TriSmallOut) + sizeof(float2) * 2 * RS_TRI_SMALL, hipHostMallocDefault) != hipSuccess)
+            return rs_fail(ctx, RS_ERR_NOMEM, "pinned block of the small triangulation");
+        ((TriSmallOut*)ctx->tri_pin)->flag = 0;
+    }
+    TriSmallOut* out = (TriSmallOut*)ctx->tri_pin;
+    float2* uv = (float2*)(out + 1);
+    TriPoses ps;
+    memcpy(ps.T1, h_pose1, sizeof ps.T1);
+    memcpy(ps.T2, h_pose2, sizeof ps.T2);
+    float2 a0 = make_float2(h_uv1[0], h_uv1[1]), b0 = make_float2(h_uv2[0], h_uv2[1]);
+    if (n > 1) {
+        memcpy(uv, h_uv1, sizeof(float2) * (size_t)n);
+        memcpy(uv + n, h_uv2, sizeof(float2) * (size_t)n);
+    }
+    const TriParams prm = {h_intrinsics[0], h_intrinsics[1], h_intrinsics[2], h_intrinsics[3], min_parallax_cosine, max_reprojection_error};
+    const int ticket = ++ctx->tri_ticket;
+    {
+        rs_prof_scope psx(ctx, "K4s_triangulate_small");
+        hipLaunchKernelGGL(k4_small, dim3(1), dim3(RS_TRI_SMALL), 0, ctx->stream, (const float2*)uv, n, a0, b0, ps, prm, out, ticket);
+    }
+    RS_HIP(ctx, hipGetLastError());
+    long spins = 0;
+    while (out->flag != ticket) {
+        if ((++spins & 0x3FFFF) == 0 && hipStreamQuery(ctx->stream) != hipErrorNotReady) break;      // the stream drained without the flag: a failed launch
+    }
+    if (out->flag != ticket) RS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (out->flag != ticket) return rs_fail(ctx, RS_ERR_HIP, "small triangulation did not complete");
+    const int m = out->count;
+    memcpy(h_out_index, out->index, sizeof(int32_t) * (size_t)m);
+    memcpy(h_out_xyz, out->xyz, sizeof(float) * 3 * (size_t)m);
+    *h_count = m;
+    return RS_OK;
+}
+
 extern "C" int rs_triangulate_matches(rs_context* ctx, const float* d_kp1, const float* d_kp2,
                                       const int32_t* d_match_train, const int32_t* d_match_query,
                                       const int32_t* d_n_matches, int max_matches, const float* d_poses,

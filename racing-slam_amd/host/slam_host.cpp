@@ -300,23 +300,16 @@ std::vector<TriangulatedPoint> triangulate_points(const std::vector<Vec2f>& poin
     if (points1.empty() || points2.empty()) return {};         // :46-48
     rs_context* ctx = Session::get().ctx();
     const size_t n = points1.size();
-    std::vector<float> uv1(2 * n), uv2(2 * n), poses(32);
-    for (size_t i = 0; i < n; i++) { uv1[2 * i] = points1[i].x; uv1[2 * i + 1] = points1[i].y; uv2[2 * i] = points2[i].x; uv2[2 * i + 1] = points2[i].y; }
-    std::memcpy(poses.data(), pose1.data(), 64);
-    std::memcpy(poses.data() + 16, pose2.data(), 64);
-    StageScope stage;
-    DevBuf<float> d1(uv1), d2(uv2), dp(poses), xyz(3 * n), oxyz(3 * n);
-    DevBuf<uint8_t> keep(n);
-    DevBuf<int32_t> oidx(n), cnt(1);
+    // host in, host out: Vec2f is two packed floats, so the vectors ARE the [n][2] arrays.  Up to 256 correspondences
+    // (Mapper::triangulate_tracks calls this with ONE) take a single launch with the result in pinned memory.
+    static_assert(sizeof(Vec2f) == 2 * sizeof(float), "Vec2f must be two packed floats");
+    std::vector<int32_t> hi(n);
+    std::vector<float> hx(3 * n);
+    int m = 0;
     const float K[4] = {camera.fx(), camera.fy(), camera.cx(), camera.cy()};
-    if (!rs_ok(rs_triangulate(ctx, d1.get(), d2.get(), (int)n, dp.get(), 2, nullptr, nullptr, K, min_parallax_cosine,
-                              max_reprojection_error, xyz.get(), keep.get(), oidx.get(), oxyz.get(), cnt.get()), "rs_triangulate"))
+    if (!rs_ok(rs_triangulate_host(ctx, &points1[0].x, &points2[0].x, (int)n, pose1.data(), pose2.data(), K, min_parallax_cosine,
+                                   max_reprojection_error, hi.data(), hx.data(), &m), "rs_triangulate_host"))
         return {};
-    const auto hm = cnt.fetch(1);
-    const auto hi = oidx.fetch(n);
-    const auto hx = oxyz.fetch(3 * n);
-    stage_sync();
-    const int m = hm[0];
     std::vector<TriangulatedPoint> out((size_t)m);
     for (int i = 0; i < m; i++) out[(size_t)i] = TriangulatedPoint{Vec3f{hx[3 * i], hx[3 * i + 1], hx[3 * i + 2]}, hi[(size_t)i]};
     return out;

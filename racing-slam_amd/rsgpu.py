@@ -17,7 +17,7 @@ EXPORTS = [
     "rs_context_synchronize", "rs_context_set_int", "rs_stage_begin", "rs_stage_alloc", "rs_stage_upload", "rs_stage_download", "rs_stage_sync", "rs_last_error", "rs_hamming_knn2", "rs_match_descriptors",
     "rs_kdtree_build", "rs_kdtree_pack", "rs_reproj_match", "rs_map_create", "rs_map_destroy", "rs_frame_create", "rs_frame_destroy",
     "rs_map_add_keyframe", "rs_map_set_keyframe_pose", "rs_map_add_point", "rs_map_set_position", "rs_map_remove_point",
-    "rs_map_add_observation", "rs_map_remove_observation", "rs_map_counts", "rs_map_get_positions", "rs_map_match", "rs_map_pose_graph", "rs_pose_graph", "rs_pose_relative", "rs_transform_points", "rs_map_bundle_adjust", "rs_triangulate", "rs_triangulate_matches", "rs_triangulate_matches_batch", "rs_triangulate_tracks", "rs_point_errors", "rs_ba_default_options",
+    "rs_map_add_observation", "rs_map_remove_observation", "rs_map_counts", "rs_map_get_positions", "rs_map_match", "rs_map_pose_graph", "rs_pose_graph", "rs_pose_relative", "rs_transform_points", "rs_map_bundle_adjust", "rs_triangulate", "rs_triangulate_host", "rs_triangulate_matches", "rs_triangulate_matches_batch", "rs_triangulate_tracks", "rs_point_errors", "rs_ba_default_options",
     "rs_bundle_adjust", "rs_bundle_adjust_batch", "rs_ba_get_trace", "rs_ba_get_stats", "rs_ba_get_cameras", "rs_reanchor_points", "rs_refine_pose", "rs_bundle_adjust_inertial", "rs_refine_pose_inertial", "rs_pack_pose", "rs_unpack_pose", "rs_pack_poses", "rs_unpack_poses", "rs_build_local_window",
     "rs_comm_get_unique_id", "rs_comm_init_rank", "rs_comm_destroy", "rs_comm_init_local", "rs_comm_count", "rs_prof_begin", "rs_prof_end", "rs_prof_counters", "rs_prof_empty_launch",
 ]
@@ -356,6 +356,21 @@ class Context:
                                             _dp(out["out_index"]), _dp(out["out_xyz"]), _dp(out["count"])),
                     "rs_triangulate")
         return out
+
+    def triangulate_host(self, uv1, uv2, pose1, pose2, K, min_parallax_cosine=0.9999, max_reproj=2.0):
+        """rs_triangulate_host: numpy in, (match_index [m], xyz [m][3]) out; one launch for n <= 256."""
+        a = np.ascontiguousarray(uv1, np.float32).reshape(-1, 2)
+        b = np.ascontiguousarray(uv2, np.float32).reshape(-1, 2)
+        n = len(a)
+        p1 = np.ascontiguousarray(pose1, np.float32).reshape(16)
+        p2 = np.ascontiguousarray(pose2, np.float32).reshape(16)
+        Kc = (C.c_float * 4)(*[float(v) for v in K])
+        idx, xyz = np.zeros(max(n, 1), np.int32), np.zeros((max(n, 1), 3), np.float32)
+        cnt = C.c_int(0)
+        vp = lambda x: x.ctypes.data_as(C.c_void_p)      # noqa: E731
+        self._check(self.lib.rs_triangulate_host(self.h, vp(a), vp(b), n, vp(p1), vp(p2), Kc, C.c_float(min_parallax_cosine),
+                                                 C.c_float(max_reproj), vp(idx), vp(xyz), C.byref(cnt)), "rs_triangulate_host")
+        return idx[:cnt.value].copy(), xyz[:cnt.value].copy()
 
     def triangulate_matches(self, d_kp1, d_kp2, d_mt, d_mq, d_cnt, max_matches, d_poses, K,
                             min_parallax_cosine=0.9999, max_reproj=2.0, out=None):

@@ -194,6 +194,7 @@ def test_bundle_adjust_round_in_one_launch(ctx, oracle, synth, kw):
     w = synth.make_ba_window(**kw)
     _, _, os_, otr = oracle.bundle_adjust_trace(w["cams"], w["cam_free"], w["points"], w["obs_ptr"], w["obs_cam"], w["obs_uv"], w["K"])
     runs = []
+    retries_before = ctx.ba_stats()["handoff_retries"]
     try:
         for mode in (1,) + (3,) * 12:
             ctx.set_int("ba_fuse_mode", mode)
@@ -214,7 +215,7 @@ def test_bundle_adjust_round_in_one_launch(ctx, oracle, synth, kw):
         assert np.allclose([t["cost"] for t in tr], [t["cost"] for t in otr], rtol=1e-9)
         assert np.isclose(s["final_cost"], s1["final_cost"], rtol=1e-10)
         assert np.allclose(c, c1, rtol=1e-9, atol=1e-11) and np.allclose(p, p1, rtol=1e-9, atol=1e-10)
-    assert ctx.ba_stats()["handoff_retries"] == 0
+    assert ctx.ba_stats()["handoff_retries"] == retries_before
 
 
 def _sharded_solve(rs, synth, w, shards, inertial=None, knobs=()):
@@ -339,3 +340,27 @@ def test_comm_count_and_empty_launch(ctx, rs):
         ctx.comm_destroy()
     us = ctx.empty_launch_us(500)
     assert 0.5 < us < 100.0
+
+
+@pytest.mark.parametrize("n", [1, 2, 7, 64, 255, 256, 257, 2000])
+def test_triangulate_host_fast_path(ctx, oracle, synth, n):
+    """VERDICT r2 #6a: triangulate_points as the reference's callers use it (host vectors in / out; ONE correspondence per
+    call in Mapper::triangulate_tracks, src/Mapper.cpp:253).  rs_triangulate_host runs n <= 256 as a single one-workgroup
+    launch with the result in pinned memory behind a completion flag, larger n through the staging pool; both must give
+    the oracle's list bit for bit (indices, f32 positions), for both gate settings, and repeated calls must not see a
+    previous call's flag or result."""
+    pr = synth.make_pair(2)
+    mq, mt = oracle.match_descriptors(pr["desc2"], pr["desc1"])
+    reps = max(1, -(-n // len(mq)))
+    uv1 = np.tile(pr["kp1"][mt], (reps, 1))[:n]
+    uv2 = np.tile(pr["kp2"][mq], (reps, 1))[:n]
+    uv2 = uv2 + (np.arange(n)[:, None] % 5 == 4) * np.float32(9.0)      # every fifth correspondence is wrong: gates reject some
+    for cos, err in ((0.9999, 2.0), (1.0, 4.0)):
+        ref = oracle.triangulate(uv1, uv2, pr["poses"], pr["K"], None, None, cos, err)
+        for _ in range(3):
+            idx, xyz = ctx.triangulate_host(uv1, uv2, pr["poses"][0], pr["poses"][1], pr["K"], cos, err)
+            assert np.array_equal(idx, ref["out_index"])
+            assert np.array_equal(xyz.view(np.uint32), ref["out_xyz"].view(np.uint32))
+    assert 0 < len(ref["out_index"]) or n < 5
+    idx, xyz = ctx.triangulate_host(uv1[:0], uv2[:0], pr["poses"][0], pr["poses"][1], pr["K"])
+    assert len(idx) == 0
