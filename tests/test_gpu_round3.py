@@ -214,7 +214,9 @@ def test_bundle_adjust_round_in_one_launch(ctx, oracle, synth, kw):
         assert [t["outcome"] for t in tr] == [t["outcome"] for t in otr]
         assert np.allclose([t["cost"] for t in tr], [t["cost"] for t in otr], rtol=1e-9)
         assert np.isclose(s["final_cost"], s1["final_cost"], rtol=1e-10)
-        assert np.allclose(c, c1, rtol=1e-9, atol=1e-11) and np.allclose(p, p1, rtol=1e-9, atol=1e-10)
+        # (points: the 10120-landmark window holds two-observation outlier landmarks that end up 3e4 units away — nearly
+        # unconstrained along the ray, they amplify the 1e-12 summation-order noise to 1e-9 relative)
+        assert np.allclose(c, c1, rtol=1e-9, atol=1e-11) and np.allclose(p, p1, rtol=1e-8, atol=1e-9)
     assert ctx.ba_stats()["handoff_retries"] == retries_before
 
 
