@@ -451,11 +451,12 @@ int rs_bundle_adjust(rs_context* ctx,
                      rs_ba_summary* h_summary);
 
 /* optimization::bundle_adjust (src/Optimization.cpp:269-374, vision-only) on the resident map: the window
- * (h_kfs [n_kfs] key-frame handles in FrameConfig order, h_free [n_kfs] = FrameConfig::optimize) is flattened from the
- * library's mirror, solved with rs_bundle_adjust, and on a usable solve the map takes the result.  The caller gets the
- * same for its own objects: h_out_poses [n_kfs][16] (unchanged rows for fixed key frames / unusable solves) and the
- * free points with their new positions (h_out_points / h_out_xyz, `capacity` entries; *h_n_points = how many there
- * were). */
+ * (h_kfs [n_kfs] key-frame handles in FrameConfig order, h_free [n_kfs] = FrameConfig::optimize) is flattened ON THE
+ * DEVICE from the resident image (three small kernels over the map's point slots), solved with rs_bundle_adjust, and on
+ * a usable solve the map — device image and mirror — takes the result.  The caller gets the same for its own objects:
+ * h_out_poses [n_kfs][16] (unchanged rows for fixed key frames / unusable solves) and the free points, in ascending
+ * slot order, with their new positions (h_out_points / h_out_xyz, `capacity` entries; *h_n_points = how many there
+ * were).  Free points: alive, >= 2 observations, matched by an optimised frame of the list (:287-302). */
 int rs_map_bundle_adjust(rs_context* ctx, rs_map* map, const int32_t* h_kfs, const uint8_t* h_free, int n_kfs,
                          const float h_intrinsics[4], const rs_ba_options* options, rs_ba_summary* h_summary,
                          float* h_out_poses, int32_t* h_out_points, float* h_out_xyz, int capacity, int* h_n_points);

@@ -50,6 +50,9 @@ struct rs_map {
     float* d_pos = nullptr; uint8_t* d_alive = nullptr; int32_t* d_obs_ptr = nullptr;
     int32_t* d_obs_kf = nullptr; int32_t* d_obs_desc = nullptr; float* d_centres = nullptr;
     uint8_t* d_pool = nullptr; uint8_t* d_elig = nullptr; uint8_t* d_flag = nullptr;
+    float* d_kp_pool = nullptr;                     // [pool rows][2] keypoints of the key frames, row for row with the descriptor pool
+    size_t cap_kp_pool = 0;
+    int32_t* d_win = nullptr; size_t cap_win = 0;   // scratch of rs_map_bundle_adjust: pid [P] | obs offset [P]
     size_t cap_points = 0, cap_obs = 0, cap_kf = 0, cap_pool_bytes = 0, pool_rows = 0, n_obs = 0;
     // scratch for match results
     int32_t* d_out = nullptr; size_t cap_out = 0;
@@ -100,7 +103,8 @@ extern "C" int rs_map_destroy(rs_map* m)
     (void)hipSetDevice(m->ctx->device);
     (void)hipStreamSynchronize(m->ctx->stream);
     for (void* p : {(void*)m->d_pos, (void*)m->d_alive, (void*)m->d_obs_ptr, (void*)m->d_obs_kf, (void*)m->d_obs_desc,
-                    (void*)m->d_centres, (void*)m->d_pool, (void*)m->d_elig, (void*)m->d_flag, (void*)m->d_out})
+                    (void*)m->d_centres, (void*)m->d_pool, (void*)m->d_elig, (void*)m->d_flag, (void*)m->d_out, (void*)m->d_kp_pool,
+                    (void*)m->d_win})
         if (p) (void)hipFree(p);
     delete m;
     return RS_OK;
@@ -168,7 +172,9 @@ extern "C" int rs_map_add_keyframe(rs_map* m, const rs_frame* f, const float h_p
     rs_context* ctx = m->ctx;
     RS_HIP(ctx, hipSetDevice(ctx->device));
     const size_t rows = m->pool_rows + (size_t)f->n;
-    const int rc = grow(ctx, &m->d_pool, &m->cap_pool_bytes, 32 * (rows > 0 ? rows : 1), 32 * m->pool_rows);   // keeps the rows already there
+    int rc = grow(ctx, &m->d_pool, &m->cap_pool_bytes, 32 * (rows > 0 ? rows : 1), 32 * m->pool_rows);   // keeps the rows already there
+    if (rc) return rc;
+    rc = grow(ctx, &m->d_kp_pool, &m->cap_kp_pool, 2 * (rows > 0 ? rows : 1), sizeof(float) * 2 * m->pool_rows);
     if (rc) return rc;
     MapKeyFrame k;
     k.n = f->n;
@@ -178,6 +184,8 @@ extern "C" int rs_map_add_keyframe(rs_map* m, const rs_frame* f, const float h_p
     k.kp_point.assign((size_t)f->n, -1);
     if (f->n > 0)
         RS_HIP(ctx, hipMemcpyAsync(m->d_pool + 32 * m->pool_rows, f->d_desc, 32 * (size_t)f->n, hipMemcpyDeviceToDevice, ctx->stream));
+    if (f->n > 0)
+        RS_HIP(ctx, hipMemcpyAsync(m->d_kp_pool + 2 * m->pool_rows, f->d_kp, sizeof(float) * 2 * (size_t)f->n, hipMemcpyDeviceToDevice, ctx->stream));
     m->pool_rows = rows;
     m->kfs.push_back(std::move(k));
     m->dirty_centres = true;
@@ -495,12 +503,95 @@ extern "C" int rs_map_match(rs_context* ctx, rs_map* m, rs_frame* f, const float
 }
 
 // ------------------------------------------------------------------------------------------------ local BA
-// optimization::bundle_adjust on the resident map (reference src/Optimization.cpp:269-374): the window's key frames
-// (h_kfs, with FrameConfig::optimize in h_free) are flattened from the mirror — no hash maps, no pointer chasing —
-// solved with rs_bundle_adjust, and on a usable solve the mirror and the device image take the result (poses of the
-// free key frames, positions of the free points).  The caller receives the same to update its own objects:
+// optimization::bundle_adjust on the resident map (reference src/Optimization.cpp:269-374).  The window's problem — free
+// points, observation CSR by landmark, observation pixels, f64 points — is built ON THE DEVICE from the resident image
+// (observation CSR by point, key-point pool): three small kernels over the map's point slots instead of three host passes
+// over 20 x 2000 key-point tables plus 1 MB of uploads.  The host packs the <= ~40 poses, reads back two counters, calls
+// rs_bundle_adjust, and on a usable solve a write-back kernel puts the positions into the device image while the mirror
+// and the caller get them through one download.
+//   free points      alive, >= 2 observations in the whole map, matched by an optimised frame of the list (:287-302), in
+//                    ascending SLOT order (the reference walks its frames' match tables; the set is the same, and the
+//                    order only decides f64 summation order);
+//   residual blocks  every listed frame x its matched free points (:304-315), CSR by point, frames in list order.
 //   h_out_poses [n_kfs][16]           (rows of fixed key frames are their unchanged poses)
-//   h_out_points [cap], h_out_xyz [cap][3], *h_n_points    the free points and their new positions
+//   h_out_points [cap], h_out_xyz [cap][3], *h_n_points    the free points (slots) and their new positions
+__global__ __launch_bounds__(256) void k_win_count(int P, const uint8_t* __restrict__ alive, const int32_t* __restrict__ obs_ptr,
+                                                   const int32_t* __restrict__ obs_kf, const int32_t* __restrict__ win_of_kf,
+                                                   int32_t* __restrict__ flag, int32_t* __restrict__ cnt)
+{
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= P) return;
+    const int o0 = obs_ptr[p], o1 = obs_ptr[p + 1];
+    int c = 0, fr = 0;
+    for (int o = o0; o < o1; o++) {
+        const int w = win_of_kf[obs_kf[o]];       // -1: not in the list; else list index | free << 16
+        if (w >= 0) { c++; fr |= w >> 16; }
+    }
+    const int f = (alive[p] != 0 && o1 - o0 >= 2 && fr) ? 1 : 0;
+    flag[p] = f;
+    cnt[p] = f ? c : 0;
+}
+
+// exclusive scans of flag -> pid and cnt -> obs offset in place, totals to h_tot (one workgroup; the map has 1e4 - 1e5 slots)
+__global__ __launch_bounds__(1024) void k_win_scan(int P, int32_t* __restrict__ flag, int32_t* __restrict__ cnt, int32_t* __restrict__ tot)
+{
+    __shared__ int carry[2];
+    if (threadIdx.x == 0) { carry[0] = 0; carry[1] = 0; }
+    __syncthreads();
+    for (int base = 0; base < P; base += 1024) {
+        const int i = base + (int)threadIdx.x;
+        const int f = i < P ? flag[i] : 0, c = i < P ? cnt[i] : 0;
+        int tf, tc;
+        const int of = rs_block_exclusive_scan(f, &tf);
+        const int oc = rs_block_exclusive_scan(c, &tc);
+        if (i < P) { flag[i] = f ? carry[0] + of : -1; cnt[i] = carry[1] + oc; }
+        __syncthreads();
+        if (threadIdx.x == 0) { carry[0] += tf; carry[1] += tc; }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) { tot[0] = carry[0]; tot[1] = carry[1]; }
+}
+
+__global__ __launch_bounds__(256) void k_win_fill(int P, int C, const int32_t* __restrict__ pid, const int32_t* __restrict__ off,
+                                                  const int32_t* __restrict__ obs_ptr, const int32_t* __restrict__ obs_kf,
+                                                  const int32_t* __restrict__ obs_desc, const int32_t* __restrict__ win_of_kf,
+                                                  const float* __restrict__ pos, const float2* __restrict__ kp_pool,
+                                                  double* __restrict__ pts, int32_t* __restrict__ list, int32_t* __restrict__ optr,
+                                                  int32_t* __restrict__ ocam, float2* __restrict__ ouv, int n_free, int n_obs)
+{
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p == 0) optr[n_free] = n_obs;
+    if (p >= P) return;
+    const int q = pid[p];
+    if (q < 0) return;
+    list[q] = p;
+#pragma unroll
+    for (int k = 0; k < 3; k++) pts[3 * (size_t)q + k] = (double)pos[3 * (size_t)p + k];
+    int w = off[p];
+    optr[q] = w;
+    const int o0 = obs_ptr[p], o1 = obs_ptr[p + 1];
+    // frames in LIST order (a point has at most one observation per key frame)
+    for (int c = 0; c < C; c++)
+        for (int o = o0; o < o1; o++) {
+            const int wk = win_of_kf[obs_kf[o]];
+            if (wk >= 0 && (wk & 0xFFFF) == c) { ocam[w] = c; ouv[w] = kp_pool[obs_desc[o]]; w++; }
+        }
+}
+
+__global__ __launch_bounds__(256) void k_win_writeback(int n_free, const int32_t* __restrict__ list, const double* __restrict__ pts,
+                                                       float* __restrict__ pos, float* __restrict__ oxyz)
+{
+    const int q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= n_free) return;
+    const int p = list[q];
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        const float v = (float)pts[3 * (size_t)q + k];                              // :369-372
+        pos[3 * (size_t)p + k] = v;
+        oxyz[3 * (size_t)q + k] = v;
+    }
+}
+
 extern "C" int rs_map_bundle_adjust(rs_context* ctx, rs_map* m, const int32_t* h_kfs, const uint8_t* h_free, int n_kfs,
                                     const float h_intrinsics[4], const rs_ba_options* options, rs_ba_summary* h_summary,
                                     float* h_out_poses, int32_t* h_out_points, float* h_out_xyz, int capacity, int* h_n_points)
@@ -508,78 +599,81 @@ extern "C" int rs_map_bundle_adjust(rs_context* ctx, rs_map* m, const int32_t* h
     if (!ctx || !m || m->ctx != ctx || !h_kfs || !h_free || n_kfs < 0 || !h_intrinsics || !h_summary || !h_n_points) return RS_ERR_INVALID;
     *h_n_points = 0;
     memset(h_summary, 0, sizeof *h_summary);
-    const size_t C = (size_t)n_kfs;
-    for (size_t c = 0; c < C; c++)
-        if (h_kfs[c] < 0 || h_kfs[c] >= (int)m->kfs.size()) return rs_fail(ctx, RS_ERR_INVALID, "unknown key frame");
-    // free points: matched by an optimised frame, >= 2 observations, in first-seen order (:287-302)
-    std::vector<int32_t> pid(m->alive.size(), -1), free_pts;
+    const size_t C = (size_t)n_kfs, KF = m->kfs.size(), P = m->alive.size();
+    if (C > 65535) return rs_fail(ctx, RS_ERR_UNSUPPORTED, "more than 65535 frames in a window");
+    std::vector<int32_t> win(KF ? KF : 1, -1);
     for (size_t c = 0; c < C; c++) {
-        if (!h_free[c]) continue;
-        for (int32_t p : m->kfs[(size_t)h_kfs[c]].kp_point)
-            if (p >= 0 && pid[(size_t)p] < 0 && m->obs[(size_t)p].size() >= 2) { pid[(size_t)p] = (int32_t)free_pts.size(); free_pts.push_back(p); }
+        if (h_kfs[c] < 0 || h_kfs[c] >= (int)KF) return rs_fail(ctx, RS_ERR_INVALID, "unknown key frame");
+        if (win[(size_t)h_kfs[c]] >= 0) return rs_fail(ctx, RS_ERR_INVALID, "key frame %d listed twice", h_kfs[c]);
+        win[(size_t)h_kfs[c]] = (int32_t)c | (h_free[c] ? 1 << 16 : 0);
     }
-    const size_t P = free_pts.size();
-    // residual blocks: every listed frame x its matched free points (:304-315), CSR by point in frame order
-    std::vector<int32_t> count(P + 1, 0);
-    for (size_t c = 0; c < C; c++)
-        for (int32_t p : m->kfs[(size_t)h_kfs[c]].kp_point)
-            if (p >= 0 && pid[(size_t)p] >= 0) count[(size_t)pid[(size_t)p] + 1]++;
-    std::vector<int32_t> obs_ptr(P + 1, 0);
-    for (size_t p = 0; p < P; p++) obs_ptr[p + 1] = obs_ptr[p] + count[p + 1];
-    const size_t M = (size_t)obs_ptr[P];
-    if (P == 0 || M == 0) { h_summary->termination = RS_BA_FAILURE; return RS_OK; }
-    std::vector<int32_t> obs_cam(M), cursor(obs_ptr.begin(), obs_ptr.end() - 1);
-    std::vector<float> obs_uv(2 * M);
-    for (size_t c = 0; c < C; c++) {
-        const MapKeyFrame& k = m->kfs[(size_t)h_kfs[c]];
-        for (int i = 0; i < k.n; i++) {
-            const int32_t p = k.kp_point[(size_t)i];
-            if (p < 0 || pid[(size_t)p] < 0) continue;
-            const size_t o = (size_t)cursor[(size_t)pid[(size_t)p]]++;
-            obs_cam[o] = (int32_t)c;
-            obs_uv[2 * o] = k.kp[2 * (size_t)i];
-            obs_uv[2 * o + 1] = k.kp[2 * (size_t)i + 1];
-        }
-    }
-    std::vector<double> cams(6 * C), pts(3 * P);
-    for (size_t c = 0; c < C; c++) rs_pack_pose(m->kfs[(size_t)h_kfs[c]].pose, &cams[6 * c]);
-    for (size_t p = 0; p < P; p++)
-        for (int k = 0; k < 3; k++) pts[3 * p + k] = (double)m->pos[3 * (size_t)free_pts[p] + k];
-    int rc = rs_stage_begin(ctx);
-    if (rc) return rc;
-    double *d_cams = nullptr, *d_pts = nullptr;
-    int32_t *d_ptr = nullptr, *d_cam = nullptr;
-    float* d_uv = nullptr;
-    if ((rc = rs_stage_upload(ctx, cams.data(), sizeof(double) * 6 * C, (void**)&d_cams))) return rc;
-    if ((rc = rs_stage_upload(ctx, pts.data(), sizeof(double) * 3 * P, (void**)&d_pts))) return rc;
-    if ((rc = rs_stage_upload(ctx, obs_ptr.data(), sizeof(int32_t) * (P + 1), (void**)&d_ptr))) return rc;
-    if ((rc = rs_stage_upload(ctx, obs_cam.data(), sizeof(int32_t) * M, (void**)&d_cam))) return rc;
-    if ((rc = rs_stage_upload(ctx, obs_uv.data(), sizeof(float) * 2 * M, (void**)&d_uv))) return rc;
-    rc = rs_bundle_adjust(ctx, (int)C, (int)P, (int)M, d_cams, h_free, d_pts, d_ptr, d_cam, d_uv, h_intrinsics, options, h_summary);
-    if (rc) return rc;
-    if (!h_summary->usable) {
+    auto keep_poses = [&]() {
         if (h_out_poses) for (size_t c = 0; c < C; c++) memcpy(h_out_poses + 16 * c, m->kfs[(size_t)h_kfs[c]].pose, sizeof(float) * 16);
-        return RS_OK;
+    };
+    if (P == 0 || C == 0) { h_summary->termination = RS_BA_FAILURE; keep_poses(); return RS_OK; }
+    RS_HIP(ctx, hipSetDevice(ctx->device));
+    int rc = map_sync_device(m);
+    if (rc) return rc;
+    size_t cw = m->cap_win;
+    rc = grow(ctx, &m->d_win, &cw, 2 * P + 2, 0);
+    if (rc) return rc;
+    m->cap_win = cw;
+    if ((rc = rs_stage_begin(ctx))) return rc;
+    hipStream_t s = ctx->stream;
+    int32_t* d_winkf = nullptr;
+    if ((rc = rs_stage_upload(ctx, win.data(), sizeof(int32_t) * win.size(), (void**)&d_winkf))) return rc;
+    int32_t *d_pid = m->d_win, *d_off = d_pid + P, *d_tot = d_off + P;
+    const int pb = (int)((P + 255) / 256);
+    {
+        rs_prof_scope ps(ctx, "K9_window_build");
+        hipLaunchKernelGGL(k_win_count, dim3(pb), dim3(256), 0, s, (int)P, m->d_alive, m->d_obs_ptr, m->d_obs_kf, d_winkf, d_pid, d_off);
+        hipLaunchKernelGGL(k_win_scan, dim3(1), dim3(1024), 0, s, (int)P, d_pid, d_off, d_tot);
     }
+    int32_t tot[2] = {0, 0};
+    if ((rc = rs_stage_download(ctx, d_tot, sizeof tot, tot))) return rc;
+    if ((rc = rs_stage_sync(ctx))) return rc;
+    const size_t Pf = (size_t)tot[0], M = (size_t)tot[1];
+    if (Pf == 0 || M == 0) { h_summary->termination = RS_BA_FAILURE; keep_poses(); return RS_OK; }
+    std::vector<double> cams(6 * C);
+    for (size_t c = 0; c < C; c++) rs_pack_pose(m->kfs[(size_t)h_kfs[c]].pose, &cams[6 * c]);
+    double *d_cams = nullptr, *d_pts = nullptr;
+    int32_t *d_ptr = nullptr, *d_cam = nullptr, *d_list = nullptr;
+    float *d_uv = nullptr, *d_oxyz = nullptr;
+    if ((rc = rs_stage_upload(ctx, cams.data(), sizeof(double) * 6 * C, (void**)&d_cams))) return rc;
+    if ((rc = rs_stage_alloc(ctx, sizeof(double) * 3 * Pf, (void**)&d_pts))) return rc;
+    if ((rc = rs_stage_alloc(ctx, sizeof(int32_t) * (Pf + 1), (void**)&d_ptr))) return rc;
+    if ((rc = rs_stage_alloc(ctx, sizeof(int32_t) * M, (void**)&d_cam))) return rc;
+    if ((rc = rs_stage_alloc(ctx, sizeof(float) * 2 * M, (void**)&d_uv))) return rc;
+    if ((rc = rs_stage_alloc(ctx, sizeof(int32_t) * Pf, (void**)&d_list))) return rc;
+    if ((rc = rs_stage_alloc(ctx, sizeof(float) * 3 * Pf, (void**)&d_oxyz))) return rc;
+    {
+        rs_prof_scope ps(ctx, "K9_window_build");
+        hipLaunchKernelGGL(k_win_fill, dim3(pb), dim3(256), 0, s, (int)P, (int)C, d_pid, d_off, m->d_obs_ptr, m->d_obs_kf, m->d_obs_desc, d_winkf,
+                           m->d_pos, (const float2*)m->d_kp_pool, d_pts, d_list, d_ptr, d_cam, (float2*)d_uv, (int)Pf, (int)M);
+    }
+    rc = rs_bundle_adjust(ctx, (int)C, (int)Pf, (int)M, d_cams, h_free, d_pts, d_ptr, d_cam, d_uv, h_intrinsics, options, h_summary);
+    if (rc) return rc;
+    if (!h_summary->usable) { keep_poses(); return RS_OK; }
     rc = rs_ba_get_cameras(ctx, cams.data(), (int)C);
     if (rc) return rc;
-    if ((rc = rs_stage_download(ctx, d_pts, sizeof(double) * 3 * P, pts.data()))) return rc;
+    hipLaunchKernelGGL(k_win_writeback, dim3((int)((Pf + 255) / 256)), dim3(256), 0, s, (int)Pf, d_list, d_pts, m->d_pos, d_oxyz);
+    std::vector<int32_t> list(Pf);
+    std::vector<float> xyz(3 * Pf);
+    if ((rc = rs_stage_download(ctx, d_list, sizeof(int32_t) * Pf, list.data()))) return rc;
+    if ((rc = rs_stage_download(ctx, d_oxyz, sizeof(float) * 3 * Pf, xyz.data()))) return rc;
     if ((rc = rs_stage_sync(ctx))) return rc;
     for (size_t c = 0; c < C; c++) {
         MapKeyFrame& k = m->kfs[(size_t)h_kfs[c]];
         if (h_free[c]) { rs_unpack_pose(&cams[6 * c], k.pose); m->dirty_centres = true; }     // :363-368
         if (h_out_poses) memcpy(h_out_poses + 16 * c, k.pose, sizeof(float) * 16);
     }
-    for (size_t p = 0; p < P; p++) {
-        float* x = &m->pos[3 * (size_t)free_pts[p]];
-        for (int k = 0; k < 3; k++) x[k] = (float)pts[3 * p + k];                            // :369-372
-        if ((int)p < capacity && h_out_points && h_out_xyz) {
-            h_out_points[p] = free_pts[p];
-            memcpy(h_out_xyz + 3 * p, x, sizeof(float) * 3);
-        }
+    for (size_t q = 0; q < Pf; q++) memcpy(&m->pos[3 * (size_t)list[q]], &xyz[3 * q], sizeof(float) * 3);   // the mirror follows the device image
+    const size_t nout = Pf < (size_t)(capacity > 0 ? capacity : 0) ? Pf : (size_t)(capacity > 0 ? capacity : 0);
+    if (h_out_points && h_out_xyz && nout) {
+        memcpy(h_out_points, list.data(), sizeof(int32_t) * nout);
+        memcpy(h_out_xyz, xyz.data(), sizeof(float) * 3 * nout);
     }
-    m->dirty_positions = true;
-    *h_n_points = (int)P;
+    *h_n_points = (int)Pf;
     return RS_OK;
 }
 

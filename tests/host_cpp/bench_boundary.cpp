@@ -51,6 +51,23 @@ static Stat measure(int reps, F&& fn)
     return Stat{t[t.size() / 2], t[t.size() / 10], t[(t.size() * 9) / 10]};
 }
 
+// the same with an untimed preparation step in front of every repetition
+template <class P, class F>
+static Stat measure_with_setup(int reps, P&& prep, F&& fn)
+{
+    prep(); fn();
+    prep(); fn();
+    std::vector<double> t;
+    for (int r = 0; r < reps; r++) {
+        prep();
+        const auto t0 = clk::now();
+        fn();
+        t.push_back(std::chrono::duration<double, std::micro>(clk::now() - t0).count());
+    }
+    std::sort(t.begin(), t.end());
+    return Stat{t[t.size() / 2], t[t.size() / 10], t[(t.size() * 9) / 10]};
+}
+
 int main(int argc, char** argv)
 {
     const int reps = argc > 1 ? std::atoi(argv[1]) : 30;
@@ -201,13 +218,32 @@ int main(int argc, char** argv)
         std::vector<float> outpose(16 * NKF), outxyz(3 * map.size());
         rs_ba_summary bs{};
         int npts = 0;
-        const Stat s_rb = measure(std::max(reps / 3, 5), [&] {
+        // (untimed: the perturbed poses and the positions are put back, and a match call brings the device image up to date —
+        // in a running system the map is in that state when Mapper::bundle_adjust is called)
+        const Stat s_rb = measure_with_setup(std::max(reps / 3, 5), [&] {
             for (int k = 0; k < NKF; k++) rs_map_set_keyframe_pose(rmap, kf_handle[(size_t)k], pert[(size_t)k].data());
             for (size_t i = 0; i < map.size(); i++) { const Vec3f& X = map[i].position(); const float xyz[3] = {X.x, X.y, X.z}; rs_map_set_position(rmap, (int)i, xyz); }
+            rs_map_match(ctx, rmap, fr, new_frame.pose().data(), K, W, H, kpm.data(), nullptr, 0, -1, nullptr, -1, 0, 64, mk.data(), mp.data(), &cnt);
+        }, [&] {
             rs_map_bundle_adjust(ctx, rmap, wk.data(), wf.data(), NKF, K, nullptr, &bs, outpose.data(), outp.data(), outxyz.data(), (int)map.size(), &npts);
         });
-        std::snprintf(ex, sizeof ex, "\"iterations\": %d, \"usable\": %d, \"free_points\": %d, \"note\": \"includes restoring 20 poses and all positions in the mirror\"",
-                      bs.iterations, bs.usable, npts);
+        // kernel time inside one call (HIP events per launch)
+        double kern_us = 0.0;
+        {
+            for (int k = 0; k < NKF; k++) rs_map_set_keyframe_pose(rmap, kf_handle[(size_t)k], pert[(size_t)k].data());
+            for (size_t i = 0; i < map.size(); i++) { const Vec3f& X = map[i].position(); const float xyz[3] = {X.x, X.y, X.z}; rs_map_set_position(rmap, (int)i, xyz); }
+            rs_map_match(ctx, rmap, fr, new_frame.pose().data(), K, W, H, kpm.data(), nullptr, 0, -1, nullptr, -1, 0, 64, mk.data(), mp.data(), &cnt);
+            rs_prof_begin(ctx);
+            rs_map_bundle_adjust(ctx, rmap, wk.data(), wf.data(), NKF, K, nullptr, &bs, outpose.data(), outp.data(), outxyz.data(), (int)map.size(), &npts);
+            rs_prof_entry pe[RS_PROF_MAX];
+            int np = 0;
+            rs_prof_end(ctx, pe, &np);
+            for (int q = 0; q < np; q++) kern_us += 1e3 * pe[q].total_ms;
+        }
+        int bstats[8] = {0};
+        rs_ba_get_stats(ctx, bstats);
+        std::snprintf(ex, sizeof ex, "\"iterations\": %d, \"usable\": %d, \"free_points\": %d, \"kernels_us\": %.1f, \"ba_rounds\": %d, \"note\": \"the call alone: window built on the device, solve, write-back into the device image, the mirror and the caller's arrays\"",
+                      bs.iterations, bs.usable, npts, kern_us, bstats[0]);
         add("bundle_adjust_resident", s_rb, ex);
         rs_frame_destroy(fr);
         rs_map_destroy(rmap);

@@ -179,7 +179,7 @@ def test_resident_map_incremental_updates(ctx, rs, oracle, synth):
 
 
 def test_resident_map_bundle_adjust_equals_flat_solve(ctx, rs, oracle, synth):
-    """rs_map_bundle_adjust flattens the window from the library's mirror; the flat problem built here from the python
+    """rs_map_bundle_adjust flattens the window on the device from the resident image; the flat problem built here from the python
     model is the same, so poses and points must agree to the last bits of the solver's own noise, and the map must
     carry the result afterwards (checked through a match against the flat path with the new state)."""
     sc = Scene(ctx, rs, synth, n_kf=7, n_points=500, seed=7)
@@ -204,6 +204,9 @@ def test_resident_map_bundle_adjust_equals_flat_solve(ctx, rs, oracle, synth):
                 p = kp_point[c][kp]
                 if p not in pid and len(sc.obs[p]) >= 2:
                     pid[p] = len(order); order.append(p)
+    # the library lists the free points in ascending slot order (the reference walks its frames' match tables: same set)
+    order = sorted(order)
+    pid = {p: i for i, p in enumerate(order)}
     per = [[] for _ in order]
     for c in range(7):
         for kp in sorted(kp_point[c]):
