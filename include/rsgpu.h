@@ -78,6 +78,10 @@ int rs_context_synchronize(rs_context* ctx);
  * latency for one session; several sessions on one GPU get more aggregate throughput from two launches), 1 never,
  * 2 wherever possible, 3 the WHOLE round — linearisation, reduced solve, back-substitution — as one launch wherever the
  * window allows it (every workgroup resident at once: one item of landmarks per compute unit); same results.
+ * "ba_band_mode": windows beyond the local-window kernels (more than 21 optimised cameras) — 0 (default) when no landmark is
+ * seen by key frames more than 9 slots apart the reduced camera matrix is block-banded and is factorised by ONE launch
+ * (the sparsity the reference's SPARSE_SCHUR solve exploits, src/Optimization.cpp:360), 1 always the general blocked
+ * factorisation (two launches per 48 columns); same results to rounding.
  * "ba_handoff_timeout_us": how long (1 .. 1000000, default 4000) a workgroup of that fused launch waits for a hand-off
  * word before it gives up; a solve in which that happened is re-run once as separate launches from its untouched
  * inputs (rs_ba_get_stats [4] counts them) — the caller sees the same result either way.

@@ -831,6 +831,22 @@ static int ba_solve_once(rs_context* ctx, int n_cameras, int n_points, int n_obs
         rc = ba_launch_grouping(ctx, d, b, grp);
         if (rc) return rc;
     }
+    // Blocked reduced solve: is S block-banded?  The grouping has just computed the largest camera span of a landmark; one
+    // word travels to the host (the solve is milliseconds: the wait costs a few per cent of one round) and decides between
+    // the one-launch banded factorisation and the general blocked one.  Sharded solves keep the general form: every rank
+    // must run the same arithmetic on the all-reduced system.
+    bool band = false;
+    if (solve_big && use_mfma && !in && !rs_comm_active(ctx) && ctx->ba_band_mode != 1) {
+        volatile int32_t* h_span = (volatile int32_t*)((char*)pin + pin_prog + 32);
+        *h_span = -1;
+        RS_HIP(ctx, hipMemcpyAsync((void*)h_span, grp.maxspan, sizeof(int32_t), hipMemcpyDeviceToHost, s));
+        long spins = 0;
+        while (*h_span < 0) {
+            if ((++spins & 0x3FFFF) == 0 && hipStreamQuery(s) != hipErrorNotReady) break;
+        }
+        if (*h_span < 0) RS_HIP(ctx, hipStreamSynchronize(s));
+        band = *h_span >= 0 && *h_span <= ba_band_max_span();
+    }
     // One ROUND = K5 + K7 + K8 and evaluates the next `ns` LM iterations of the sequential loop (all of them only if
     // the first ns - 1 are rejected).  At least ceil(max_iter / ns) rounds are needed and at most max_iter; beyond the
     // minimum the host follows the state machine through the progress word the first kernel of every round publishes
@@ -891,7 +907,7 @@ static int ba_solve_once(rs_context* ctx, int n_cameras, int n_points, int n_obs
             ba_launch_reduced_solve_lds(s, d, b, opt);
         } else if (solve_big) {
             rs_prof_scope ps(ctx, "K7_ba_reduced_solve_blocked");
-            int rc2 = ba_launch_reduced_solve_big(ctx, d, b, opt, ws + o_big);
+            int rc2 = ba_launch_reduced_solve_big(ctx, d, b, opt, ws + o_big, band);
             if (rc2) return rc2;
         } else {
             rs_prof_scope ps(ctx, "K7_ba_reduced_solve_global");

@@ -511,6 +511,7 @@ struct BaGroup {
     int n_items;
     int n_buckets;
     int it_l;               // landmarks per item (40 or 64)
+    int32_t* maxspan;       // [1] largest (last - first) free-camera slot of a landmark: the block bandwidth of S (behind the cursors)
 };
 
 
@@ -553,7 +554,8 @@ void ba_launch_schur(hipStream_t s, const BaDims& d, const BaBufs& b, const BaOp
 // ---- blocked reduced solve for n > BA_MAX_LDS_N (ba_solve_big.hip)
 struct rs_context;
 size_t ba_big_bytes(int n);
-int ba_launch_reduced_solve_big(rs_context* ctx, const BaDims& d, const BaBufs& b, const BaOpt& opt, char* ws);
+int ba_launch_reduced_solve_big(rs_context* ctx, const BaDims& d, const BaBufs& b, const BaOpt& opt, char* ws, bool band);
+int ba_band_max_span();
 // ---- inertial reduced solve (ba_solve_big.hip): N = 6 Cf + 9 Ci unknowns
 size_t ba_inertial_bytes(int N, int n_fac, int C);
 void ba_inertial_carve(char* ws, int N, int n_fac, int C, BaImu* imu, ImuFactorDev** d_fac, int32_t** d_inert);

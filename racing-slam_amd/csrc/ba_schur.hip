@@ -59,6 +59,7 @@ static __device__ __forceinline__ void ba_group_count_body(const BaDims& d, cons
         g.mask[2 * (size_t)p + 1] = m1;
         const int bk = last < 0 ? d.Cf * d.Cf : first * d.Cf + last;
         g.bucket[p] = bk;
+        if (last > first) atomicMax(g.maxspan, last - first);
         if (use_lds) atomicAdd(&lh[bk], 1); else atomicAdd(&hist[bk], 1);
     }
     __syncthreads();
@@ -205,7 +206,7 @@ size_t ba_group_bytes(int P, int Cf, int M)
 {
     const size_t nb = ((size_t)Cf * Cf + 2) * GRP_REP;
     const size_t ni = ((size_t)P + IT_L_SMALL - 1) / IT_L_SMALL + 1;
-    return 256 * 10 + sizeof(int32_t) * (2 * (size_t)P + 2 * nb + (size_t)M) + sizeof(int4) * (size_t)P +
+    return 256 * 10 + sizeof(int32_t) * (2 * (size_t)P + 2 * nb + 16 + (size_t)M) + sizeof(int4) * (size_t)P +
            sizeof(uint64_t) * (2 * (size_t)P + 2 * ni);
 }
 
@@ -238,6 +239,7 @@ __global__ __launch_bounds__(1024) void ba_group_small(BaDims d, BaBufs b, BaGro
         g.mask[2 * (size_t)p + 1] = m1;
         const int bk = last < 0 ? d.Cf * d.Cf : first * d.Cf + last;
         g.bucket[p] = bk;
+        if (last > first) atomicMax(g.maxspan, last - first);
         atomicAdd(&lh[bk], 1);
     }
     __syncthreads();
@@ -290,7 +292,7 @@ __global__ __launch_bounds__(1024) void ba_group_small(BaDims d, BaBufs b, BaGro
 void ba_group_zero_range(const BaGroup& g, int32_t** ptr, int* count)
 {
     *ptr = g.hist;          // the histogram and, behind it, the cursors (ba_group_scatter_scan counts from zero)
-    *count = (int)(g.cursor - g.hist) + (g.n_buckets + 1) * GRP_REP;
+    *count = (int)(g.maxspan - g.hist) + 1;      // histogram, cursors and the span word behind them
 }
 
 static size_t al256(size_t v) { return (v + 255) & ~(size_t)255; }
@@ -305,7 +307,8 @@ void ba_group_carve(char* base, int P, int Cf, int M, BaGroup* g)
     g->sorted = (int32_t*)(base + off); off += al256(sizeof(int32_t) * P);
     g->bucket = (int32_t*)(base + off); off += al256(sizeof(int32_t) * P);
     g->hist = (int32_t*)(base + off); off += al256(sizeof(int32_t) * nb);
-    g->cursor = (int32_t*)(base + off); off += al256(sizeof(int32_t) * nb);
+    g->cursor = (int32_t*)(base + off); off += al256(sizeof(int32_t) * (nb + 16));
+    g->maxspan = g->cursor + nb;
     g->mask = (uint64_t*)(base + off); off += al256(sizeof(uint64_t) * 2 * P);
     g->item_mask = (uint64_t*)(base + off); off += al256(sizeof(uint64_t) * 2 * ni_max);
     g->lm = (int4*)(base + off); off += al256(sizeof(int4) * P);

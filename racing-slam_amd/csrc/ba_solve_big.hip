@@ -449,6 +449,296 @@ __global__ __launch_bounds__(256) void ba_big_update(BaDims d, BaBufs b, BigBufs
     }
 }
 
+// ------------------------------------------------------------------ banded factorisation (one launch)
+// A window whose landmarks are each seen by key frames at most `span` apart gives a BLOCK-BANDED reduced matrix: S(i, j) = 0
+// for cameras more than `span` slots apart (a local map: every landmark lives for a few key frames; cfg 5: span 9, i.e. a
+// bandwidth of 59 columns of the 588).  This is the sparsity the reference's SPARSE_SCHUR solve exploits through Eigen's sparse
+// Cholesky (src/Optimization.cpp:360).  With 64-column blocks and a bandwidth of at most 64 columns only ONE sub-diagonal
+// block per block column is non-zero and L D L^T creates no fill outside the band, so the whole factorisation runs in ONE
+// workgroup on a window in LDS —
+//     rows 0..63   D = A[J][J]        rows 64..127  P = A[J+1][J]       row 128  the right-hand side's entries of block J
+//     T = A[J+1][J+1],  the right-hand side's entries of block J+1
+// — per block: the 129-row panel is factored as four 16-column sub-blocks exactly as ba_big_diag does (wave 0: the 16 x 16
+// diagonal sub-block in registers; one lane per row below: forward substitution; all threads: rank-16 update of the panel's
+// remaining columns), which leaves L_JJ, D_J, the multipliers L_{J+1,J} and D^-1 L^-1 g in place; then T -= L_P D L_P^T on
+// the matrix cores, the factor's blocks go to memory for the backward substitution, T becomes the next D, and the next P / T
+// (prefetched into registers at the start of the step: they are original entries of S — nothing outside the band ever
+// updates them) move in.  10 block steps at n = 588 instead of 13 + 12 dependent launches.
+#define WB 64
+#define WBS 65
+#define WROWS (2 * WB + 1)
+#define WTILES ((WROWS + 15) / 16)          // row tiles of the panel (9)
+// barrier for LDS traffic only: __syncthreads() also waits for every global access in flight (vmcnt), which would serialise
+// the prefetch of the next blocks and the stores of the factor with the factorisation
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+__global__ __launch_bounds__(1024) void ba_band_factor(BaDims d, BaBufs b, BigBufs g)
+{
+    if (b.st->done) return;
+    extern __shared__ __attribute__((aligned(16))) double wl[];
+    double* Pm = wl;                               // [WROWS][WBS] the tall panel of block column J
+    double* Tm = Pm + WROWS * WBS;                 // [WB][WBS] A[J+1][J+1]
+    double* yP = Tm + WB * WBS;                    // [WB] right-hand side, block J+1
+    double* Tt = yP + WB;                          // [16 WTILES][17] T = R L^-T of the current sub-block, by row below
+    double* Mi = Tt + 16 * WTILES * 17;            // [16][17] inverse of the sub-block's unit-lower L
+    double* rdl = Mi + 16 * 17;                    // [16] 1 / d of the current sub-block
+    double* dvl = rdl + 16;                        // [WB] d of the block
+    const int n = d.n, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int lr = lane & 15, lk = lane >> 4;
+    const int NBLK = (n + WB - 1) / WB;
+#if RS_STAMPS
+    unsigned long long tq = wall_clock64(), acc_t[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#define BAND_STAMP(i) do { if (tid == 0) { const unsigned long long t_ = wall_clock64(); acc_t[i] += t_ - tq; tq = t_; } } while (0)
+#else
+#define BAND_STAMP(i) do { } while (0)
+#endif
+    if (tid < WB) dvl[tid] = 1.0;
+    // block 0: D, P, T, right-hand sides from memory; identity padding beyond the matrix
+    {
+        const int w0 = min(WB, n), hp0 = max(0, min(WB, n - WB));
+        for (int idx = tid; idx < WB * WB; idx += 1024) {
+            const int r = idx / WB, k = idx % WB;
+            Pm[r * WBS + k] = (r < w0 && k < w0) ? b.S[(size_t)r * n + k] : (r == k ? 1.0 : 0.0);
+            Pm[(WB + r) * WBS + k] = (r < hp0 && k < w0) ? b.S[(size_t)(WB + r) * n + k] : 0.0;
+            Tm[r * WBS + k] = (r < hp0 && k < hp0) ? b.S[(size_t)(WB + r) * n + WB + k] : (r == k ? 1.0 : 0.0);
+        }
+        if (tid < WB) { Pm[2 * WB * WBS + tid] = tid < w0 ? b.dc[tid] : 0.0; yP[tid] = tid < hp0 ? b.dc[WB + tid] : 0.0; }
+    }
+    bool bad = false;
+    for (int J = 0; J < NBLK; J++) {
+        const int c0 = WB * J, w = min(WB, n - c0);
+        const int r1 = c0 + WB, hp = max(0, min(WB, n - r1));          // rows of block J+1
+        const int r2 = r1 + WB, hq = max(0, min(WB, n - r2));          // rows of block J+2 (the P of the next step)
+        // the NEXT step's P (A[J+2][J+1]), T (A[J+2][J+2]) and right-hand side go out now and land in registers under the
+        // factorisation (original entries of S: nothing outside the band ever updates them)
+        // (clamped addresses, masks applied when the values are placed: a conditional load is waited for on the spot)
+        double nP[4], nT[4], nY;
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const int idx = tid + 1024 * u, r = idx / WB, k = idx % WB;
+            const size_t rowa = (size_t)min(r2 + r, n - 1) * n;
+            nP[u] = b.S[rowa + min(r1 + k, n - 1)];
+            nT[u] = b.S[rowa + min(r2 + k, n - 1)];
+        }
+        nY = b.dc[min(r2 + (tid & (WB - 1)), n - 1)];
+        lds_barrier();
+        BAND_STAMP(0);
+        // ---- factor the panel: four 16-column sub-blocks
+        for (int c = 0; c < w; c += 16) {
+            if (wave == 0) {
+                // A: the 16 x 16 diagonal sub-block in registers (lane = row; pivots and column entries by v_readlane)
+                int r = lr;
+                double a[16];
+#pragma unroll
+                for (int k = 0; k < 16; k++) a[k] = Pm[(c + r) * WBS + c + k];
+                double my_rd = 1.0, my_piv = 1.0;
+#pragma unroll
+                for (int cc = 0; cc < 16; cc++) {
+                    asm volatile("" : "+v"(r));
+                    const double piv = rl64(a[cc], cc);
+                    bad = bad || !(piv > 0.0) || !isfinite(piv);
+                    const double rd = rcp_nr(piv);
+                    const double lc = a[cc] * rd;
+#pragma unroll
+                    for (int k = cc + 1; k < 16; k++) a[k] -= lc * rl64(a[cc], k);
+                    a[cc] = r > cc ? lc : a[cc];
+                    my_rd = r == cc ? rd : my_rd;
+                    my_piv = r == cc ? piv : my_piv;
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                if (lane < 16) {
+#pragma unroll
+                    for (int k = 0; k < 16; k++) Pm[(c + r) * WBS + c + k] = a[k];      // multipliers below the diagonal, d on it
+                    rdl[r] = my_rd;
+                    dvl[c + r] = my_piv;
+                }
+                // A': row r of M = L^-1 (unit lower) by lane r: m_rj = -sum_{k > j} m_rk l_kj for j < r.  L is read back from the
+                // panel image just written — the same address in every lane, i.e. LDS broadcasts — with two partial sums per
+                // entry (as v_readlane broadcasts from the lanes' registers the 120 column entries cost 2.5 us per sub-block).
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                if (lane < 16) {
+                    double m[16];
+#pragma unroll
+                    for (int k = 0; k < 16; k++) m[k] = (k == r) ? 1.0 : 0.0;
+#pragma unroll
+                    for (int jj = 14; jj >= 0; jj--) {
+                        asm volatile("" : "+v"(r));
+                        double s0 = 0.0, s1 = 0.0;
+#pragma unroll
+                        for (int k = jj + 1; k < 16; k += 2) {
+                            s0 -= m[k] * Pm[(c + k) * WBS + c + jj];             // m[k] = 0 beyond the row's diagonal
+                            if (k + 1 < 16) s1 -= m[k + 1] * Pm[(c + k + 1) * WBS + c + jj];
+                        }
+                        m[jj] = jj < r ? s0 + s1 : m[jj];
+                    }
+#pragma unroll
+                    for (int k = 0; k < 16; k++) Mi[r * 17 + k] = m[k];
+                }
+            }
+            lds_barrier();
+            BAND_STAMP(1);
+            const int wpad = (w + 15) & ~15;                                    // (rows w .. wpad-1 are identity padding: whole tiles)
+            const int below = max(0, wpad - c - 16);                            // D rows under the sub-block
+            const int nrows = below + hp + 1;                                   // + P rows + the right-hand side row
+            auto row_of = [&](int pr) { return pr < below ? c + 16 + pr : (pr < below + hp ? WB + (pr - below) : 2 * WB); };
+            const int ntile = (nrows + 15) / 16;
+            // B: T = R M^T on the matrix cores, one 16-row tile of the rows below per wave; multipliers = T D^-1
+            if (wave < ntile) {
+                const int prA = min(16 * wave + lr, nrows - 1);                  // operand row of this lane (clamped: masked at the store)
+                const double* R = Pm + row_of(prA) * WBS + c + lk;
+                const double* Mr = Mi + lr * 17 + lk;
+                double ra[4], mb[4];
+#pragma unroll
+                for (int kc = 0; kc < 4; kc++) { ra[kc] = R[4 * kc]; mb[kc] = Mr[4 * kc]; }
+                d4 acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                for (int kc = 0; kc < 4; kc++) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(ra[kc], mb[kc], acc, 0, 0, 0);
+                const double rdj = rdl[lr];
+#pragma unroll
+                for (int reg = 0; reg < 4; reg++) {
+                    const int pr = 16 * wave + lk + 4 * reg;
+                    Tt[pr * 17 + lr] = acc[reg];
+                    if (pr < nrows) Pm[row_of(pr) * WBS + c + lr] = acc[reg] * rdj;
+                }
+            }
+            lds_barrier();
+            BAND_STAMP(2);
+            // C: rank-16 update of the panel's remaining columns on the matrix cores: rows below x D rows below
+            {
+                const int ctile = below / 16;                                    // w - c - 16 is a multiple of 16 (identity padding)
+                for (int t = wave; t < ntile * ctile; t += 16) {
+                    const int tr = t / ctile, tc = t % ctile;
+                    const double* X = Tt + (16 * tr + lr) * 17 + lk;
+                    const double* Z = Pm + (c + 16 + 16 * tc + lr) * WBS + c + lk;
+                    double xa[4], zb[4];
+#pragma unroll
+                    for (int kc = 0; kc < 4; kc++) { xa[kc] = X[4 * kc]; zb[kc] = Z[4 * kc]; }
+                    d4 acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                    for (int kc = 0; kc < 4; kc++) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(xa[kc], zb[kc], acc, 0, 0, 0);
+#pragma unroll
+                    for (int reg = 0; reg < 4; reg++) {
+                        const int pr = 16 * tr + lk + 4 * reg, qq = 16 * tc + lr;
+                        if (pr < nrows && (pr >= below || qq <= pr)) Pm[row_of(pr) * WBS + c + 16 + qq] -= acc[reg];
+                    }
+                }
+            }
+            lds_barrier();
+            BAND_STAMP(3);
+        }
+        // ---- the factor's blocks -> memory (the backward substitution reads them), D^-1 L^-1 g, D
+        for (int idx = tid; idx < w * w; idx += 1024) {
+            const int r = idx / w, k = idx % w;
+            g.Ls[(size_t)(c0 + r) * n + c0 + k] = k < r ? Pm[r * WBS + k] : (k == r ? 1.0 : 0.0);
+        }
+        for (int idx = tid; idx < hp * w; idx += 1024) {
+            const int r = idx / w, k = idx % w;
+            g.Ls[(size_t)(r1 + r) * n + c0 + k] = Pm[(WB + r) * WBS + k];
+        }
+        if (tid < w) { g.yf[c0 + tid] = Pm[2 * WB * WBS + tid]; g.dv[c0 + tid] = dvl[tid]; }
+        BAND_STAMP(4);
+        if (hp == 0) break;                                                      // last block
+        // ---- trailing update on the matrix cores: T -= (L_P D) L_P^T (lower tiles), yP -= L_P D yf
+        {
+            const int tr = wave >> 2, tc = wave & 3;                             // 16 waves = 4 x 4 tiles
+            if (tr >= tc) {
+                d4 acc = {0.0, 0.0, 0.0, 0.0};
+                const double* X = Pm + (WB + 16 * tr + lr) * WBS + lk;
+                const double* Z = Pm + (WB + 16 * tc + lr) * WBS + lk;
+#pragma unroll 4
+                for (int kc = 0; kc < WB / 4; kc++)
+                    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(X[4 * kc] * dvl[4 * kc + lk], Z[4 * kc], acc, 0, 0, 0);
+#pragma unroll
+                for (int reg = 0; reg < 4; reg++) Tm[(16 * tr + lk + 4 * reg) * WBS + 16 * tc + lr] -= acc[reg];
+            }
+            if (tr == 0 && tc >= 1) {
+                // the right-hand side on three of the idle waves: column tile tc - 1 (and 3 by wave 1 as well) of the one-row
+                // product  yP -= (yf D) L_P^T: operand row 0 = yf D, rows 1..15 zero
+                for (int ct = tc - 1; ct < 4; ct += 3) {
+                    d4 acc = {0.0, 0.0, 0.0, 0.0};
+                    const double* Y = Pm + 2 * WB * WBS + lk;
+                    const double* Z = Pm + (WB + 16 * ct + lr) * WBS + lk;
+#pragma unroll 4
+                    for (int kc = 0; kc < WB / 4; kc++)
+                        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(lr == 0 ? Y[4 * kc] * dvl[4 * kc + lk] : 0.0, Z[4 * kc], acc, 0, 0, 0);
+                    if (lk == 0) yP[16 * ct + lr] -= acc[0];                      // output row 0 = lanes with lk == 0, register 0
+                }
+            }
+        }
+        lds_barrier();
+        BAND_STAMP(5);
+        // ---- shift the window: T -> D, yP -> rhs row, the prefetched blocks -> P / T / yP
+        for (int idx = tid; idx < WB * WB; idx += 1024) {
+            const int r = idx / WB, k = idx % WB;
+            Pm[r * WBS + k] = Tm[r * WBS + k];
+        }
+        if (tid < WB) Pm[2 * WB * WBS + tid] = yP[tid];
+        lds_barrier();
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const int idx = tid + 1024 * u, r = idx / WB, k = idx % WB;
+            Pm[(WB + r) * WBS + k] = (r < hq && k < hp) ? nP[u] : 0.0;
+            Tm[r * WBS + k] = (r < hq && k < hq) ? nT[u] : (r == k ? 1.0 : 0.0);
+        }
+        if (tid < WB) { yP[tid] = tid < hq ? nY : 0.0; dvl[tid] = 1.0; }
+        BAND_STAMP(6);
+    }
+    if (__any(bad) && lane == 0) *g.fail = 1;
+#if RS_STAMPS
+    if (tid == 0) for (int q = 0; q < 8; q++) b.dbg[16 + q] += acc_t[q];
+#endif
+}
+
+// the band's backward substitution L^T x = D^-1 L^-1 g: per 64-column block, from the last,
+//   v = yf_J - L_{J+1,J}^T x_{J+1}  (64 x 64, all threads),   L_JJ^T x_J = v  (one wave, the block's columns in registers)
+static __device__ __forceinline__ void band_backsub(const BigBufs& g, int n, double* y, double* Lb)
+{
+    const int tid = threadIdx.x, nt = blockDim.x;
+    double* part = Lb + WB * WBS;                   // [16][WB] partial sums
+    for (int i = tid; i < n; i += nt) y[i] = g.yf[i];
+    const int NBLK = (n + WB - 1) / WB;
+    __syncthreads();
+    for (int J = NBLK - 1; J >= 0; J--) {
+        const int c0 = WB * J, w = min(WB, n - c0);
+        const int r1 = c0 + WB, hp = max(0, min(WB, n - r1));
+        // diagonal block -> Lb; partial sums of L_P^T x_{J+1}: thread (k = column, grp = 16 slices of 4 rows)
+        for (int idx = tid; idx < WB * WB; idx += nt) {
+            const int r = idx / WB, k = idx % WB;
+            Lb[r * WBS + k] = (r < w && k < w) ? g.Ls[(size_t)(c0 + r) * n + c0 + k] : 0.0;
+        }
+        {
+            const int k = tid & 63, grp = tid >> 6;            // nt = 1024: 16 groups
+            double acc = 0.0;
+            if (k < w) {
+                double l[4];
+#pragma unroll
+                for (int u = 0; u < 4; u++) { const int r = 4 * grp + u; l[u] = r < hp ? g.Ls[(size_t)(r1 + r) * n + c0 + k] : 0.0; }
+#pragma unroll
+                for (int u = 0; u < 4; u++) { const int r = 4 * grp + u; acc += r < hp ? l[u] * y[r1 + r] : 0.0; }
+            }
+            part[grp * WB + k] = acc;
+        }
+        __syncthreads();
+        if (tid < 64) {
+            double v = 0.0;
+            if (tid < w) {
+                v = y[c0 + tid];
+                for (int q = 0; q < 16; q++) v -= part[q * WB + tid];
+            }
+            double l[WB];
+#pragma unroll
+            for (int t = 0; t < WB; t++) l[t] = Lb[t * WBS + tid];            // column `tid` of the unit-lower block (t > tid is used)
+#pragma unroll
+            for (int t = WB - 1; t >= 0; t--) {
+                const double xt = rl64(v, t);
+                v -= (tid < t) ? l[t] * xt : 0.0;
+            }
+            if (tid < w) y[c0 + tid] = v;
+        }
+        __syncthreads();
+    }
+}
+
 // block backward substitution L^T x = D^-1 L^-1 g by one workgroup: y (LDS, [n]) becomes x; Lb is an LDS block buffer
 static __device__ __forceinline__ void big_backsub(const BigBufs& g, int n, double* y, double* Lb)
 {
@@ -519,7 +809,7 @@ static __device__ __forceinline__ void big_backsub(const BigBufs& g, int n, doub
 }
 
 // ------------------------------------------------------------------ finish
-__global__ __launch_bounds__(1024) void ba_big_finish(BaDims d, BaBufs b, BaOpt opt, BigBufs g)
+__global__ __launch_bounds__(1024) void ba_big_finish(BaDims d, BaBufs b, BaOpt opt, BigBufs g, int band)
 {
     extern __shared__ __attribute__((aligned(16))) double sm[];
     const int n = d.n, tid = threadIdx.x, nt = blockDim.x;
@@ -535,7 +825,8 @@ __global__ __launch_bounds__(1024) void ba_big_finish(BaDims d, BaBufs b, BaOpt 
         if (tid == 0) { st.solver_failed = 1; *b.st = st; }
         return;
     }
-    big_backsub(g, n, y, Lb);
+    if (band) band_backsub(g, n, y, Lb);
+    else big_backsub(g, n, y, Lb);
     // delta_c = -x, candidate cameras, camera part of the step scalars (as ba_solve.hip (5))
     const double* lam = b.rhs;
     double mcc = 0.0, ssq = 0.0, xsq = 0.0;
@@ -606,21 +897,31 @@ size_t ba_big_bytes(int n)
     return sizeof(double) * ((size_t)n * n + BB * BB + 2 * (size_t)n) + 256 * 5;
 }
 
-int ba_launch_reduced_solve_big(rs_context* ctx, const BaDims& d, const BaBufs& b, const BaOpt& opt, char* ws)
+// largest camera span (slots) whose block band fits the one-launch factorisation: 6 span + 5 <= WB columns
+int ba_band_max_span() { return (WB - 5) / 6; }
+
+int ba_launch_reduced_solve_big(rs_context* ctx, const BaDims& d, const BaBufs& b, const BaOpt& opt, char* ws, bool band)
 {
     const size_t n = (size_t)d.n;
     BigBufs g;
     big_carve(ws, n, &g);
     hipStream_t s = ctx->stream;
-    const size_t lds_fin = sizeof(double) * (n + BB * BBS + 1024);       // y, diagonal block, backsub partial sums
+    const size_t lds_fin = sizeof(double) * (n + WB * WBS + 1024);       // y, diagonal block, backsub partial sums
     if (lds_fin > 48 * 1024)
         RS_HIP(ctx, rs_lds_attr((const void*)ba_big_finish, lds_fin));
     const size_t lds_upd = sizeof(double) * (6 * BB * BBS + 2 * BB * 17 + BB);
     RS_HIP(ctx, rs_lds_attr((const void*)ba_big_update, lds_upd));
     hipLaunchKernelGGL(ba_big_prologue, dim3(1), dim3(1024), 0, s, d, b, opt, g);
     hipLaunchKernelGGL(ba_big_assemble, dim3(256), dim3(256), 0, s, d, b);
-    big_launch_factor(s, d, b, g, lds_upd);
-    hipLaunchKernelGGL(ba_big_finish, dim3(1), dim3(1024), lds_fin, s, d, b, opt, g);
+    if (band) {
+        const size_t lds_band = sizeof(double) * ((size_t)WROWS * WBS + WB * WBS + WB + (size_t)16 * WTILES * 17 + 16 * 17 + 16 + WB);
+        RS_HIP(ctx, rs_lds_attr((const void*)ba_band_factor, lds_band));
+        rs_prof_scope ps(ctx, "K7b_band_factor");
+        hipLaunchKernelGGL(ba_band_factor, dim3(1), dim3(1024), lds_band, s, d, b, g);
+    } else {
+        big_launch_factor(s, d, b, g, lds_upd);
+    }
+    hipLaunchKernelGGL(ba_big_finish, dim3(1), dim3(1024), lds_fin, s, d, b, opt, g, band ? 1 : 0);
     return RS_OK;
 }
 

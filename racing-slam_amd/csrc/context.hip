@@ -97,6 +97,11 @@ extern "C" int rs_context_set_int(rs_context* ctx, const char* name, int value)
         ctx->ba_fuse_mode = value;
         return RS_OK;
     }
+    if (strcmp(name, "ba_band_mode") == 0) {
+        if (value < 0 || value > 1) return rs_fail(ctx, RS_ERR_INVALID, "ba_band_mode must be 0 (banded factorisation where the reduced matrix is block-banded) or 1 (always the general blocked one)");
+        ctx->ba_band_mode = value;
+        return RS_OK;
+    }
     if (strcmp(name, "ba_s_replicas") == 0) {
         if (value != 0 && value != 1 && value != 2 && value != 4 && value != 8) return rs_fail(ctx, RS_ERR_INVALID, "ba_s_replicas must be 0 (default), 1, 2, 4 or 8");
         ctx->ba_s_replicas = value;

@@ -366,3 +366,44 @@ def test_triangulate_host_fast_path(ctx, oracle, synth, n):
     assert 0 < len(ref["out_index"]) or n < 5
     idx, xyz = ctx.triangulate_host(uv1[:0], uv2[:0], pr["poses"][0], pr["poses"][1], pr["K"])
     assert len(idx) == 0
+
+
+@pytest.mark.parametrize("kw,banded", [(dict(n_kf=100, n_points=1500, run_min=2, run_max=10, config_id=140), True),
+                                       (dict(n_kf=60, n_points=2500, run_min=2, run_max=10, config_id=141), True),      # n = 348: 5 full blocks + 28 columns
+                                       (dict(n_kf=33, n_points=900, run_min=2, run_max=10, config_id=142), True),       # n = 186
+                                       (dict(n_kf=40, n_points=4000, run_min=3, run_max=24, config_id=143), False)])    # spans up to 23: not banded
+def test_bundle_adjust_banded_reduced_solve(ctx, oracle, synth, kw, banded):
+    """VERDICT r2 #5 (cfg 5's reduced solve was 13 + 12 dependent launches per LM step): when every landmark is seen by key
+    frames at most 9 slots apart, S is block-banded and is factorised by ONE launch (csrc/ba_solve_big.hip, ba_band_factor;
+    the sparsity Ceres' SPARSE_SCHUR exploits, src/Optimization.cpp:360).  Against the oracle and against the general
+    blocked factorisation ("ba_band_mode" 1), incl. a matrix size that ends in a partial block and a window that is NOT
+    banded (must take the general path by itself)."""
+    w = synth.make_ba_window(**kw)
+    _, _, os_, otr = oracle.bundle_adjust_trace(w["cams"], w["cam_free"], w["points"], w["obs_ptr"], w["obs_cam"], w["obs_uv"], w["K"])
+    rc, rp, _ = oracle.bundle_adjust(w["cams"], w["cam_free"], w["points"], w["obs_ptr"], w["obs_cam"], w["obs_uv"], w["K"])
+    runs = {}
+    try:
+        for mode in (0, 1):
+            ctx.set_int("ba_band_mode", mode)
+            dc, dp = ctx.dev(w["cams"]), ctx.dev(w["points"])
+            ctx.prof_begin()
+            s = ctx.bundle_adjust(dc, w["cam_free"], dp, ctx.dev(w["obs_ptr"]), ctx.dev(w["obs_cam"]), ctx.dev(w["obs_uv"]), w["K"])
+            prof = ctx.prof_end()
+            runs[mode] = (s, ctx.ba_trace(), to_np(dc), to_np(dp), prof)
+    finally:
+        ctx.set_int("ba_band_mode", 0)
+    assert ("K7b_band_factor" in runs[0][4]) == banded and "K7b_band_factor" not in runs[1][4]
+    for mode in (0, 1):
+        s, tr, c, p, _ = runs[mode]
+        assert (s["iterations"], s["successful_steps"], s["termination"], s["usable"]) == \
+               (os_["iterations"], os_["successful_steps"], os_["termination"], os_["usable"]), mode
+        assert [t["outcome"] for t in tr] == [t["outcome"] for t in otr], mode
+        assert np.allclose([t["cost"] for t in tr], [t["cost"] for t in otr], rtol=1e-7), mode      # (two f64 trajectories from a far-off start: 2e-9 by the fifth step)
+        assert np.isclose(s["final_cost"], os_["final_cost"], rtol=1e-7), mode
+        # (the long-track window is weakly constrained along its gauge directions: 5e-8 on rotation components there)
+        tol = (1e-6, 1e-8, 1e-7) if banded else (1e-5, 1e-6, 1e-5)
+        assert np.allclose(c, rc, rtol=tol[0], atol=tol[1]) and np.allclose(p, rp, rtol=tol[0], atol=tol[2]), mode
+    if banded:
+        assert np.allclose(runs[0][2], runs[1][2], rtol=1e-8, atol=1e-10)
+    else:
+        assert np.array_equal(runs[0][2], runs[1][2]) or np.allclose(runs[0][2], runs[1][2], rtol=1e-9, atol=1e-11)
