@@ -440,7 +440,12 @@ typedef struct rs_ba_summary {
  *             free frame, :287-302); points that are not free are not passed
  *   observations sorted by point (CSR): d_obs_ptr [P+1], d_obs_cam [M], d_obs_uv [M][2] f32
  * d_cameras / d_points are overwritten only when summary.usable is 1, exactly
- * like the reference writes back only on an accepted solve (:360-372).
+ * like the reference writes back only on an accepted solve (:360-372).  They are
+ * STREAM-ordered results: the call returns as soon as the summary (and the pinned
+ * camera mirror, rs_ba_get_cameras) is on the host, possibly while the copy into
+ * d_cameras / d_points is still running on the context's stream; anything that
+ * reads them on that stream is ordered behind it, any other reader synchronises
+ * first (rs_context_synchronize).
  * With an RCCL communicator attached (rs_comm_init_rank) the points/observations
  * are this rank's landmark shard, cameras are replicated, and the reduced
  * camera system and the cost are all-reduced every LM step. */

@@ -475,26 +475,31 @@ static __device__ __forceinline__ void ba_finalize_body(const BaDims& d, const B
     const int tid = blockIdx.x * blockDim.x + threadIdx.x, nth = gridDim.x * blockDim.x;
     const double* Xc = b.Xc + (size_t)cur * d.C * 6;
     const double* Xp = b.Xp + (size_t)cur * d.P * 3;
-    // the cameras as the caller will see them in d_cameras, mirrored into pinned host memory: poses are host-owned
-    // objects in the reference (Frame::set_pose, src/Optimization.cpp:363-368), so the shim needs them there anyway
-    for (int i = tid; i < d.C * 6; i += nth) host_cams[i] = (usable && cam_free[i / 6]) ? Xc[i] : cams_out[i];
-    if (host_vb)        // inertial solve: velocity | bias of the accepted state (the host applies the write-back rule)
-        for (int i = tid; i < d.C * 9; i += nth) host_vb[i] = b.imu.Xv[(size_t)cur * d.C * 9 + i];
+    // Everything the HOST waits for is written by workgroup 0 alone and fenced once: the summary and the trace (above), and
+    // the cameras as the caller will see them in d_cameras, mirrored into pinned host memory (poses are host-owned objects in
+    // the reference — Frame::set_pose, src/Optimization.cpp:363-368 — so the shim needs them there anyway).  Then it raises
+    // the completion flag the host spins on (hipStreamSynchronize is a blocking wait whose wake-up costs tens of
+    // microseconds).  The device-side results (d_cameras, d_points) are written by the whole grid and are STREAM-ordered:
+    // the call may return while those copies are still running; whatever reads them on the context's stream — the next
+    // library call, a staged download, a torch op — is ordered behind them.
+    if (blockIdx.x == 0) {
+        for (int i = threadIdx.x; i < d.C * 6; i += blockDim.x) host_cams[i] = (usable && cam_free[i / 6]) ? Xc[i] : cams_out[i];
+        if (host_vb)        // inertial solve: velocity | bias of the accepted state (the host applies the write-back rule)
+            for (int i = threadIdx.x; i < d.C * 9; i += blockDim.x) host_vb[i] = b.imu.Xv[(size_t)cur * d.C * 9 + i];
+        if (host_done) {
+            __threadfence_system();
+            __syncthreads();
+            if (threadIdx.x == 0) *host_done = it + 1;
+        } else {
+            __syncthreads();     // (host_cams reads cams_out before the grid rewrites it: this workgroup's share of that is below)
+        }
+    }
     if (usable) {
+        // (workgroup 0 has read cams_out for the mirror above; the other workgroups only touch entries of FREE cameras, whose
+        // mirror value comes from Xc, so no ordering between the workgroups is needed)
         for (int i = tid; i < d.C * 6; i += nth)
             if (cam_free[i / 6]) cams_out[i] = Xc[i];
         for (int i = tid; i < d.P * 3; i += nth) pts_out[i] = Xp[i];
-    }
-    // Completion flag in pinned host memory, raised by the last workgroup to get here: the host spins on it instead of
-    // calling hipStreamSynchronize (a blocking wait whose wake-up costs tens to hundreds of microseconds on a busy host —
-    // more than a kernel of this solve).  Every workgroup's writes to host memory are fenced before it counts itself.
-    if (host_done) {
-        __threadfence_system();
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            const unsigned long long arrived = atomicAdd(&b.dbg[62], 1ull);
-            if (arrived == gridDim.x - 1) { __threadfence_system(); *host_done = it + 1; __threadfence_system(); }
-        }
     }
 }
 
