@@ -1100,7 +1100,6 @@ static int ba_solve_batch_grid(rs_context* ctx, int B, const rs_ba_problem* Q, c
         pin_off[(size_t)i] = pin_total;
         pin_total += align_up(sizeof(BaState), 64) + 64 + align_up(sizeof(BaTrace) * (size_t)(opt.max_iter + 1), 64) + align_up(sizeof(double) * 6 * C, 64);
         max_P = std::max(max_P, d.P); max_n = std::max(max_n, d.n); max_C = std::max(max_C, d.C);
-        k5_lds = std::max(k5_lds, ba_schur_lds_bytes(d.C, d.Cf));
         k8_lds = std::max(k8_lds, ba_backsub_lds_bytes(d.C, d.n));
     }
     void* wsv = nullptr;
@@ -1122,9 +1121,10 @@ static int ba_solve_batch_grid(rs_context* ctx, int B, const rs_ba_problem* Q, c
         b.obs_ptr = q.d_obs_ptr; b.obs_cam = q.d_obs_cam; b.obs_uv = (const float2*)q.d_obs_uv;
         ba_bind(b, base, L, d, ns, 1, 0);
         ba_group_carve(base + L.grp, d.P, d.Cf, d.M, &w.g);
-        ba_group_set_items(&w.g, d.P, true);
+        ba_group_set_items(&w.g, d.P, true, ctx->ba_batch_item);
         b.obs_cs = w.g.obs_cs;
         max_items = std::max(max_items, w.g.n_items);
+        k5_lds = std::max(k5_lds, ba_schur_lds_bytes(d.C, d.Cf, w.g.it_l));
         w.st_base = b.st; w.pts_base = b.pt_scal; w.set_base = b.set_out; w.pts_block = L.pts_block;
         char* hp = pin + pin_off[(size_t)i];
         w.h_st = (BaState*)hp;
@@ -1152,7 +1152,7 @@ static int ba_solve_batch_grid(rs_context* ctx, int B, const rs_ba_problem* Q, c
         ba_launch_grouping_batch(s, d_wins, B, max_P, max_items);
     }
     auto enqueue_round = [&](int it) {
-        { rs_prof_scope ps(ctx, "K5_ba_schur_mfma"); ba_launch_schur_batch(s, d_wins, B, opt, it, max_items, 64, k5_lds); }
+        { rs_prof_scope ps(ctx, "K5_ba_schur_mfma"); ba_launch_schur_batch(s, d_wins, B, opt, it, max_items, wins[0].g.it_l, k5_lds); }
         { rs_prof_scope ps(ctx, "K7_ba_reduced_solve"); ba_launch_reduced_solve_lds_batch(s, d_wins, B, opt, it, ns, max_n); }
         { rs_prof_scope ps(ctx, "K8_ba_backsub_cost"); ba_launch_backsub_batch(s, d_wins, B, it, ns, max_P, k8_lds); }
     };

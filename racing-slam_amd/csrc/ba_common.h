@@ -542,13 +542,13 @@ void ba_launch_reduced_solve_lds_batch(hipStream_t s, const BaWin* d_wins, int B
 int ba_prepare_reduced_solve_lds_batch(int max_n);
 int ba_prepare_schur_batch(size_t lds);
 void ba_launch_backsub_batch(hipStream_t s, const BaWin* d_wins, int B, int it, int ns, int max_P, size_t lds);
-void ba_group_set_items(BaGroup* g, int P, bool throughput);   // landmarks per item: 64 in throughput mode, else as ba_group_carve chose
+void ba_group_set_items(BaGroup* g, int P, bool throughput, int batch_item = 0);   // landmarks per item: 32 (or batch_item) in throughput mode, else as ba_group_carve chose
 
 size_t ba_group_bytes(int P, int Cf, int M);
 void ba_group_carve(char* base, int P, int Cf, int M, BaGroup* g);
 void ba_group_zero_range(const BaGroup& g, int32_t** ptr, int* count);
 int ba_launch_grouping(rs_context* ctx, const BaDims& d, const BaBufs& b, const BaGroup& g);
-size_t ba_schur_lds_bytes(int C, int Cf);
+size_t ba_schur_lds_bytes(int C, int Cf, int it_l = 64);
 int ba_prepare_schur(int C, int Cf);
 void ba_launch_schur(hipStream_t s, const BaDims& d, const BaBufs& b, const BaOpt& opt, const BaGroup& g, int it);
 // ---- blocked reduced solve for n > BA_MAX_LDS_N (ba_solve_big.hip)

@@ -205,7 +205,7 @@ __global__ __launch_bounds__(64 * SCH_WAVES) void ba_schur_mfma_batch(const BaWi
 size_t ba_group_bytes(int P, int Cf, int M)
 {
     const size_t nb = ((size_t)Cf * Cf + 2) * GRP_REP;
-    const size_t ni = ((size_t)P + IT_L_SMALL - 1) / IT_L_SMALL + 1;
+    const size_t ni = ((size_t)P + 31) / 32 + 1;                 // (the smallest item: 32 landmarks, throughput mode)
     return 256 * 10 + sizeof(int32_t) * (2 * (size_t)P + 2 * nb + 16 + (size_t)M) + sizeof(int4) * (size_t)P +
            sizeof(uint64_t) * (2 * (size_t)P + 2 * ni);
 }
@@ -300,7 +300,7 @@ static size_t al256(size_t v) { return (v + 255) & ~(size_t)255; }
 void ba_group_carve(char* base, int P, int Cf, int M, BaGroup* g)
 {
     const size_t nb = ((size_t)Cf * Cf + 2) * GRP_REP;
-    const size_t ni_max = ((size_t)P + IT_L_SMALL - 1) / IT_L_SMALL + 1;
+    const size_t ni_max = ((size_t)P + 31) / 32 + 1;
     g->it_l = P <= 256 * IT_L_SMALL ? IT_L_SMALL : IT_L;
     const size_t ni = P > 0 ? ((size_t)P + g->it_l - 1) / g->it_l : 1;     // an empty landmark shard keeps one (empty) item:
     size_t off = 0;                                                            // its workgroup runs the round's decision
@@ -338,11 +338,11 @@ int ba_launch_grouping(rs_context* ctx, const BaDims& d, const BaBufs& b, const 
     return RS_OK;
 }
 
-size_t ba_schur_lds_bytes(int C, int Cf)
+size_t ba_schur_lds_bytes(int C, int Cf, int it_l)
 {
     (void)Cf;
     const size_t prep = C <= SCH_MAXC_LDS ? (size_t)C * BA_PREP_LDS : 0;
-    return sizeof(double) * ((size_t)YT_DOUBLES + (size_t)SCH_UCAP * 42 + prep + 6 * IT_L) + sizeof(int) * 32;   // + Mt
+    return sizeof(double) * ((size_t)sch_tile_doubles(it_l) + (size_t)SCH_UCAP * 42 + prep + 6 * IT_L) + sizeof(int) * 32;   // + Mt
 }
 
 int ba_prepare_schur(int C, int Cf)
@@ -354,9 +354,9 @@ int ba_prepare_schur(int C, int Cf)
 void ba_launch_schur(hipStream_t s, const BaDims& d, const BaBufs& b, const BaOpt& opt, const BaGroup& g, int it)
 {
     if (d.C <= SCH_MAXC_LDS)
-        hipLaunchKernelGGL(ba_schur_mfma, dim3(g.n_items), dim3(8 * g.it_l), ba_schur_lds_bytes(d.C, d.Cf), s, d, b, opt, g, it);
+        hipLaunchKernelGGL(ba_schur_mfma, dim3(g.n_items), dim3(8 * g.it_l), ba_schur_lds_bytes(d.C, d.Cf, g.it_l), s, d, b, opt, g, it);
     else
-        hipLaunchKernelGGL(ba_schur_mfma_big, dim3(g.n_items), dim3(8 * g.it_l), ba_schur_lds_bytes(d.C, d.Cf), s, d, b, opt, g, it);
+        hipLaunchKernelGGL(ba_schur_mfma_big, dim3(g.n_items), dim3(8 * g.it_l), ba_schur_lds_bytes(d.C, d.Cf, g.it_l), s, d, b, opt, g, it);
 }
 
 // ---- batched launches (one per kernel for B windows)
@@ -379,8 +379,11 @@ void ba_launch_schur_batch(hipStream_t s, const BaWin* d_wins, int B, const BaOp
     hipLaunchKernelGGL(ba_schur_mfma_batch, dim3(max_items, 1, B), dim3(8 * it_l), lds, s, d_wins, opt, it);
 }
 
-void ba_group_set_items(BaGroup* g, int P, bool throughput)
+void ba_group_set_items(BaGroup* g, int P, bool throughput, int batch_item)
 {
-    g->it_l = throughput ? IT_L : (P <= 256 * IT_L_SMALL ? IT_L_SMALL : IT_L);
+    // throughput mode (windows batched in one grid): 32 landmarks per item by default — a 75 KB LDS image, so that TWO
+    // workgroups share a compute unit and one's barriers / LDS round trips are covered by the other's arithmetic
+    const int tp = (batch_item == 32 || batch_item == 40 || batch_item == 64) ? batch_item : 32;
+    g->it_l = throughput ? tp : (P <= 256 * IT_L_SMALL ? IT_L_SMALL : IT_L);
     g->n_items = P > 0 ? (P + g->it_l - 1) / g->it_l : 1;
 }

@@ -14,7 +14,13 @@
                                 // half-wave column groups of a ds_read_b64 on disjoint banks; 3*81*2 = 6 mod 32
                                 // spreads the 16 producer lanes over 16 bank pairs)
 #define YT_STRIDE8 145          // NT = 8: 128 rows + 17
-#define YT_DOUBLES (192 * YT_STRIDE4)  // 15552 doubles = 124416 B per workgroup (NT=8: 96 cols * 145 = 13920)
+#define YT_DOUBLES (192 * YT_STRIDE4)  // 15552 doubles = 124416 B per workgroup of 64 landmarks (NT=8: 96 cols * 145 = 13920)
+// doubles of the LDS tile of an item of it_l landmarks: 3 it_l columns of the 4x4-tile class, or two half batches of the 8x8 class
+__host__ __device__ __forceinline__ int sch_tile_doubles(int it_l)
+{
+    const int a = 3 * it_l * YT_STRIDE4, b8 = 3 * (it_l / 2) * YT_STRIDE8;
+    return ((a > b8 ? a : b8) + 1) & ~1;
+}
 #define SCH_PRE 3               // observation rounds prefetched per lane (covers 12 observations per landmark)
 #define SCH_MAXC_LDS 64         // cameras staged in LDS when the window has at most this many
 
@@ -225,7 +231,7 @@ static __device__ __forceinline__ void ba_schur_body(const BaDims& d, const BaBu
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     double* yt = lds;                                            // WG tile
-    double* ulds = lds + YT_DOUBLES;                             // [SCH_UCAP][42], by rank in the item's camera union
+    double* ulds = lds + sch_tile_doubles(g.it_l);               // [SCH_UCAP][42], by rank in the item's camera union
     double* cprep = ulds + SCH_UCAP * 42;                        // [C][BA_PREP_LDS] camera blocks (PREP_LDS only)
     int* gslot = (int*)(cprep + (PREP_LDS ? (size_t)d.C * BA_PREP_LDS : 0));   // [24]
     const int nlds = SCH_UCAP * 42;

@@ -97,6 +97,11 @@ extern "C" int rs_context_set_int(rs_context* ctx, const char* name, int value)
         ctx->ba_fuse_mode = value;
         return RS_OK;
     }
+    if (strcmp(name, "ba_batch_item_landmarks") == 0) {
+        if (value != 0 && value != 32 && value != 40 && value != 64) return rs_fail(ctx, RS_ERR_INVALID, "ba_batch_item_landmarks must be 0 (default), 32, 40 or 64");
+        ctx->ba_batch_item = value;
+        return RS_OK;
+    }
     if (strcmp(name, "ba_band_mode") == 0) {
         if (value < 0 || value > 1) return rs_fail(ctx, RS_ERR_INVALID, "ba_band_mode must be 0 (banded factorisation where the reduced matrix is block-banded) or 1 (always the general blocked one)");
         ctx->ba_band_mode = value;
