@@ -144,9 +144,10 @@ static __device__ __forceinline__ void ba_reduced_solve_lds_body(const BaDims& d
             if (i >= n) keep[h] = b.Ukeep[i - n];                      // U | gc of the last fresh linearisation
         }
     }
-    // (Tried: S through LDS — all threads read the needed half of S with consecutive lanes on consecutive entries of a row
-    // into the panel area, the tile waves gather from there — 23 dependent-looking iterations and two more barriers: K7
-    // 37.9 -> 47.5 us.  The gather below keeps 24 independent loads per lane in flight.)
+    // (Tried twice: S through LDS — all 512 threads read S with consecutive lanes on consecutive entries of a row into the
+    // panel area, the tile waves gather from there.  As a rolled loop of 8-byte loads: K7 37.9 -> 47.5 us; as 16 16-byte
+    // loads per thread all in flight: 40.6 -> 44.1 us (64 more live registers, two more barriers, a 2- to 4-way bank
+    // conflicted LDS gather).  The gather below keeps 24 independent loads per lane in flight and costs ~2 us.)
     double sv[K7_TPW][4];                                              // tile waves: their entries of S
 #pragma unroll
     for (int s = 0; s < K7_TPW; s++) {
