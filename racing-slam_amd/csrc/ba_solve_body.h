@@ -100,7 +100,7 @@ static __device__ __forceinline__ void ba_reduced_solve_lds_body(const BaDims& d
             const unsigned long long want = (unsigned long long)(unsigned)s0.n_rounds * (unsigned long long)n_items;
             const unsigned long long t0 = wall_clock64();
             unsigned lost = 0;
-            while (__hip_atomic_load(b.dbg + BA_SDONE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want) {
+            while (ba_load_word_sc1(b.dbg + BA_SDONE) < want) {
                 if (wall_clock64() - t0 > b.hand_timeout) { lost = 1; break; }
                 __builtin_amdgcn_s_sleep(2);
             }
@@ -116,7 +116,7 @@ static __device__ __forceinline__ void ba_reduced_solve_lds_body(const BaDims& d
             if (tid == 0) {
                 atomicAdd(b.dbg + BA_HAND_ERR, 1ull);
                 const unsigned long long w = ((unsigned long long)(unsigned)s0.n_rounds << 2) | 2ull;
-                __hip_atomic_store(b.dbg + BA_HAND_TAKEN + set, w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                ba_store_word_sc1(b.dbg + BA_HAND_TAKEN + set, w);
             }
             return;
         }
@@ -178,7 +178,7 @@ static __device__ __forceinline__ void ba_reduced_solve_lds_body(const BaDims& d
 #if RS_STAMPS
                 if (set == 0) b.dbg[word == BA_HAND ? 40 : 43] = wall_clock64();
 #endif
-                __hip_atomic_store(b.dbg + word + set, epoch | code, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                ba_store_word_sc1(b.dbg + word + set, epoch | code);
             }
         }
     };
