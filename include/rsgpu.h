@@ -221,6 +221,19 @@ int rs_reproj_match(rs_context* ctx, const rs_frame_view* frame,
                     int32_t* d_match_kp, int32_t* d_match_point,
                     int32_t* d_match_count);
 
+/* SURVEY.md 8(e) row 2 — the same match with the MAP SHARDED over the ranks of the attached communicator (RCCL or the
+ * in-process group): mp_shard holds this rank's points, point_base the map order of its first point.  The per-keypoint
+ * proposal table (distance << 32 | global map order) is MIN-all-reduced before the accept step — one
+ * ncclAllReduce(min, u64) of 8 N bytes — so every rank returns the unsharded result, ties included.  d_prop_point and
+ * d_match_point hold GLOBAL map indices; d_point_kp / d_point_dist cover the shard.  Every rank must make the call (an
+ * empty shard is valid).  Without a communicator it is rs_reproj_match with an index offset.  Worth it for maps far
+ * beyond 1e5 points; smaller maps are better served by replicas. */
+int rs_reproj_match_sharded(rs_context* ctx, const rs_frame_view* frame, const rs_map_view* mp_shard, int point_base,
+                            int replace, int max_distance,
+                            int32_t* d_point_kp, int32_t* d_point_dist,
+                            int32_t* d_prop_point, int32_t* d_prop_dist,
+                            int32_t* d_match_kp, int32_t* d_match_point, int32_t* d_match_count);
+
 /* ---------------------------------------- §8(f) rank 4: the map, resident on the device */
 
 /* MapMatcher::match walks the whole map twice per frame (src/MapMatcher.cpp:165-175); flattening the reference's

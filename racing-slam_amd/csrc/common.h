@@ -136,5 +136,6 @@ __device__ __forceinline__ int rs_block_exclusive_scan(int v, int* total)
 // sum all-reduce of f64 on the context stream over the attached communicator (RCCL or the in-process group);
 // no-op without one
 int rs_allreduce_f64(rs_context* ctx, double* d_buf, size_t count, bool is_max);
+int rs_allreduce_min_u64(rs_context* ctx, unsigned long long* d_buf, size_t count);   // element-wise minimum of unsigned 64-bit keys
 static inline bool rs_comm_active(const rs_context* ctx) { return ctx->comm != nullptr || ctx->local != nullptr; }
 

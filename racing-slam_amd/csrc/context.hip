@@ -441,8 +441,17 @@ __global__ void rs_local_sum(LocalBufs b, int n, size_t count, double* __restric
         out[i] = v;
     }
 }
+__global__ void rs_local_min_u64(LocalBufs b, int n, size_t count, double* __restrict__ out)
+{
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (size_t)gridDim.x * blockDim.x) {
+        unsigned long long v = ~0ull;
+        for (int r = 0; r < n; r++) { const unsigned long long x = ((const unsigned long long*)b.p[r])[i]; v = x < v ? x : v; }
+        ((unsigned long long*)out)[i] = v;
+    }
+}
 
-static int local_allreduce(rs_context* ctx, double* d_buf, size_t count)
+// (8-byte elements: f64 sums, or unsigned 64-bit minima when min_u64 is set)
+static int local_allreduce(rs_context* ctx, double* d_buf, size_t count, bool min_u64 = false)
 {
     rs_local_group* g = ctx->local;
     const int r = ctx->rank;
@@ -460,7 +469,8 @@ static int local_allreduce(rs_context* ctx, double* d_buf, size_t count)
     for (int q = 0; q < g->n; q++)
         if (q != r) RS_HIP(ctx, hipStreamWaitEvent(ctx->stream, g->ready[q], 0));
     const int blocks = (int)((count + 255) / 256 < 512 ? (count + 255) / 256 : 512);
-    hipLaunchKernelGGL(rs_local_sum, dim3(blocks), dim3(256), 0, ctx->stream, lb, g->n, count, g->scratch[r]);
+    if (min_u64) hipLaunchKernelGGL(rs_local_min_u64, dim3(blocks), dim3(256), 0, ctx->stream, lb, g->n, count, g->scratch[r]);
+    else hipLaunchKernelGGL(rs_local_sum, dim3(blocks), dim3(256), 0, ctx->stream, lb, g->n, count, g->scratch[r]);
     RS_HIP(ctx, hipEventRecord(g->read_done[r], ctx->stream));
     local_barrier(g);
     for (int q = 0; q < g->n; q++)
@@ -508,6 +518,16 @@ extern "C" int rs_comm_destroy(rs_context* ctx)
     }
     ctx->n_ranks = 1;
     ctx->rank = 0;
+    return RS_OK;
+}
+
+int rs_allreduce_min_u64(rs_context* ctx, unsigned long long* d_buf, size_t count)
+{
+    if (ctx->local) return local_allreduce(ctx, (double*)d_buf, count, true);
+    if (!ctx->comm) return RS_OK;
+    // ncclUint64 = 5, ncclMin = 3
+    int e = g_rccl.allreduce(d_buf, d_buf, count, 5, 3, ctx->comm, ctx->stream);
+    if (e != 0) return rs_fail(ctx, RS_ERR_RCCL, "ncclAllReduce(min, u64): %s", g_rccl.errstr ? g_rccl.errstr(e) : "?");
     return RS_OK;
 }
 

@@ -41,6 +41,7 @@ struct K2Frame {
 
 struct K2Map {
     int n_points;
+    int point_base;          // map order of this view's point 0 (a shard of a larger map: rs_reproj_match_sharded); 0 otherwise
     const float* pos;
     const uint8_t* eligible;
     const int32_t* obs_ptr;
@@ -403,7 +404,7 @@ __global__ __launch_bounds__(K2_THREADS) void k2_reproj_match(K2Frame f, K2Map m
             out_kp = best_kp;
             out_d = best_d;
             // :95-97 sequential strict-'<' over map order == atomicMin of (dist, map order)
-            atomicMin(&prop[best_kp], ((unsigned long long)(unsigned)best_d << 32) | (unsigned)p);
+            atomicMin(&prop[best_kp], ((unsigned long long)(unsigned)best_d << 32) | (unsigned)(m.point_base + p));
         }
     } while (0);
     if (p < m.n_points) {
@@ -680,7 +681,7 @@ __global__ __launch_bounds__(K2G_THREADS_T) void k2_reproj_match_grouped(K2Frame
             out_kp = best_kp;
             out_d = best_d;
             // :95-97 sequential strict-'<' over map order == atomicMin of (dist, map order)
-            if (sub == 0) atomicMin(&prop[best_kp], ((unsigned long long)(unsigned)best_d << 32) | (unsigned)p);
+            if (sub == 0) atomicMin(&prop[best_kp], ((unsigned long long)(unsigned)best_d << 32) | (unsigned)(m.point_base + p));
         }
     } while (0);
     if (have && sub == 0) {
@@ -700,14 +701,20 @@ __global__ __launch_bounds__(1024) void k3_accept(unsigned long long* __restrict
     k3_accept_body(prop, n, max_distance, prop_point, prop_dist, match_kp, match_point, match_count);
 }
 
-extern "C" int rs_reproj_match(rs_context* ctx, const rs_frame_view* fr, const rs_map_view* mp, int replace,
-                               int max_distance, int32_t* d_point_kp, int32_t* d_point_dist,
-                               int32_t* d_prop_point, int32_t* d_prop_dist, int32_t* d_match_kp,
-                               int32_t* d_match_point, int32_t* d_match_count)
+// the map sharded over ranks (point_base = map order of this shard's first point).  Every rank runs
+// K2 on its points; the per-keypoint proposal table — packed (distance << 32 | GLOBAL map order), built with atomicMin —
+// is then MIN-all-reduced over the communicator (one ncclAllReduce(min, u64) of 8 N bytes; the in-process group: an
+// on-device minimum), so that every rank's K3 accepts the same winners: exactly the unsharded result, ties included
+// (src/MapMatcher.cpp:95-97: first in map order wins).  d_prop_point / d_match_point hold GLOBAL map indices;
+// d_point_kp / d_point_dist are this shard's.
+static int reproj_match_impl(rs_context* ctx, const rs_frame_view* fr, const rs_map_view* mp, int point_base, bool reduce, int replace,
+                             int max_distance, int32_t* d_point_kp, int32_t* d_point_dist,
+                             int32_t* d_prop_point, int32_t* d_prop_dist, int32_t* d_match_kp,
+                             int32_t* d_match_point, int32_t* d_match_count)
 {
     if (!ctx || !fr || !mp) return RS_ERR_INVALID;
     const int N = fr->n_keypoints, P = mp->n_points;
-    if (N < 0 || P < 0) return rs_fail(ctx, RS_ERR_INVALID, "negative size");
+    if (N < 0 || P < 0 || point_base < 0) return rs_fail(ctx, RS_ERR_INVALID, "negative size");
     if (!d_match_count) return rs_fail(ctx, RS_ERR_INVALID, "null match_count");
     if (N >= (1 << 30)) return rs_fail(ctx, RS_ERR_UNSUPPORTED, "too many keypoints");
     RS_HIP(ctx, hipSetDevice(ctx->device));
@@ -742,7 +749,7 @@ extern "C" int rs_reproj_match(rs_context* ctx, const rs_frame_view* fr, const r
         f.packed = (const float4*)fr->d_kd_packed;
         if (((uintptr_t)f.packed) & 15) return rs_fail(ctx, RS_ERR_INVALID, "d_kd_packed must be 16-byte aligned");
         K2Map m;
-        m.n_points = P; m.pos = mp->d_positions; m.eligible = mp->d_eligible; m.obs_ptr = mp->d_obs_ptr;
+        m.n_points = P; m.point_base = point_base; m.pos = mp->d_positions; m.eligible = mp->d_eligible; m.obs_ptr = mp->d_obs_ptr;
         m.obs_kf = mp->d_obs_kf; m.obs_desc = mp->d_obs_desc; m.kf_centers = mp->d_kf_centers;
         m.pool = (const uint4*)mp->d_desc_pool;
         const int tree_in_lds = N <= K2_MAX_LDS_NODES ? 1 : 0;
@@ -763,6 +770,11 @@ extern "C" int rs_reproj_match(rs_context* ctx, const rs_frame_view* fr, const r
                                ctx->stream, f, m, replace, max_distance, tree_in_lds, d_point_kp, d_point_dist, prop);
         }
     }
+    if (reduce && rs_comm_active(ctx)) {
+        rs_prof_scope ps(ctx, "C3_allreduce_min_proposals");
+        const int rc = rs_allreduce_min_u64(ctx, prop, (size_t)N);
+        if (rc) return rc;
+    }
     {
         rs_prof_scope ps(ctx, "K3_accept");
         hipLaunchKernelGGL(k3_accept, dim3(1), dim3(1024), 0, ctx->stream, prop, N, max_distance, d_prop_point,
@@ -770,6 +782,24 @@ extern "C" int rs_reproj_match(rs_context* ctx, const rs_frame_view* fr, const r
     }
     RS_HIP(ctx, hipGetLastError());
     return RS_OK;
+}
+
+extern "C" int rs_reproj_match(rs_context* ctx, const rs_frame_view* fr, const rs_map_view* mp, int replace,
+                               int max_distance, int32_t* d_point_kp, int32_t* d_point_dist,
+                               int32_t* d_prop_point, int32_t* d_prop_dist, int32_t* d_match_kp,
+                               int32_t* d_match_point, int32_t* d_match_count)
+{
+    return reproj_match_impl(ctx, fr, mp, 0, false, replace, max_distance, d_point_kp, d_point_dist, d_prop_point, d_prop_dist, d_match_kp,
+                             d_match_point, d_match_count);
+}
+
+extern "C" int rs_reproj_match_sharded(rs_context* ctx, const rs_frame_view* fr, const rs_map_view* mp_shard, int point_base, int replace,
+                                       int max_distance, int32_t* d_point_kp, int32_t* d_point_dist,
+                                       int32_t* d_prop_point, int32_t* d_prop_dist, int32_t* d_match_kp,
+                                       int32_t* d_match_point, int32_t* d_match_count)
+{
+    return reproj_match_impl(ctx, fr, mp_shard, point_base, true, replace, max_distance, d_point_kp, d_point_dist, d_prop_point, d_prop_dist,
+                             d_match_kp, d_match_point, d_match_count);
 }
 
 // rs_kdtree_pack: the frame's KD-tree as K2 wants it in LDS — {x, y, left, right} per node, then the node's keypoint

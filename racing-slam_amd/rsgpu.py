@@ -15,7 +15,7 @@ LIB_PATH = os.path.join(_HERE, "librsgpu.so")
 EXPORTS = [
     "rs_abi_version", "rs_context_create", "rs_context_destroy", "rs_context_set_stream",
     "rs_context_synchronize", "rs_context_set_int", "rs_stage_begin", "rs_stage_alloc", "rs_stage_upload", "rs_stage_download", "rs_stage_sync", "rs_last_error", "rs_hamming_knn2", "rs_match_descriptors",
-    "rs_kdtree_build", "rs_kdtree_pack", "rs_reproj_match", "rs_map_create", "rs_map_destroy", "rs_frame_create", "rs_frame_destroy",
+    "rs_kdtree_build", "rs_kdtree_pack", "rs_reproj_match", "rs_reproj_match_sharded", "rs_map_create", "rs_map_destroy", "rs_frame_create", "rs_frame_destroy",
     "rs_map_add_keyframe", "rs_map_set_keyframe_pose", "rs_map_add_point", "rs_map_set_position", "rs_map_remove_point",
     "rs_map_add_observation", "rs_map_remove_observation", "rs_map_counts", "rs_map_get_positions", "rs_map_match", "rs_map_pose_graph", "rs_pose_graph", "rs_pose_relative", "rs_transform_points", "rs_map_bundle_adjust", "rs_triangulate", "rs_triangulate_host", "rs_triangulate_matches", "rs_triangulate_matches_batch", "rs_triangulate_tracks", "rs_point_errors", "rs_ba_default_options",
     "rs_bundle_adjust", "rs_bundle_adjust_batch", "rs_ba_get_trace", "rs_ba_get_stats", "rs_ba_get_cameras", "rs_reanchor_points", "rs_refine_pose", "rs_bundle_adjust_inertial", "rs_refine_pose_inertial", "rs_pack_pose", "rs_unpack_pose", "rs_pack_poses", "rs_unpack_poses", "rs_build_local_window",
@@ -326,6 +326,20 @@ class Context:
             keep[name] = self.dev(mp[key], dt)
             setattr(mv, name, keep[name].data_ptr())
         return mv, keep
+
+    def reproj_match_sharded(self, fv, mv, point_base, replace=0, max_distance=64):
+        """rs_reproj_match_sharded: mv is this rank's shard, point_base its first point's map order."""
+        t = self.torch
+        N, P = fv.n_keypoints, mv.n_points
+        out = dict(point_kp=self.empty((max(P, 1),), t.int32), point_dist=self.empty((max(P, 1),), t.int32),
+                   prop_point=self.empty((max(N, 1),), t.int32), prop_dist=self.empty((max(N, 1),), t.int32),
+                   match_kp=self.empty((max(N, 1),), t.int32), match_point=self.empty((max(N, 1),), t.int32),
+                   count=self.empty((1,), t.int32))
+        self._check(self.lib.rs_reproj_match_sharded(self.h, C.byref(fv), C.byref(mv), int(point_base), int(replace), int(max_distance),
+                                                     _dp(out["point_kp"]), _dp(out["point_dist"]), _dp(out["prop_point"]),
+                                                     _dp(out["prop_dist"]), _dp(out["match_kp"]), _dp(out["match_point"]),
+                                                     _dp(out["count"])), "rs_reproj_match_sharded")
+        return out
 
     def reproj_match(self, fv, mv, replace=0, max_distance=64, out=None):
         t = self.torch

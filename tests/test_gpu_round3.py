@@ -407,3 +407,71 @@ def test_bundle_adjust_banded_reduced_solve(ctx, oracle, synth, kw, banded):
         assert np.allclose(runs[0][2], runs[1][2], rtol=1e-8, atol=1e-10)
     else:       # (the same kernels both times; two runs of this weakly constrained window differ by 3e-9 through the atomics' order)
         assert np.allclose(runs[0][2], runs[1][2], rtol=1e-5, atol=1e-6)
+
+
+@pytest.mark.parametrize("bounds", [(0, 1000, 2000, 3000), (0, 1700, 1700, 3000), (0, 5, 2990, 3000)])
+def test_reproj_match_sharded_map_min_reduction(rs, oracle, synth, bounds):
+    """SURVEY.md 8(e) row 2 / VERDICT r2 #10: the map sharded over ranks, one min-reduction of the packed per-keypoint
+    proposals (distance << 32 | global map order) before the accept step.  Three contexts of one process joined by
+    rs_comm_init_local (on-device minimum instead of ncclAllReduce(min, u64)), uneven shards incl. an EMPTY one: every rank
+    must return the unsharded result and the oracle's, bit for bit — ties between points of different shards included
+    (duplicated descriptors force them).  Reference tie rule: src/MapMatcher.cpp:95-97."""
+    import torch
+    w = synth.make_ba_window(n_kf=10, n_points=3000)
+    frame, mp = synth.make_match_scene(w, n_keypoints=1500, kdtree_build=rs.kdtree_build)
+    rng = np.random.default_rng(17)
+    # duplicated descriptors across the map: distance ties between points that live on different shards
+    mp["desc_pool"][:] = mp["desc_pool"][rng.integers(0, 60, len(mp["desc_pool"]))]
+    frame["descriptors"][:] = mp["desc_pool"][rng.integers(0, 60, len(frame["descriptors"]))]
+    ref = oracle.reproj_match(frame, mp, replace=0)
+    assert len(ref["match_kp"]) > 50
+    P = len(mp["positions"])
+    n = len(bounds) - 1
+    ctxs = [rs.Context(0) for _ in range(n)]
+    streams = [torch.cuda.Stream(device=ctxs[0].device) for _ in range(n)]
+    for c, st in zip(ctxs, streams):
+        c.use_stream(st)
+    rs.Context.comm_init_local(ctxs)
+    out = [None] * n
+
+    def shard(lo, hi):
+        o0, o1 = int(mp["obs_ptr"][lo]), int(mp["obs_ptr"][hi])
+        return dict(mp, positions=mp["positions"][lo:hi], eligible=mp["eligible"][lo:hi], obs_ptr=(mp["obs_ptr"][lo:hi + 1] - o0).astype(np.int32),
+                    obs_kf=mp["obs_kf"][o0:o1] if o1 > o0 else np.zeros(1, np.int32), obs_desc=mp["obs_desc"][o0:o1] if o1 > o0 else np.zeros(1, np.int32))
+
+    def work(r):
+        try:
+            c = ctxs[r]
+            with torch.cuda.stream(streams[r]):
+                lo, hi = bounds[r], bounds[r + 1]
+                sh = shard(lo, hi)
+                if hi == lo:
+                    sh["positions"] = np.zeros((0, 3), np.float32); sh["eligible"] = np.zeros(0, np.uint8); sh["obs_ptr"] = np.zeros(1, np.int32)
+                fv, k1 = c.make_frame_view(frame, pack=True)
+                mv, k2 = c.make_map_view(sh)
+                mv.n_points = hi - lo
+                streams[r].synchronize()
+                o = c.reproj_match_sharded(fv, mv, lo)
+                streams[r].synchronize()
+                cnt = int(to_np(o["count"])[0])
+                out[r] = (to_np(o["match_kp"])[:cnt].copy(), to_np(o["match_point"])[:cnt].copy(), to_np(o["prop_point"])[:1500].copy(),
+                          to_np(o["point_kp"])[:hi - lo].copy())
+        except Exception as ex:      # noqa: BLE001
+            out[r] = ex
+
+    threads = [threading.Thread(target=work, args=(r,)) for r in range(n)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=120)
+    assert not any(t.is_alive() for t in threads), "a rank is stuck in the exchange step"
+    for c in ctxs:
+        c.comm_destroy()
+        c.close()
+    for r in range(n):
+        assert not isinstance(out[r], Exception), out[r]
+        mk, mpt, prop, pkp = out[r]
+        assert np.array_equal(mk, ref["match_kp"]) and np.array_equal(mpt, ref["match_point"]), r
+        assert np.array_equal(prop, ref["prop_point"]), r
+        assert np.array_equal(pkp, ref["point_kp"][bounds[r]:bounds[r + 1]]), r
+    assert P == bounds[-1]
