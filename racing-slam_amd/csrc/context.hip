@@ -418,6 +418,7 @@ struct rs_local_group {
     std::condition_variable cv;
     int arrived = 0;
     unsigned long generation = 0;
+    bool failed = false;             // a member hit an error inside an exchange step: every member returns RS_ERR_HIP from it
     double* buf[RS_LOCAL_MAX] = {};
     hipEvent_t ready[RS_LOCAL_MAX] = {}, read_done[RS_LOCAL_MAX] = {};
     double* scratch[RS_LOCAL_MAX] = {};
@@ -453,30 +454,48 @@ __global__ void rs_local_min_u64(LocalBufs b, int n, size_t count, double* __res
 // (8-byte elements: f64 sums, or unsigned 64-bit minima when min_u64 is set)
 static int local_allreduce(rs_context* ctx, double* d_buf, size_t count, bool min_u64 = false)
 {
+    // A member that hits a HIP error must still arrive at BOTH host barriers — the others would otherwise wait for it for
+    // ever — so errors are collected (first one kept in ctx->err), flagged on the group, and every member returns after the
+    // second barrier.
     rs_local_group* g = ctx->local;
     const int r = ctx->rank;
+    bool bad = false;
+    auto chk = [&](hipError_t e, const char* what) {
+        if (e != hipSuccess && !bad) { bad = true; rs_fail(ctx, RS_ERR_HIP, "%s failed in the in-process exchange step: %s", what, hipGetErrorString(e)); }
+    };
     if (count > g->scratch_cap[r]) {
-        if (g->scratch[r]) RS_HIP(ctx, hipFree(g->scratch[r]));
+        if (g->scratch[r]) chk(hipFree(g->scratch[r]), "hipFree");
         g->scratch[r] = nullptr;
-        RS_HIP(ctx, hipMalloc(&g->scratch[r], sizeof(double) * count));
-        g->scratch_cap[r] = count;
+        g->scratch_cap[r] = 0;
+        chk(hipMalloc(&g->scratch[r], sizeof(double) * count), "hipMalloc");
+        if (!bad) g->scratch_cap[r] = count;
     }
     g->buf[r] = d_buf;
-    RS_HIP(ctx, hipEventRecord(g->ready[r], ctx->stream));
+    chk(hipEventRecord(g->ready[r], ctx->stream), "hipEventRecord");
+    if (bad) { std::lock_guard<std::mutex> lk(g->m); g->failed = true; }
     local_barrier(g);
-    LocalBufs lb;
-    for (int q = 0; q < RS_LOCAL_MAX; q++) lb.p[q] = q < g->n ? g->buf[q] : nullptr;
-    for (int q = 0; q < g->n; q++)
-        if (q != r) RS_HIP(ctx, hipStreamWaitEvent(ctx->stream, g->ready[q], 0));
-    const int blocks = (int)((count + 255) / 256 < 512 ? (count + 255) / 256 : 512);
-    if (min_u64) hipLaunchKernelGGL(rs_local_min_u64, dim3(blocks), dim3(256), 0, ctx->stream, lb, g->n, count, g->scratch[r]);
-    else hipLaunchKernelGGL(rs_local_sum, dim3(blocks), dim3(256), 0, ctx->stream, lb, g->n, count, g->scratch[r]);
-    RS_HIP(ctx, hipEventRecord(g->read_done[r], ctx->stream));
+    bool group_bad;
+    { std::lock_guard<std::mutex> lk(g->m); group_bad = g->failed; }
+    if (!group_bad) {
+        LocalBufs lb;
+        for (int q = 0; q < RS_LOCAL_MAX; q++) lb.p[q] = q < g->n ? g->buf[q] : nullptr;
+        for (int q = 0; q < g->n; q++)
+            if (q != r) chk(hipStreamWaitEvent(ctx->stream, g->ready[q], 0), "hipStreamWaitEvent");
+        const int blocks = (int)((count + 255) / 256 < 512 ? (count + 255) / 256 : 512);
+        if (!bad) {
+            if (min_u64) hipLaunchKernelGGL(rs_local_min_u64, dim3(blocks), dim3(256), 0, ctx->stream, lb, g->n, count, g->scratch[r]);
+            else hipLaunchKernelGGL(rs_local_sum, dim3(blocks), dim3(256), 0, ctx->stream, lb, g->n, count, g->scratch[r]);
+        }
+        chk(hipEventRecord(g->read_done[r], ctx->stream), "hipEventRecord");
+        if (bad) { std::lock_guard<std::mutex> lk(g->m); g->failed = true; }
+    }
     local_barrier(g);
+    { std::lock_guard<std::mutex> lk(g->m); group_bad = g->failed; }
+    if (group_bad) return bad ? RS_ERR_HIP : rs_fail(ctx, RS_ERR_HIP, "another member of the in-process group failed in the exchange step");
     for (int q = 0; q < g->n; q++)
-        if (q != r) RS_HIP(ctx, hipStreamWaitEvent(ctx->stream, g->read_done[q], 0));
-    RS_HIP(ctx, hipMemcpyAsync(d_buf, g->scratch[r], sizeof(double) * count, hipMemcpyDeviceToDevice, ctx->stream));
-    return RS_OK;
+        if (q != r) chk(hipStreamWaitEvent(ctx->stream, g->read_done[q], 0), "hipStreamWaitEvent");
+    chk(hipMemcpyAsync(d_buf, g->scratch[r], sizeof(double) * count, hipMemcpyDeviceToDevice, ctx->stream), "hipMemcpyAsync");
+    return bad ? RS_ERR_HIP : RS_OK;
 }
 
 extern "C" int rs_comm_init_local(rs_context** ctxs, int n)
@@ -583,10 +602,14 @@ int rs_allreduce_f64(rs_context* ctx, double* d_buf, size_t count, bool is_max)
 #include <unordered_map>
 hipError_t rs_lds_attr(const void* fn, size_t bytes)
 {
+    // the attribute belongs to the function ON THE CURRENT DEVICE: the cache is keyed by (device, function), so that a
+    // process with contexts on several devices sets it on each of them
     static std::mutex mu;
-    static std::unordered_map<const void*, size_t> have;
+    static std::unordered_map<unsigned long long, size_t> have;
+    int dev = 0;
+    (void)hipGetDevice(&dev);
     std::lock_guard<std::mutex> lock(mu);
-    size_t& cur = have[fn];
+    size_t& cur = have[(unsigned long long)(uintptr_t)fn * 64ull + (unsigned long long)(dev & 63)];
     if (bytes <= cur) return hipSuccess;
     const hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
     if (e == hipSuccess) cur = bytes;
