@@ -425,12 +425,22 @@ struct rs_local_group {
     size_t scratch_cap[RS_LOCAL_MAX] = {};
 };
 
+// Host barrier of the group's member threads.  A member that never arrives (its call failed before the exchange step, or
+// its thread died) must not strand the others: the wait is bounded (RS_LOCAL_BARRIER_SECONDS), and a timed-out barrier
+// marks the group failed — every later exchange step of every member then returns an error.
+#include <chrono>
+#define RS_LOCAL_BARRIER_SECONDS 30
 static void local_barrier(rs_local_group* g)
 {
     std::unique_lock<std::mutex> lk(g->m);
     const unsigned long gen = g->generation;
-    if (++g->arrived == g->n) { g->arrived = 0; g->generation++; g->cv.notify_all(); }
-    else g->cv.wait(lk, [&] { return g->generation != gen; });
+    if (++g->arrived == g->n) { g->arrived = 0; g->generation++; g->cv.notify_all(); return; }
+    if (!g->cv.wait_for(lk, std::chrono::seconds(RS_LOCAL_BARRIER_SECONDS), [&] { return g->generation != gen; })) {
+        g->failed = true;                 // give up: release whoever else waits in this generation
+        g->arrived = 0;
+        g->generation++;
+        g->cv.notify_all();
+    }
 }
 
 struct LocalBufs { double* p[RS_LOCAL_MAX]; };
