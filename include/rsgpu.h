@@ -365,7 +365,12 @@ int rs_triangulate_matches_batch(rs_context* ctx, int batch,
  * Outputs, all device: d_status[t] 0 none / 1 candidate / 2 inconsistent; d_xyz[t][3];
  * d_parallax_cos[t]; d_required_cos[t]; d_accepted[0..counts[0]) track indices in creation order
  * (the last counts[1] of them are the top-up); d_inconsistent[0..counts[2]); d_counts[3].
- * Point creation / association (:306-330) is pointer work and stays with the caller. */
+ * Point creation / association (:306-330) is pointer work and stays with the caller.
+ * d_required_by_pose [n_poses] or NULL: `required` depends only on the pair (pose of the first sighting, key-frame pose),
+ * and it is the one quantity of this function that goes through libm (std::acos, std::cos, :282-288).  With the table —
+ * rs_parallax_requirements, a HOST function using the host's libm like the reference does — required, and therefore the
+ * accepted list, are bit-identical to the CPU path; with NULL the device's acosf / cosf are used (<= 3e-7 apart, which may
+ * decide a track that sits exactly on its requirement differently). */
 int rs_triangulate_tracks(rs_context* ctx, int n_tracks, const float* d_track_uv /*[T][2]*/,
                           const uint8_t* d_skip /*[T] or NULL*/, const int32_t* d_sight_ptr /*[T+1]*/,
                           const int32_t* d_sight_pose /*[S]*/, const float* d_sight_uv /*[S][2]*/,
@@ -374,7 +379,12 @@ int rs_triangulate_tracks(rs_context* ctx, int n_tracks, const float* d_track_uv
                           float max_reprojection_error, float min_parallax_cosine,
                           float rotation_parallax_factor, int min_new_points, uint8_t* d_status,
                           float* d_xyz, float* d_parallax_cos, float* d_required_cos,
-                          int32_t* d_accepted, int32_t* d_inconsistent, int32_t* d_counts /*[3]*/);
+                          int32_t* d_accepted, int32_t* d_inconsistent, int32_t* d_counts /*[3]*/,
+                          const float* d_required_by_pose /*[n_poses] or NULL*/);
+/* Host function (no context): h_required[p] = min(min_parallax_cosine, cos(rotation_parallax_factor * turn(p))) with
+ * turn(p) = acos(clamp((trace(R_kf R_p^T) - 1) / 2)) in f32, operation for operation src/Mapper.cpp:281-288. */
+int rs_parallax_requirements(const float* h_poses /*[n_poses][16]*/, int n_poses, int kf_pose,
+                             float min_parallax_cosine, float rotation_parallax_factor, float* h_required /*[n_poses]*/);
 
 /* §8(f) rank 3 — the arithmetic of Mapper::cull_points (reference src/Mapper.cpp:396-431) and of
  * Slam::reprojection_error (src/Slam.cpp:302-317): for every point p with observations CSR

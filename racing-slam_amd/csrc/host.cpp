@@ -207,3 +207,29 @@ extern "C" int rs_build_local_window(int n_key_frames, int new_frame, int window
     *out_count = count;
     return RS_OK;
 }
+
+// The rotation-dependent parallax requirement of Mapper::triangulate_tracks (reference src/Mapper.cpp:281-288) per pose of a
+// first sighting: the one quantity of that function that goes through libm.  Computed here with the HOST's acosf / cosf —
+// what the reference itself calls — in the oracle's operation order (f32, dot products as (a0 b0 + a1 b1) + a2 b2, no FMA
+// contraction: this file is built with -ffp-contract=off), so that K6 with this table selects exactly the CPU path's tracks.
+extern "C" int rs_parallax_requirements(const float* h_poses, int n_poses, int kf_pose, float min_parallax_cosine,
+                                        float rotation_parallax_factor, float* h_required)
+{
+    if (n_poses < 0 || (n_poses > 0 && (!h_poses || !h_required))) return RS_ERR_INVALID;
+    if (n_poses == 0) return RS_OK;
+    if (kf_pose < 0 || kf_pose >= n_poses) return RS_ERR_INVALID;
+    const float* Tk = h_poses + 16 * (size_t)kf_pose;
+    for (int p = 0; p < n_poses; p++) {
+        const float* Tf = h_poses + 16 * (size_t)p;
+        float tr[3];
+        for (int i = 0; i < 3; i++) tr[i] = (Tk[4 * i] * Tf[4 * i] + Tk[4 * i + 1] * Tf[4 * i + 1]) + Tk[4 * i + 2] * Tf[4 * i + 2];
+        const float trace = (tr[0] + tr[1]) + tr[2];
+        float cosine = (trace - 1.0f) / 2.0f;
+        cosine = cosine < -1.0f ? -1.0f : cosine;
+        cosine = cosine > 1.0f ? 1.0f : cosine;
+        const float turned = acosf(cosine);
+        const float need = cosf(rotation_parallax_factor * turned);
+        h_required[p] = min_parallax_cosine < need ? min_parallax_cosine : need;
+    }
+    return RS_OK;
+}

@@ -25,7 +25,7 @@ __global__ __launch_bounds__(64) void k6_tracks(const float2* __restrict__ track
                                                const float2* __restrict__ sight_uv, const float* __restrict__ poses,
                                                int n_tracks, TrackParams prm, uint8_t* __restrict__ status,
                                                float* __restrict__ xyz, float* __restrict__ parallax_cos,
-                                               float* __restrict__ required_cos)
+                                               float* __restrict__ required_cos, const float* __restrict__ required_by_pose)
 {
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= n_tracks) return;
@@ -68,11 +68,15 @@ __global__ __launch_bounds__(64) void k6_tracks(const float2* __restrict__ track
                 float cosine = (trace - 1.0f) / 2.0f;
                 cosine = cosine < -1.0f ? -1.0f : cosine;
                 cosine = cosine > 1.0f ? 1.0f : cosine;
-                const float turned = acosf(cosine);
-                const float need = cosf(prm.rotation_factor * turned);
                 st = 1;
                 pc = dot3f(a, b);                                          // :287
-                rc = prm.min_parallax_cosine < need ? prm.min_parallax_cosine : need;   // :288
+                if (required_by_pose) {
+                    rc = required_by_pose[sight_pose[s0]];                 // the host's libm (rs_parallax_requirements): bit-exact
+                } else {
+                    const float turned = acosf(cosine);
+                    const float need = cosf(prm.rotation_factor * turned);
+                    rc = prm.min_parallax_cosine < need ? prm.min_parallax_cosine : need;   // :288
+                }
             }
         }
     }
@@ -136,7 +140,8 @@ extern "C" int rs_triangulate_tracks(rs_context* ctx, int n_tracks, const float*
                                      float max_reprojection_error, float min_parallax_cosine,
                                      float rotation_parallax_factor, int min_new_points, uint8_t* d_status,
                                      float* d_xyz, float* d_parallax_cos, float* d_required_cos,
-                                     int32_t* d_accepted, int32_t* d_inconsistent, int32_t* d_counts)
+                                     int32_t* d_accepted, int32_t* d_inconsistent, int32_t* d_counts,
+                                     const float* d_required_by_pose)
 {
     if (!ctx) return RS_ERR_INVALID;
     if (n_tracks < 0 || n_poses < 0) return rs_fail(ctx, RS_ERR_INVALID, "negative size");
@@ -163,7 +168,7 @@ extern "C" int rs_triangulate_tracks(rs_context* ctx, int n_tracks, const float*
         rs_prof_scope ps(ctx, "K6_tracks");
         hipLaunchKernelGGL(k6_tracks, dim3((n_tracks + 63) / 64), dim3(64), 0, ctx->stream, (const float2*)d_track_uv,
                            d_skip, d_sight_ptr, d_sight_pose, (const float2*)d_sight_uv, d_poses, n_tracks, prm,
-                           d_status, d_xyz, d_parallax_cos, d_required_cos);
+                           d_status, d_xyz, d_parallax_cos, d_required_cos, d_required_by_pose);
     }
     {
         rs_prof_scope ps(ctx, "K6b_select");

@@ -358,11 +358,17 @@ Selection select_track_points(const KeyFrame& key_frame, const std::vector<Track
     DevBuf<uint8_t> d_skip(skip), d_status(T);
     DevBuf<int32_t> d_sptr(sight_ptr), d_spose(sight_pose), d_acc(T), d_inc(T), d_cnt(3);
     const float K[4] = {camera.fx(), camera.fy(), camera.cx(), camera.cy()};
+    // the rotation-dependent requirement per first-sighting pose on the HOST (libm as the reference calls it, :281-288)
+    std::vector<float> required((size_t)kf_pose + 1);
+    if (!rs_ok(rs_parallax_requirements(poses.data(), kf_pose + 1, kf_pose, TRACK_MIN_PARALLAX_COSINE, ROTATION_PARALLAX_FACTOR,
+                                        required.data()), "rs_parallax_requirements"))
+        return out;
+    DevBuf<float> d_req(required);
     if (!rs_ok(rs_triangulate_tracks(ctx, (int)T, d_tuv.get(), d_skip.get(), d_sptr.get(), d_spose.get(), d_suv.get(),
                                      d_poses.get(), kf_pose + 1, kf_pose, K, ANY_PARALLAX_COSINE,
                                      TRACK_MAX_REPROJECTION_ERROR, TRACK_MIN_PARALLAX_COSINE, ROTATION_PARALLAX_FACTOR,
                                      (int)min_new_points, d_status.get(), d_xyz.get(), d_pc.get(), d_rc.get(), d_acc.get(),
-                                     d_inc.get(), d_cnt.get()), "rs_triangulate_tracks"))
+                                     d_inc.get(), d_cnt.get(), d_req.get()), "rs_triangulate_tracks"))
         return out;
     const auto cnt = d_cnt.fetch(3);
     const auto acc = d_acc.fetch(T);

@@ -17,7 +17,7 @@ EXPORTS = [
     "rs_context_synchronize", "rs_context_set_int", "rs_stage_begin", "rs_stage_alloc", "rs_stage_upload", "rs_stage_download", "rs_stage_sync", "rs_last_error", "rs_hamming_knn2", "rs_match_descriptors",
     "rs_kdtree_build", "rs_kdtree_pack", "rs_reproj_match", "rs_reproj_match_sharded", "rs_map_create", "rs_map_destroy", "rs_frame_create", "rs_frame_destroy",
     "rs_map_add_keyframe", "rs_map_set_keyframe_pose", "rs_map_add_point", "rs_map_set_position", "rs_map_remove_point",
-    "rs_map_add_observation", "rs_map_remove_observation", "rs_map_counts", "rs_map_get_positions", "rs_map_match", "rs_map_pose_graph", "rs_pose_graph", "rs_pose_relative", "rs_transform_points", "rs_map_bundle_adjust", "rs_triangulate", "rs_triangulate_host", "rs_triangulate_matches", "rs_triangulate_matches_batch", "rs_triangulate_tracks", "rs_point_errors", "rs_ba_default_options",
+    "rs_map_add_observation", "rs_map_remove_observation", "rs_map_counts", "rs_map_get_positions", "rs_map_match", "rs_map_pose_graph", "rs_pose_graph", "rs_pose_relative", "rs_transform_points", "rs_map_bundle_adjust", "rs_triangulate", "rs_triangulate_host", "rs_triangulate_matches", "rs_triangulate_matches_batch", "rs_triangulate_tracks", "rs_parallax_requirements", "rs_point_errors", "rs_ba_default_options",
     "rs_bundle_adjust", "rs_bundle_adjust_batch", "rs_ba_get_trace", "rs_ba_get_stats", "rs_ba_get_cameras", "rs_reanchor_points", "rs_refine_pose", "rs_bundle_adjust_inertial", "rs_refine_pose_inertial", "rs_pack_pose", "rs_unpack_pose", "rs_pack_poses", "rs_unpack_poses", "rs_build_local_window",
     "rs_comm_get_unique_id", "rs_comm_init_rank", "rs_comm_destroy", "rs_comm_init_local", "rs_comm_count", "rs_prof_begin", "rs_prof_end", "rs_prof_counters", "rs_prof_empty_launch",
 ]
@@ -201,6 +201,17 @@ def unpack_poses(cams, mask, out):
     m = None if mask is None else np.ascontiguousarray(mask, np.uint8)
     load().rs_unpack_poses(c.ctypes.data_as(C.c_void_p), len(c), None if m is None else m.ctypes.data_as(C.c_void_p),
                            out.ctypes.data_as(C.c_void_p))
+    return out
+
+
+def parallax_requirements(poses, kf_pose, min_parallax_cosine=0.999848, rotation_parallax_factor=0.20):
+    """rs_parallax_requirements (host, the host's libm): required parallax cosine per first-sighting pose [n] f32."""
+    P = np.ascontiguousarray(poses, np.float32).reshape(-1, 16)
+    out = np.zeros(len(P), np.float32)
+    rc = load().rs_parallax_requirements(P.ctypes.data_as(C.c_void_p), len(P), int(kf_pose), C.c_float(min_parallax_cosine),
+                                         C.c_float(rotation_parallax_factor), out.ctypes.data_as(C.c_void_p))
+    if rc:
+        raise RsError(f"rs_parallax_requirements -> {rc}")
     return out
 
 
@@ -421,7 +432,7 @@ class Context:
     # -- §8(f) rank 1: Mapper::triangulate_tracks body
     def triangulate_tracks(self, d_track_uv, d_sight_ptr, d_sight_pose, d_sight_uv, d_poses, kf_pose, K, d_skip=None,
                            any_parallax_cosine=1.0, max_reproj=4.0, min_parallax_cosine=0.999848,
-                           rotation_parallax_factor=0.20, min_new_points=100, out=None):
+                           rotation_parallax_factor=0.20, min_new_points=100, out=None, d_required=None):
         t = self.torch
         n = int(d_track_uv.shape[0])
         m = max(n, 1)
@@ -436,7 +447,8 @@ class Context:
             _dp(d_sight_uv), _dp(d_poses), int(d_poses.shape[0]), int(kf_pose), Kc, C.c_float(any_parallax_cosine),
             C.c_float(max_reproj), C.c_float(min_parallax_cosine), C.c_float(rotation_parallax_factor),
             int(min_new_points), _dp(out["status"]), _dp(out["xyz"]), _dp(out["parallax_cos"]),
-            _dp(out["required_cos"]), _dp(out["accepted"]), _dp(out["inconsistent"]), _dp(out["counts"])),
+            _dp(out["required_cos"]), _dp(out["accepted"]), _dp(out["inconsistent"]), _dp(out["counts"]),
+            None if d_required is None else _dp(d_required)),
             "rs_triangulate_tracks")
         return out
 

@@ -178,6 +178,19 @@ def test_triangulate_tracks_body(ctx, oracle, synth, kw, quota):
     else:       # decisions may differ only on the boundary tracks
         diff = set(to_np(d["accepted"])[:cnt[0]].tolist()) ^ set(ref["accepted"].tolist())
         assert len(diff) <= 2 * int(boundary.sum())
+    # round 3: with the requirement table from the host's libm (rs_parallax_requirements — what the shims pass) `required`
+    # and the accepted list are bit-identical, boundary tracks or not
+    import importlib
+    rsgpu = importlib.import_module("racing-slam_amd").rsgpu
+    req = rsgpu.parallax_requirements(sc["poses"], sc["kf_pose"])
+    e = ctx.triangulate_tracks(ctx.dev(sc["track_uv"]), ctx.dev(sc["sight_ptr"]), ctx.dev(sc["sight_pose"]),
+                               ctx.dev(sc["sight_uv"]), ctx.dev(sc["poses"]), sc["kf_pose"], sc["K"],
+                               d_skip=ctx.dev(sc["skip"]), min_new_points=quota, d_required=ctx.dev(req))
+    ce = to_np(e["counts"])
+    assert np.array_equal(to_np(e["status"])[:n], ref["status"])
+    assert np.array_equal(to_np(e["required_cos"])[:n].view(np.uint32), ref["required_cos"].view(np.uint32))
+    assert ce[1] == ref["n_topped_up"] and np.array_equal(to_np(e["accepted"])[:ce[0]], ref["accepted"])
+    assert np.array_equal(to_np(e["inconsistent"])[:ce[2]], ref["inconsistent"])
 
 
 def test_triangulate_tracks_body_edge_cases(ctx, synth):

@@ -43,7 +43,7 @@ def test_bench_pass_inputs_against_oracle(ctx, rs, oracle, synth):
     ok, report = bench.check_pass_parity(meta, cpu_pass, oracle)
     assert ok, report
     for k in ("match_descriptors.query", "match_key_frame.points", "match_map.points", "triangulate.xyz", "tracks.status",
-              "build_local_window.frames", "bundle_adjust.schedule"):
+              "tracks.required_cos", "tracks.accepted", "build_local_window.frames", "bundle_adjust.schedule"):
         assert report[k] is True, (k, report)
     # the side stages the bench line reports beside the pass
     meta["cull_stage"]()

@@ -599,3 +599,19 @@ def test_inertial_bundle_adjust_reduces_to_vision_only_without_factors(oracle, s
     fr = np.flatnonzero(w["cam_free"])
     assert s["usable"] == 1
     assert np.abs(v - imu["cam_velocity_true"])[fr].max() < 0.7 * np.abs(imu["cam_velocity"] - imu["cam_velocity_true"])[fr].max()
+
+
+def test_parallax_requirements_host_function_equals_the_oracle_bit_for_bit(rs, oracle, synth):
+    """rs_parallax_requirements (host code of the product, no GPU): the rotation-dependent parallax requirement per
+    first-sighting pose (reference src/Mapper.cpp:281-288) through the host's libm — must equal, bit for bit, what the
+    oracle computes per track, so that K6 with this table selects exactly the CPU path's tracks."""
+    for kw in (dict(n_tracks=2000, config_id=6), dict(n_tracks=5000, n_frames=16, max_sightings=14, config_id=9)):
+        sc = synth.make_tracks(**kw)
+        ref = oracle.triangulate_tracks(sc["track_uv"], sc["sight_ptr"], sc["sight_pose"], sc["sight_uv"], sc["poses"],
+                                        sc["kf_pose"], sc["K"], skip=sc["skip"])
+        req = rs.parallax_requirements(sc["poses"], sc["kf_pose"])
+        cand = np.flatnonzero(ref["status"] == 1)
+        assert len(cand) > 100
+        first_pose = sc["sight_pose"][sc["sight_ptr"][cand]]
+        assert np.array_equal(req[first_pose].view(np.uint32), ref["required_cos"][cand].view(np.uint32))
+        assert np.all(req <= np.float32(0.999848))
