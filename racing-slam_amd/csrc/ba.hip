@@ -840,7 +840,7 @@ static int ba_solve_once(rs_context* ctx, int n_cameras, int n_points, int n_obs
     // word travels to the host (the solve is milliseconds: the wait costs a few per cent of one round) and decides between
     // the one-launch banded factorisation and the general blocked one.  Sharded solves keep the general form: every rank
     // must run the same arithmetic on the all-reduced system.
-    bool band = false;
+    int band = 0;                     // 1: one workgroup, 2: two-sided (ba_solve_big.hip)
     if (solve_big && use_mfma && !in && !rs_comm_active(ctx) && ctx->ba_band_mode != 1) {
         volatile int32_t* h_span = (volatile int32_t*)((char*)pin + pin_prog + 32);
         *h_span = -1;
@@ -850,7 +850,7 @@ static int ba_solve_once(rs_context* ctx, int n_cameras, int n_points, int n_obs
             if ((++spins & 0x3FFFF) == 0 && hipStreamQuery(s) != hipErrorNotReady) break;
         }
         if (*h_span < 0) RS_HIP(ctx, hipStreamSynchronize(s));
-        band = *h_span >= 0 && *h_span <= ba_band_max_span();
+        if (*h_span >= 0 && *h_span <= ba_band_max_span()) band = ctx->ba_band_mode == 2 ? 1 : 2;
     }
     // One ROUND = K5 + K7 + K8 and evaluates the next `ns` LM iterations of the sequential loop (all of them only if
     // the first ns - 1 are rejected).  At least ceil(max_iter / ns) rounds are needed and at most max_iter; beyond the

@@ -554,7 +554,7 @@ void ba_launch_schur(hipStream_t s, const BaDims& d, const BaBufs& b, const BaOp
 // ---- blocked reduced solve for n > BA_MAX_LDS_N (ba_solve_big.hip)
 struct rs_context;
 size_t ba_big_bytes(int n);
-int ba_launch_reduced_solve_big(rs_context* ctx, const BaDims& d, const BaBufs& b, const BaOpt& opt, char* ws, bool band);
+int ba_launch_reduced_solve_big(rs_context* ctx, const BaDims& d, const BaBufs& b, const BaOpt& opt, char* ws, int band);   // band: 0 general blocked, 1 banded (one workgroup), 2 banded, two-sided
 int ba_band_max_span();
 // ---- inertial reduced solve (ba_solve_big.hip): N = 6 Cf + 9 Ci unknowns
 size_t ba_inertial_bytes(int N, int n_fac, int C);

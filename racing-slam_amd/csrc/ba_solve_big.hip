@@ -29,6 +29,7 @@ struct BigBufs {
     double* dv;      // [n] D
     double* yf;      // [n] D^-1 L^-1 g
     int* fail;       // [1]
+    double* sep;     // [2][WB * WB + WB] two-sided banded factorisation: each side's Schur update of the separator block + right-hand side
 };
 
 __device__ __forceinline__ double rl64(double v, int lane)
@@ -472,7 +473,134 @@ __global__ __launch_bounds__(256) void ba_big_update(BaDims d, BaBufs b, BigBufs
 // the prefetch of the next blocks and the stores of the factor with the factorisation
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
-__global__ __launch_bounds__(1024) void ba_band_factor(BaDims d, BaBufs b, BigBufs g)
+// The 129-row panel [D; P; rhs] of one block column in LDS, factored in place as four 16-column sub-blocks (all 16 waves of
+// the workgroup call this together): afterwards D holds L_JJ below its diagonal and d on it, P the multipliers L_{J+1,J},
+// the right-hand side row D^-1 L^-1 g, dvl the pivots.  w: columns of the block, hp: rows of P, c_first: first sub-block
+// that is not identity padding.
+static __device__ __forceinline__ void band_panel(double* Pm, double* Tt, double* Mi, double* rdl, double* dvl, int w, int hp, int c_first,
+                                                  bool& bad, unsigned long long* acc_t, unsigned long long& tq)
+{
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int lr = lane & 15, lk = lane >> 4;
+#if RS_STAMPS
+#define PANEL_STAMP(i) do { if (tid == 0) { const unsigned long long t_ = wall_clock64(); acc_t[i] += t_ - tq; tq = t_; } } while (0)
+#else
+#define PANEL_STAMP(i) do { } while (0)
+#endif
+    for (int c = c_first; c < w; c += 16) {
+        if (wave == 0) {
+            // A: the 16 x 16 diagonal sub-block in registers (lane = row; pivots and column entries by v_readlane)
+            int r = lr;
+            double a[16];
+#pragma unroll
+            for (int k = 0; k < 16; k++) a[k] = Pm[(c + r) * WBS + c + k];
+            double my_rd = 1.0, my_piv = 1.0;
+#pragma unroll
+            for (int cc = 0; cc < 16; cc++) {
+                asm volatile("" : "+v"(r));
+                const double piv = rl64(a[cc], cc);
+                bad = bad || !(piv > 0.0) || !isfinite(piv);
+                const double rd = rcp_nr(piv);
+                const double lc = a[cc] * rd;
+#pragma unroll
+                for (int k = cc + 1; k < 16; k++) a[k] -= lc * rl64(a[cc], k);
+                a[cc] = r > cc ? lc : a[cc];
+                my_rd = r == cc ? rd : my_rd;
+                my_piv = r == cc ? piv : my_piv;
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if (lane < 16) {
+#pragma unroll
+                for (int k = 0; k < 16; k++) Pm[(c + r) * WBS + c + k] = a[k];      // multipliers below the diagonal, d on it
+                rdl[r] = my_rd;
+                dvl[c + r] = my_piv;
+            }
+            // A': row r of M = L^-1 (unit lower) by lane r: m_rj = -sum_{k > j} m_rk l_kj for j < r.  L is read back from the
+            // panel image just written — the same address in every lane, i.e. LDS broadcasts — with two partial sums per
+            // entry (as v_readlane broadcasts from the lanes' registers the 120 column entries cost 2.5 us per sub-block).
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            if (lane < 16) {
+                double m[16];
+#pragma unroll
+                for (int k = 0; k < 16; k++) m[k] = (k == r) ? 1.0 : 0.0;
+#pragma unroll
+                for (int jj = 14; jj >= 0; jj--) {
+                    asm volatile("" : "+v"(r));
+                    double s0 = 0.0, s1 = 0.0;
+#pragma unroll
+                    for (int k = jj + 1; k < 16; k += 2) {
+                        s0 -= m[k] * Pm[(c + k) * WBS + c + jj];             // m[k] = 0 beyond the row's diagonal
+                        if (k + 1 < 16) s1 -= m[k + 1] * Pm[(c + k + 1) * WBS + c + jj];
+                    }
+                    m[jj] = jj < r ? s0 + s1 : m[jj];
+                }
+#pragma unroll
+                for (int k = 0; k < 16; k++) Mi[r * 17 + k] = m[k];
+            }
+        }
+        lds_barrier();
+        PANEL_STAMP(1);
+        const int wpad = (w + 15) & ~15;                                    // (rows w .. wpad-1 are identity padding: whole tiles)
+        const int below = max(0, wpad - c - 16);                            // D rows under the sub-block
+        const int nrows = below + hp + 1;                                   // + P rows + the right-hand side row
+        auto row_of = [&](int pr) { return pr < below ? c + 16 + pr : (pr < below + hp ? WB + (pr - below) : 2 * WB); };
+        const int ntile = (nrows + 15) / 16;
+        // B: T = R M^T on the matrix cores, one 16-row tile of the rows below per wave; multipliers = T D^-1
+        if (wave < ntile) {
+            const int prA = min(16 * wave + lr, nrows - 1);                  // operand row of this lane (clamped: masked at the store)
+            const double* R = Pm + row_of(prA) * WBS + c + lk;
+            const double* Mr = Mi + lr * 17 + lk;
+            double ra[4], mb[4];
+#pragma unroll
+            for (int kc = 0; kc < 4; kc++) { ra[kc] = R[4 * kc]; mb[kc] = Mr[4 * kc]; }
+            d4 acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int kc = 0; kc < 4; kc++) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(ra[kc], mb[kc], acc, 0, 0, 0);
+            const double rdj = rdl[lr];
+#pragma unroll
+            for (int reg = 0; reg < 4; reg++) {
+                const int pr = 16 * wave + lk + 4 * reg;
+                Tt[pr * 17 + lr] = acc[reg];
+                if (pr < nrows) Pm[row_of(pr) * WBS + c + lr] = acc[reg] * rdj;
+            }
+        }
+        lds_barrier();
+        PANEL_STAMP(2);
+        // C: rank-16 update of the panel's remaining columns on the matrix cores: rows below x D rows below
+        {
+            const int ctile = below / 16;                                    // w - c - 16 is a multiple of 16 (identity padding)
+            for (int t = wave; t < ntile * ctile; t += 16) {
+                const int tr = t / ctile, tc = t % ctile;
+                const double* X = Tt + (16 * tr + lr) * 17 + lk;
+                const double* Z = Pm + (c + 16 + 16 * tc + lr) * WBS + c + lk;
+                double xa[4], zb[4];
+#pragma unroll
+                for (int kc = 0; kc < 4; kc++) { xa[kc] = X[4 * kc]; zb[kc] = Z[4 * kc]; }
+                d4 acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                for (int kc = 0; kc < 4; kc++) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(xa[kc], zb[kc], acc, 0, 0, 0);
+#pragma unroll
+                for (int reg = 0; reg < 4; reg++) {
+                    const int pr = 16 * tr + lk + 4 * reg, qq = 16 * tc + lr;
+                    if (pr < nrows && (pr >= below || qq <= pr)) Pm[row_of(pr) * WBS + c + 16 + qq] -= acc[reg];
+                }
+            }
+        }
+        lds_barrier();
+        PANEL_STAMP(3);
+    }
+#undef PANEL_STAMP
+}
+
+// Two-sided form (`split`): the band is cut at a SEPARATOR block column Js = (NB - 1) / 2.  Workgroup 0 eliminates the block
+// columns above it in order, workgroup 1 the ones below it in REVERSE order (the same algorithm on the matrix with rows and
+// columns reversed, v -> 64 NB - 1 - v: a band stays a band; the identity padding of the last real block becomes the head of
+// its first block and whole padded sub-blocks are skipped); the bandwidth (<= 64) keeps the two sides uncoupled.  Each side
+// leaves its Schur update of the separator block — side 0: A_ss - update, side 1: - update (in its reversed order) — in
+// g.sep; ba_big_finish adds them, factors the separator and substitutes backwards on both sides in lock step.  The chain of
+// dependent 16-column sub-blocks is 17 + 4 instead of 37 at n = 588.  Factor blocks are stored at the REAL positions of their
+// (virtual) rows and columns, so side 1's land in the upper triangle of g.Ls.
+__global__ __launch_bounds__(1024) void ba_band_factor(BaDims d, BaBufs b, BigBufs g, int split)
 {
     if (b.st->done) return;
     extern __shared__ __attribute__((aligned(16))) double wl[];
@@ -485,30 +613,47 @@ __global__ __launch_bounds__(1024) void ba_band_factor(BaDims d, BaBufs b, BigBu
     double* dvl = rdl + 16;                        // [WB] d of the block
     const int n = d.n, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int lr = lane & 15, lk = lane >> 4;
-    const int NBLK = (n + WB - 1) / WB;
+    const int NB = (n + WB - 1) / WB, np = NB * WB;
+    const int rev = split ? (int)blockIdx.x : 0;
+    const int Js = (NB - 1) / 2;
+    const int ND = split ? (rev ? NB - 1 - Js : Js) : NB;     // block columns this workgroup eliminates
+    const int pad = np - n;                                     // identity padding: the tail of the real order = the head of the reversed one
+    // virtual index -> real index; entries outside the matrix are identity
+    auto phi = [&](int v) { return rev ? np - 1 - v : v; };
+    auto inside = [&](int v) { return (unsigned)phi(v) < (unsigned)n; };
+    auto addr = [&](int r, int k) {                             // (clamped) address of A'(r, k) in the lower triangle of S
+        const int i = min(max(phi(r), 0), n - 1), j = min(max(phi(k), 0), n - 1);
+        return (size_t)max(i, j) * n + min(i, j);
+    };
+    auto rhs_at = [&](int v) { return min(max(phi(v), 0), n - 1); };
 #if RS_STAMPS
     unsigned long long tq = wall_clock64(), acc_t[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 #define BAND_STAMP(i) do { if (tid == 0) { const unsigned long long t_ = wall_clock64(); acc_t[i] += t_ - tq; tq = t_; } } while (0)
 #else
+    unsigned long long tq = 0, *acc_t = nullptr;
 #define BAND_STAMP(i) do { } while (0)
 #endif
     if (tid < WB) dvl[tid] = 1.0;
-    // block 0: D, P, T, right-hand sides from memory; identity padding beyond the matrix
+    // block 0: D, P, T, right-hand sides from memory.  Side 1 starts the separator's block from zero: it contributes updates only.
     {
-        const int w0 = min(WB, n), hp0 = max(0, min(WB, n - WB));
+        const bool tz = split && rev && ND == 1;
         for (int idx = tid; idx < WB * WB; idx += 1024) {
             const int r = idx / WB, k = idx % WB;
-            Pm[r * WBS + k] = (r < w0 && k < w0) ? b.S[(size_t)r * n + k] : (r == k ? 1.0 : 0.0);
-            Pm[(WB + r) * WBS + k] = (r < hp0 && k < w0) ? b.S[(size_t)(WB + r) * n + k] : 0.0;
-            Tm[r * WBS + k] = (r < hp0 && k < hp0) ? b.S[(size_t)(WB + r) * n + WB + k] : (r == k ? 1.0 : 0.0);
+            const double ident = r == k ? 1.0 : 0.0;
+            Pm[r * WBS + k] = (inside(r) && inside(k)) ? b.S[addr(r, k)] : ident;
+            Pm[(WB + r) * WBS + k] = (inside(WB + r) && inside(k)) ? b.S[addr(WB + r, k)] : 0.0;
+            Tm[r * WBS + k] = tz ? 0.0 : ((inside(WB + r) && inside(WB + k)) ? b.S[addr(WB + r, WB + k)] : ident);
         }
-        if (tid < WB) { Pm[2 * WB * WBS + tid] = tid < w0 ? b.dc[tid] : 0.0; yP[tid] = tid < hp0 ? b.dc[WB + tid] : 0.0; }
+        if (tid < WB) {
+            Pm[2 * WB * WBS + tid] = inside(tid) ? b.dc[rhs_at(tid)] : 0.0;
+            yP[tid] = (!tz && inside(WB + tid)) ? b.dc[rhs_at(WB + tid)] : 0.0;
+        }
     }
     bool bad = false;
-    for (int J = 0; J < NBLK; J++) {
-        const int c0 = WB * J, w = min(WB, n - c0);
-        const int r1 = c0 + WB, hp = max(0, min(WB, n - r1));          // rows of block J+1
-        const int r2 = r1 + WB, hq = max(0, min(WB, n - r2));          // rows of block J+2 (the P of the next step)
+    for (int J = 0; J < ND; J++) {
+        const int c0 = WB * J, w = rev ? WB : min(WB, n - c0);
+        const int r1 = c0 + WB, hp = J + 1 < NB ? (rev ? WB : min(WB, n - r1)) : 0;      // rows of block J+1
+        const int r2 = r1 + WB;                                                         // block J+2 (the P of the next step)
         // the NEXT step's P (A[J+2][J+1]), T (A[J+2][J+2]) and right-hand side go out now and land in registers under the
         // factorisation (original entries of S: nothing outside the band ever updates them)
         // (clamped addresses, masks applied when the values are placed: a conditional load is waited for on the spot)
@@ -516,126 +661,25 @@ __global__ __launch_bounds__(1024) void ba_band_factor(BaDims d, BaBufs b, BigBu
 #pragma unroll
         for (int u = 0; u < 4; u++) {
             const int idx = tid + 1024 * u, r = idx / WB, k = idx % WB;
-            const size_t rowa = (size_t)min(r2 + r, n - 1) * n;
-            nP[u] = b.S[rowa + min(r1 + k, n - 1)];
-            nT[u] = b.S[rowa + min(r2 + k, n - 1)];
+            nP[u] = b.S[addr(r2 + r, r1 + k)];
+            nT[u] = b.S[addr(r2 + r, r2 + k)];
         }
-        nY = b.dc[min(r2 + (tid & (WB - 1)), n - 1)];
+        nY = b.dc[rhs_at(r2 + (tid & (WB - 1)))];
         lds_barrier();
         BAND_STAMP(0);
-        // ---- factor the panel: four 16-column sub-blocks
-        for (int c = 0; c < w; c += 16) {
-            if (wave == 0) {
-                // A: the 16 x 16 diagonal sub-block in registers (lane = row; pivots and column entries by v_readlane)
-                int r = lr;
-                double a[16];
-#pragma unroll
-                for (int k = 0; k < 16; k++) a[k] = Pm[(c + r) * WBS + c + k];
-                double my_rd = 1.0, my_piv = 1.0;
-#pragma unroll
-                for (int cc = 0; cc < 16; cc++) {
-                    asm volatile("" : "+v"(r));
-                    const double piv = rl64(a[cc], cc);
-                    bad = bad || !(piv > 0.0) || !isfinite(piv);
-                    const double rd = rcp_nr(piv);
-                    const double lc = a[cc] * rd;
-#pragma unroll
-                    for (int k = cc + 1; k < 16; k++) a[k] -= lc * rl64(a[cc], k);
-                    a[cc] = r > cc ? lc : a[cc];
-                    my_rd = r == cc ? rd : my_rd;
-                    my_piv = r == cc ? piv : my_piv;
-                    __builtin_amdgcn_sched_barrier(0);
-                }
-                if (lane < 16) {
-#pragma unroll
-                    for (int k = 0; k < 16; k++) Pm[(c + r) * WBS + c + k] = a[k];      // multipliers below the diagonal, d on it
-                    rdl[r] = my_rd;
-                    dvl[c + r] = my_piv;
-                }
-                // A': row r of M = L^-1 (unit lower) by lane r: m_rj = -sum_{k > j} m_rk l_kj for j < r.  L is read back from the
-                // panel image just written — the same address in every lane, i.e. LDS broadcasts — with two partial sums per
-                // entry (as v_readlane broadcasts from the lanes' registers the 120 column entries cost 2.5 us per sub-block).
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                if (lane < 16) {
-                    double m[16];
-#pragma unroll
-                    for (int k = 0; k < 16; k++) m[k] = (k == r) ? 1.0 : 0.0;
-#pragma unroll
-                    for (int jj = 14; jj >= 0; jj--) {
-                        asm volatile("" : "+v"(r));
-                        double s0 = 0.0, s1 = 0.0;
-#pragma unroll
-                        for (int k = jj + 1; k < 16; k += 2) {
-                            s0 -= m[k] * Pm[(c + k) * WBS + c + jj];             // m[k] = 0 beyond the row's diagonal
-                            if (k + 1 < 16) s1 -= m[k + 1] * Pm[(c + k + 1) * WBS + c + jj];
-                        }
-                        m[jj] = jj < r ? s0 + s1 : m[jj];
-                    }
-#pragma unroll
-                    for (int k = 0; k < 16; k++) Mi[r * 17 + k] = m[k];
-                }
-            }
-            lds_barrier();
-            BAND_STAMP(1);
-            const int wpad = (w + 15) & ~15;                                    // (rows w .. wpad-1 are identity padding: whole tiles)
-            const int below = max(0, wpad - c - 16);                            // D rows under the sub-block
-            const int nrows = below + hp + 1;                                   // + P rows + the right-hand side row
-            auto row_of = [&](int pr) { return pr < below ? c + 16 + pr : (pr < below + hp ? WB + (pr - below) : 2 * WB); };
-            const int ntile = (nrows + 15) / 16;
-            // B: T = R M^T on the matrix cores, one 16-row tile of the rows below per wave; multipliers = T D^-1
-            if (wave < ntile) {
-                const int prA = min(16 * wave + lr, nrows - 1);                  // operand row of this lane (clamped: masked at the store)
-                const double* R = Pm + row_of(prA) * WBS + c + lk;
-                const double* Mr = Mi + lr * 17 + lk;
-                double ra[4], mb[4];
-#pragma unroll
-                for (int kc = 0; kc < 4; kc++) { ra[kc] = R[4 * kc]; mb[kc] = Mr[4 * kc]; }
-                d4 acc = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-                for (int kc = 0; kc < 4; kc++) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(ra[kc], mb[kc], acc, 0, 0, 0);
-                const double rdj = rdl[lr];
-#pragma unroll
-                for (int reg = 0; reg < 4; reg++) {
-                    const int pr = 16 * wave + lk + 4 * reg;
-                    Tt[pr * 17 + lr] = acc[reg];
-                    if (pr < nrows) Pm[row_of(pr) * WBS + c + lr] = acc[reg] * rdj;
-                }
-            }
-            lds_barrier();
-            BAND_STAMP(2);
-            // C: rank-16 update of the panel's remaining columns on the matrix cores: rows below x D rows below
-            {
-                const int ctile = below / 16;                                    // w - c - 16 is a multiple of 16 (identity padding)
-                for (int t = wave; t < ntile * ctile; t += 16) {
-                    const int tr = t / ctile, tc = t % ctile;
-                    const double* X = Tt + (16 * tr + lr) * 17 + lk;
-                    const double* Z = Pm + (c + 16 + 16 * tc + lr) * WBS + c + lk;
-                    double xa[4], zb[4];
-#pragma unroll
-                    for (int kc = 0; kc < 4; kc++) { xa[kc] = X[4 * kc]; zb[kc] = Z[4 * kc]; }
-                    d4 acc = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-                    for (int kc = 0; kc < 4; kc++) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(xa[kc], zb[kc], acc, 0, 0, 0);
-#pragma unroll
-                    for (int reg = 0; reg < 4; reg++) {
-                        const int pr = 16 * tr + lk + 4 * reg, qq = 16 * tc + lr;
-                        if (pr < nrows && (pr >= below || qq <= pr)) Pm[row_of(pr) * WBS + c + 16 + qq] -= acc[reg];
-                    }
-                }
-            }
-            lds_barrier();
-            BAND_STAMP(3);
-        }
+        // ---- factor the panel: four 16-column sub-blocks (whole sub-blocks of side 1's padding are identity already)
+        const int c_first = (rev && J == 0) ? (pad & ~15) : 0;
+        band_panel(Pm, Tt, Mi, rdl, dvl, w, hp, c_first, bad, acc_t, tq);
         // ---- the factor's blocks -> memory (the backward substitution reads them), D^-1 L^-1 g, D
-        for (int idx = tid; idx < w * w; idx += 1024) {
-            const int r = idx / w, k = idx % w;
-            g.Ls[(size_t)(c0 + r) * n + c0 + k] = k < r ? Pm[r * WBS + k] : (k == r ? 1.0 : 0.0);
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const int idx = tid + 1024 * u, r = idx / WB, k = idx % WB;
+            if (inside(c0 + r) && inside(c0 + k))
+                g.Ls[(size_t)phi(c0 + r) * n + phi(c0 + k)] = k < r ? Pm[r * WBS + k] : (k == r ? 1.0 : 0.0);
+            if (r < hp && inside(r1 + r) && inside(c0 + k))
+                g.Ls[(size_t)phi(r1 + r) * n + phi(c0 + k)] = Pm[(WB + r) * WBS + k];
         }
-        for (int idx = tid; idx < hp * w; idx += 1024) {
-            const int r = idx / w, k = idx % w;
-            g.Ls[(size_t)(r1 + r) * n + c0 + k] = Pm[(WB + r) * WBS + k];
-        }
-        if (tid < w) { g.yf[c0 + tid] = Pm[2 * WB * WBS + tid]; g.dv[c0 + tid] = dvl[tid]; }
+        if (tid < WB && inside(c0 + tid)) { g.yf[phi(c0 + tid)] = Pm[2 * WB * WBS + tid]; g.dv[phi(c0 + tid)] = dvl[tid]; }
         BAND_STAMP(4);
         if (hp == 0) break;                                                      // last block
         // ---- trailing update on the matrix cores: T -= (L_P D) L_P^T (lower tiles), yP -= L_P D yf
@@ -667,6 +711,16 @@ __global__ __launch_bounds__(1024) void ba_band_factor(BaDims d, BaBufs b, BigBu
         }
         lds_barrier();
         BAND_STAMP(5);
+        if (split && J == ND - 1) {
+            // the separator's block as this side leaves it (lower triangle, this side's order) and its right-hand side
+            double* sp = g.sep + (size_t)rev * (WB * WB + WB);
+            for (int idx = tid; idx < WB * WB; idx += 1024) {
+                const int r = idx / WB, k = idx % WB;
+                if (k <= r) sp[idx] = Tm[r * WBS + k];
+            }
+            if (tid < WB) sp[WB * WB + tid] = yP[tid];
+            break;
+        }
         // ---- shift the window: T -> D, yP -> rhs row, the prefetched blocks -> P / T / yP
         for (int idx = tid; idx < WB * WB; idx += 1024) {
             const int r = idx / WB, k = idx % WB;
@@ -674,18 +728,22 @@ __global__ __launch_bounds__(1024) void ba_band_factor(BaDims d, BaBufs b, BigBu
         }
         if (tid < WB) Pm[2 * WB * WBS + tid] = yP[tid];
         lds_barrier();
+        {
+            const bool tz = split && rev && J + 2 == ND;                         // side 1 reaches the separator: updates only
 #pragma unroll
-        for (int u = 0; u < 4; u++) {
-            const int idx = tid + 1024 * u, r = idx / WB, k = idx % WB;
-            Pm[(WB + r) * WBS + k] = (r < hq && k < hp) ? nP[u] : 0.0;
-            Tm[r * WBS + k] = (r < hq && k < hq) ? nT[u] : (r == k ? 1.0 : 0.0);
+            for (int u = 0; u < 4; u++) {
+                const int idx = tid + 1024 * u, r = idx / WB, k = idx % WB;
+                const bool vr = J + 2 < NB && inside(r2 + r);
+                Pm[(WB + r) * WBS + k] = (vr && inside(r1 + k)) ? nP[u] : 0.0;
+                Tm[r * WBS + k] = tz ? 0.0 : ((vr && inside(r2 + k)) ? nT[u] : (r == k ? 1.0 : 0.0));
+            }
+            if (tid < WB) { yP[tid] = (!tz && J + 2 < NB && inside(r2 + tid)) ? nY : 0.0; dvl[tid] = 1.0; }
         }
-        if (tid < WB) { yP[tid] = tid < hq ? nY : 0.0; dvl[tid] = 1.0; }
         BAND_STAMP(6);
     }
     if (__any(bad) && lane == 0) *g.fail = 1;
 #if RS_STAMPS
-    if (tid == 0) for (int q = 0; q < 8; q++) b.dbg[16 + q] += acc_t[q];
+    if (tid == 0 && blockIdx.x == 0) for (int q = 0; q < 8; q++) b.dbg[16 + q] += acc_t[q];
 #endif
 }
 
@@ -734,6 +792,100 @@ static __device__ __forceinline__ void band_backsub(const BigBufs& g, int n, dou
                 v -= (tid < t) ? l[t] * xt : 0.0;
             }
             if (tid < w) y[c0 + tid] = v;
+        }
+        __syncthreads();
+    }
+}
+
+// Two-sided form: the separator's block (both sides' updates added) is factored here, then x_s, then both sides substitute
+// backwards away from the separator in lock step — side 0 in the real order, side 1 in its reversed order — each with half
+// of the workgroup for the product L_P^T x and one wave (on different SIMDs) for the triangular solve.
+//   W: LDS window of band_panel ([WROWS][WBS] panel, Tt, Mi, rdl, dvl); afterwards the same memory serves as two diagonal
+//   blocks [2][WB][WBS] + partial sums [2][8][WB].
+static __device__ __forceinline__ void band_sep_backsub(const BigBufs& g, int n, double* y, double* W, int* s_fail)
+{
+    const int tid = threadIdx.x, nt = blockDim.x, lane = tid & 63, wave = tid >> 6;
+    const int NB = (n + WB - 1) / WB, np = NB * WB, Js = (NB - 1) / 2;
+    double* Pm = W;
+    double* Tt = Pm + WROWS * WBS;
+    double* Mi = Tt + 16 * WTILES * 17;
+    double* rdl = Mi + 16 * 17;
+    double* dvl = rdl + 16;
+    const int s0 = WB * Js;                                        // first real index of the separator
+    // separator: lower triangle = side 0's block + side 1's update (transposed back from its reversed order)
+    for (int idx = tid; idx < WB * WB; idx += nt) {
+        const int r = idx / WB, k = idx % WB;
+        const int lo = min(r, k), hi = max(r, k);                  // symmetric image; only hi >= lo is stored by the sides
+        Pm[r * WBS + k] = g.sep[hi * WB + lo] + g.sep[WB * WB + WB + (WB - 1 - lo) * WB + (WB - 1 - hi)];
+    }
+    if (tid < WB) {
+        Pm[2 * WB * WBS + tid] = g.sep[WB * WB + tid] + g.sep[WB * WB + WB + WB * WB + (WB - 1 - tid)];
+        dvl[tid] = 1.0;
+    }
+    for (int i = tid; i < n; i += nt) y[i] = g.yf[i];
+    lds_barrier();
+    bool bad = false;
+    unsigned long long tq = 0;
+    band_panel(Pm, Tt, Mi, rdl, dvl, WB, 0, 0, bad, nullptr, tq);
+    if (__any(bad) && lane == 0) *s_fail = 1;
+    // x_s = L_s^-T (D^-1 L^-1 y_s): one wave, the block's columns in registers
+    if (tid < 64) {
+        double v = Pm[2 * WB * WBS + tid];
+        double l[WB];
+#pragma unroll
+        for (int t = 0; t < WB; t++) l[t] = Pm[t * WBS + tid];
+#pragma unroll
+        for (int t = WB - 1; t >= 0; t--) {
+            const double xt = rl64(v, t);
+            v -= (tid < t) ? l[t] * xt : 0.0;
+        }
+        y[s0 + tid] = v;
+    }
+    __syncthreads();
+    // both sides, away from the separator
+    double* Lb = W;                                                // [2][WB][WBS]
+    double* part = Lb + 2 * WB * WBS;                              // [2][8][WB]
+    const int side = tid >> 9, t9 = tid & 511;
+    const int ND0 = Js, ND1 = NB - 1 - Js;
+    auto phi = [&](int sd, int v) { return sd ? np - 1 - v : v; };
+    for (int step = 1; step <= max(ND0, ND1); step++) {
+        const int J = (side ? ND1 : ND0) - step;                   // this side's (virtual) block column
+        const int c0 = WB * J, r1 = c0 + WB;
+        if (J >= 0) {
+            for (int idx = t9; idx < WB * WB; idx += 512) {
+                const int r = idx / WB, k = idx % WB;
+                const int i = phi(side, c0 + r), j = phi(side, c0 + k);
+                Lb[(side * WB + r) * WBS + k] = (i < n && j < n) ? g.Ls[(size_t)i * n + j] : 0.0;
+            }
+            const int k = t9 & 63, grp = t9 >> 6;                  // 8 groups of 8 rows of L_P
+            const int j = phi(side, c0 + k);
+            double l[8], acc = 0.0;
+#pragma unroll
+            for (int u = 0; u < 8; u++) l[u] = g.Ls[(size_t)phi(side, r1 + 8 * grp + u) * n + min(j, n - 1)];
+#pragma unroll
+            for (int u = 0; u < 8; u++) acc += l[u] * y[phi(side, r1 + 8 * grp + u)];
+            part[(side * 8 + grp) * WB + k] = j < n ? acc : 0.0;
+        }
+        __syncthreads();
+        if (wave < 2) {
+            const int sd = wave, Jw = (sd ? ND1 : ND0) - step;
+            if (Jw >= 0) {
+                const int cw = WB * Jw, i = phi(sd, cw + lane);
+                double v = 0.0;
+                if (i < n) {
+                    v = y[i];
+                    for (int q = 0; q < 8; q++) v -= part[(sd * 8 + q) * WB + lane];
+                }
+                double l[WB];
+#pragma unroll
+                for (int t = 0; t < WB; t++) l[t] = Lb[(sd * WB + t) * WBS + lane];
+#pragma unroll
+                for (int t = WB - 1; t >= 0; t--) {
+                    const double xt = rl64(v, t);
+                    v -= (lane < t) ? l[t] * xt : 0.0;
+                }
+                if (i < n) y[i] = v;
+            }
         }
         __syncthreads();
     }
@@ -825,7 +977,8 @@ __global__ __launch_bounds__(1024) void ba_big_finish(BaDims d, BaBufs b, BaOpt 
         if (tid == 0) { st.solver_failed = 1; *b.st = st; }
         return;
     }
-    if (band) band_backsub(g, n, y, Lb);
+    if (band == 2) band_sep_backsub(g, n, y, Lb, &s_fail);
+    else if (band) band_backsub(g, n, y, Lb);
     else big_backsub(g, n, y, Lb);
     // delta_c = -x, candidate cameras, camera part of the step scalars (as ba_solve.hip (5))
     const double* lam = b.rhs;
@@ -889,24 +1042,27 @@ static void big_carve(char* ws, size_t n, BigBufs* g)
     g->M = (double*)(ws + off); off += al(sizeof(double) * BB * BB);
     g->dv = (double*)(ws + off); off += al(sizeof(double) * n);
     g->yf = (double*)(ws + off); off += al(sizeof(double) * n);
-    g->fail = (int*)(ws + off);
+    g->fail = (int*)(ws + off); off += 256;
+    g->sep = (double*)(ws + off);
 }
 
 size_t ba_big_bytes(int n)
 {
-    return sizeof(double) * ((size_t)n * n + BB * BB + 2 * (size_t)n) + 256 * 5;
+    return sizeof(double) * ((size_t)n * n + BB * BB + 2 * (size_t)n + 2 * (64 * 64 + 64)) + 256 * 6;
 }
 
 // largest camera span (slots) whose block band fits the one-launch factorisation: 6 span + 5 <= WB columns
 int ba_band_max_span() { return (WB - 5) / 6; }
 
-int ba_launch_reduced_solve_big(rs_context* ctx, const BaDims& d, const BaBufs& b, const BaOpt& opt, char* ws, bool band)
+int ba_launch_reduced_solve_big(rs_context* ctx, const BaDims& d, const BaBufs& b, const BaOpt& opt, char* ws, int band)
 {
     const size_t n = (size_t)d.n;
     BigBufs g;
     big_carve(ws, n, &g);
     hipStream_t s = ctx->stream;
-    const size_t lds_fin = sizeof(double) * (n + WB * WBS + 1024);       // y, diagonal block, backsub partial sums
+    if (band == 2 && (d.n + WB - 1) / WB < 3) band = 1;                  // no room for a separator between two sides
+    // y, diagonal block, backsub partial sums; two-sided band: y + the panel window of the separator's factorisation
+    const size_t lds_fin = sizeof(double) * (n + (band == 2 ? (size_t)WROWS * WBS + 16 * WTILES * 17 + 16 * 17 + 16 + WB : (size_t)WB * WBS + 1024));
     if (lds_fin > 48 * 1024)
         RS_HIP(ctx, rs_lds_attr((const void*)ba_big_finish, lds_fin));
     const size_t lds_upd = sizeof(double) * (6 * BB * BBS + 2 * BB * 17 + BB);
@@ -917,11 +1073,11 @@ int ba_launch_reduced_solve_big(rs_context* ctx, const BaDims& d, const BaBufs& 
         const size_t lds_band = sizeof(double) * ((size_t)WROWS * WBS + WB * WBS + WB + (size_t)16 * WTILES * 17 + 16 * 17 + 16 + WB);
         RS_HIP(ctx, rs_lds_attr((const void*)ba_band_factor, lds_band));
         rs_prof_scope ps(ctx, "K7b_band_factor");
-        hipLaunchKernelGGL(ba_band_factor, dim3(1), dim3(1024), lds_band, s, d, b, g);
+        hipLaunchKernelGGL(ba_band_factor, dim3(band == 2 ? 2 : 1), dim3(1024), lds_band, s, d, b, g, band == 2 ? 1 : 0);
     } else {
         big_launch_factor(s, d, b, g, lds_upd);
     }
-    hipLaunchKernelGGL(ba_big_finish, dim3(1), dim3(1024), lds_fin, s, d, b, opt, g, band ? 1 : 0);
+    hipLaunchKernelGGL(ba_big_finish, dim3(1), dim3(1024), lds_fin, s, d, b, opt, g, band);
     return RS_OK;
 }
 

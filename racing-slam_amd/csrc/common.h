@@ -58,7 +58,7 @@ struct rs_context {
     int ba_trace_n = 0;
     int ba_stats[8] = {0, 0, 0, 0, 0, 0, 0, 0};     // rs_ba_get_stats
     int ba_batch_item = 0;              // landmarks per item of rs_bundle_adjust_batch's grid mode: 0 = default (32), or 32 / 40 / 64
-    int ba_band_mode = 0;               // blocked reduced solve: 0 = the one-launch banded factorisation when S is block-banded, 1 = never
+    int ba_band_mode = 0;               // blocked reduced solve: 0 = the banded factorisation (two-sided) when S is block-banded, 1 = never, 2 = banded in one workgroup
     int ba_s_replicas = 0;              // replicas of S on the local-window path (0 = library default; "ba_s_replicas")
     int ba_handoff_timeout_us = 4000;   // fused K7 + K8 launch: how long a K8 workgroup waits for its hand-off word ("ba_handoff_timeout_us")
     const double* ba_cams = nullptr;    // cameras after the last rs_bundle_adjust, mirrored in the pinned block

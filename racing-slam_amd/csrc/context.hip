@@ -103,7 +103,7 @@ extern "C" int rs_context_set_int(rs_context* ctx, const char* name, int value)
         return RS_OK;
     }
     if (strcmp(name, "ba_band_mode") == 0) {
-        if (value < 0 || value > 1) return rs_fail(ctx, RS_ERR_INVALID, "ba_band_mode must be 0 (banded factorisation where the reduced matrix is block-banded) or 1 (always the general blocked one)");
+        if (value < 0 || value > 2) return rs_fail(ctx, RS_ERR_INVALID, "ba_band_mode must be 0 (banded factorisation where the reduced matrix is block-banded), 1 (always the general blocked one) or 2 (banded, one workgroup instead of two sides)");
         ctx->ba_band_mode = value;
         return RS_OK;
     }

@@ -375,7 +375,8 @@ def test_triangulate_host_fast_path(ctx, oracle, synth, n):
 def test_bundle_adjust_banded_reduced_solve(ctx, oracle, synth, kw, banded):
     """VERDICT r2 #5 (cfg 5's reduced solve was 13 + 12 dependent launches per LM step): when every landmark is seen by key
     frames at most 9 slots apart, S is block-banded and is factorised by ONE launch (csrc/ba_solve_big.hip, ba_band_factor;
-    the sparsity Ceres' SPARSE_SCHUR exploits, src/Optimization.cpp:360).  Against the oracle and against the general
+    the sparsity Ceres' SPARSE_SCHUR exploits, src/Optimization.cpp:360) — two workgroups eliminating towards a separator
+    block from both ends (default) or one workgroup ("ba_band_mode" 2).  Against the oracle and against the general
     blocked factorisation ("ba_band_mode" 1), incl. a matrix size that ends in a partial block and a window that is NOT
     banded (must take the general path by itself)."""
     w = synth.make_ba_window(**kw)
@@ -383,7 +384,7 @@ def test_bundle_adjust_banded_reduced_solve(ctx, oracle, synth, kw, banded):
     rc, rp, _ = oracle.bundle_adjust(w["cams"], w["cam_free"], w["points"], w["obs_ptr"], w["obs_cam"], w["obs_uv"], w["K"])
     runs = {}
     try:
-        for mode in (0, 1):
+        for mode in (0, 2, 1):
             ctx.set_int("ba_band_mode", mode)
             dc, dp = ctx.dev(w["cams"]), ctx.dev(w["points"])
             ctx.prof_begin()
@@ -393,7 +394,8 @@ def test_bundle_adjust_banded_reduced_solve(ctx, oracle, synth, kw, banded):
     finally:
         ctx.set_int("ba_band_mode", 0)
     assert ("K7b_band_factor" in runs[0][4]) == banded and "K7b_band_factor" not in runs[1][4]
-    for mode in (0, 1):
+    assert ("K7b_band_factor" in runs[2][4]) == banded
+    for mode in (0, 2, 1):
         s, tr, c, p, _ = runs[mode]
         assert (s["iterations"], s["successful_steps"], s["termination"], s["usable"]) == \
                (os_["iterations"], os_["successful_steps"], os_["termination"], os_["usable"]), mode
@@ -405,6 +407,7 @@ def test_bundle_adjust_banded_reduced_solve(ctx, oracle, synth, kw, banded):
         assert np.allclose(c, rc, rtol=tol[0], atol=tol[1]) and np.allclose(p, rp, rtol=tol[0], atol=tol[2]), mode
     if banded:
         assert np.allclose(runs[0][2], runs[1][2], rtol=1e-8, atol=1e-10)
+        assert np.allclose(runs[0][2], runs[2][2], rtol=1e-8, atol=1e-10)      # two-sided against the one-workgroup form
     else:       # (the same kernels both times; two runs of this weakly constrained window differ by 3e-9 through the atomics' order)
         assert np.allclose(runs[0][2], runs[1][2], rtol=1e-5, atol=1e-6)
 

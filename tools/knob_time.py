@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """A/B of context knobs on the cfg-3 bundle adjustment: us per solve + per-scope kernel averages per setting.
 
-    knob_time.py name=v1,v2,... [name2=...] [--window cfg3|clean] [--reps N]
+    knob_time.py name=v1,v2,... [name2=...] [--window cfg3|cfg5|clean] [--reps N]
 
 e.g.  knob_time.py ba_s_replicas=1,2,4,8        (every combination of the listed values is run, twice, interleaved)"""
 import importlib
@@ -27,7 +27,7 @@ while args:
         k, v = a.split("=")
         knobs.append((k, [int(x) for x in v.split(",")]))
 ctx = rs.Context(0)
-kw = dict() if window == "cfg3" else dict(outlier_frac=0.0, pixel_noise=0.3, rot_noise_deg=0.2, config_id=23)
+kw = {"cfg3": dict(), "cfg5": dict(n_kf=100, n_points=80000, config_id=5)}.get(window, dict(outlier_frac=0.0, pixel_noise=0.3, rot_noise_deg=0.2, config_id=23))
 w = synth.make_ba_window(**kw)
 dev = [ctx.dev(w[k]) for k in ("obs_ptr", "obs_cam", "obs_uv")]
 c0, p0 = ctx.dev(w["cams"]), ctx.dev(w["points"])
