@@ -402,7 +402,7 @@ def boundary_timings(reps=30):
 
 
 # =============================================================================================== pass
-def build_pass(e):
+def build_pass(e, streams=1, graph=False):
     """Inputs of one pass, resident in HBM, and the closures that run it on the GPU and on the CPU."""
     ctx, rs, synth, torch = e.ctx, e.rs, e.synth, e.torch
     world, rank = e.world, e.rank
@@ -508,12 +508,62 @@ def build_pass(e):
     def refine_stage():
         last["refine"] = ctx.refine_pose(refine_in["cam"], *refine_dev, window["K"])
 
-    def one_pass():
+    # The four front-end chains of a pass — descriptor match -> triangulation, the two reprojection matches, the track
+    # triangulation — share no data (inputs are the frame / the map as they were before the pass, every call has its own
+    # outputs), and each is a handful of launches that fill a fraction of the chip.  `streams` > 1 issues them side by side:
+    # the first chain on the library's stream, the others through contexts of their own on their own HIP streams, forked
+    # from and joined back into the library's stream by events (rs_context_fork / rs_context_wait_for), so the pass stays self-contained (nothing of it starts
+    # before the previous pass has ended, the bundle adjustment starts when all four chains are done).
+    side = []
+    if streams > 1:
+        for _ in range(3):
+            c = rs.Context(e.local_rank)
+            st = torch.cuda.Stream(device=ctx.device)
+            c.use_stream(st)
+            side.append((c, st))
+    last["side_contexts"] = side
+    side_ctx = [c for c, _ in side]
+
+    def front_end(serial):
+        if serial or not side:
+            ctx.match_descriptors(d["q"], d["t"], nq, nt, out=m_out)
+            ctx.reproj_match(fv_a, mv_a, out=r_a)                   # match_key_frame
+            ctx.reproj_match(fv_b, mv_b, out=r_b)                   # match_map
+            ctx.triangulate_matches(d["kp1"], d["kp2"], m_out["mt"], m_out["mq"], m_out["cnt"], nq, d["poses"], pair["K"], out=t_out)
+            ctx.triangulate_tracks(*tk_dev, tk["kf_pose"], tk["K"], d_skip=tk_skip, out=k_out, d_required=tk_req)      # Mapper::triangulate_tracks
+            return
+        ctx.fork(*side_ctx)                                     # nothing of this pass starts before the previous one has ended
         ctx.match_descriptors(d["q"], d["t"], nq, nt, out=m_out)
-        ctx.reproj_match(fv_a, mv_a, out=r_a)                   # match_key_frame
-        ctx.reproj_match(fv_b, mv_b, out=r_b)                   # match_map
         ctx.triangulate_matches(d["kp1"], d["kp2"], m_out["mt"], m_out["mq"], m_out["cnt"], nq, d["poses"], pair["K"], out=t_out)
-        ctx.triangulate_tracks(*tk_dev, tk["kf_pose"], tk["K"], d_skip=tk_skip, out=k_out, d_required=tk_req)      # Mapper::triangulate_tracks
+        side[0][0].triangulate_tracks(*tk_dev, tk["kf_pose"], tk["K"], d_skip=tk_skip, out=k_out, d_required=tk_req)
+        side[1][0].reproj_match(fv_b, mv_b, out=r_b)            # match_map
+        side[2][0].reproj_match(fv_a, mv_a, out=r_a)            # match_key_frame
+        ctx.wait_for(*side_ctx)                                 # join: what follows on the library stream needs all four chains
+
+    # ... and as ONE hipGraph: the library's front-end entry points only enqueue (kernel launches on the context's stream;
+    # their workspaces are grow-only and warm after the first call), so the four chains with their fork / join edges are
+    # stream-captured once and a pass replays them with a single graph launch — the host no longer issues ten launches
+    # one by one while the GPU waits for them.
+    fe_graph = None
+    if side and graph:
+        for _ in range(3):
+            front_end(False)
+        torch.cuda.synchronize()
+        cap = torch.cuda.Stream(device=ctx.device)
+        fe_graph = torch.cuda.CUDAGraph()
+        ctx.use_stream(cap)                                     # (the legacy default stream cannot be captured)
+        try:
+            with torch.cuda.graph(fe_graph, stream=cap, capture_error_mode="relaxed"):
+                front_end(False)
+        finally:
+            ctx.use_stream(None)
+        last["front_end_graph"] = fe_graph
+
+    def one_pass(serial=False):
+        if fe_graph is not None and not serial:
+            fe_graph.replay()
+        else:
+            front_end(serial)
         last["window"] = rs.build_local_window(*lw_args)        # host, overlaps the kernels enqueued above
         state.copy_(state0)
         last["ba"] = ctx.bundle_adjust(d["cams"], window["cam_free"], d["pts"], d["optr"], d["ocam"], d["ouv"], window["K"])
@@ -571,7 +621,7 @@ def build_pass(e):
                 n_single=n_single, match_key_frame_points=int(mp_a["eligible"].sum()), match_map_points=int(elig_b.sum()),
                 frame_a=frame, mp_a=mp_a, frame_b=frame_b, mp_b=mp_b, tracks=tk, cull_in=cull_in, refine_in=refine_in,
                 cull_stage=cull_stage, refine_stage=refine_stage, cpu_cull=cpu_cull, cpu_refine=cpu_refine,
-                gpu_results=gpu_results, n_track_sightings=int(tk["sight_ptr"][-1]))
+                gpu_results=gpu_results, n_track_sightings=int(tk["sight_ptr"][-1]), one_pass_serial=lambda: one_pass(True), front_end=front_end)
     return one_pass, cpu_pass, meta
 
 
@@ -633,11 +683,20 @@ def check_pass_parity(meta, cpu_pass, O):
 def bench_pass(e, args):
     ctx = e.ctx
     attach_comm(e)
-    one_pass, cpu_pass, meta = build_pass(e)
+    # `value` is the pass as a serial caller issues it: every launch on ONE stream (--streams 1, the default).  The same pass
+    # with its four front-end chains side by side on streams of their own is timed beside it (or becomes `value` with
+    # --streams 4): that form assumes a caller whose chains are data-independent — true of this benchmark's inputs; in the
+    # reference's frame flow Mapper::triangulate_tracks consumes the matches of the same frame (src/Mapper.cpp:246-305).
+    overlapped, cpu_pass, meta = build_pass(e, 4, graph=args.graph)
+    serial = meta["one_pass_serial"]
+    one_pass = overlapped if args.streams > 1 else serial
+    other = serial if args.streams > 1 else overlapped
     elapsed = timed(e, one_pass, args.steps, args.warmup)
     ms_per_step = 1e3 * elapsed / max(args.steps, 1)
     value = e.world * args.steps / elapsed
-    per_kernel = profiled(e, one_pass, args.steps)
+    other_ms = 1e3 * timed(e, other, args.steps, args.warmup) / max(args.steps, 1)
+    per_kernel = profiled(e, serial, args.steps)     # (HIP events of one context on one stream)
+    one_pass()                                       # the parity check below looks at what the LAST pass left behind: make it `value`'s form
     stats = ctx.ba_stats()
     # in-run parity: the oracle on the very inputs of the timed pass against what the GPU's last pass left behind
     parity = None
@@ -727,6 +786,10 @@ def bench_pass(e, args):
                                "Mapper::triangulate_tracks (2000 tracks, per-track DLT + sighting checks + quota) + "
                                "Mapper::bundle_adjust on cfg3 (build_local_window, 20 KF x 10k landmarks x ~60k obs, "
                                "10 LM iterations, pose read-back, re-anchoring of 2000 single-observation points) per GPU",
+                   "streams": ("the four independent front-end chains (match -> triangulate | match_key_frame | match_map | "
+                               "triangulate_tracks) side by side on 4 HIP streams, forked from / joined into the library stream "
+                               "by events; the bundle adjustment starts when all four are done" +
+                               ("; captured once, replayed as one hipGraph launch per pass" if args.graph else "")) if args.streams > 1 else "one stream",
                    "passes_per_step": e.world,
                    "ba_landmarks_total": int(len(meta["window_all"]["points"])),
                    "ba_obs_per_gpu": int(len(window["obs_cam"])),
@@ -735,6 +798,11 @@ def bench_pass(e, args):
         "roofline": roofline,
         "cpu_baseline": cpu["one"] if cpu else None,
         "cpu_baseline_all_cores": cpu["all"] if cpu else None,
+        ("ms_per_step_one_stream" if args.streams > 1 else "ms_per_step_front_end_on_4_streams"): other_ms,
+        "front_end_streams_note": "the same pass with match->triangulate | match_key_frame | match_map | triangulate_tracks side by side on four "
+                                  "HIP streams (rs_context_wait_for fork / join): valid for a caller whose four chains are data-independent, "
+                                  "as this benchmark's inputs are; not `value` by default because in the reference's frame flow "
+                                  "triangulate_tracks consumes the same frame's matches",
         "per_kernel_us": {k: round(v["avg_us"], 2) for k, v in sorted(per_kernel.items())},
         "per_kernel_launches_per_pass": {k: v["launches"] / max(args.steps, 1) for k, v in sorted(per_kernel.items())},
         "ba_summary": meta["last"].get("ba"), "ba_rounds": stats,
@@ -970,6 +1038,9 @@ def main():
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--config", default="pass", choices=["pass", "cfg2", "cfg3", "cfg4", "cfg5"])
+    ap.add_argument("--streams", type=int, default=1, choices=[1, 4],
+                    help="pass: 1 = every launch on one stream (default), 4 = the four front-end chains side by side on HIP streams of their own")
+    ap.add_argument("--graph", action="store_true", help="pass, overlapped form: replay the front-end chains as one captured hipGraph instead of issuing them call by call")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-boundary", dest="boundary", action="store_false",
                     help="skip the end-to-end interface timings (tests/host_cpp/bench_boundary.bin) of --config pass")

@@ -67,6 +67,15 @@ int rs_context_destroy(rs_context* ctx);
 /* `hip_stream` is a hipStream_t (NULL = the legacy default stream). */
 int rs_context_set_stream(rs_context* ctx, void* hip_stream);
 int rs_context_synchronize(rs_context* ctx);
+/* Stream ordering between contexts of one process, without the host: everything enqueued on `ctx` after this call
+ * waits for everything enqueued so far on each of `others[0 .. n)` (one event record + one stream wait per context).
+ * For hosts that run independent calls side by side — the reference's match_map, match_key_frame,
+ * triangulate_tracks and match_descriptors -> triangulate_points chains share no data — on contexts of their own and
+ * join them before the call that needs all their results (bench.py's pass does). */
+int rs_context_wait_for(rs_context* ctx, rs_context* const* others, int n);
+/* The other direction with ONE event: everything enqueued on each of `others` after this call waits for everything
+ * enqueued so far on `ctx` (the fork in front of side-by-side chains). */
+int rs_context_fork(rs_context* ctx, rs_context* const* others, int n);
 /* Tuning knobs (integers by name).  "ba_speculative_sets": 1 .. 3 trust-region radii evaluated per round of
  * rs_bundle_adjust on the local-window path (0 = library default); the LM schedule, iteration count and
  * results do not depend on it (tests/test_gpu_parity.py), only the number of launches does.

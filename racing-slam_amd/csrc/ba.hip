@@ -793,7 +793,10 @@ static int ba_solve_once(rs_context* ctx, int n_cameras, int n_points, int n_obs
     if (use_mfma && ba_prepare_schur(d.C, d.Cf) != 0) return rs_fail(ctx, RS_ERR_HIP, "LDS attribute (K5)");
     BaGroup grp;
     memset(&grp, 0, sizeof grp);
-    if (use_mfma) ba_group_carve(ws + o_grp, d.P, d.Cf, d.M, &grp);
+    if (use_mfma) {
+        ba_group_carve(ws + o_grp, d.P, d.Cf, d.M, &grp);
+        if (ctx->ba_item) ba_group_set_items(&grp, d.P, true, ctx->ba_item);
+    }
     b.obs_cs = use_mfma ? grp.obs_cs : nullptr;
 
     const int pblocks = d.P > 0 ? (d.P + BA_THREADS - 1) / BA_THREADS : 1;      // (an empty shard still runs the round's decision)

@@ -57,6 +57,7 @@ struct rs_context {
     const void* ba_trace = nullptr;
     int ba_trace_n = 0;
     int ba_stats[8] = {0, 0, 0, 0, 0, 0, 0, 0};     // rs_ba_get_stats
+    int ba_item = 0;                    // landmarks per item of a single solve: 0 = by window size (40 / 64), or 32 / 40 / 64
     int ba_batch_item = 0;              // landmarks per item of rs_bundle_adjust_batch's grid mode: 0 = default (32), or 32 / 40 / 64
     int ba_band_mode = 0;               // blocked reduced solve: 0 = the banded factorisation (two-sided) when S is block-banded, 1 = never, 2 = banded in one workgroup
     int ba_s_replicas = 0;              // replicas of S on the local-window path (0 = library default; "ba_s_replicas")
@@ -77,6 +78,7 @@ struct rs_context {
     // proposal table of rs_reproj_match: persistent, always left at all-ones by the accept tail
     unsigned long long* prop = nullptr;
     size_t prop_cap = 0;
+    hipEvent_t sync_ev = nullptr;       // rs_context_wait_for: "everything enqueued on this context so far"
     void* tri_pin = nullptr;            // pinned in / out block + completion flag of rs_triangulate_host's one-launch path
     int tri_ticket = 0;
     void* k1_top = nullptr;             // [batch][nq] {best, second} packed keys of rs_match_descriptors; all-ones between calls

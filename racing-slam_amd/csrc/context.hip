@@ -66,6 +66,7 @@ extern "C" int rs_context_destroy(rs_context* ctx)
     if (ctx->k1_top) (void)hipFree(ctx->k1_top);
     if (ctx->pinned) (void)hipHostFree(ctx->pinned);
     if (ctx->tri_pin) (void)hipHostFree(ctx->tri_pin);
+    if (ctx->sync_ev) (void)hipEventDestroy(ctx->sync_ev);
     for (auto& s : ctx->prof)
         for (auto e : s.ev) (void)hipEventDestroy(e);
     delete ctx;
@@ -76,6 +77,44 @@ extern "C" int rs_context_set_stream(rs_context* ctx, void* s)
 {
     if (!ctx) return RS_ERR_INVALID;
     ctx->stream = (hipStream_t)s;
+    return RS_OK;
+}
+
+extern "C" int rs_context_wait_for(rs_context* ctx, rs_context* const* others, int n)
+{
+    if (!ctx || n < 0 || (n > 0 && !others)) return rs_fail(ctx, RS_ERR_INVALID, "rs_context_wait_for: bad arguments");
+    for (int i = 0; i < n; i++) {
+        rs_context* o = others[i];
+        if (!o) return rs_fail(ctx, RS_ERR_INVALID, "rs_context_wait_for: null context");
+        if (o == ctx || o->stream == ctx->stream) continue;             // same stream: ordered already
+        if (!o->sync_ev) {
+            RS_HIP(ctx, hipSetDevice(o->device));
+            RS_HIP(ctx, hipEventCreateWithFlags(&o->sync_ev, hipEventDisableTiming));
+        }
+        RS_HIP(ctx, hipEventRecord(o->sync_ev, o->stream));
+        RS_HIP(ctx, hipStreamWaitEvent(ctx->stream, o->sync_ev, 0));
+    }
+    return RS_OK;
+}
+
+extern "C" int rs_context_fork(rs_context* ctx, rs_context* const* others, int n)
+{
+    if (!ctx || n < 0 || (n > 0 && !others)) return rs_fail(ctx, RS_ERR_INVALID, "rs_context_fork: bad arguments");
+    bool recorded = false;
+    for (int i = 0; i < n; i++) {
+        rs_context* o = others[i];
+        if (!o) return rs_fail(ctx, RS_ERR_INVALID, "rs_context_fork: null context");
+        if (o == ctx || o->stream == ctx->stream) continue;
+        if (!recorded) {
+            if (!ctx->sync_ev) {
+                RS_HIP(ctx, hipSetDevice(ctx->device));
+                RS_HIP(ctx, hipEventCreateWithFlags(&ctx->sync_ev, hipEventDisableTiming));
+            }
+            RS_HIP(ctx, hipEventRecord(ctx->sync_ev, ctx->stream));
+            recorded = true;
+        }
+        RS_HIP(ctx, hipStreamWaitEvent(o->stream, ctx->sync_ev, 0));
+    }
     return RS_OK;
 }
 
@@ -95,6 +134,11 @@ extern "C" int rs_context_set_int(rs_context* ctx, const char* name, int value)
     if (strcmp(name, "ba_fuse_mode") == 0) {
         if (value < 0 || value > 3) return rs_fail(ctx, RS_ERR_INVALID, "ba_fuse_mode must be 0 (solve + back-substitution in one launch when no other solve of the process is in flight), 1 (separate launches), 2 (solve + back-substitution in one launch wherever possible) or 3 (the whole round in one launch wherever possible)");
         ctx->ba_fuse_mode = value;
+        return RS_OK;
+    }
+    if (strcmp(name, "ba_item_landmarks") == 0) {
+        if (value != 0 && value != 32 && value != 40 && value != 64) return rs_fail(ctx, RS_ERR_INVALID, "ba_item_landmarks must be 0 (default), 32, 40 or 64");
+        ctx->ba_item = value;
         return RS_OK;
     }
     if (strcmp(name, "ba_batch_item_landmarks") == 0) {

@@ -13,7 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "librsgpu.so")
 
 EXPORTS = [
-    "rs_abi_version", "rs_context_create", "rs_context_destroy", "rs_context_set_stream",
+    "rs_abi_version", "rs_context_create", "rs_context_destroy", "rs_context_set_stream", "rs_context_wait_for", "rs_context_fork",
     "rs_context_synchronize", "rs_context_set_int", "rs_stage_begin", "rs_stage_alloc", "rs_stage_upload", "rs_stage_download", "rs_stage_sync", "rs_last_error", "rs_hamming_knn2", "rs_match_descriptors",
     "rs_kdtree_build", "rs_kdtree_pack", "rs_reproj_match", "rs_reproj_match_sharded", "rs_map_create", "rs_map_destroy", "rs_frame_create", "rs_frame_destroy",
     "rs_map_add_keyframe", "rs_map_set_keyframe_pose", "rs_map_add_point", "rs_map_set_position", "rs_map_remove_point",
@@ -261,7 +261,21 @@ class Context:
         self.use_stream(torch.cuda.current_stream(self.device))
 
     def use_stream(self, stream):
-        self._check(self.lib.rs_context_set_stream(self.h, C.c_void_p(stream.cuda_stream)), "set_stream")
+        self._check(self.lib.rs_context_set_stream(self.h, C.c_void_p(stream.cuda_stream if stream is not None else None)), "set_stream")
+
+    def wait_for(self, *others):
+        """Everything enqueued on this context from now on waits for what is enqueued so far on `others` (no host wait)."""
+        arr = self.__dict__.setdefault("_wait_arrays", {}).get(others)
+        if arr is None:
+            arr = self._wait_arrays[others] = (C.c_void_p * len(others))(*[o.h.value for o in others])
+        self._check(self.lib.rs_context_wait_for(self.h, arr, len(others)), "rs_context_wait_for")
+
+    def fork(self, *others):
+        """Everything enqueued on `others` from now on waits for what is enqueued so far on this context (one event)."""
+        arr = self.__dict__.setdefault("_wait_arrays", {}).get(others)
+        if arr is None:
+            arr = self._wait_arrays[others] = (C.c_void_p * len(others))(*[o.h.value for o in others])
+        self._check(self.lib.rs_context_fork(self.h, arr, len(others)), "rs_context_fork")
 
     def set_int(self, name, value):
         self._check(self.lib.rs_context_set_int(self.h, name.encode(), int(value)), "rs_context_set_int")
