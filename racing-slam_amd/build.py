@@ -53,8 +53,9 @@ def _stale(target, deps):
 
 def build(force=False, verbose=False):
     cc = hipcc()
-    objdir = os.path.join(HERE, "build")
+    objdir = os.path.join(HERE, "build_stamps" if STAMPS else "build")     # (instrumented objects never mix with the product's)
     os.makedirs(objdir, exist_ok=True)
+    force = force or bool(STAMPS)
     # every header of csrc/ is a dependency of every object: a stale .so must never ship
     headers = sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h"))
     headers += [os.path.join(HERE, "..", "include", "rsgpu.h"), __file__]

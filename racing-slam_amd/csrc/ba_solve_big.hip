@@ -473,12 +473,16 @@ __global__ __launch_bounds__(256) void ba_big_update(BaDims d, BaBufs b, BigBufs
 // the prefetch of the next blocks and the stores of the factor with the factorisation
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
-// The 129-row panel [D; P; rhs] of one block column in LDS, factored in place as four 16-column sub-blocks (all 16 waves of
-// the workgroup call this together): afterwards D holds L_JJ below its diagonal and d on it, P the multipliers L_{J+1,J},
-// the right-hand side row D^-1 L^-1 g, dvl the pivots.  w: columns of the block, hp: rows of P, c_first: first sub-block
-// that is not identity padding.
-static __device__ __forceinline__ void band_panel(double* Pm, double* Tt, double* Mi, double* rdl, double* dvl, int w, int hp, int c_first,
-                                                  bool& bad, unsigned long long* acc_t, unsigned long long& tq)
+// The 129-row panel [D; P; rhs] of one block column in LDS (three buffers: Dm [WB][WBS], Pp [WB][WBS], yrow [WB]), factored
+// in place as four 16-column sub-blocks (all 16 waves of the workgroup call this together): afterwards D holds L_JJ below
+// its diagonal and d on it, P the multipliers L_{J+1,J}, the right-hand side row D^-1 L^-1 g, dvl the pivots.  w: columns of
+// the block, hp: rows of P, c_first: first sub-block that is not identity padding.  idle(): what waves 1..15 do while wave 0
+// factors the FIRST diagonal sub-block (they would wait at the barrier: the banded kernel has them fetch the next blocks —
+// in a branch of their own, so the fetched values do not add to the register pressure of wave 0's chain).
+template <typename Idle>
+static __device__ __forceinline__ void band_panel(double* Dm, double* Pp, double* yrow, double* Tt, double* Mi, double* rdl, double* dvl,
+                                                  int w, int hp, int c_first, bool& bad, unsigned long long* acc_t, unsigned long long& tq,
+                                                  Idle&& idle)
 {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int lr = lane & 15, lk = lane >> 4;
@@ -493,7 +497,7 @@ static __device__ __forceinline__ void band_panel(double* Pm, double* Tt, double
             int r = lr;
             double a[16];
 #pragma unroll
-            for (int k = 0; k < 16; k++) a[k] = Pm[(c + r) * WBS + c + k];
+            for (int k = 0; k < 16; k++) a[k] = Dm[(c + r) * WBS + c + k];
             double my_rd = 1.0, my_piv = 1.0;
 #pragma unroll
             for (int cc = 0; cc < 16; cc++) {
@@ -511,7 +515,7 @@ static __device__ __forceinline__ void band_panel(double* Pm, double* Tt, double
             }
             if (lane < 16) {
 #pragma unroll
-                for (int k = 0; k < 16; k++) Pm[(c + r) * WBS + c + k] = a[k];      // multipliers below the diagonal, d on it
+                for (int k = 0; k < 16; k++) Dm[(c + r) * WBS + c + k] = a[k];      // multipliers below the diagonal, d on it
                 rdl[r] = my_rd;
                 dvl[c + r] = my_piv;
             }
@@ -529,26 +533,28 @@ static __device__ __forceinline__ void band_panel(double* Pm, double* Tt, double
                     double s0 = 0.0, s1 = 0.0;
 #pragma unroll
                     for (int k = jj + 1; k < 16; k += 2) {
-                        s0 -= m[k] * Pm[(c + k) * WBS + c + jj];             // m[k] = 0 beyond the row's diagonal
-                        if (k + 1 < 16) s1 -= m[k + 1] * Pm[(c + k + 1) * WBS + c + jj];
+                        s0 -= m[k] * Dm[(c + k) * WBS + c + jj];             // m[k] = 0 beyond the row's diagonal
+                        if (k + 1 < 16) s1 -= m[k + 1] * Dm[(c + k + 1) * WBS + c + jj];
                     }
                     m[jj] = jj < r ? s0 + s1 : m[jj];
                 }
 #pragma unroll
                 for (int k = 0; k < 16; k++) Mi[r * 17 + k] = m[k];
             }
+        } else if (c == c_first) {
+            idle();
         }
         lds_barrier();
         PANEL_STAMP(1);
         const int wpad = (w + 15) & ~15;                                    // (rows w .. wpad-1 are identity padding: whole tiles)
         const int below = max(0, wpad - c - 16);                            // D rows under the sub-block
         const int nrows = below + hp + 1;                                   // + P rows + the right-hand side row
-        auto row_of = [&](int pr) { return pr < below ? c + 16 + pr : (pr < below + hp ? WB + (pr - below) : 2 * WB); };
+        auto rowp = [&](int pr) -> double* { return pr < below ? Dm + (c + 16 + pr) * WBS : (pr < below + hp ? Pp + (pr - below) * WBS : yrow); };
         const int ntile = (nrows + 15) / 16;
         // B: T = R M^T on the matrix cores, one 16-row tile of the rows below per wave; multipliers = T D^-1
         if (wave < ntile) {
             const int prA = min(16 * wave + lr, nrows - 1);                  // operand row of this lane (clamped: masked at the store)
-            const double* R = Pm + row_of(prA) * WBS + c + lk;
+            const double* R = rowp(prA) + c + lk;
             const double* Mr = Mi + lr * 17 + lk;
             double ra[4], mb[4];
 #pragma unroll
@@ -561,7 +567,7 @@ static __device__ __forceinline__ void band_panel(double* Pm, double* Tt, double
             for (int reg = 0; reg < 4; reg++) {
                 const int pr = 16 * wave + lk + 4 * reg;
                 Tt[pr * 17 + lr] = acc[reg];
-                if (pr < nrows) Pm[row_of(pr) * WBS + c + lr] = acc[reg] * rdj;
+                if (pr < nrows) rowp(pr)[c + lr] = acc[reg] * rdj;
             }
         }
         lds_barrier();
@@ -572,7 +578,7 @@ static __device__ __forceinline__ void band_panel(double* Pm, double* Tt, double
             for (int t = wave; t < ntile * ctile; t += 16) {
                 const int tr = t / ctile, tc = t % ctile;
                 const double* X = Tt + (16 * tr + lr) * 17 + lk;
-                const double* Z = Pm + (c + 16 + 16 * tc + lr) * WBS + c + lk;
+                const double* Z = Dm + (c + 16 + 16 * tc + lr) * WBS + c + lk;
                 double xa[4], zb[4];
 #pragma unroll
                 for (int kc = 0; kc < 4; kc++) { xa[kc] = X[4 * kc]; zb[kc] = Z[4 * kc]; }
@@ -582,7 +588,7 @@ static __device__ __forceinline__ void band_panel(double* Pm, double* Tt, double
 #pragma unroll
                 for (int reg = 0; reg < 4; reg++) {
                     const int pr = 16 * tr + lk + 4 * reg, qq = 16 * tc + lr;
-                    if (pr < nrows && (pr >= below || qq <= pr)) Pm[row_of(pr) * WBS + c + 16 + qq] -= acc[reg];
+                    if (pr < nrows && (pr >= below || qq <= pr)) rowp(pr)[c + 16 + qq] -= acc[reg];
                 }
             }
         }
@@ -590,6 +596,42 @@ static __device__ __forceinline__ void band_panel(double* Pm, double* Tt, double
         PANEL_STAMP(3);
     }
 #undef PANEL_STAMP
+}
+
+// What the 15 idle waves of ba_band_factor do during the first diagonal sub-block of block column J: T = A'[J+1][J+1] and the
+// right-hand side of block J+1, Pn = A'[J+2][J+1], from the lower triangle of S through the side's index map (v -> np - 1 - v
+// for the reversed side), identity / zero outside the matrix, zeros for T when it is the separator's block seen from side 1.
+// A function of its own: inlined, the compiler computes its 20 addresses in front of the branch, in wave 0's path as well,
+// and spills them.
+static __device__ __attribute__((noinline)) void band_fetch(const double* __restrict__ S, const double* __restrict__ dc, int n, int np, int rev,
+                                                            int J, int NB, bool tz, double* Tm, double* Pn, double* yP)
+{
+    const int t = (int)threadIdx.x - 64;                                     // 0 .. 959
+    const int r1 = WB * (J + 1), r2 = r1 + WB;
+    auto phi = [&](int v) { return rev ? np - 1 - v : v; };
+    auto inside = [&](int v) { return (unsigned)phi(v) < (unsigned)n; };
+    auto addr = [&](int r, int k) {
+        const int i = min(max(phi(r), 0), n - 1), j = min(max(phi(k), 0), n - 1);
+        return (size_t)max(i, j) * n + min(i, j);
+    };
+    double vT[5], vP[5];
+#pragma unroll
+    for (int u = 0; u < 5; u++) {                                            // (clamped addresses; masks when the values are placed)
+        const int idx = min(t + 960 * u, WB * WB - 1), r = idx / WB, k = idx % WB;
+        vT[u] = S[addr(r1 + r, r1 + k)];
+        vP[u] = S[addr(r2 + r, r1 + k)];
+    }
+    const double vy = dc[min(max(phi(r1 + (t & (WB - 1))), 0), n - 1)];
+#pragma unroll
+    for (int u = 0; u < 5; u++) {
+        const int idx = t + 960 * u, r = idx / WB, k = idx % WB;
+        if (idx < WB * WB) {
+            const bool vr1 = J + 1 < NB && inside(r1 + r), vr2 = J + 2 < NB && inside(r2 + r), vk = J + 1 < NB && inside(r1 + k);
+            Tm[r * WBS + k] = tz ? 0.0 : ((vr1 && vk) ? vT[u] : (r == k ? 1.0 : 0.0));
+            Pn[r * WBS + k] = (vr2 && vk) ? vP[u] : 0.0;
+        }
+    }
+    if (t < WB) yP[t] = (!tz && J + 1 < NB && inside(r1 + t)) ? vy : 0.0;
 }
 
 // Two-sided form (`split`): the band is cut at a SEPARATOR block column Js = (NB - 1) / 2.  Workgroup 0 eliminates the block
@@ -604,9 +646,14 @@ __global__ __launch_bounds__(1024) void ba_band_factor(BaDims d, BaBufs b, BigBu
 {
     if (b.st->done) return;
     extern __shared__ __attribute__((aligned(16))) double wl[];
-    double* Pm = wl;                               // [WROWS][WBS] the tall panel of block column J
-    double* Tm = Pm + WROWS * WBS;                 // [WB][WBS] A[J+1][J+1]
-    double* yP = Tm + WB * WBS;                    // [WB] right-hand side, block J+1
+    // the window: D = A[J][J] and T = A[J+1][J+1] alternate between two buffers (T becomes the next D by a pointer swap), P =
+    // A[J+1][J] and the NEXT block's P likewise, and so do the right-hand sides of blocks J and J+1
+    double* Dm = wl;                               // [WB][WBS]
+    double* Tm = Dm + WB * WBS;                    // [WB][WBS]
+    double* Pp = Tm + WB * WBS;                    // [WB][WBS]
+    double* Pn = Pp + WB * WBS;                    // [WB][WBS] A[J+2][J+1], fetched during block J
+    double* yrow = Pn + WB * WBS;                  // [WB] right-hand side, block J
+    double* yP = yrow + WB;                        // [WB] right-hand side, block J+1
     double* Tt = yP + WB;                          // [16 WTILES][17] T = R L^-T of the current sub-block, by row below
     double* Mi = Tt + 16 * WTILES * 17;            // [16][17] inverse of the sub-block's unit-lower L
     double* rdl = Mi + 16 * 17;                    // [16] 1 / d of the current sub-block
@@ -634,52 +681,36 @@ __global__ __launch_bounds__(1024) void ba_band_factor(BaDims d, BaBufs b, BigBu
 #define BAND_STAMP(i) do { } while (0)
 #endif
     if (tid < WB) dvl[tid] = 1.0;
-    // block 0: D, P, T, right-hand sides from memory.  Side 1 starts the separator's block from zero: it contributes updates only.
-    {
-        const bool tz = split && rev && ND == 1;
-        for (int idx = tid; idx < WB * WB; idx += 1024) {
-            const int r = idx / WB, k = idx % WB;
-            const double ident = r == k ? 1.0 : 0.0;
-            Pm[r * WBS + k] = (inside(r) && inside(k)) ? b.S[addr(r, k)] : ident;
-            Pm[(WB + r) * WBS + k] = (inside(WB + r) && inside(k)) ? b.S[addr(WB + r, k)] : 0.0;
-            Tm[r * WBS + k] = tz ? 0.0 : ((inside(WB + r) && inside(WB + k)) ? b.S[addr(WB + r, WB + k)] : ident);
-        }
-        if (tid < WB) {
-            Pm[2 * WB * WBS + tid] = inside(tid) ? b.dc[rhs_at(tid)] : 0.0;
-            yP[tid] = (!tz && inside(WB + tid)) ? b.dc[rhs_at(WB + tid)] : 0.0;
-        }
+    // block 0: D, P and the right-hand side from memory (identity / zero outside the matrix)
+    for (int idx = tid; idx < WB * WB; idx += 1024) {
+        const int r = idx / WB, k = idx % WB;
+        Dm[r * WBS + k] = (inside(r) && inside(k)) ? b.S[addr(r, k)] : (r == k ? 1.0 : 0.0);
+        Pp[r * WBS + k] = (inside(WB + r) && inside(k)) ? b.S[addr(WB + r, k)] : 0.0;
     }
+    if (tid < WB) yrow[tid] = inside(tid) ? b.dc[rhs_at(tid)] : 0.0;
+    lds_barrier();
     bool bad = false;
     for (int J = 0; J < ND; J++) {
         const int c0 = WB * J, w = rev ? WB : min(WB, n - c0);
         const int r1 = c0 + WB, hp = J + 1 < NB ? (rev ? WB : min(WB, n - r1)) : 0;      // rows of block J+1
-        const int r2 = r1 + WB;                                                         // block J+2 (the P of the next step)
-        // the NEXT step's P (A[J+2][J+1]), T (A[J+2][J+2]) and right-hand side go out now and land in registers under the
-        // factorisation (original entries of S: nothing outside the band ever updates them)
-        // (clamped addresses, masks applied when the values are placed: a conditional load is waited for on the spot)
-        double nP[4], nT[4], nY;
-#pragma unroll
-        for (int u = 0; u < 4; u++) {
-            const int idx = tid + 1024 * u, r = idx / WB, k = idx % WB;
-            nP[u] = b.S[addr(r2 + r, r1 + k)];
-            nT[u] = b.S[addr(r2 + r, r2 + k)];
-        }
-        nY = b.dc[rhs_at(r2 + (tid & (WB - 1)))];
-        lds_barrier();
-        BAND_STAMP(0);
+        // While wave 0 factors the first diagonal sub-block the other 15 waves fetch this step's T = A[J+1][J+1] and the
+        // right-hand side of block J+1 (needed by the trailing update at the end of the step; their buffers were the previous
+        // step's D and right-hand side row) and the NEXT step's P = A[J+2][J+1] — original entries of S: nothing outside the
+        // band ever updates them.  Side 1 starts the separator's block from zero: it contributes updates only.
+        auto fetch = [&]() { band_fetch(b.S, b.dc, n, np, rev, J, NB, split && rev && J + 1 == ND, Tm, Pn, yP); };
         // ---- factor the panel: four 16-column sub-blocks (whole sub-blocks of side 1's padding are identity already)
         const int c_first = (rev && J == 0) ? (pad & ~15) : 0;
-        band_panel(Pm, Tt, Mi, rdl, dvl, w, hp, c_first, bad, acc_t, tq);
+        band_panel(Dm, Pp, yrow, Tt, Mi, rdl, dvl, w, hp, c_first, bad, acc_t, tq, fetch);
         // ---- the factor's blocks -> memory (the backward substitution reads them), D^-1 L^-1 g, D
 #pragma unroll
         for (int u = 0; u < 4; u++) {
             const int idx = tid + 1024 * u, r = idx / WB, k = idx % WB;
             if (inside(c0 + r) && inside(c0 + k))
-                g.Ls[(size_t)phi(c0 + r) * n + phi(c0 + k)] = k < r ? Pm[r * WBS + k] : (k == r ? 1.0 : 0.0);
+                g.Ls[(size_t)phi(c0 + r) * n + phi(c0 + k)] = k < r ? Dm[r * WBS + k] : (k == r ? 1.0 : 0.0);
             if (r < hp && inside(r1 + r) && inside(c0 + k))
-                g.Ls[(size_t)phi(r1 + r) * n + phi(c0 + k)] = Pm[(WB + r) * WBS + k];
+                g.Ls[(size_t)phi(r1 + r) * n + phi(c0 + k)] = Pp[r * WBS + k];
         }
-        if (tid < WB && inside(c0 + tid)) { g.yf[phi(c0 + tid)] = Pm[2 * WB * WBS + tid]; g.dv[phi(c0 + tid)] = dvl[tid]; }
+        if (tid < WB && inside(c0 + tid)) { g.yf[phi(c0 + tid)] = yrow[tid]; g.dv[phi(c0 + tid)] = dvl[tid]; }
         BAND_STAMP(4);
         if (hp == 0) break;                                                      // last block
         // ---- trailing update on the matrix cores: T -= (L_P D) L_P^T (lower tiles), yP -= L_P D yf
@@ -687,8 +718,8 @@ __global__ __launch_bounds__(1024) void ba_band_factor(BaDims d, BaBufs b, BigBu
             const int tr = wave >> 2, tc = wave & 3;                             // 16 waves = 4 x 4 tiles
             if (tr >= tc) {
                 d4 acc = {0.0, 0.0, 0.0, 0.0};
-                const double* X = Pm + (WB + 16 * tr + lr) * WBS + lk;
-                const double* Z = Pm + (WB + 16 * tc + lr) * WBS + lk;
+                const double* X = Pp + (16 * tr + lr) * WBS + lk;
+                const double* Z = Pp + (16 * tc + lr) * WBS + lk;
 #pragma unroll 4
                 for (int kc = 0; kc < WB / 4; kc++)
                     acc = __builtin_amdgcn_mfma_f64_16x16x4f64(X[4 * kc] * dvl[4 * kc + lk], Z[4 * kc], acc, 0, 0, 0);
@@ -700,8 +731,8 @@ __global__ __launch_bounds__(1024) void ba_band_factor(BaDims d, BaBufs b, BigBu
                 // product  yP -= (yf D) L_P^T: operand row 0 = yf D, rows 1..15 zero
                 for (int ct = tc - 1; ct < 4; ct += 3) {
                     d4 acc = {0.0, 0.0, 0.0, 0.0};
-                    const double* Y = Pm + 2 * WB * WBS + lk;
-                    const double* Z = Pm + (WB + 16 * ct + lr) * WBS + lk;
+                    const double* Y = yrow + lk;
+                    const double* Z = Pp + (16 * ct + lr) * WBS + lk;
 #pragma unroll 4
                     for (int kc = 0; kc < WB / 4; kc++)
                         acc = __builtin_amdgcn_mfma_f64_16x16x4f64(lr == 0 ? Y[4 * kc] * dvl[4 * kc + lk] : 0.0, Z[4 * kc], acc, 0, 0, 0);
@@ -721,29 +752,15 @@ __global__ __launch_bounds__(1024) void ba_band_factor(BaDims d, BaBufs b, BigBu
             if (tid < WB) sp[WB * WB + tid] = yP[tid];
             break;
         }
-        // ---- shift the window: T -> D, yP -> rhs row, the prefetched blocks -> P / T / yP
-        for (int idx = tid; idx < WB * WB; idx += 1024) {
-            const int r = idx / WB, k = idx % WB;
-            Pm[r * WBS + k] = Tm[r * WBS + k];
-        }
-        if (tid < WB) Pm[2 * WB * WBS + tid] = yP[tid];
-        lds_barrier();
-        {
-            const bool tz = split && rev && J + 2 == ND;                         // side 1 reaches the separator: updates only
-#pragma unroll
-            for (int u = 0; u < 4; u++) {
-                const int idx = tid + 1024 * u, r = idx / WB, k = idx % WB;
-                const bool vr = J + 2 < NB && inside(r2 + r);
-                Pm[(WB + r) * WBS + k] = (vr && inside(r1 + k)) ? nP[u] : 0.0;
-                Tm[r * WBS + k] = tz ? 0.0 : ((vr && inside(r2 + k)) ? nT[u] : (r == k ? 1.0 : 0.0));
-            }
-            if (tid < WB) { yP[tid] = (!tz && J + 2 < NB && inside(r2 + tid)) ? nY : 0.0; dvl[tid] = 1.0; }
-        }
+        // ---- shift the window by swapping buffers: T becomes D, yP the right-hand side row, the fetched P the panel's (every
+        // reader of the old D, P and right-hand side row is behind the barrier above)
+        { double* t_ = Dm; Dm = Tm; Tm = t_; t_ = yrow; yrow = yP; yP = t_; t_ = Pp; Pp = Pn; Pn = t_; }
+        if (tid < WB) dvl[tid] = 1.0;                                            // (wave 0, which is also the next writer)
         BAND_STAMP(6);
     }
     if (__any(bad) && lane == 0) *g.fail = 1;
 #if RS_STAMPS
-    if (tid == 0 && blockIdx.x == 0) for (int q = 0; q < 8; q++) b.dbg[16 + q] += acc_t[q];
+    if (tid == 0) for (int q = 0; q < 8; q++) b.dbg[(blockIdx.x == 0 ? 16 : 40) + q] += acc_t[q];     // side 0: 16.., side 1: 40..
 #endif
 }
 
@@ -806,7 +823,8 @@ static __device__ __forceinline__ void band_sep_backsub(const BigBufs& g, int n,
 {
     const int tid = threadIdx.x, nt = blockDim.x, lane = tid & 63, wave = tid >> 6;
     const int NB = (n + WB - 1) / WB, np = NB * WB, Js = (NB - 1) / 2;
-    double* Pm = W;
+    double* Pm = W;                                                // [WB][WBS] the separator's block, then its right-hand side row
+    double* ys = Pm + WB * WBS;
     double* Tt = Pm + WROWS * WBS;
     double* Mi = Tt + 16 * WTILES * 17;
     double* rdl = Mi + 16 * 17;
@@ -819,18 +837,18 @@ static __device__ __forceinline__ void band_sep_backsub(const BigBufs& g, int n,
         Pm[r * WBS + k] = g.sep[hi * WB + lo] + g.sep[WB * WB + WB + (WB - 1 - lo) * WB + (WB - 1 - hi)];
     }
     if (tid < WB) {
-        Pm[2 * WB * WBS + tid] = g.sep[WB * WB + tid] + g.sep[WB * WB + WB + WB * WB + (WB - 1 - tid)];
+        ys[tid] = g.sep[WB * WB + tid] + g.sep[WB * WB + WB + WB * WB + (WB - 1 - tid)];
         dvl[tid] = 1.0;
     }
     for (int i = tid; i < n; i += nt) y[i] = g.yf[i];
     lds_barrier();
     bool bad = false;
-    unsigned long long tq = 0;
-    band_panel(Pm, Tt, Mi, rdl, dvl, WB, 0, 0, bad, nullptr, tq);
+    unsigned long long tq = 0, acc_t[8] = {0, 0, 0, 0, 0, 0, 0, 0};      // (phase stamps of RS_STAMPS builds: unused here)
+    band_panel(Pm, nullptr, ys, Tt, Mi, rdl, dvl, WB, 0, 0, bad, acc_t, tq, []() {});
     if (__any(bad) && lane == 0) *s_fail = 1;
     // x_s = L_s^-T (D^-1 L^-1 y_s): one wave, the block's columns in registers
     if (tid < 64) {
-        double v = Pm[2 * WB * WBS + tid];
+        double v = ys[tid];
         double l[WB];
 #pragma unroll
         for (int t = 0; t < WB; t++) l[t] = Pm[t * WBS + tid];
@@ -1070,7 +1088,7 @@ int ba_launch_reduced_solve_big(rs_context* ctx, const BaDims& d, const BaBufs& 
     hipLaunchKernelGGL(ba_big_prologue, dim3(1), dim3(1024), 0, s, d, b, opt, g);
     hipLaunchKernelGGL(ba_big_assemble, dim3(256), dim3(256), 0, s, d, b);
     if (band) {
-        const size_t lds_band = sizeof(double) * ((size_t)WROWS * WBS + WB * WBS + WB + (size_t)16 * WTILES * 17 + 16 * 17 + 16 + WB);
+        const size_t lds_band = sizeof(double) * ((size_t)4 * WB * WBS + 2 * WB + (size_t)16 * WTILES * 17 + 16 * 17 + 16 + WB);
         RS_HIP(ctx, rs_lds_attr((const void*)ba_band_factor, lds_band));
         rs_prof_scope ps(ctx, "K7b_band_factor");
         hipLaunchKernelGGL(ba_band_factor, dim3(band == 2 ? 2 : 1), dim3(1024), lds_band, s, d, b, g, band == 2 ? 1 : 0);

@@ -478,3 +478,50 @@ def test_reproj_match_sharded_map_min_reduction(rs, oracle, synth, bounds):
         assert np.array_equal(prop, ref["prop_point"]), r
         assert np.array_equal(pkp, ref["point_kp"][bounds[r]:bounds[r + 1]]), r
     assert P == bounds[-1]
+
+
+def test_context_fork_and_wait_for_order_streams(rs, oracle, synth):
+    """rs_context_fork / rs_context_wait_for: stream ordering between contexts without the host.  Producer -> consumer across
+    two contexts on streams of their own (the match list of rs_match_descriptors feeds rs_triangulate_matches on the other
+    context), behind a long-running kernel sequence on the producer's stream so that an unordered consumer would read the
+    list too early; then the reverse edge, many times.  Same stream / same context are no-ops; bad arguments are refused."""
+    import torch
+    a, b = rs.Context(0), rs.Context(0)
+    sa, sb = torch.cuda.Stream(device=a.device), torch.cuda.Stream(device=a.device)
+    a.use_stream(sa)
+    b.use_stream(sb)
+    try:
+        pr = synth.make_pair(2)
+        nq, nt = len(pr["desc2"]), len(pr["desc1"])
+        dq, dt = a.dev(pr["desc2"]), a.dev(pr["desc1"])
+        dk1, dk2, dpo = a.dev(pr["kp1"]), a.dev(pr["kp2"]), a.dev(pr["poses"])
+        torch.cuda.synchronize()
+        mq, mt = oracle.match_descriptors(pr["desc2"], pr["desc1"])
+        ref = oracle.triangulate(pr["kp1"][mt], pr["kp2"][mq], pr["poses"], pr["K"])
+        m = a.match_descriptors(dq, dt, nq, nt)
+        t = b.triangulate_matches(dk1, dk2, m["mt"], m["mq"], m["cnt"], nq, dpo, pr["K"])
+        torch.cuda.synchronize()
+        for rep in range(10):
+            for o in (m["mq"], m["mt"], m["cnt"], t["out_index"], t["count"]):
+                o.zero_()
+            torch.cuda.synchronize()
+            b.fork(a)                                  # a's work waits for b's (nothing there yet): exercises the edge b -> a
+            for _ in range(6):                         # ~60 us of matching in front of the list the consumer needs
+                a.match_descriptors(dq, dt, nq, nt, out=m)
+            if rep % 2:
+                b.wait_for(a)
+            else:
+                a.fork(b)
+            b.triangulate_matches(dk1, dk2, m["mt"], m["mq"], m["cnt"], nq, dpo, pr["K"], out=t)
+            a.wait_for(b)
+            a.wait_for(a, b)                           # own stream: skipped
+            torch.cuda.synchronize()
+            cnt = int(to_np(t["count"])[0])
+            assert cnt == len(ref["out_index"]) and cnt > 100, rep
+            assert np.array_equal(to_np(t["out_index"])[:cnt], ref["out_index"]), rep
+            assert np.array_equal(to_np(t["out_xyz"])[:cnt].view(np.uint32), ref["out_xyz"].view(np.uint32)), rep
+        assert a.lib.rs_context_wait_for(a.h, None, 2) != 0 and a.lib.rs_context_fork(None, None, 0) != 0
+    finally:
+        torch.cuda.synchronize()
+        a.close()
+        b.close()

@@ -15,7 +15,9 @@ for rep in range(2):
     dc, dp = ctx.dev(w["cams"]), ctx.dev(w["points"])
     s = ctx.bundle_adjust(dc, w["cam_free"], dp, *dev, w["K"])
     ctx.synchronize()
-    c = ctx.prof_counters(32)
+    c = ctx.prof_counters(48)
     names = ["load/prefetch", "A diag 16x16", "B forward subst", "C rank-16 update", "store factor", "trailing MFMA", "shift window"]
-    print({n: round(v / 100.0 / max(s["iterations"], 1), 2) for n, v in zip(names, c[16:23])}, "total", round(sum(c[16:23]) / 100.0 / s["iterations"], 1))
+    for side, base in ((0, 16), (1, 40)):       # the two sides of the two-sided form (side 1 is idle in "ba_band_mode" 2)
+        print("side", side, {n: round(v / 100.0 / max(s["iterations"], 1), 2) for n, v in zip(names, c[base:base + 7])},
+              "total", round(sum(c[base:base + 7]) / 100.0 / s["iterations"], 1))
 ctx.close()
