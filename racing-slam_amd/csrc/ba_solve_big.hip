@@ -603,23 +603,37 @@ static __device__ __forceinline__ void band_panel(double* Dm, double* Pp, double
 // for the reversed side), identity / zero outside the matrix, zeros for T when it is the separator's block seen from side 1.
 // A function of its own: inlined, the compiler computes its 20 addresses in front of the branch, in wave 0's path as well,
 // and spills them.
-static __device__ __attribute__((noinline)) void band_fetch(const double* __restrict__ S, const double* __restrict__ dc, int n, int np, int rev,
+// entry (hi, lo), hi >= lo, of the damped reduced matrix from the accumulators as K5 / the prologue leave them — S in its UPPER
+// triangle, the cameras' own blocks in U, the damping in lam — summed in ba_big_assemble's order (the banded path has no
+// assemble launch: nothing outside the band is ever needed)
+struct BandSrc { const double* S; const double* U; const double* lam; const double* dc; int n; };
+static __device__ __forceinline__ double band_entry(const BandSrc& a, int hi, int lo)
+{
+    double v = a.S[(size_t)lo * a.n + hi];
+    const double u = a.U[(hi / 6) * 36 + (lo % 6) * 6 + (hi % 6)], l = a.lam[hi];
+    if (hi / 6 == lo / 6) v += u;
+    if (hi == lo) v += l;
+    return v;
+}
+static __device__ __attribute__((noinline)) void band_fetch(const double* __restrict__ S, const double* __restrict__ U, const double* __restrict__ lam,
+                                                            const double* __restrict__ dc, int n, int np, int rev,
                                                             int J, int NB, bool tz, double* Tm, double* Pn, double* yP)
 {
+    const BandSrc src = {S, U, lam, dc, n};
     const int t = (int)threadIdx.x - 64;                                     // 0 .. 959
     const int r1 = WB * (J + 1), r2 = r1 + WB;
     auto phi = [&](int v) { return rev ? np - 1 - v : v; };
     auto inside = [&](int v) { return (unsigned)phi(v) < (unsigned)n; };
-    auto addr = [&](int r, int k) {
+    auto entry = [&](int r, int k) {
         const int i = min(max(phi(r), 0), n - 1), j = min(max(phi(k), 0), n - 1);
-        return (size_t)max(i, j) * n + min(i, j);
+        return band_entry(src, max(i, j), min(i, j));
     };
     double vT[5], vP[5];
 #pragma unroll
     for (int u = 0; u < 5; u++) {                                            // (clamped addresses; masks when the values are placed)
         const int idx = min(t + 960 * u, WB * WB - 1), r = idx / WB, k = idx % WB;
-        vT[u] = S[addr(r1 + r, r1 + k)];
-        vP[u] = S[addr(r2 + r, r1 + k)];
+        vT[u] = entry(r1 + r, r1 + k);
+        vP[u] = entry(r2 + r, r1 + k);
     }
     const double vy = dc[min(max(phi(r1 + (t & (WB - 1))), 0), n - 1)];
 #pragma unroll
@@ -668,9 +682,10 @@ __global__ __launch_bounds__(1024) void ba_band_factor(BaDims d, BaBufs b, BigBu
     // virtual index -> real index; entries outside the matrix are identity
     auto phi = [&](int v) { return rev ? np - 1 - v : v; };
     auto inside = [&](int v) { return (unsigned)phi(v) < (unsigned)n; };
-    auto addr = [&](int r, int k) {                             // (clamped) address of A'(r, k) in the lower triangle of S
+    const BandSrc src = {b.S, b.U, b.rhs, b.dc, n};             // (the prologue left the damping in b.rhs)
+    auto entry = [&](int r, int k) {                            // A'(r, k), clamped to the matrix (masked by the caller)
         const int i = min(max(phi(r), 0), n - 1), j = min(max(phi(k), 0), n - 1);
-        return (size_t)max(i, j) * n + min(i, j);
+        return band_entry(src, max(i, j), min(i, j));
     };
     auto rhs_at = [&](int v) { return min(max(phi(v), 0), n - 1); };
 #if RS_STAMPS
@@ -684,8 +699,8 @@ __global__ __launch_bounds__(1024) void ba_band_factor(BaDims d, BaBufs b, BigBu
     // block 0: D, P and the right-hand side from memory (identity / zero outside the matrix)
     for (int idx = tid; idx < WB * WB; idx += 1024) {
         const int r = idx / WB, k = idx % WB;
-        Dm[r * WBS + k] = (inside(r) && inside(k)) ? b.S[addr(r, k)] : (r == k ? 1.0 : 0.0);
-        Pp[r * WBS + k] = (inside(WB + r) && inside(k)) ? b.S[addr(WB + r, k)] : 0.0;
+        Dm[r * WBS + k] = (inside(r) && inside(k)) ? entry(r, k) : (r == k ? 1.0 : 0.0);
+        Pp[r * WBS + k] = (inside(WB + r) && inside(k)) ? entry(WB + r, k) : 0.0;
     }
     if (tid < WB) yrow[tid] = inside(tid) ? b.dc[rhs_at(tid)] : 0.0;
     lds_barrier();
@@ -697,7 +712,7 @@ __global__ __launch_bounds__(1024) void ba_band_factor(BaDims d, BaBufs b, BigBu
         // right-hand side of block J+1 (needed by the trailing update at the end of the step; their buffers were the previous
         // step's D and right-hand side row) and the NEXT step's P = A[J+2][J+1] — original entries of S: nothing outside the
         // band ever updates them.  Side 1 starts the separator's block from zero: it contributes updates only.
-        auto fetch = [&]() { band_fetch(b.S, b.dc, n, np, rev, J, NB, split && rev && J + 1 == ND, Tm, Pn, yP); };
+        auto fetch = [&]() { band_fetch(b.S, b.U, b.rhs, b.dc, n, np, rev, J, NB, split && rev && J + 1 == ND, Tm, Pn, yP); };
         // ---- factor the panel: four 16-column sub-blocks (whole sub-blocks of side 1's padding are identity already)
         const int c_first = (rev && J == 0) ? (pad & ~15) : 0;
         band_panel(Dm, Pp, yrow, Tt, Mi, rdl, dvl, w, hp, c_first, bad, acc_t, tq, fetch);
@@ -1086,7 +1101,7 @@ int ba_launch_reduced_solve_big(rs_context* ctx, const BaDims& d, const BaBufs& 
     const size_t lds_upd = sizeof(double) * (6 * BB * BBS + 2 * BB * 17 + BB);
     RS_HIP(ctx, rs_lds_attr((const void*)ba_big_update, lds_upd));
     hipLaunchKernelGGL(ba_big_prologue, dim3(1), dim3(1024), 0, s, d, b, opt, g);
-    hipLaunchKernelGGL(ba_big_assemble, dim3(256), dim3(256), 0, s, d, b);
+    if (!band) hipLaunchKernelGGL(ba_big_assemble, dim3(256), dim3(256), 0, s, d, b);
     if (band) {
         const size_t lds_band = sizeof(double) * ((size_t)4 * WB * WBS + 2 * WB + (size_t)16 * WTILES * 17 + 16 * 17 + 16 + WB);
         RS_HIP(ctx, rs_lds_attr((const void*)ba_band_factor, lds_band));
