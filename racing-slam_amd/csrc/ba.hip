@@ -631,7 +631,7 @@ static void ba_bind(BaBufs& b, char* ws, const BaLayout& L, const BaDims& d, int
     b.acc = (double*)(ws + L.acc); b.acc_count = L.acc_count;
     b.S = b.acc; b.rhs = b.S + (size_t)srep * ns * n * n; b.U = b.rhs + (size_t)ns * n; b.gc = b.U + (size_t)d.Cf * 36;
     b.cam_stride = L.cam_stride; b.scal = b.rhs + (size_t)BA_UREP * L.cam_stride;
-    b.gmax_all = b.scal + (size_t)BA_NSLOT * BA_SLOT_STRIDE; b.gmax_blocks = n_ranks;
+    b.gmax_all = b.scal + (size_t)BA_NSLOT * BA_SLOT_STRIDE; b.gmax_blocks = n_ranks; b.decided = 0;
     b.gmax = b.gmax_all + (size_t)rank * BA_NSLOT * BA_SLOT_STRIDE;
     b.pt_scal = (double*)(ws + L.pts); b.pt_prev = b.pt_scal; b.dc = (double*)(ws + L.dc);
     b.st = (BaState*)(ws + L.st); b.st_prev = b.st;
@@ -888,7 +888,11 @@ static int ba_solve_once(rs_context* ctx, int n_cameras, int n_points, int n_obs
         }
         if (use_mfma) {
             rs_prof_scope ps(ctx, "K5_ba_schur_mfma");
+            // more items than compute units: the round's decision once, in front, instead of in every item's prologue
+            b.decided = grp.n_items > ctx->n_cu ? 1 : 0;
+            if (b.decided) ba_launch_decide(s, b, opt, it);
             ba_launch_schur(s, d, b, opt, grp, it);
+            b.decided = 0;
         } else {
             rs_prof_scope ps(ctx, "K5_ba_linearize_schur");
             hipLaunchKernelGGL(ba_linearize_schur, dim3(pblocks), dim3(BA_THREADS), k5_lds, s, d, b, opt, it);
@@ -1155,7 +1159,7 @@ static int ba_solve_batch_grid(rs_context* ctx, int B, const rs_ba_problem* Q, c
         ba_launch_grouping_batch(s, d_wins, B, max_P, max_items);
     }
     auto enqueue_round = [&](int it) {
-        { rs_prof_scope ps(ctx, "K5_ba_schur_mfma"); ba_launch_schur_batch(s, d_wins, B, opt, it, max_items, wins[0].g.it_l, k5_lds); }
+        { rs_prof_scope ps(ctx, "K5_ba_schur_mfma"); ba_launch_decide_batch(s, d_wins, B, opt, it); ba_launch_schur_batch(s, d_wins, B, opt, it, max_items, wins[0].g.it_l, k5_lds); }
         { rs_prof_scope ps(ctx, "K7_ba_reduced_solve"); ba_launch_reduced_solve_lds_batch(s, d_wins, B, opt, it, ns, max_n); }
         { rs_prof_scope ps(ctx, "K8_ba_backsub_cost"); ba_launch_backsub_batch(s, d_wins, B, it, ns, max_P, k8_lds); }
     };

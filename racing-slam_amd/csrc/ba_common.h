@@ -121,6 +121,8 @@ struct BaBufs {
     double* gmax;    // [BA_NSLOT][8] per slot: bits of a non-negative double (max; K7 folds); THIS rank's block of gmax_all
     double* gmax_all;   // [gmax_blocks][BA_NSLOT][8], inside the all-reduced accumulator block: rank r only writes block r,
     int gmax_blocks;    //   so that the SUM all-reduce of the accumulators also delivers every rank's maximum (no max collective)
+    int decided;        // the round's state block *st was written by ba_decide_round in front of K5 (launches with more items than
+                        // compute units, batched windows): K5's workgroups load it instead of each re-deriving the decision
     double* pt_scal; // [ns][BA_NSLOT][8] per slot, K8 of THIS round: cand_cost, mcc_p, step_sq_p, x_sq_p
     const double* pt_prev;   // the same block of the PREVIOUS round (read by the next linearisation's decision)
     double* dc;      // [ns][BA_DC_STRIDE(n)]
@@ -442,6 +444,11 @@ __device__ __forceinline__ void ba_decide(const BaBufs& b, const BaOpt& opt, int
 // entries and tells the host.
 __device__ __forceinline__ BaState ba_round_state(const BaBufs& b, const BaOpt& opt, int it, BaState* sh, bool owner)
 {
+    if (b.decided) {
+        if (threadIdx.x == 0) *sh = *b.st;
+        __syncthreads();
+        return *sh;
+    }
     if (threadIdx.x < 64) {
         ba_decide(b, opt, it, owner ? b.trace : nullptr, sh);
         if (threadIdx.x == 0 && owner) {
@@ -537,6 +544,8 @@ __device__ __forceinline__ BaBufs ba_win_round(const BaWin& w, int it, bool last
     return b;
 }
 void ba_launch_grouping_batch(hipStream_t s, const BaWin* d_wins, int B, int max_P, int max_items);
+void ba_launch_decide(hipStream_t s, const BaBufs& b, const BaOpt& opt, int it);                 // one wave: the round's decision -> *b.st (owner duties incl.)
+void ba_launch_decide_batch(hipStream_t s, const BaWin* d_wins, int B, const BaOpt& opt, int it);
 void ba_launch_schur_batch(hipStream_t s, const BaWin* d_wins, int B, const BaOpt& opt, int it, int max_items, int it_l, size_t lds);
 void ba_launch_reduced_solve_lds_batch(hipStream_t s, const BaWin* d_wins, int B, const BaOpt& opt, int it, int ns, int max_n);
 int ba_prepare_reduced_solve_lds_batch(int max_n);

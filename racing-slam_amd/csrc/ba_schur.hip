@@ -181,6 +181,22 @@ __global__ __launch_bounds__(256) void ba_group_scatter_scan(BaDims d, BaBufs b,
     g.lm[pos] = make_int4(p, o0, b.obs_ptr[p + 1] - o0, 0);
 }
 __global__ __launch_bounds__(256) void ba_group_items(BaDims d, BaGroup g) { ba_group_items_body(d, g); }
+// The round's decision as a launch of its own (one wave per window), for K5 launches whose workgroups do not all run at
+// once: there every item re-deriving it (slot lines, twelve wave reductions, the trust-region logic: 2.7 us) is serial work
+// per compute unit — 5 item rounds at cfg 5, 20 in a batch of 32 windows.
+__global__ __launch_bounds__(64) void ba_decide_round(BaBufs b, BaOpt opt, int it)
+{
+    __shared__ BaState sh;
+    b.decided = 0;
+    (void)ba_round_state(b, opt, it, &sh, true);
+}
+__global__ __launch_bounds__(64) void ba_decide_round_batch(const BaWin* w, BaOpt opt, int it)
+{
+    __shared__ BaState sh;
+    BaBufs b = ba_win_round(w[blockIdx.x], it, false);
+    b.decided = 0;
+    (void)ba_round_state(b, opt, it, &sh, true);
+}
 __global__ __launch_bounds__(256) void ba_group_count_batch(const BaWin* w) { const BaWin& x = w[blockIdx.z]; if ((int)(blockIdx.x * 256) < x.d.P) ba_group_count_body(x.d, x.b, x.g); }
 __global__ __launch_bounds__(1024) void ba_group_scan_batch(const BaWin* w) { ba_group_scan_body(w[blockIdx.z].g); }
 __global__ __launch_bounds__(256) void ba_group_scatter_batch(const BaWin* w) { const BaWin& x = w[blockIdx.z]; ba_group_scatter_body(x.d, x.b, x.g); }
@@ -189,7 +205,8 @@ __global__ __launch_bounds__(64 * SCH_WAVES) void ba_schur_mfma_batch(const BaWi
 {
     const BaWin& x = w[blockIdx.z];
     if ((int)blockIdx.x >= x.g.n_items) return;
-    const BaBufs b = ba_win_round(x, it, false);
+    BaBufs b = ba_win_round(x, it, false);
+    b.decided = 1;                       // ba_decide_round_batch ran in front of this launch
     __shared__ BaState st_sh;
     ba_schur_body<true, false>(x.d, b, opt, x.g, it, (int)blockIdx.x, &st_sh);
 }
@@ -350,6 +367,15 @@ void ba_launch_schur(hipStream_t s, const BaDims& d, const BaBufs& b, const BaOp
         hipLaunchKernelGGL(ba_schur_mfma, dim3(g.n_items), dim3(8 * g.it_l), ba_schur_lds_bytes(d.C, d.Cf, g.it_l), s, d, b, opt, g, it);
     else
         hipLaunchKernelGGL(ba_schur_mfma_big, dim3(g.n_items), dim3(8 * g.it_l), ba_schur_lds_bytes(d.C, d.Cf, g.it_l), s, d, b, opt, g, it);
+}
+
+void ba_launch_decide(hipStream_t s, const BaBufs& b, const BaOpt& opt, int it)
+{
+    hipLaunchKernelGGL(ba_decide_round, dim3(1), dim3(64), 0, s, b, opt, it);
+}
+void ba_launch_decide_batch(hipStream_t s, const BaWin* d_wins, int B, const BaOpt& opt, int it)
+{
+    hipLaunchKernelGGL(ba_decide_round_batch, dim3(B), dim3(64), 0, s, d_wins, opt, it);
 }
 
 // ---- batched launches (one per kernel for B windows)
