@@ -499,18 +499,28 @@ static __device__ __forceinline__ void band_panel(double* Dm, double* Pp, double
 #pragma unroll
             for (int k = 0; k < 16; k++) a[k] = Dm[(c + r) * WBS + c + k];
             double my_rd = 1.0, my_piv = 1.0;
+            // software-pipelined: column cc + 1 is updated first and its pivot's reciprocal (a chain of ten dependent
+            // instructions) is in flight under the updates of columns cc + 2 .. 15 — the same operations in another order
+            double piv = rl64(a[0], 0);
+            double rd = rcp_nr(piv);
+            double lc = a[0] * rd;
 #pragma unroll
             for (int cc = 0; cc < 16; cc++) {
                 asm volatile("" : "+v"(r));
-                const double piv = rl64(a[cc], cc);
-                bad = bad || !(piv > 0.0) || !isfinite(piv);
-                const double rd = rcp_nr(piv);
-                const double lc = a[cc] * rd;
+                double piv_n = 1.0, rd_n = 1.0, lc_n = 0.0;
+                if (cc + 1 < 16) {
+                    a[cc + 1] -= lc * rl64(a[cc], cc + 1);
+                    piv_n = rl64(a[cc + 1], cc + 1);
+                    rd_n = rcp_nr(piv_n);
+                    lc_n = a[cc + 1] * rd_n;
+                }
 #pragma unroll
-                for (int k = cc + 1; k < 16; k++) a[k] -= lc * rl64(a[cc], k);
+                for (int k = cc + 2; k < 16; k++) a[k] -= lc * rl64(a[cc], k);
+                bad = bad || !(piv > 0.0) || !isfinite(piv);
                 a[cc] = r > cc ? lc : a[cc];
                 my_rd = r == cc ? rd : my_rd;
                 my_piv = r == cc ? piv : my_piv;
+                piv = piv_n; rd = rd_n; lc = lc_n;
                 __builtin_amdgcn_sched_barrier(0);
             }
             if (lane < 16) {
