@@ -371,6 +371,7 @@ def test_triangulate_host_fast_path(ctx, oracle, synth, n):
 @pytest.mark.parametrize("kw,banded", [(dict(n_kf=100, n_points=1500, run_min=2, run_max=10, config_id=140), True),
                                        (dict(n_kf=60, n_points=2500, run_min=2, run_max=10, config_id=141), True),      # n = 348: 5 full blocks + 28 columns
                                        (dict(n_kf=33, n_points=900, run_min=2, run_max=10, config_id=142), True),       # n = 186
+                                       (dict(n_kf=34, n_points=900, run_min=2, run_max=10, config_id=144), True),       # n = 192: whole blocks, no padding
                                        (dict(n_kf=40, n_points=4000, run_min=3, run_max=24, config_id=143), False)])    # spans up to 23: not banded
 def test_bundle_adjust_banded_reduced_solve(ctx, oracle, synth, kw, banded):
     """VERDICT r2 #5 (cfg 5's reduced solve was 13 + 12 dependent launches per LM step): when every landmark is seen by key
@@ -525,3 +526,28 @@ def test_context_fork_and_wait_for_order_streams(rs, oracle, synth):
         torch.cuda.synchronize()
         a.close()
         b.close()
+
+
+def test_bundle_adjust_item_size_and_decision_launch(ctx, oracle, synth):
+    """"ba_item_landmarks" (32 / 40 / 64 landmarks per workgroup of K5) and the round's decision as a launch of its own in front
+    of K5 (taken when a solve has more items than compute units: 9000 landmarks in items of 32 = 282 items): the LM schedule
+    and the results do not depend on either (atomic order only)."""
+    w = synth.make_ba_window(n_kf=12, n_points=9000, config_id=151)
+    _, _, os_, otr = oracle.bundle_adjust_trace(w["cams"], w["cam_free"], w["points"], w["obs_ptr"], w["obs_cam"], w["obs_uv"], w["K"])
+    rc, rp, _ = oracle.bundle_adjust(w["cams"], w["cam_free"], w["points"], w["obs_ptr"], w["obs_cam"], w["obs_uv"], w["K"])
+    runs = {}
+    try:
+        for item in (0, 32, 40, 64):
+            ctx.set_int("ba_item_landmarks", item)
+            dc, dp = ctx.dev(w["cams"]), ctx.dev(w["points"])
+            s = ctx.bundle_adjust(dc, w["cam_free"], dp, ctx.dev(w["obs_ptr"]), ctx.dev(w["obs_cam"]), ctx.dev(w["obs_uv"]), w["K"])
+            runs[item] = (s, ctx.ba_trace(), to_np(dc), to_np(dp))
+    finally:
+        ctx.set_int("ba_item_landmarks", 0)
+    for item, (s, tr, c, p) in runs.items():
+        assert (s["iterations"], s["successful_steps"], s["termination"]) == (os_["iterations"], os_["successful_steps"], os_["termination"]), item
+        assert [t["outcome"] for t in tr] == [t["outcome"] for t in otr], item
+        assert np.allclose([t["cost"] for t in tr], [t["cost"] for t in otr], rtol=1e-8), item
+        assert np.allclose(c, rc, rtol=1e-7, atol=1e-9) and np.allclose(p, rp, rtol=1e-7, atol=1e-8), item
+    with pytest.raises(Exception):
+        ctx.set_int("ba_item_landmarks", 48)
