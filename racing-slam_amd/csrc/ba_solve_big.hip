@@ -885,53 +885,91 @@ static __device__ __forceinline__ void band_sep_backsub(const BigBufs& g, int n,
         y[s0 + tid] = v;
     }
     __syncthreads();
-    // both sides, away from the separator
-    double* Lb = W;                                                // [2][WB][WBS]
-    double* part = Lb + 2 * WB * WBS;                              // [2][8][WB]
-    const int side = tid >> 9, t9 = tid & 511;
-    const int ND0 = Js, ND1 = NB - 1 - Js;
+    // both sides, away from the separator, in two roles with the same barrier sequence: wave 0 / wave 1 (different SIMDs)
+    // run the triangular solve of side 0 / side 1 (the block's columns read from LDS sixteen at a time: sixty-four of them
+    // in registers would be the whole register file of a wave at this workgroup size); the other 14 waves form the products
+    // L_P^T x, and request the factor's blocks of step s + 1 (diagonal block and multipliers, 2 x 32 KB per side) at the
+    // start of step s so that they travel under its arithmetic — the multipliers reach LDS in the solve phase (their buffer
+    // is free: the products of step s are done), the diagonal block after the barrier that ends it.
+    double* Lb = W;                                                // [2][WB][WBS] diagonal blocks
+    double* Lp = Lb + 2 * WB * WBS;                                // [2][WB][WBS] multipliers L_{J+1,J}
+    double* part = Lp + 2 * WB * WBS;                              // [2][7][WB]
+    const int ND0 = Js, ND1 = NB - 1 - Js, nsteps = max(ND0, ND1);
     auto phi = [&](int sd, int v) { return sd ? np - 1 - v : v; };
-    for (int step = 1; step <= max(ND0, ND1); step++) {
-        const int J = (side ? ND1 : ND0) - step;                   // this side's (virtual) block column
-        const int c0 = WB * J, r1 = c0 + WB;
-        if (J >= 0) {
-            for (int idx = t9; idx < WB * WB; idx += 512) {
-                const int r = idx / WB, k = idx % WB;
-                const int i = phi(side, c0 + r), j = phi(side, c0 + k);
-                Lb[(side * WB + r) * WBS + k] = (i < n && j < n) ? g.Ls[(size_t)i * n + j] : 0.0;
-            }
-            const int k = t9 & 63, grp = t9 >> 6;                  // 8 groups of 8 rows of L_P
-            const int j = phi(side, c0 + k);
-            double l[8], acc = 0.0;
-#pragma unroll
-            for (int u = 0; u < 8; u++) l[u] = g.Ls[(size_t)phi(side, r1 + 8 * grp + u) * n + min(j, n - 1)];
-#pragma unroll
-            for (int u = 0; u < 8; u++) acc += l[u] * y[phi(side, r1 + 8 * grp + u)];
-            part[(side * 8 + grp) * WB + k] = j < n ? acc : 0.0;
-        }
-        __syncthreads();
-        if (wave < 2) {
-            const int sd = wave, Jw = (sd ? ND1 : ND0) - step;
+    if (wave < 2) {
+        const int sd = wave, ND = sd ? ND1 : ND0;
+        __syncthreads();                                           // step 1's blocks are in LDS
+        for (int step = 1; step <= nsteps; step++) {
+            const int Jw = ND - step;
+            __syncthreads();                                       // products of this step
             if (Jw >= 0) {
-                const int cw = WB * Jw, i = phi(sd, cw + lane);
+                const int i = phi(sd, WB * Jw + lane);
                 double v = 0.0;
                 if (i < n) {
                     v = y[i];
-                    for (int q = 0; q < 8; q++) v -= part[(sd * 8 + q) * WB + lane];
+                    for (int q = 0; q < 7; q++) v -= part[(sd * 7 + q) * WB + lane];
                 }
-                double l[WB];
 #pragma unroll
-                for (int t = 0; t < WB; t++) l[t] = Lb[(sd * WB + t) * WBS + lane];
+                for (int tc = WB - 16; tc >= 0; tc -= 16) {
+                    double l[16];
 #pragma unroll
-                for (int t = WB - 1; t >= 0; t--) {
-                    const double xt = rl64(v, t);
-                    v -= (lane < t) ? l[t] * xt : 0.0;
+                    for (int t = 0; t < 16; t++) l[t] = Lb[(sd * WB + tc + t) * WBS + lane];
+#pragma unroll
+                    for (int t = 15; t >= 0; t--) {
+                        const double xt = rl64(v, tc + t);
+                        v -= (lane < tc + t) ? l[t] * xt : 0.0;
+                    }
                 }
                 if (i < n) y[i] = v;
             }
+            __syncthreads();                                       // x of this block
         }
+    } else {
+        const int t = tid - 128;                                   // 0 .. 895
+        double vv[19];
+        // entry e of the 2 x 2 x 4096 values of a step: side, which block (0 diagonal, 1 multipliers), row, column
+        auto request = [&](int step) {                             // (clamped addresses; masked when placed)
+#pragma unroll
+            for (int u = 0; u < 19; u++) {
+                const int e = min(t + 896 * u, 4 * WB * WB - 1), sd = e >> 13, which = (e >> 12) & 1, r = (e >> 6) & 63, k = e & 63;
+                const int J = max((sd ? ND1 : ND0) - step, 0), c0 = WB * J;
+                const int i = min(phi(sd, (which ? c0 + WB : c0) + r), n - 1), j = min(phi(sd, c0 + k), n - 1);
+                vv[u] = g.Ls[(size_t)i * n + j];
+            }
+        };
+        auto place = [&](int step, int which_now) {
+#pragma unroll
+            for (int u = 0; u < 19; u++) {
+                const int e = t + 896 * u, sd = e >> 13, which = (e >> 12) & 1, r = (e >> 6) & 63, k = e & 63;
+                const int J = (sd ? ND1 : ND0) - step, c0 = WB * J;
+                if (e >= 4 * WB * WB || which != which_now || J < 0) continue;
+                const bool vk = phi(sd, c0 + k) < n;
+                if (which) Lp[(sd * WB + r) * WBS + k] = vk ? vv[u] : 0.0;         // (rows of block J + 1 are inside the matrix)
+                else Lb[(sd * WB + r) * WBS + k] = (vk && phi(sd, c0 + r) < n) ? vv[u] : 0.0;
+            }
+        };
+        request(1);
+        place(1, 0);
+        place(1, 1);
         __syncthreads();
+        for (int step = 1; step <= nsteps; step++) {
+            if (step < nsteps) request(step + 1);
+            {
+                const int sd = t / 448, q = (t % 448) >> 6, k = t & 63;         // 2 sides x 7 row groups x 64 columns
+                const int J = (sd ? ND1 : ND0) - step, r1 = WB * J + WB;
+                if (J >= 0) {
+                    double acc = 0.0;
+                    for (int r = 10 * q; r < min(10 * q + 10, WB); r++) acc += Lp[(sd * WB + r) * WBS + k] * y[phi(sd, r1 + r)];
+                    part[(sd * 7 + q) * WB + k] = acc;
+                }
+            }
+            __syncthreads();
+            if (step < nsteps) place(step + 1, 1);
+            __syncthreads();
+            if (step < nsteps) place(step + 1, 0);
+        }
     }
+    __syncthreads();
 }
 
 // block backward substitution L^T x = D^-1 L^-1 g by one workgroup: y (LDS, [n]) becomes x; Lb is an LDS block buffer
@@ -1105,7 +1143,8 @@ int ba_launch_reduced_solve_big(rs_context* ctx, const BaDims& d, const BaBufs& 
     hipStream_t s = ctx->stream;
     if (band == 2 && (d.n + WB - 1) / WB < 3) band = 1;                  // no room for a separator between two sides
     // y, diagonal block, backsub partial sums; two-sided band: y + the panel window of the separator's factorisation
-    const size_t lds_fin = sizeof(double) * (n + (band == 2 ? (size_t)WROWS * WBS + 16 * WTILES * 17 + 16 * 17 + 16 + WB : (size_t)WB * WBS + 1024));
+    // (two-sided band: the panel window of the separator's factorisation, then two diagonal blocks + two multiplier blocks + partial sums)
+    const size_t lds_fin = sizeof(double) * (n + (band == 2 ? (size_t)4 * WB * WBS + 1024 : (size_t)WB * WBS + 1024));
     if (lds_fin > 48 * 1024)
         RS_HIP(ctx, rs_lds_attr((const void*)ba_big_finish, lds_fin));
     const size_t lds_upd = sizeof(double) * (6 * BB * BBS + 2 * BB * 17 + BB);
