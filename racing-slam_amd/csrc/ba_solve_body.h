@@ -6,7 +6,22 @@
 #include "ba_backsub_body.h"
 
 #define K7_THREADS 512
-#define K7_TPW 6       // tiles per tile wave: 6 tile waves x 6 = the 36 lower-triangle tiles of a 128 x 128 matrix
+// K7_CHAIN_SIMDS 1 (default): chain waves 0 and 4 share SIMD 0, six tile waves on SIMDs 1-3.  2: chain waves 0 and 1 have a
+// SIMD each (while both work — more than 64 rows left — two chain waves on one SIMD take turns: 1.4 us per block step
+// against 1.0), waves 2, 3, 6, 7 are the tile waves on SIMDs 2 and 3 with nine tiles each, waves 4 and 5 only keep the
+// barriers.  Built, parity-green and measured in round 3: the fused launch 45.0 -> 51.0 us, the two-launch K7 40.6 -> 46.9 —
+// four tile waves do not keep up with the chain (eighteen MFMAs, nine operand pairs and up to nine publishes per wave and
+// step), so the trailing update becomes the critical path.  Kept as a compile-time switch.
+#ifndef K7_CHAIN_SIMDS
+#define K7_CHAIN_SIMDS 1
+#endif
+#if K7_CHAIN_SIMDS == 2
+#define K7_TPW 9       // tiles per tile wave: 4 tile waves x 9 = the 36 lower-triangle tiles of a 128 x 128 matrix
+#define K7_NTW 4
+#else
+#define K7_TPW 6       // 6 tile waves x 6
+#define K7_NTW 6
+#endif
 
 typedef __attribute__((ext_vector_type(4))) double d4;
 
@@ -68,20 +83,29 @@ static __device__ __forceinline__ void ba_reduced_solve_lds_body(const BaDims& d
     // SIMD.  So the latency chain of the factorisation (diagonal block -> panel -> next diagonal block)
     // gets a SIMD of its own: waves 0 and 4 are the CHAIN waves (one matrix row per lane, 128 >= n+1-6
     // rows), waves 1,2,3,5,6,7 are the TILE waves that keep the trailing matrix in MFMA accumulators.
+#if K7_CHAIN_SIMDS == 2
+    const bool chain = wave < 2;                   // waves 0 and 1
+    const bool idle = wave == 4 || wave == 5;      // (they share the chain waves' SIMDs)
+    const int tw = (wave & 1) + 2 * (wave >> 2);   // tile waves 2, 3, 6, 7 -> 0 .. 3
+    const int cw = wave;                           // chain wave index
+#else
     const bool chain = (wave & 3) == 0;            // waves 0 and 4
+    const bool idle = false;
     const int tw = chain ? 0 : wave - 1 - (wave >> 2);     // tile wave index 0..5
-    // slot s of tile wave tw holds lower-triangle tile number t = 6 s + tw, tiles numbered row by row
+    const int cw = wave >> 2;
+#endif
+    // slot s of tile wave tw holds lower-triangle tile number t = K7_NTW s + tw, tiles numbered row by row
     int tr[K7_TPW], tc[K7_TPW];
     bool tv[K7_TPW];
 #pragma unroll
     for (int s = 0; s < K7_TPW; s++) {
-        const int t = 6 * s + tw;
+        const int t = K7_NTW * s + tw;
         int r = 0;
 #pragma unroll
         for (int q = 1; q < 8; q++) r += (t >= q * (q + 1) / 2) ? 1 : 0;
         tr[s] = r;
         tc[s] = t - r * (r + 1) / 2;
-        tv[s] = !chain && r < NTL;
+        tv[s] = !chain && !idle && r < NTL;
     }
 
     // accumulators: plain loads behind a kernel boundary, L1-bypassing ones when they were produced inside this launch
@@ -261,13 +285,13 @@ static __device__ __forceinline__ void ba_reduced_solve_lds_body(const BaDims& d
     //       tiles: load the MFMA operands of step J
     if (chain) {
         BA_STAMP(b, 1);
-        const int crow = (wave >> 2) * 64 + lane;  // row slot 0..127 (n + 1 - 6 <= 121 rows)
+        const int crow = cw * 64 + lane;           // row slot 0..127 (n + 1 - 6 <= 121 rows)
         __syncthreads();                           // block column 0 published by the tile waves
         for (int J = 0; J < NB; J++) {
             const int c0 = 6 * J, r0 = c0 + 6;
             const int irow = r0 + crow;
             const bool has_row = irow <= n;
-            if (wave != 0 && r0 + 64 > n) {        // wave 4 has no rows left: leave the SIMD to wave 0
+            if (wave != 0 && r0 + 64 > n) {        // the second chain wave has no rows left
                 __syncthreads();
                 __syncthreads();
                 continue;
