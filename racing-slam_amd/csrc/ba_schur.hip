@@ -34,35 +34,57 @@
 #define GRP_REP 8
 #define GRP_LDS_BINS 4096
 
+// 1024 threads, 128 landmarks per workgroup, EIGHT lanes per landmark: the observations of a landmark go out together (one
+// lane each, then the next eight) instead of as a chain of dependent loads in one thread (obs_cam -> slot, six deep: the
+// kernel was 9 us for a 10 k-landmark window and 240 us for a batch of 32 of them), and the lanes combine mask, first and last
+// slot with three xor-shuffles.  The histogram replica of a landmark is the one the scatter kernel will draw its position
+// from: (landmark / 256) mod GRP_REP.
+#define GRP_COUNT_LM 128
 static __device__ __forceinline__ void ba_group_count_body(const BaDims& d, const BaBufs& b, const BaGroup& g)
 {
     __shared__ int lh[GRP_LDS_BINS];
+    __shared__ int s_span;                 // the workgroup's largest span: ONE atomic on the window's word per workgroup (atomic
+                                           // instructions on one address serialise at ~10 ns each whatever their lane count)
     const int nb = g.n_buckets + 1;
     const bool use_lds = nb <= GRP_LDS_BINS;
     if (use_lds) for (int i = threadIdx.x; i < nb; i += blockDim.x) lh[i] = 0;
+    if (threadIdx.x == 0) s_span = 0;
     __syncthreads();
-    const int p = blockIdx.x * blockDim.x + threadIdx.x;
-    int* hist = g.hist + (size_t)(blockIdx.x & (GRP_REP - 1)) * nb;
-    if (p < d.P) {
+    const int p = blockIdx.x * GRP_COUNT_LM + (int)(threadIdx.x >> 3), sub = threadIdx.x & 7;
+    int* hist = g.hist + (size_t)((blockIdx.x * GRP_COUNT_LM >> 8) & (GRP_REP - 1)) * nb;
+    {
         uint64_t m0 = 0, m1 = 0;
         int first = 1 << 30, last = -1;
-        for (int o = b.obs_ptr[p]; o < b.obs_ptr[p + 1]; o++) {
-            const int c = b.obs_cam[o];
-            const int s = b.slot[c];
-            g.obs_cs[o] = c | ((s + 1) << 16);
-            if (s < 0) continue;
-            if (s < 64) m0 |= 1ull << s; else m1 |= 1ull << (s - 64);
-            first = min(first, s);
-            last = max(last, s);
+        if (p < d.P) {
+            const int o1 = b.obs_ptr[p + 1];
+            for (int o = b.obs_ptr[p] + sub; o < o1; o += 8) {
+                const int c = b.obs_cam[o];
+                const int s = b.slot[c];
+                g.obs_cs[o] = c | ((s + 1) << 16);
+                if (s < 0) continue;
+                if (s < 64) m0 |= 1ull << s; else m1 |= 1ull << (s - 64);
+                first = min(first, s);
+                last = max(last, s);
+            }
         }
-        g.mask[2 * (size_t)p] = m0;
-        g.mask[2 * (size_t)p + 1] = m1;
-        const int bk = last < 0 ? d.Cf * d.Cf : first * d.Cf + last;
-        g.bucket[p] = bk;
-        if (last > first) atomicMax(g.maxspan, last - first);
-        if (use_lds) atomicAdd(&lh[bk], 1); else atomicAdd(&hist[bk], 1);
+#pragma unroll
+        for (int off = 1; off < 8; off <<= 1) {
+            m0 |= __shfl_xor(m0, off, 64);
+            m1 |= __shfl_xor(m1, off, 64);
+            first = min(first, __shfl_xor(first, off, 64));
+            last = max(last, __shfl_xor(last, off, 64));
+        }
+        if (p < d.P && sub == 0) {
+            g.mask[2 * (size_t)p] = m0;
+            g.mask[2 * (size_t)p + 1] = m1;
+            const int bk = last < 0 ? d.Cf * d.Cf : first * d.Cf + last;
+            g.bucket[p] = bk;
+            if (last > first) atomicMax(&s_span, last - first);
+            if (use_lds) atomicAdd(&lh[bk], 1); else atomicAdd(&hist[bk], 1);
+        }
     }
     __syncthreads();
+    if (threadIdx.x == 0 && s_span > 0) atomicMax(g.maxspan, s_span);
     if (use_lds)
         for (int i = threadIdx.x; i < nb; i += blockDim.x) { const int v = lh[i]; if (v) atomicAdd(&hist[i], v); }
 }
@@ -161,7 +183,7 @@ __global__ __launch_bounds__(64 * SCH_WAVES) void ba_schur_mfma_big(BaDims d, Ba
 
 
 // single-window and batched (blockIdx.z = window, arguments from the device array) entry points of the grouping kernels
-__global__ __launch_bounds__(256) void ba_group_count(BaDims d, BaBufs b, BaGroup g) { ba_group_count_body(d, b, g); }
+__global__ __launch_bounds__(1024) void ba_group_count(BaDims d, BaBufs b, BaGroup g) { ba_group_count_body(d, b, g); }
 __global__ __launch_bounds__(1024) void ba_group_scan(BaGroup g) { ba_group_scan_body(g); }
 __global__ __launch_bounds__(256) void ba_group_scatter(BaDims d, BaBufs b, BaGroup g) { ba_group_scatter_body(d, b, g); }
 
@@ -218,7 +240,7 @@ __global__ __launch_bounds__(64) void ba_decide_round_batch(const BaWin* w, BaOp
     b.decided = 0;
     (void)ba_round_state(b, opt, it, &sh, true);
 }
-__global__ __launch_bounds__(256) void ba_group_count_batch(const BaWin* w) { const BaWin& x = w[blockIdx.z]; if ((int)(blockIdx.x * 256) < x.d.P) ba_group_count_body(x.d, x.b, x.g); }
+__global__ __launch_bounds__(1024) void ba_group_count_batch(const BaWin* w) { const BaWin& x = w[blockIdx.z]; if ((int)(blockIdx.x * GRP_COUNT_LM) < x.d.P) ba_group_count_body(x.d, x.b, x.g); }
 __global__ __launch_bounds__(1024) void ba_group_scan_batch(const BaWin* w) { ba_group_scan_body(w[blockIdx.z].g); }
 __global__ __launch_bounds__(256) void ba_group_scatter_batch(const BaWin* w) { const BaWin& x = w[blockIdx.z]; ba_group_scatter_body(x.d, x.b, x.g); }
 __global__ __launch_bounds__(256) void ba_group_items_batch(const BaWin* w) { const BaWin& x = w[blockIdx.z]; ba_group_items_body(x.d, x.g); }
@@ -358,7 +380,7 @@ int ba_launch_grouping(rs_context* ctx, const BaDims& d, const BaBufs& b, const 
     }
     // g.hist was zeroed by ba_init (ba_group_zero_range)
     const int pb = (d.P + 255) / 256;
-    hipLaunchKernelGGL(ba_group_count, dim3(pb), dim3(256), 0, s, d, b, g);
+    hipLaunchKernelGGL(ba_group_count, dim3((d.P + GRP_COUNT_LM - 1) / GRP_COUNT_LM), dim3(1024), 0, s, d, b, g);
     if ((g.n_buckets + 1) * GRP_REP <= GRP_SCAN_LDS) {
         hipLaunchKernelGGL(ba_group_scatter_scan, dim3(pb), dim3(256), 0, s, d, b, g);
     } else {
@@ -403,7 +425,7 @@ void ba_launch_decide_batch(hipStream_t s, const BaWin* d_wins, int B, const BaO
 void ba_launch_grouping_batch(hipStream_t s, const BaWin* d_wins, int B, int max_P, int max_items)
 {
     const int pb = (max_P + 255) / 256;
-    hipLaunchKernelGGL(ba_group_count_batch, dim3(pb, 1, B), dim3(256), 0, s, d_wins);
+    hipLaunchKernelGGL(ba_group_count_batch, dim3((max_P + GRP_COUNT_LM - 1) / GRP_COUNT_LM, 1, B), dim3(1024), 0, s, d_wins);
     hipLaunchKernelGGL(ba_group_scan_batch, dim3(1, 1, B), dim3(1024), 0, s, d_wins);
     hipLaunchKernelGGL(ba_group_scatter_batch, dim3(pb, 1, B), dim3(256), 0, s, d_wins);
     hipLaunchKernelGGL(ba_group_items_batch, dim3((max_items + 3) / 4, 1, B), dim3(256), 0, s, d_wins);
