@@ -455,22 +455,23 @@ __global__ __launch_bounds__(256) void ba_big_update(BaDims d, BaBufs b, BigBufs
 // for cameras more than `span` slots apart (a local map: every landmark lives for a few key frames; cfg 5: span 9, i.e. a
 // bandwidth of 59 columns of the 588).  This is the sparsity the reference's SPARSE_SCHUR solve exploits through Eigen's sparse
 // Cholesky (src/Optimization.cpp:360).  With 64-column blocks and a bandwidth of at most 64 columns only ONE sub-diagonal
-// block per block column is non-zero and L D L^T creates no fill outside the band, so the whole factorisation runs in ONE
-// workgroup on a window in LDS —
-//     rows 0..63   D = A[J][J]        rows 64..127  P = A[J+1][J]       row 128  the right-hand side's entries of block J
-//     T = A[J+1][J+1],  the right-hand side's entries of block J+1
-// — per block: the 129-row panel is factored as four 16-column sub-blocks exactly as ba_big_diag does (wave 0: the 16 x 16
-// diagonal sub-block in registers; one lane per row below: forward substitution; all threads: rank-16 update of the panel's
-// remaining columns), which leaves L_JJ, D_J, the multipliers L_{J+1,J} and D^-1 L^-1 g in place; then T -= L_P D L_P^T on
-// the matrix cores, the factor's blocks go to memory for the backward substitution, T becomes the next D, and the next P / T
-// (prefetched into registers at the start of the step: they are original entries of S — nothing outside the band ever
-// updates them) move in.  10 block steps at n = 588 instead of 13 + 12 dependent launches.
+// block per block column is non-zero and L D L^T creates no fill outside the band, so a workgroup factors block column after
+// block column on a window in LDS —
+//     D = A[J][J] (64 x 64),  P = A[J+1][J],  the right-hand side's entries of block J      (the 129-row panel)
+//     T = A[J+1][J+1],  the right-hand side's entries of block J+1,  and the NEXT step's P
+// — per block: the panel is factored as four 16-column sub-blocks (band_panel: wave 0 the 16 x 16 diagonal sub-block in
+// registers and its inverse; the rows below and the rank-16 update of the remaining columns on the matrix cores), which leaves
+// L_JJ, D_J, the multipliers L_{J+1,J} and D^-1 L^-1 g in place; then T -= L_P D L_P^T on the matrix cores, the factor's
+// blocks go to memory for the backward substitution, T becomes the next D by a pointer swap.  The blocks of the next step
+// (original entries of S: nothing outside the band ever updates them) are fetched by the waves that would wait while wave 0
+// factors the first diagonal sub-block.  ba_band_factor runs as ONE workgroup over all block columns, or as TWO that
+// eliminate from both ends of the band towards a separator block (see there).
 #define WB 64
 #define WBS 65
 #define WROWS (2 * WB + 1)
 #define WTILES ((WROWS + 15) / 16)          // row tiles of the panel (9)
 // barrier for LDS traffic only: __syncthreads() also waits for every global access in flight (vmcnt), which would serialise
-// the prefetch of the next blocks and the stores of the factor with the factorisation
+// the stores of the factor with the factorisation
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
 // The 129-row panel [D; P; rhs] of one block column in LDS (three buffers: Dm [WB][WBS], Pp [WB][WBS], yrow [WB]), factored
@@ -842,7 +843,7 @@ static __device__ __forceinline__ void band_backsub(const BigBufs& g, int n, dou
 // Two-sided form: the separator's block (both sides' updates added) is factored here, then x_s, then both sides substitute
 // backwards away from the separator in lock step — side 0 in the real order, side 1 in its reversed order — each with half
 // of the workgroup for the product L_P^T x and one wave (on different SIMDs) for the triangular solve.
-//   W: LDS window of band_panel ([WROWS][WBS] panel, Tt, Mi, rdl, dvl); afterwards the same memory serves as two diagonal
+//   W: LDS window of band_panel (the separator's block and right-hand side row, Tt, Mi, rdl, dvl); afterwards the same memory serves as two diagonal
 //   blocks [2][WB][WBS] + partial sums [2][8][WB].
 static __device__ __forceinline__ void band_sep_backsub(const BigBufs& g, int n, double* y, double* W, int* s_fail)
 {
