@@ -841,10 +841,9 @@ static __device__ __forceinline__ void band_backsub(const BigBufs& g, int n, dou
 }
 
 // Two-sided form: the separator's block (both sides' updates added) is factored here, then x_s, then both sides substitute
-// backwards away from the separator in lock step — side 0 in the real order, side 1 in its reversed order — each with half
-// of the workgroup for the product L_P^T x and one wave (on different SIMDs) for the triangular solve.
-//   W: LDS window of band_panel (the separator's block and right-hand side row, Tt, Mi, rdl, dvl); afterwards the same memory serves as two diagonal
-//   blocks [2][WB][WBS] + partial sums [2][8][WB].
+// backwards away from the separator in lock step — side 0 in the real order, side 1 in its reversed order (roles: below).
+//   W: LDS window of band_panel (the separator's block and right-hand side row, Tt, Mi, rdl, dvl); afterwards the same memory
+//   serves as two diagonal blocks + two multiplier blocks [2][2][WB][WBS] + partial sums [2][7][WB].
 static __device__ __forceinline__ void band_sep_backsub(const BigBufs& g, int n, double* y, double* W, int* s_fail)
 {
     const int tid = threadIdx.x, nt = blockDim.x, lane = tid & 63, wave = tid >> 6;
