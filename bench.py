@@ -593,8 +593,7 @@ def build_pass(e, streams=1, graph=False):
         # poses are host-owned objects in the reference (Frame::set_pose): read back, unpack (f32), re-anchor
         ctx.ba_cameras(h_cams_np)
         rs.unpack_poses(h_cams_np, window["cam_free"], h_after.numpy())
-        d["after"].copy_(h_after, non_blocking=True)
-        ctx.reanchor_points(None, d["single_frame"], d["before"], d["after"], d["single"])
+        ctx.reanchor_points_host_poses(None, d["single_frame"], poses_before, h_after.numpy(), d["single"])   # (poses as kernel arguments)
 
     def one_pass_serial():
         one_pass(True)

@@ -424,6 +424,12 @@ int rs_point_errors(rs_context* ctx, int n_points, const float* d_positions /*[P
 int rs_reanchor_points(rs_context* ctx, int n, const int32_t* d_point_idx, const int32_t* d_frame_idx,
                        const float* d_poses_before, const float* d_poses_after, int n_frames,
                        float* d_positions);
+/* The same with the poses where the reference keeps them — on the HOST (Frame::pose(), src/Mapper.cpp:366-393):
+ * h_poses_before / h_poses_after [n_frames][16] are read before the call returns.  Up to 32 frames travel as kernel
+ * arguments (no upload, no extra launch: a local window has 20); more are copied to the device first. */
+int rs_reanchor_points_host_poses(rs_context* ctx, int n, const int32_t* d_point_idx, const int32_t* d_frame_idx,
+                                  const float* h_poses_before, const float* h_poses_after, int n_frames,
+                                  float* d_positions);
 
 /* ----------------------------------------------------- a9-a13: optimisation */
 

@@ -246,10 +246,11 @@ bool pose_graph(const std::vector<std::shared_ptr<KeyFrame>>& key_frames, const 
     }
     {
         rs_shim::Stage stage;
-        rs_shim::DevBuf<float> d_before(before), d_after(after), d_pos(positions);
+        rs_shim::DevBuf<float> d_pos(positions);
         rs_shim::DevBuf<int32_t> d_owner(owner_slot);
-        if (!rs_shim::ok(rs_reanchor_points(rs_shim::context(), (int)moved.size(), nullptr, d_owner.p, d_before.p, d_after.p, (int)n, d_pos.p),
-                         "rs_reanchor_points"))
+        // the poses stay where the reference keeps them: host arrays (kernel arguments for up to 32 frames, no upload)
+        if (!rs_shim::ok(rs_reanchor_points_host_poses(rs_shim::context(), (int)moved.size(), nullptr, d_owner.p, before.data(), after.data(), (int)n, d_pos.p),
+                         "rs_reanchor_points_host_poses"))
             return false;
         std::vector<float> out = d_pos.fetch(positions.size());
         stage.sync();

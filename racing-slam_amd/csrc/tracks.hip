@@ -320,6 +320,68 @@ extern "C" int rs_reanchor_points(rs_context* ctx, int n, const int32_t* d_point
     return RS_OK;
 }
 
+// K13 with the poses in the kernel's argument block: rows 0..2 of each 4 x 4 pose (the arithmetic reads nothing else)
+#define K13_ARG_FRAMES 32
+struct K13Poses { float before[K13_ARG_FRAMES][12]; float after[K13_ARG_FRAMES][12]; };
+__global__ __launch_bounds__(256) void k13_reanchor_args(int n, const int32_t* __restrict__ point_idx,
+                                                         const int32_t* __restrict__ frame_idx, K13Poses poses,
+                                                         float* __restrict__ pos)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int p = point_idx ? point_idx[i] : i;
+    const int f = frame_idx[i];
+    const float* B = poses.before[f];
+    const float* A = poses.after[f];
+    const float X[3] = {pos[3 * (size_t)p], pos[3 * (size_t)p + 1], pos[3 * (size_t)p + 2]};
+    float c[3], d[3];
+#pragma unroll
+    for (int r = 0; r < 3; r++) {
+        c[r] = ((B[4 * r] * X[0] + B[4 * r + 1] * X[1]) + B[4 * r + 2] * X[2]) + B[4 * r + 3];     // :389
+        d[r] = c[r] - A[4 * r + 3];
+    }
+#pragma unroll
+    for (int r = 0; r < 3; r++)                                                                       // :390
+        pos[3 * (size_t)p + r] = (A[r] * d[0] + A[4 + r] * d[1]) + A[8 + r] * d[2];
+}
+
+extern "C" int rs_reanchor_points_host_poses(rs_context* ctx, int n, const int32_t* d_point_idx, const int32_t* d_frame_idx,
+                                             const float* h_poses_before, const float* h_poses_after, int n_frames,
+                                             float* d_positions)
+{
+    if (!ctx) return RS_ERR_INVALID;
+    if (n < 0 || n_frames < 0) return rs_fail(ctx, RS_ERR_INVALID, "negative size");
+    if (n == 0) return RS_OK;
+    if (!d_frame_idx || !h_poses_before || !h_poses_after || !d_positions || n_frames == 0) return rs_fail(ctx, RS_ERR_INVALID, "null pointer");
+    RS_HIP(ctx, hipSetDevice(ctx->device));
+    if (n_frames <= K13_ARG_FRAMES) {
+        K13Poses P;
+        for (int f = 0; f < n_frames; f++) {
+            memcpy(P.before[f], h_poses_before + 16 * (size_t)f, sizeof(float) * 12);
+            memcpy(P.after[f], h_poses_after + 16 * (size_t)f, sizeof(float) * 12);
+        }
+        for (int f = n_frames; f < K13_ARG_FRAMES; f++) { memset(P.before[f], 0, sizeof P.before[f]); memset(P.after[f], 0, sizeof P.after[f]); }
+        rs_prof_scope ps(ctx, "K13_reanchor");
+        hipLaunchKernelGGL(k13_reanchor_args, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, n, d_point_idx, d_frame_idx, P, d_positions);
+    } else {
+        // larger sets of frames: both pose arrays through the context's workspace (copied before this call returns)
+        void* ws = nullptr;
+        const size_t bytes = sizeof(float) * 16 * (size_t)n_frames;
+        const int rc = rs_workspace(ctx, 2 * bytes + 256, &ws);
+        if (rc) return rc;
+        float* d_before = (float*)ws;
+        float* d_after = (float*)((char*)ws + ((bytes + 255) & ~(size_t)255));
+        RS_HIP(ctx, hipMemcpyAsync(d_before, h_poses_before, bytes, hipMemcpyHostToDevice, ctx->stream));
+        RS_HIP(ctx, hipMemcpyAsync(d_after, h_poses_after, bytes, hipMemcpyHostToDevice, ctx->stream));
+        RS_HIP(ctx, hipStreamSynchronize(ctx->stream));          // pageable sources: the copies have read them
+        rs_prof_scope ps(ctx, "K13_reanchor");
+        hipLaunchKernelGGL(k13_reanchor, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, n, d_point_idx, d_frame_idx,
+                           d_before, d_after, d_positions);
+    }
+    RS_HIP(ctx, hipGetLastError());
+    return RS_OK;
+}
+
 // ------------------------------------------------------------------------------------------------ K14
 // transform_points of the pose graph (reference src/Optimization.cpp:512-536): after a loop closure moved the key
 // frames, every map point that has observations moves rigidly with its OWNER, the observing key frame of smallest

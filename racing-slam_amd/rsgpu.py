@@ -18,7 +18,7 @@ EXPORTS = [
     "rs_kdtree_build", "rs_kdtree_pack", "rs_reproj_match", "rs_reproj_match_sharded", "rs_map_create", "rs_map_destroy", "rs_frame_create", "rs_frame_destroy",
     "rs_map_add_keyframe", "rs_map_set_keyframe_pose", "rs_map_add_point", "rs_map_set_position", "rs_map_remove_point",
     "rs_map_add_observation", "rs_map_remove_observation", "rs_map_counts", "rs_map_get_positions", "rs_map_match", "rs_map_pose_graph", "rs_pose_graph", "rs_pose_relative", "rs_transform_points", "rs_map_bundle_adjust", "rs_triangulate", "rs_triangulate_host", "rs_triangulate_matches", "rs_triangulate_matches_batch", "rs_triangulate_tracks", "rs_parallax_requirements", "rs_point_errors", "rs_ba_default_options",
-    "rs_bundle_adjust", "rs_bundle_adjust_batch", "rs_ba_get_trace", "rs_ba_get_stats", "rs_ba_get_cameras", "rs_reanchor_points", "rs_refine_pose", "rs_bundle_adjust_inertial", "rs_refine_pose_inertial", "rs_pack_pose", "rs_unpack_pose", "rs_pack_poses", "rs_unpack_poses", "rs_build_local_window",
+    "rs_bundle_adjust", "rs_bundle_adjust_batch", "rs_ba_get_trace", "rs_ba_get_stats", "rs_ba_get_cameras", "rs_reanchor_points", "rs_reanchor_points_host_poses", "rs_refine_pose", "rs_bundle_adjust_inertial", "rs_refine_pose_inertial", "rs_pack_pose", "rs_unpack_pose", "rs_pack_poses", "rs_unpack_poses", "rs_build_local_window",
     "rs_comm_get_unique_id", "rs_comm_init_rank", "rs_comm_destroy", "rs_comm_init_local", "rs_comm_count", "rs_prof_begin", "rs_prof_end", "rs_prof_counters", "rs_prof_empty_launch",
 ]
 
@@ -583,6 +583,14 @@ class Context:
         self._check(self.lib.rs_reanchor_points(self.h, n, None if d_point_idx is None else _dp(d_point_idx),
                                                 _dp(d_frame_idx), _dp(d_before), _dp(d_after), int(d_before.shape[0]),
                                                 _dp(d_positions)), "rs_reanchor_points")
+
+    def reanchor_points_host_poses(self, d_point_idx, d_frame_idx, h_before, h_after, d_positions):
+        """rs_reanchor_points with the poses in host arrays ([n_frames][16] f32, C order), as the reference holds them."""
+        assert h_before.dtype == np.float32 and h_after.dtype == np.float32 and h_before.flags.c_contiguous and h_after.flags.c_contiguous
+        n = int(d_frame_idx.shape[0])
+        self._check(self.lib.rs_reanchor_points_host_poses(self.h, n, None if d_point_idx is None else _dp(d_point_idx),
+                                                           _dp(d_frame_idx), C.c_void_p(h_before.ctypes.data), C.c_void_p(h_after.ctypes.data),
+                                                           int(h_before.shape[0]), _dp(d_positions)), "rs_reanchor_points_host_poses")
 
     def transform_points(self, d_obs_ptr, d_obs_kf, d_before, d_after, d_positions):
         """transform_points of the pose graph (src/Optimization.cpp:512-536); d_positions [P][3] f32 is updated in place."""

@@ -686,6 +686,20 @@ def test_reanchor_points(ctx, oracle, rs, synth):
     ctx.reanchor_points(ctx.dev(idx), ctx.dev(fi[idx]), ctx.dev(before), ctx.dev(after), dX2)
     assert np.array_equal(to_np(dX2).view(np.uint32), ref2.view(np.uint32))
     ctx.reanchor_points(None, ctx.dev(fi[:0]), ctx.dev(before), ctx.dev(after), dX2)       # n = 0
+    # poses in host arrays, as the reference holds them: 9 frames travel as kernel arguments, 40 through a device copy
+    dX3 = ctx.dev(X)
+    ctx.reanchor_points_host_poses(None, ctx.dev(fi), before, after, dX3)
+    assert np.array_equal(to_np(dX3).view(np.uint32), ref.view(np.uint32))
+    dX4 = ctx.dev(X)
+    ctx.reanchor_points_host_poses(ctx.dev(idx), ctx.dev(fi[idx]), before, after, dX4)
+    assert np.array_equal(to_np(dX4).view(np.uint32), ref2.view(np.uint32))
+    before40 = np.ascontiguousarray(np.tile(before, (5, 1))[:40])
+    after40 = np.ascontiguousarray(np.tile(after, (5, 1))[:40])
+    fi40 = rng.integers(0, 40, n).astype(np.int32)
+    ref40 = oracle.reanchor_points(None, fi40, before40, after40, X)
+    dX5 = ctx.dev(X)
+    ctx.reanchor_points_host_poses(None, ctx.dev(fi40), before40, after40, dX5)
+    assert np.array_equal(to_np(dX5).view(np.uint32), ref40.view(np.uint32))
 
 
 def test_bundle_adjust_launch_accounting(ctx, synth):
