@@ -497,6 +497,8 @@ def build_pass(e, streams=1, graph=False):
     h_cams_np = np.zeros((n_kf, 6), np.float64)
     h_after = torch.empty((n_kf, 16), dtype=torch.float32).pin_memory()
     h_after.copy_(torch.from_numpy(poses_before))
+    h_after_np = h_after.numpy()
+    cam_free_u8 = np.ascontiguousarray(window["cam_free"], np.uint8)
     m_out = ctx.match_descriptors(d["q"], d["t"], nq, nt)
     t_out = ctx.triangulate_matches(d["kp1"], d["kp2"], m_out["mt"], m_out["mq"], m_out["cnt"], nq, d["poses"], pair["K"])
     # (3b) Mapper::triangulate_tracks (src/Mapper.cpp:246-305): 2000 tracks of the new key frame
@@ -592,8 +594,8 @@ def build_pass(e, streams=1, graph=False):
         last["ba"] = ctx.bundle_adjust(d["cams"], window["cam_free"], d["pts"], d["optr"], d["ocam"], d["ouv"], window["K"])
         # poses are host-owned objects in the reference (Frame::set_pose): read back, unpack (f32), re-anchor
         ctx.ba_cameras(h_cams_np)
-        rs.unpack_poses(h_cams_np, window["cam_free"], h_after.numpy())
-        ctx.reanchor_points_host_poses(None, d["single_frame"], poses_before, h_after.numpy(), d["single"])   # (poses as kernel arguments)
+        rs.unpack_poses(h_cams_np, cam_free_u8, h_after_np)
+        ctx.reanchor_points_host_poses(None, d["single_frame"], poses_before, h_after_np, d["single"])   # (poses as kernel arguments)
 
     def one_pass_serial():
         one_pass(True)

@@ -194,13 +194,26 @@ def unpack_pose(cam):
     return p.reshape(4, 4)
 
 
+_HOST_PTR = {}
+
+
+def _hp(a):
+    """Boxed address of a host array, cached per array object (ndarray.ctypes costs ~2 us a time; the per-frame calls of a
+    pass hand the same few arrays over and over).  The cache keeps the array alive; arrays must not be resized."""
+    e = _HOST_PTR.get(id(a))
+    if e is None or e[0] is not a:
+        if len(_HOST_PTR) > 256:
+            _HOST_PTR.clear()
+        e = _HOST_PTR[id(a)] = (a, C.c_void_p(a.ctypes.data))
+    return e[1]
+
+
 def unpack_poses(cams, mask, out):
     """In place: out [n][16] f32 rows of the frames selected by mask [n] u8 (None = all) are rewritten."""
     c = np.ascontiguousarray(cams, np.float64)
     assert out.dtype == np.float32 and out.flags.c_contiguous and out.size == 16 * len(c)
     m = None if mask is None else np.ascontiguousarray(mask, np.uint8)
-    load().rs_unpack_poses(c.ctypes.data_as(C.c_void_p), len(c), None if m is None else m.ctypes.data_as(C.c_void_p),
-                           out.ctypes.data_as(C.c_void_p))
+    load().rs_unpack_poses(_hp(c), len(c), None if m is None else _hp(m), _hp(out))
     return out
 
 
@@ -569,7 +582,7 @@ class Context:
     def ba_cameras(self, out):
         """Cameras after the last bundle_adjust from the pinned mirror (no device read-back); out [C][6] f64."""
         assert out.dtype == np.float64 and out.flags.c_contiguous
-        self._check(self.lib.rs_ba_get_cameras(self.h, out.ctypes.data_as(C.c_void_p), int(out.shape[0])), "rs_ba_get_cameras")
+        self._check(self.lib.rs_ba_get_cameras(self.h, _hp(out), int(out.shape[0])), "rs_ba_get_cameras")
         return out
 
     def ba_stats(self):
@@ -589,7 +602,7 @@ class Context:
         assert h_before.dtype == np.float32 and h_after.dtype == np.float32 and h_before.flags.c_contiguous and h_after.flags.c_contiguous
         n = int(d_frame_idx.shape[0])
         self._check(self.lib.rs_reanchor_points_host_poses(self.h, n, None if d_point_idx is None else _dp(d_point_idx),
-                                                           _dp(d_frame_idx), C.c_void_p(h_before.ctypes.data), C.c_void_p(h_after.ctypes.data),
+                                                           _dp(d_frame_idx), _hp(h_before), _hp(h_after),
                                                            int(h_before.shape[0]), _dp(d_positions)), "rs_reanchor_points_host_poses")
 
     def transform_points(self, d_obs_ptr, d_obs_kf, d_before, d_after, d_positions):
