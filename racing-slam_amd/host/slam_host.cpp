@@ -116,19 +116,19 @@ void Frame::add_map_match(const MapPointMatch& m)
     MapPoint* previous = m_map_matches[m.keypoint_index];
     if (previous == &m.point) return;
     if (previous == nullptr) m_num++;
+    else m_matched_points.erase(previous);
     for (size_t i = 0; i < m_map_matches.size(); i++) {
         if (m_map_matches[i] != &m.point || i == m.keypoint_index) continue;
         m_map_matches[i] = nullptr;
         if (m_num > 0) m_num--;
     }
     m_map_matches[m.keypoint_index] = &m.point;
+    m_matched_points.insert(&m.point);
 }
 
 bool Frame::is_matched(const MapPoint& p) const
 {
-    for (MapPoint* q : m_map_matches)
-        if (q == &p) return true;
-    return false;
+    return m_matched_points.count(&p) != 0;                     // (src/Frame.cpp:148-151)
 }
 
 std::vector<MapPointMatch> Frame::map_matches() const
@@ -476,28 +476,41 @@ bool bundle_adjust(const std::vector<FrameConfig>& frames, const Camera& camera,
     // free points: matched by an optimised frame, >= 2 observations (:287-302), in first-seen order
     std::vector<MapPoint*> free_pts;
     std::unordered_map<const MapPoint*, int> pid;
+    std::vector<std::vector<MapPointMatch>> matches(C);          // (map_matches() builds a list: once per frame)
+    size_t n_matches = 0;
+    for (size_t c = 0; c < C; c++) { matches[c] = frames[c].frame->map_matches(); n_matches += matches[c].size(); }
+    pid.reserve(n_matches);
     for (size_t c = 0; c < C; c++) {
         if (!frames[c].optimize) continue;
-        for (const auto& m : frames[c].frame->map_matches()) {
+        for (const auto& m : matches[c]) {
             if (m.point.observations().size() < 2) continue;
             if (pid.emplace(&m.point, (int)free_pts.size()).second) free_pts.push_back(&m.point);
         }
     }
     const size_t P = free_pts.size();
-    // residual blocks: every listed frame (free or fixed) x its matched free points (:304-315), CSR by point
-    std::vector<std::vector<std::pair<int, Vec2f>>> per_point(P);
+    // residual blocks: every listed frame (free or fixed) x its matched free points (:304-315), CSR by point, frames in
+    // list order within a point: one pass resolves the matches to point ids, a count / prefix / fill builds the CSR
+    struct Hit { int point, cam; Vec2f uv; };
+    std::vector<Hit> hits;
+    hits.reserve(n_matches);
+    std::vector<int32_t> obs_ptr(P + 1, 0);
     for (size_t c = 0; c < C; c++)
-        for (const auto& m : frames[c].frame->map_matches()) {
+        for (const auto& m : matches[c]) {
             auto it = pid.find(&m.point);
-            if (it != pid.end()) per_point[(size_t)it->second].emplace_back((int)c, frames[c].frame->keypoint(m.keypoint_index).pt);
+            if (it == pid.end()) continue;
+            hits.push_back(Hit{it->second, (int)c, frames[c].frame->keypoint(m.keypoint_index).pt});
+            obs_ptr[(size_t)it->second + 1]++;
         }
-    std::vector<int32_t> obs_ptr(P + 1, 0), obs_cam;
-    std::vector<float> obs_uv;
+    for (size_t p = 0; p < P; p++) obs_ptr[p + 1] += obs_ptr[p];
+    std::vector<int32_t> obs_cam(hits.size()), fill(obs_ptr.begin(), obs_ptr.end() - 1);
+    std::vector<float> obs_uv(2 * hits.size());
+    for (const Hit& h : hits) {                                  // (hits are in frame order: so is every point's slice)
+        const size_t o = (size_t)fill[(size_t)h.point]++;
+        obs_cam[o] = h.cam; obs_uv[2 * o] = h.uv.x; obs_uv[2 * o + 1] = h.uv.y;
+    }
     std::vector<double> pts(3 * P);
     for (size_t p = 0; p < P; p++) {
         pts[3 * p] = free_pts[p]->position().x; pts[3 * p + 1] = free_pts[p]->position().y; pts[3 * p + 2] = free_pts[p]->position().z;
-        for (const auto& o : per_point[p]) { obs_cam.push_back(o.first); obs_uv.insert(obs_uv.end(), {o.second.x, o.second.y}); }
-        obs_ptr[p + 1] = (int32_t)obs_cam.size();
     }
     if (P == 0 || obs_cam.empty()) return false;
     StageScope stage;

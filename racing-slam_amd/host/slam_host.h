@@ -14,6 +14,7 @@
 #include <cstddef>
 #include <cstdint>
 #include <memory>
+#include <unordered_set>
 #include <utility>
 #include <vector>
 
@@ -85,6 +86,7 @@ class Frame {
     ExtractedFeatures m_features;
     Mat4f m_pose = identity4();
     std::vector<MapPoint*> m_map_matches;
+    std::unordered_set<const MapPoint*> m_matched_points;      // the points in m_map_matches (src/Frame.h:72): is_matched(point) is a lookup
     size_t m_num = 0;
     std::vector<int32_t> m_kd_node_kp, m_kd_left, m_kd_right;
     int m_kd_root = -1;
