@@ -602,6 +602,13 @@ def build_pass(e, streams=1, graph=False):
 
     one_pass.prepare = prepare
     one_pass_serial.prepare = prepare
+    # set-up, not warm-up: the first bundle adjustment of a process loads its kernels' code objects and allocates the solver's
+    # workspace (milliseconds); every other stage has run once above.  --warmup W passes still follow in timed().
+    for _ in range(2):
+        one_pass_serial()
+    if side:
+        one_pass()
+    torch.cuda.synchronize()
 
     def cpu_pass(O, keep_results=None):
         mq, mt = O.match_descriptors(pair["desc2"], pair["desc1"])
