@@ -994,6 +994,8 @@ def bench_ba(e, args, cfg):
         last["ba"] = ctx.bundle_adjust(a, w["cam_free"], b_, *dev, w["K"])
 
     step.prepare = prepare
+    step()                                                   # set-up: code objects, workspace (not a warm-up pass)
+    torch.cuda.synchronize()
 
     def cpu_step(O):
         O.bundle_adjust(w_all["cams"], w_all["cam_free"], w_all["points"], w_all["obs_ptr"], w_all["obs_cam"], w_all["obs_uv"], w_all["K"])
