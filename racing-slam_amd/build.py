@@ -12,6 +12,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "librsgpu.so")
+OUT_STAMPS = os.path.join(HERE, "librsgpu_stamps.so")       # RS_STAMPS=1 build (in-kernel timers): never the product library
 ARCH = "gfx950"
 
 # (source, extra flags).  The f32-gate kernels are compiled without FMA
@@ -34,6 +35,10 @@ SOURCES = [
     ("pose_graph.cpp", ["-ffp-contract=off"]),
 ]
 STAMPS = ["-DRS_STAMPS=1"] if os.environ.get("RS_STAMPS") else []
+# A/B builds: RS_VARIANT=<name> RS_DEFS="-DK7_V2=0 ..." -> librsgpu_<name>.so from objects of its own (tools/ab_time.py
+# loads it through RS_LIB); never the product library
+VARIANT = os.environ.get("RS_VARIANT", "")
+STAMPS = STAMPS + os.environ.get("RS_DEFS", "").split() if VARIANT else STAMPS
 COMMON = STAMPS + ["-O3", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function", "-Wno-pass-failed", f"--offload-arch={ARCH}"]
 
 
@@ -53,9 +58,8 @@ def _stale(target, deps):
 
 def build(force=False, verbose=False):
     cc = hipcc()
-    objdir = os.path.join(HERE, "build_stamps" if STAMPS else "build")     # (instrumented objects never mix with the product's)
+    objdir = os.path.join(HERE, "build_" + VARIANT if VARIANT else ("build_stamps" if STAMPS else "build"))     # (instrumented objects never mix with the product's)
     os.makedirs(objdir, exist_ok=True)
-    force = force or bool(STAMPS)
     # every header of csrc/ is a dependency of every object: a stale .so must never ship
     headers = sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h"))
     headers += [os.path.join(HERE, "..", "include", "rsgpu.h"), __file__]
@@ -72,12 +76,13 @@ def build(force=False, verbose=False):
                 print(" ".join(cmd), flush=True)
             subprocess.check_call(cmd)
             rebuilt = True
-    if rebuilt or not os.path.exists(OUT):
-        cmd = [cc, "-shared", "-fPIC", f"--offload-arch={ARCH}", "-o", OUT] + objs + ["-ldl"]
+    out = os.path.join(HERE, f"librsgpu_{VARIANT}.so") if VARIANT else (OUT_STAMPS if STAMPS else OUT)
+    if rebuilt or not os.path.exists(out):
+        cmd = [cc, "-shared", "-fPIC", f"--offload-arch={ARCH}", "-o", out] + objs + ["-ldl"]
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.check_call(cmd)
-    return OUT
+    return out
 
 
 if __name__ == "__main__":

@@ -15,6 +15,18 @@
 #ifndef K7_CHAIN_SIMDS
 #define K7_CHAIN_SIMDS 1
 #endif
+// K7_V2 1 (round 4; built, parity-green, NOT faster — profiles/round4_k7_step_breakdown.txt): the chain waves keep a FIXED row -> lane map (wave 0: rows 0 .. 63, wave 4: rows 64 .. n), so the
+// rank-6 fix-up of the next block column stays in registers from step to step instead of travelling through LDS; the six
+// rows of the diagonal block go through a 36-double scratch, with a word per chain wave where the block straddles row 64
+// (no workgroup barrier); the tile waves derive their MFMA operands from the factor panel itself (A, row-major) and the
+// pivots; a block step costs ONE workgroup barrier instead of two.  Sized by tools/microbench/f64_latency.hip: one wave
+// issues a vector instruction every ~6 cycles whether or not it depends on the one before (f64 fma 6.0 dependent, 5.5
+// independent; v_rcp_f64 26; a double through v_readlane 48; dependent ds_read 60), and two waves on one SIMD each keep that
+// rate — the chain is bound by the instruction COUNT per wave, so the step's row work is split over two waves and nothing
+// is computed or moved twice.  K7_V2 0 (default) is round 1's two-barrier form.
+#ifndef K7_V2
+#define K7_V2 0
+#endif
 #if K7_CHAIN_SIMDS == 2
 #define K7_TPW 9       // tiles per tile wave: 4 tile waves x 9 = the 36 lower-triangle tiles of a 128 x 128 matrix
 #define K7_NTW 4
@@ -88,6 +100,10 @@ static __device__ __forceinline__ void ba_reduced_solve_lds_body(const BaDims& d
     const bool idle = wave == 4 || wave == 5;      // (they share the chain waves' SIMDs)
     const int tw = (wave & 1) + 2 * (wave >> 2);   // tile waves 2, 3, 6, 7 -> 0 .. 3
     const int cw = wave;                           // chain wave index
+#elif K7_V2
+    const bool chain = (wave & 3) == 0;            // waves 0 and 4: rows 0 .. 63 and 64 .. n (one row per lane, fixed)
+    const bool idle = false;
+    const int tw = chain ? 0 : wave - 1 - (wave >> 2);     // tile wave index 0..5
 #else
     const bool chain = (wave & 3) == 0;            // waves 0 and 4
     const bool idle = false;
@@ -215,6 +231,11 @@ static __device__ __forceinline__ void ba_reduced_solve_lds_body(const BaDims& d
         else *z = 0.0;
     }
     for (int i = tid; i < 2 * 8 * 128; i += nt) Pd[i] = 0.0;
+#if K7_V2
+    // the chain reads whole block columns, entries above the diagonal included (they only reach dead values, but must be
+    // finite), and the tile waves read operand rows of A that were never published
+    for (int i = tid; i < (n + 1) * LD; i += nt) A[i] = 0.0;
+#endif
     // fold the replicas of the camera-side accumulators (replica layout: rhs[n] U[Cf*36] gc[n])
 #pragma unroll
     for (int h = 0; h < 2; h++) {
@@ -283,10 +304,259 @@ static __device__ __forceinline__ void ba_reduced_solve_lds_body(const BaDims& d
     //       chain: apply step J's update to the 6 entries of block column J+1 of its row (36 FMAs), so
     //              the next diagonal block never waits for the matrix cores
     //       tiles: load the MFMA operands of step J
+#if K7_V2
+    // (3) block L D L^T, one camera (6 columns) per step, ONE barrier per step.  Interval J (between barriers J - 1 and J):
+    //   chain wave: raw block column J of its two rows per lane (published by the tile waves one interval earlier: it has
+    //               the trailing updates of steps <= J - 2), minus step J - 1's rank-6 update with the panel values it still
+    //               holds in registers -> final block column J; the six lanes of the diagonal block pass it through a
+    //               scratch in LDS (the same wave reads it back: no barrier); L D L^T of the block per lane (redundantly);
+    //               F_i = row_i L^-T D^-1 for both rows; F -> A (row-major factor panel), pivots -> dd[J & 1], and
+    //               F d of the NEXT diagonal block's rows -> Pds for the next fix-up
+    //   tile waves: rank-6 trailing update of step J - 1 with operands read from the factor panel A (columns of step J - 1,
+    //               written one interval earlier) and dd[(J - 1) & 1], then publish block column J + 1 raw
+    // Nothing is read in the interval in which it is written except by the wave that wrote it.
+    double* const Dg = Pd;                 // [6][6] final diagonal block of this step (rows written by the lanes that own them)
+    double* const Pds = Pd + 64;           // [6][6] Pds[e * 6 + k] = F[r0 + k][e] d_e of the step before
+    double* const ddv = Pd + 128;          // [2][8] pivots of step J in ddv[(J & 1) * 8 + e]; entries 6, 7 stay zero
+    volatile int* const dflag = (volatile int*)(Pd + 160);   // [2] dflag[w] = J + 1: chain wave w has written its rows of block J
+    if (chain) {
+        BA_STAMP(b, 1);
+        const int sl = wave >> 2;                          // this wave's rows: 64 sl + lane
+        const int i = 64 * sl + lane, ic = min(i, n);
+        double Fp[6];
+#pragma unroll
+        for (int e = 0; e < 6; e++) Fp[e] = 0.0;
+#if RS_STAMPS
+        const unsigned long long cpre_ = wall_clock64();
+#endif
+        __syncthreads();                                   // block column 0 published by the tile waves
+#if RS_STAMPS
+        if (tid == 0 && blockIdx.x == 0) b.dbg[22] += wall_clock64() - cpre_;      // wait for the tile waves' set-up
+#endif
+#if RS_STAMPS >= 2      // per-phase stamps: every one drains the wave's LDS queue (s_memrealtime returns through lgkmcnt), so the
+                        // phases are indicative only; the coarse stamps (RS_STAMPS 1) do not disturb the loop
+        unsigned long long cs_[6] = {0, 0, 0, 0, 0, 0}, ct_ = wall_clock64();
+#define K7_CSTAMP(i) do { if (tid == 0 && blockIdx.x == 0) { const unsigned long long t__ = wall_clock64(); cs_[i] += t__ - ct_; ct_ = t__; } } while (0)
+#else
+#define K7_CSTAMP(i) do { } while (0)
+#endif
+        for (int J = 0; J < NB; J++) {
+            const int c0 = 6 * J, r0 = c0 + 6;
+            if (64 * sl + 63 < c0 || 64 * sl > n) {        // none of this wave's rows is left (or it never had any)
+                __syncthreads();
+                continue;
+            }
+            double x[6];
+#pragma unroll
+            for (int k = 0; k < 6; k++) x[k] = A[ic * LD + c0 + k];
+            if (J > 0) {
+                // step J - 1's update of block column J: A[i][c0 + k] -= sum_e F_i[e] d_e F[c0 + k][e]
+                const double2* g2 = reinterpret_cast<const double2*>(Pds);
+#pragma unroll
+                for (int e = 0; e < 6; e++) {
+                    const double2 g01 = g2[3 * e], g23 = g2[3 * e + 1], g45 = g2[3 * e + 2];
+                    x[0] -= Fp[e] * g01.x; x[1] -= Fp[e] * g01.y; x[2] -= Fp[e] * g23.x;
+                    x[3] -= Fp[e] * g23.y; x[4] -= Fp[e] * g45.x; x[5] -= Fp[e] * g45.y;
+                }
+            }
+            K7_CSTAMP(0);
+            // the diagonal block: its rows belong to one chain wave or, where it straddles row 64, to both.  Owners write
+            // their rows into the scratch and raise their word; a wave that needs rows of the other one polls that word
+            // (both waves are in the same step: the barrier below separates the steps).
+            {
+                const int a = i - c0;
+                const int o_lo = c0 >> 6, o_hi = (c0 + 5) >> 6;                    // owner waves of the first / last row
+                if (a >= 0 && a < 6) {
+#pragma unroll
+                    for (int k = 0; k < 6; k++) Dg[a * 6 + k] = x[k];
+                }
+                if (sl == o_lo || sl == o_hi) {
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                    __builtin_amdgcn_s_waitcnt(0xc07f);                           // lgkmcnt(0): the rows are in LDS
+                    if (lane == 0) dflag[sl] = J + 1;
+                }
+                const int other = sl ^ 1;
+                if (other == o_lo || other == o_hi) {
+                    while (dflag[other] < J + 1) { }
+                }
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                __builtin_amdgcn_s_waitcnt(0xc07f);
+            }
+            double Lm[6][6];
+#pragma unroll
+            for (int a = 0; a < 6; a++)
+#pragma unroll
+                for (int e = 0; e <= a; e++) Lm[a][e] = Dg[a * 6 + e];
+            K7_CSTAMP(1);
+            // (a) L D L^T of the diagonal block (every lane the same arithmetic on the same values)
+            double dinv[6], dpiv[6];
+            bool fbad = false;
+#pragma unroll
+            for (int c = 0; c < 6; c++) {
+                const double piv = Lm[c][c];
+                if (!(piv > 0.0) || !isfinite(piv)) fbad = true;
+                const double rd = fast_rcp(piv);
+                dinv[c] = rd;
+                dpiv[c] = piv;
+                double lc[6];
+#pragma unroll
+                for (int a = c + 1; a < 6; a++) lc[a] = Lm[a][c] * rd;              // l_ac; Lm[a][c] still holds l_ac * d_c
+#pragma unroll
+                for (int a = c + 1; a < 6; a++)
+#pragma unroll
+                    for (int e = c + 1; e <= a; e++) Lm[a][e] -= lc[a] * Lm[e][c];  // a_ae -= l_ac d_c l_ec
+#pragma unroll
+                for (int a = c + 1; a < 6; a++) Lm[a][c] = lc[a];
+            }
+            K7_CSTAMP(2);
+            // (b) panel row: t = row L^-T by forward substitution (unit lower L), F = t D^-1.  A row of the diagonal block
+            // itself comes out as its row of L (entries e < a; the rest is never read): the backward substitution reads the
+            // unit-lower blocks from A.
+            double F[6];
+            {
+                double t[6];
+#pragma unroll
+                for (int r = 0; r < 6; r++) {
+                    double sacc = x[r];
+#pragma unroll
+                    for (int e = 0; e < r; e++) sacc -= t[e] * Lm[r][e];
+                    t[r] = sacc;
+                }
+#pragma unroll
+                for (int r = 0; r < 6; r++) F[r] = t[r] * dinv[r];
+            }
+            K7_CSTAMP(3);
+            if (i >= c0 && i <= n) {
+#pragma unroll
+                for (int r = 0; r < 6; r++) A[i * LD + c0 + r] = F[r];
+            }
+            if (J + 1 < NB) {
+                const int k0 = i - r0;                     // rows of the next diagonal block: their F d for the next fix-up
+                if (k0 >= 0 && k0 < 6) {
+#pragma unroll
+                    for (int e = 0; e < 6; e++) Pds[e * 6 + k0] = F[e] * dpiv[e];
+                }
+                if (lane == 0 && sl == (c0 >> 6)) {
+#pragma unroll
+                    for (int e = 0; e < 6; e++) ddv[(J & 1) * 8 + e] = dpiv[e];
+                }
+            }
+#pragma unroll
+            for (int e = 0; e < 6; e++) Fp[e] = F[e];
+            if (lane == 0 && fbad) s_fail = 1;
+            K7_CSTAMP(4);
+            __syncthreads();                                               // barrier J
+            K7_CSTAMP(5);
+        }
+#if RS_STAMPS >= 2
+        if (tid == 0 && blockIdx.x == 0) { for (int q = 0; q < 6; q++) b.dbg[16 + q] += cs_[q]; }
+#endif
+#if RS_STAMPS
+        if (tid == 0 && blockIdx.x == 0) { const unsigned long long t__ = wall_clock64(); b.dbg[30] += t__ - cpre_; b.dbg[23] = t__; b.dbg[31] += 1ull; }   // set-up wait + loop
+#endif
+    } else {
+        // (2) the lower triangle + rhs row in the accumulator tiles: S (prefetched) + U + damping
+        d4 acc[K7_TPW];
+#pragma unroll
+        for (int s = 0; s < K7_TPW; s++) {
+            acc[s] = d4{0.0, 0.0, 0.0, 0.0};
+            if (!tv[s]) continue;                       // wave-uniform
+            const int k = 16 * tc[s] + lr;
+            if (tr[s] >= tc[s] + 2 && 16 * tr[s] + 15 < n) {
+                // a tile at least two tile rows below the diagonal and above the rhs row: |i - k| >= 17, so no
+                // camera block and no diagonal entry falls into it — it is S alone (wave-uniform shortcut)
+#pragma unroll
+                for (int q = 0; q < 4; q++) acc[s][q] = (k < n) ? sv[s][q] : 0.0;
+                continue;
+            }
+            const int kc = min(k, n - 1), kb = kc / 6;
+            const double gv = grs[kc];
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const int i = 16 * tr[s] + lq + 4 * q;
+                const int ic = min(i, n - 1);
+                const double uv = Us[kb * 36 + (kc - 6 * kb) * 6 + ic % 6];
+                double val = sv[s][q] + ((kb == ic / 6) ? uv : 0.0) + ((i == k) ? lam[ic] : 0.0);
+                val = (k < n && i < n && k <= i) ? val : ((i == n && k < n) ? gv : 0.0);
+                acc[s][q] = val;
+            }
+        }
+        // loop-invariant publish addressing: LDS index of this lane's first entry of slot s and the
+        // mask of its 4 rows that lie in the stored lower triangle
+        int paddr[K7_TPW];
+        unsigned pmask[K7_TPW];
+#pragma unroll
+        for (int s = 0; s < K7_TPW; s++) {
+            const int k = 16 * tc[s] + lr;
+            paddr[s] = (16 * tr[s] + lq) * LD + k;
+            unsigned m = 0;
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const int i = 16 * tr[s] + lq + 4 * q;
+                m |= (i >= k && i <= n) ? (1u << q) : 0u;
+            }
+            pmask[s] = m;
+        }
+        const int LD4 = 4 * LD;
+        // publish block column 0 (raw == final)
+#pragma unroll
+        for (int s = 0; s < K7_TPW; s++) {
+            if (!tv[s] || tc[s] != 0) continue;
+            if (lr >= 6) continue;
+#pragma unroll
+            for (int q = 0; q < 4; q++)
+                if (pmask[s] >> q & 1) A[paddr[s] + q * LD4] = acc[s][q];
+        }
+        // operand addressing: lane (lr, lq) feeds k = 4 kc + lq of the step's six columns (k = 6, 7: zero padding)
+        int arow[K7_TPW], brow[K7_TPW];
+#pragma unroll
+        for (int s = 0; s < K7_TPW; s++) { arow[s] = min(16 * tr[s] + lr, n) * LD; brow[s] = min(16 * tc[s] + lr, n) * LD; }
+        const int e1 = min(4 + lq, 5);                     // second K chunk: columns 4, 5 (lanes lq >= 2 are padding)
+        const bool pad1 = lq >= 2;
+        __syncthreads();
+        for (int J = 0; J < NB; J++) {
+            const int c0 = 6 * J, r0 = c0 + 6;
+            if (J > 0) {
+                // trailing update of step J - 1; live region: columns >= c0.  No row masks: rows that are already factored
+                // only put garbage into accumulator entries that are never read again.
+                const int cm = c0 - 6;
+                const double* dv = ddv + ((J - 1) & 1) * 8;
+                const double d0 = dv[lq], d1 = dv[4 + lq];             // d1 = 0 in the padding lanes
+#pragma unroll
+                for (int s = 0; s < K7_TPW; s++) {
+                    if (!tv[s] || 16 * tc[s] + 15 < c0) continue;                  // wave-uniform
+                    const double a0 = A[arow[s] + cm + lq], a1 = A[arow[s] + cm + e1];
+                    const double b0 = A[brow[s] + cm + lq], b1 = A[brow[s] + cm + e1];
+                    acc[s] = __builtin_amdgcn_mfma_f64_16x16x4f64(-a0, b0 * d0, acc[s], 0, 0, 0);
+                    acc[s] = __builtin_amdgcn_mfma_f64_16x16x4f64(pad1 ? 0.0 : -a1, b1 * d1, acc[s], 0, 0, 0);
+                }
+            }
+            // publish block column J + 1 raw (k in [r0, r0 + 6), rows i >= k) from the owning tiles
+            if (J + 1 < NB) {
+#pragma unroll
+                for (int s = 0; s < K7_TPW; s++) {
+                    if (!tv[s] || 16 * tc[s] + 15 < r0 || 16 * tc[s] >= r0 + 6) continue;   // wave-uniform
+                    const int k = 16 * tc[s] + lr;
+                    if (k < r0 || k >= r0 + 6) continue;
+#pragma unroll
+                    for (int q = 0; q < 4; q++)
+                        if (pmask[s] >> q & 1) A[paddr[s] + q * LD4] = acc[s][q];
+                }
+            }
+            __syncthreads();                                               // barrier J
+        }
+    }
+#else
     if (chain) {
         BA_STAMP(b, 1);
         const int crow = cw * 64 + lane;           // row slot 0..127 (n + 1 - 6 <= 121 rows)
+#if RS_STAMPS
+        const unsigned long long cpre_ = wall_clock64();
+#endif
         __syncthreads();                           // block column 0 published by the tile waves
+#if RS_STAMPS
+        if (tid == 0 && blockIdx.x == 0) b.dbg[22] += wall_clock64() - cpre_;
+#endif
         for (int J = 0; J < NB; J++) {
             const int c0 = 6 * J, r0 = c0 + 6;
             const int irow = r0 + crow;
@@ -375,6 +645,9 @@ static __device__ __forceinline__ void ba_reduced_solve_lds_body(const BaDims& d
             }
             __syncthreads();                                               // barrier A of step J+1
         }
+#if RS_STAMPS
+        if (tid == 0 && blockIdx.x == 0) { const unsigned long long t__ = wall_clock64(); b.dbg[30] += t__ - cpre_; b.dbg[23] = t__; b.dbg[31] += 1ull; }
+#endif
     } else {
         // (2) the lower triangle + rhs row in the accumulator tiles: S (prefetched) + U + damping
         d4 acc[K7_TPW];
@@ -482,6 +755,7 @@ static __device__ __forceinline__ void ba_reduced_solve_lds_body(const BaDims& d
             __syncthreads();                                               // barrier A of step J+1
         }
     }
+#endif
     __syncthreads();
     if (s_fail) {
         if (tid == 0) {
@@ -507,7 +781,7 @@ static __device__ __forceinline__ void ba_reduced_solve_lds_body(const BaDims& d
     {                                                                                                      \
         const int jj_ = max((J_), 0), cc_ = 6 * jj_;                                                       \
         _Pragma("unroll") for (int e = 1; e < 6; e++)                                                      \
-            _Pragma("unroll") for (int t = 0; t < e; t++) L_[e][t] = Minv[jj_ * 36 + e * 6 + t];           \
+            _Pragma("unroll") for (int t = 0; t < e; t++) L_[e][t] = K7_V2 ? A[(cc_ + e) * LD + cc_ + t] : Minv[jj_ * 36 + e * 6 + t]; \
         _Pragma("unroll") for (int e = 0; e < 6; e++) P0_[e] = A[(cc_ + e) * LD + i0];                     \
         if (cc_ > 64) { _Pragma("unroll") for (int e = 0; e < 6; e++) P1_[e] = A[(cc_ + e) * LD + i1]; }   \
     }
@@ -540,6 +814,9 @@ static __device__ __forceinline__ void ba_reduced_solve_lds_body(const BaDims& d
     }
     __syncthreads();
     BA_STAMP(b, 6);
+#if RS_STAMPS
+    if (tid == 0 && blockIdx.x == 0) { b.dbg[25] += wall_clock64() - b.dbg[23]; }      // end of the loop -> end of the backward substitution
+#endif
     double* dc_set = b.dc + (size_t)set * BA_DC_STRIDE(n);
     if (HANDOFF) {
         // delta_c leaves first, written through, and the set's word is published: K8's workgroups derive the candidate

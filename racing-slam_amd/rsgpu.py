@@ -10,7 +10,9 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "librsgpu.so")
+# RS_STAMPS=1 selects the instrumented build (tools/*_stamps.py); the product library otherwise
+# RS_LIB=<file name in this directory> selects an A/B build (build.py, RS_VARIANT)
+LIB_PATH = os.path.join(_HERE, os.environ.get("RS_LIB") or ("librsgpu_stamps.so" if os.environ.get("RS_STAMPS") else "librsgpu.so"))
 
 EXPORTS = [
     "rs_abi_version", "rs_context_create", "rs_context_destroy", "rs_context_set_stream", "rs_context_wait_for", "rs_context_fork",

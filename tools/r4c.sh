@@ -1,0 +1,8 @@
+set -e
+mkdir -p gpurun_out/r4c
+python -m pytest tests -m gpu -x -q -k "bundle_adjust or ba_ or smoke or inertial" > gpurun_out/r4c/tests.log 2>&1 || { tail -40 gpurun_out/r4c/tests.log; exit 1; }
+tail -2 gpurun_out/r4c/tests.log
+RS_STAMPS=1 python tools/k7_chain_stamps.py ba_fuse_mode=1
+python tools/ab_time.py
+RS_LIB=librsgpu_k7v1.so python tools/ab_time.py
+python tools/ab_time.py ba_fuse_mode=1
