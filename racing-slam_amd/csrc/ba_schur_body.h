@@ -21,6 +21,9 @@ __host__ __device__ __forceinline__ int sch_tile_doubles(int it_l)
     const int a = 3 * it_l * YT_STRIDE4, b8 = 3 * (it_l / 2) * YT_STRIDE8;
     return ((a > b8 ? a : b8) + 1) & ~1;
 }
+#ifndef K5_ALLSETS
+#define K5_ALLSETS 1            // every speculative radius in one pass over the tile (syrk_tiles_sets); 0: set by set, the tile transformed in place
+#endif
 #define SCH_PRE 3               // observation rounds prefetched per lane (covers 12 observations per landmark)
 #define SCH_MAXC_LDS 64         // cameras staged in LDS when the window has at most this many
 
@@ -156,6 +159,107 @@ __device__ __forceinline__ void syrk_scatter(const double* yt, int nchunks, int 
             const int gr = 6 * gslot[R / 6] + R % 6;
             if (Cc == nrow) atomicAdd(&rhs[gr], -v);
             else atomicAdd(&S[(size_t)gr * n + 6 * gslot[Cc / 6] + Cc % 6], -v);
+        }
+    }
+}
+
+// ---- every speculative set in ONE pass over the tile (round 4).  With V + Lambda_s = L_s L_s^T the set's tile is
+// Y_s = Y_0 (L_s^-1 L_0)^T, so  Y_s Y_s^T = Y_0 G_s Y_0^T  with the 3x3 symmetric  G_s = L_0^T (V + Lambda_s)^-1 L_0  per
+// landmark: the A operand of every set is Y_0 as it stands, the B operand of set s is Y_0 G_s, formed on the fly from the
+// landmark's three tile columns.  One K loop feeds NS accumulator sets: the tile is read once, no transform pass, no
+// barrier between the sets, and the scatter's index arithmetic is shared.  Gt[s - 1][landmark][6] (xx xy xz yy yz zz).
+template <int NM, int NS, int STRIDE>
+__device__ __forceinline__ void syrk_tiles_sets(const double* yt, const double* Gt, int it_l, int nchunks, const int* tr, const int* tc,
+                                                d4 (*acc)[3], int lr, int lk)
+{
+    // column 4 kc + lk = 3 p + kk of the tile
+    auto load = [&](int kc, double* a, double* bp, double (*yb)[3], double (*g)[3]) {
+        const int col = 4 * kc + lk;
+        const int p = col / 3, kk = col - 3 * p;
+        const double* c0 = yt + (size_t)(3 * p) * STRIDE + lr;
+        const double* ca = yt + (size_t)col * STRIDE + lr;
+#pragma unroll
+        for (int t = 0; t < NM; t++) {
+            a[t] = ca[16 * tr[t]];
+            bp[t] = ca[16 * tc[t]];                        // set 0's B operand (one more LDS read instead of a per-lane select)
+            yb[t][0] = c0[16 * tc[t]]; yb[t][1] = c0[STRIDE + 16 * tc[t]]; yb[t][2] = c0[2 * STRIDE + 16 * tc[t]];
+        }
+        // row kk of the symmetric G: (kk, 0) (kk, 1) (kk, 2) in xx xy xz yy yz zz order
+        const int i0 = kk, i1 = kk == 0 ? 1 : (kk == 1 ? 3 : 4), i2 = kk == 0 ? 2 : (kk == 1 ? 4 : 5);
+#pragma unroll
+        for (int s = 0; s < NS - 1; s++) {
+            const double* gp = Gt + ((size_t)s * it_l + p) * 6;
+            g[s][0] = gp[i0]; g[s][1] = gp[i1]; g[s][2] = gp[i2];
+        }
+    };
+    auto mma = [&](const double* a, const double* bp, const double (*yb)[3], const double (*g)[3]) {
+#pragma unroll
+        for (int t = 0; t < NM; t++) {
+            acc[t][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[t], bp[t], acc[t][0], 0, 0, 0);
+#pragma unroll
+            for (int s = 0; s < NS - 1; s++) {
+                const double bs = fma(yb[t][2], g[s][2], fma(yb[t][1], g[s][1], yb[t][0] * g[s][0]));
+                acc[t][s + 1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[t], bs, acc[t][s + 1], 0, 0, 0);
+            }
+        }
+    };
+    double a0[NM], b0[NM], yb0[NM][3], g0[2][3], a1[NM], b1[NM], yb1[NM][3], g1[2][3];
+    load(0, a0, b0, yb0, g0);
+    for (int kc = 0; kc < nchunks; kc += 2) {
+        load(min(kc + 1, nchunks - 1), a1, b1, yb1, g1);
+        mma(a0, b0, yb0, g0);
+        load(min(kc + 2, nchunks - 1), a0, b0, yb0, g0);
+        if (kc + 1 < nchunks) mma(a1, b1, yb1, g1);
+    }
+}
+
+template <int NS, int STRIDE>
+__device__ __forceinline__ void syrk_scatter_sets(const double* yt, const double* Gt, int it_l, int nchunks, int ns, const int* gslot, int n,
+                                                  int wave, int nw, double* __restrict__ S0, double* __restrict__ rhs0)
+{
+    const int lane = threadIdx.x & 63;
+    const int lr = lane & 15, lk = lane >> 4;
+    const int nrow = 6 * ns;                 // rhs row index
+    const int nt_used = (nrow + 16) / 16;    // tile rows that carry data (incl. the rhs row), <= 4
+    const int ntiles = nt_used * (nt_used + 1) / 2;
+    const int simd = wave & 3, pos = (simd + 3) & 3;
+    const int nws = (nw - simd + 3) >> 2;    // waves of this workgroup on my SIMD; I am number wave >> 2 of them
+    d4 acc[3][3];                            // [tile][set]
+    int tr[3], tc[3];
+    int nmine = 0;
+#pragma unroll
+    for (int t = 0; t < 3; t++) {
+#pragma unroll
+        for (int s = 0; s < 3; s++) acc[t][s] = (d4){0.0, 0.0, 0.0, 0.0};
+        tr[t] = 0; tc[t] = 0;
+        const int tile = pos + 4 * ((wave >> 2) + nws * t);
+        if (tile < ntiles) { tile_rc(tile, nt_used, tr[t], tc[t]); nmine = t + 1; }
+    }
+    switch (nmine) {                          // wave-uniform
+    case 1: syrk_tiles_sets<1, NS, STRIDE>(yt, Gt, it_l, nchunks, tr, tc, acc, lr, lk); break;
+    case 2: syrk_tiles_sets<2, NS, STRIDE>(yt, Gt, it_l, nchunks, tr, tc, acc, lr, lk); break;
+    case 3: syrk_tiles_sets<3, NS, STRIDE>(yt, Gt, it_l, nchunks, tr, tc, acc, lr, lk); break;
+    default: break;
+    }
+    // C/D layout of v_mfma_f64_16x16x4_f64: col = lane & 15, row = (lane >> 4) + 4 * reg; one index computation per entry
+    // serves every set (set s of S at + s n^2, of rhs at + s n)
+    const size_t sS = (size_t)n * n;
+#pragma unroll
+    for (int t = 0; t < 3; t++) {
+        if (t >= nmine) continue;
+#pragma unroll
+        for (int reg = 0; reg < 4; reg++) {
+            const int R = 16 * tr[t] + lk + 4 * reg, Cc = 16 * tc[t] + lr;
+            if (R >= nrow || Cc > nrow || R > Cc) continue;
+            const int gr = 6 * gslot[R / 6] + R % 6;
+            if (Cc == nrow) {
+#pragma unroll
+                for (int s = 0; s < NS; s++) atomicAdd(&rhs0[(size_t)s * n + gr], -acc[t][s][reg]);
+            } else {
+                double* dst = &S0[(size_t)gr * n + 6 * gslot[Cc / 6] + Cc % 6];
+#pragma unroll
+                for (int s = 0; s < NS; s++) atomicAdd(dst + s * sS, -acc[t][s][reg]);
+            }
         }
     }
 }
@@ -366,8 +470,122 @@ static __device__ __forceinline__ void ba_schur_body(const BaDims& d, const BaBu
     // every observation again (compact 4x4-tile items only: the 8x8 class reuses the tile for two half batches).
     double Lprev[6] = {0, 0, 0, 0, 0, 0};
     bool prev_all_ok = false;
-    double* Mt = (double*)(gslot + 32);                       // [it_l][6] behind the slot table
-    for (int set = 0; set < st.nact; set++) {
+    double* Mt = (double*)(gslot + 32);                       // [it_l][6] behind the slot table ([2][it_l][6] as Gt)
+    int set_first = 0;
+    // ---- several radii, compact 4x4-tile item: every set in ONE pass over the tile (syrk_tiles_sets above)
+    if (K5_ALLSETS && st.nact > 1 && ns > 0 && ns <= 10) {
+        double Li0[6] = {0, 0, 0, 0, 0, 0}, L0[6] = {0, 0, 0, 0, 0, 0}, Iall[BA_MAXSETS][6], lamall[BA_MAXSETS][3];
+        bool okall[BA_MAXSETS];
+#pragma unroll
+        for (int set = 0; set < BA_MAXSETS; set++) {
+            okall[set] = false;
+#pragma unroll
+            for (int k = 0; k < 6; k++) Iall[set][k] = 0.0;
+#pragma unroll
+            for (int k = 0; k < 3; k++) lamall[set][k] = 0.0;
+            if (set >= st.nact || p < 0) continue;
+            const double radius = ba_set_radius(st, set);
+#pragma unroll
+            for (int k = 0; k < 3; k++) {
+                const double s2 = sp[k] * sp[k];
+                lamall[set][k] = clampd(s2 * Vd[k], opt.dmin, opt.dmax) / (radius * s2);
+            }
+            const double Vdm[6] = {V[0] + lamall[set][0], V[1], V[2], V[3] + lamall[set][1], V[4], V[5] + lamall[set][2]};
+            double Li[6], Lc[6];
+            okall[set] = chol3_inv(Vdm, Li, Iall[set], Lc);
+            if (!okall[set]) {
+#pragma unroll
+                for (int k = 0; k < 6; k++) Iall[set][k] = 0.0;
+            }
+            if (set == 0) {
+#pragma unroll
+                for (int k = 0; k < 6; k++) { Li0[k] = okall[0] ? Li[k] : 0.0; L0[k] = okall[0] ? Lc[k] : 0.0; }
+            }
+        }
+        // a landmark whose block is not positive definite at the FIRST radius has no Y_0 to derive the later sets from:
+        // such an item (not seen on real windows) takes the set-by-set path below
+        if (__syncthreads_or((p >= 0 && !okall[0]) ? 1 : 0) == 0) {
+            if (p >= 0 && sub == 0) {
+#pragma unroll
+                for (int set = 0; set < BA_MAXSETS; set++) {
+                    if (set >= st.nact) continue;
+                    if (!okall[set]) {
+#pragma unroll
+                        for (int k = 0; k < BA_MAXSETS; k++) fail[k] = (k == set) ? 1.0 : fail[k];
+                    }
+                    double* lamp_set = b.lamp + ((size_t)set * d.P + p) * 3;
+                    double* vinv_set = b.Vinv + ((size_t)set * d.P + p) * 6;
+#pragma unroll
+                    for (int k = 0; k < 3; k++) lamp_set[k] = lamall[set][k];
+#pragma unroll
+                    for (int k = 0; k < 6; k++) vinv_set[k] = Iall[set][k];
+                }
+            }
+            if (sub == 0 && wl < g.it_l) {
+                // G_s = L_0^T I_s L_0 (symmetric; L_0 lower: 00 10 11 20 21 22; I_s: xx xy xz yy yz zz); zero for an empty slot
+#pragma unroll
+                for (int set = 1; set < BA_MAXSETS; set++) {
+                    if (set >= st.nact) continue;
+                    const double I[6] = {Iall[set][0], Iall[set][1], Iall[set][2], Iall[set][3], Iall[set][4], Iall[set][5]};
+                    // T = I L_0 (3x3): T[r][c] = sum_k I[r][k] L0[k][c]
+                    const double T00 = I[0] * L0[0] + I[1] * L0[1] + I[2] * L0[3], T01 = I[1] * L0[2] + I[2] * L0[4], T02 = I[2] * L0[5];
+                    const double T10 = I[1] * L0[0] + I[3] * L0[1] + I[4] * L0[3], T11 = I[3] * L0[2] + I[4] * L0[4], T12 = I[4] * L0[5];
+                    const double T20 = I[2] * L0[0] + I[4] * L0[1] + I[5] * L0[3], T21 = I[4] * L0[2] + I[5] * L0[4], T22 = I[5] * L0[5];
+                    double* gt = Mt + ((size_t)(set - 1) * g.it_l + wl) * 6;
+                    // G = L_0^T T: G[r][c] = sum_k L0[k][r] T[k][c]
+                    gt[0] = L0[0] * T00 + L0[1] * T10 + L0[3] * T20;
+                    gt[1] = L0[0] * T01 + L0[1] * T11 + L0[3] * T21;
+                    gt[2] = L0[0] * T02 + L0[1] * T12 + L0[3] * T22;
+                    gt[3] = L0[2] * T11 + L0[4] * T21;
+                    gt[4] = L0[2] * T12 + L0[4] * T22;
+                    gt[5] = L0[5] * T22;
+                }
+            }
+            // Y_0 into the tile (the first tile was zeroed at kernel start)
+            const double t0 = Li0[0] * gv[0], t1 = Li0[1] * gv[0] + Li0[2] * gv[1], t2 = Li0[3] * gv[0] + Li0[4] * gv[1] + Li0[5] * gv[2];
+            BA_STAMP(b, 2);
+            if (p >= 0 && okall[0] && wl < g.it_l) {
+                for (int j = sub; j < nobs; j += SCH_SUBS) {
+                    int cs = cs0;
+                    float2 uvv = uv0;                          // round 0 is still in registers
+                    if (j != sub) {
+                        int jj = j + l; while (jj >= nobs) jj -= nobs;
+                        cs = g.obs_cs[o0 + jj];
+                        uvv = b.obs_uv[o0 + jj];
+                    }
+                    const int c = cs & 0xFFFF;
+                    const int s = (cs >> 16) - 1;
+                    if (s < 0) continue;
+                    obs_eval<true>(prep + (size_t)c * PSTR, X, uvv, d, o);
+                    const int pos = rank_in_mask(um0, um1, s);
+                    double* dst = yt + (size_t)(3 * wl) * YT_STRIDE4 + 6 * pos;
+#pragma unroll
+                    for (int a = 0; a < 6; a++) {
+                        const double w0 = o.w * (o.jc[a] * o.jp[0] + o.jc[6 + a] * o.jp[3]);
+                        const double w1 = o.w * (o.jc[a] * o.jp[1] + o.jc[6 + a] * o.jp[4]);
+                        const double w2 = o.w * (o.jc[a] * o.jp[2] + o.jc[6 + a] * o.jp[5]);
+                        dst[a] = w0 * Li0[0];
+                        dst[YT_STRIDE4 + a] = w0 * Li0[1] + w1 * Li0[2];
+                        dst[2 * YT_STRIDE4 + a] = w0 * Li0[3] + w1 * Li0[4] + w2 * Li0[5];
+                    }
+                }
+                if (sub == 0) {
+                    double* dst = yt + (size_t)(3 * wl) * YT_STRIDE4 + 6 * ns;
+                    dst[0] = t0; dst[YT_STRIDE4] = t1; dst[2 * YT_STRIDE4] = t2;
+                }
+            }
+            __syncthreads();
+            BA_STAMP(b, 4);
+            {
+                const int nw = (int)(blockDim.x >> 6);
+                double* const S0 = b.S + (size_t)((unsigned)item % (unsigned)b.srep) * b.s_rep_stride;
+                if (st.nact == 2) syrk_scatter_sets<2, YT_STRIDE4>(yt, Mt, g.it_l, 3 * g.it_l / 4, ns, gslot, d.n, wave, nw, S0, rhs_rep);
+                else syrk_scatter_sets<3, YT_STRIDE4>(yt, Mt, g.it_l, 3 * g.it_l / 4, ns, gslot, d.n, wave, nw, S0, rhs_rep);
+            }
+            set_first = st.nact;                               // nothing left for the set-by-set loop
+        }
+    }
+    for (int set = set_first; set < st.nact; set++) {
     const double radius = ba_set_radius(st, set);
     double* const S_set = b.S + (size_t)((unsigned)item % (unsigned)b.srep) * b.s_rep_stride + (size_t)set * d.n * d.n;
     double* const rhs_set = rhs_rep + (size_t)set * d.n;
