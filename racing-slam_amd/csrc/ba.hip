@@ -34,45 +34,10 @@
 
 #include "ba_common.h"
 #include "ba_backsub_body.h"
+#include "ba_init_body.h"
 #include "imu_dual.h"
 
-// ---------------------------------------------------------------------- K0
-static __device__ __forceinline__ void ba_init_body(const BaDims& d, const BaBufs& b, const BaOpt& opt, const double* __restrict__ cams_in,
-                                                    const double* __restrict__ pts_in, unsigned long long free_mask, int from_mask,
-                                                    uint8_t* __restrict__ cam_free, int32_t* __restrict__ zero_i32, int zero_n)
-{
-    const int tid = blockIdx.x * blockDim.x + threadIdx.x, nth = gridDim.x * blockDim.x;
-    if (from_mask && tid < d.C) {     // C <= 64: the free-camera table arrives as a kernel argument, not as two copies
-        const int fr = (int)(free_mask >> tid & 1ull);
-        b.slot[tid] = fr ? __popcll(free_mask & ((1ull << tid) - 1ull)) : -1;
-        cam_free[tid] = (uint8_t)fr;
-    }
-    for (int i = tid; i < d.C * 6; i += nth) {
-        const double v = cams_in[i];
-        for (int q = 0; q <= b.ns; q++) b.Xc[(size_t)q * d.C * 6 + i] = v;
-    }
-    for (int i = tid; i < d.P * 3; i += nth) b.Xp[i] = pts_in[i];
-    for (int c = tid; c < d.C; c += nth) cam_prepare(cams_in + 6 * c, b.prep + (size_t)c * BA_PREP);
-    for (size_t i = tid; i < b.acc_count; i += nth) b.acc[i] = 0.0;
-    for (int i = tid; i < 2 * b.ns * BA_NSLOT * BA_SLOT_STRIDE; i += nth) b.pt_scal[i] = 0.0;
-    for (int i = tid; i < BA_NSLOT * BA_SLOT_STRIDE; i += nth) b.gmax[i] = 0.0;
-    for (int i = tid; i < zero_n; i += nth) zero_i32[i] = 0;      // histogram of the landmark grouping
-    if (tid == 0) {
-        b.dbg[62] = 0ull;         // workgroups of ba_finalize that have finished (completion flag for the host)
-        for (int k = BA_HAND; k <= BA_HAND_ERR; k++) b.dbg[k] = 0ull;     // K7 -> K8 hand-off words and their error counter (ba_backsub_body.h)
-        b.dbg[BA_SDONE] = 0ull;
-        b.dbg[37] = 0ull; b.dbg[38] = 0ull; b.dbg[26] = 0ull; b.dbg[27] = ~0ull; b.dbg[28] = 0ull; b.dbg[29] = ~0ull;
-        BaState s;
-        s.radius = opt.r0; s.decrease_factor = 2.0; s.x_cost = 0.0; s.initial_cost = 0.0;
-        s.cam_scal[0] = s.cam_scal[1] = s.cam_scal[2] = s.cam_scal[3] = 0.0;
-        s.iter = 0; s.successful = 0; s.invalid_steps = 0; s.done = 0;
-        s.termination = 0; s.cur = 0; s.have_scale = 0; s.solver_failed = 0;
-        s.fresh = 1; s.usable = 0; s.consec_accepts = 0; s.nact = 1;
-        s.n_rounds = 0; s.n_fresh = 0; s.n_sets = 0; s.hand_lost = 0;
-        b.st[1] = s;      // the state iteration 0 starts from (st[(0 + 1) & 1])
-    }
-}
-
+// ---------------------------------------------------------------------- K0 (body: ba_init_body.h)
 __global__ void ba_init(BaDims d, BaBufs b, BaOpt opt, const double* __restrict__ cams_in,
                         const double* __restrict__ pts_in, unsigned long long free_mask, int from_mask,
                         uint8_t* __restrict__ cam_free, int32_t* __restrict__ zero_i32, int zero_n)
@@ -441,7 +406,7 @@ __global__ __launch_bounds__(BA_THREADS) void ba_backsub_cost(BaDims d, BaBufs b
 static __device__ __forceinline__ void ba_finalize_body(const BaDims& d, const BaBufs& b, const BaOpt& opt, int it, double* __restrict__ cams_out,
                                                         const uint8_t* __restrict__ cam_free, double* __restrict__ pts_out, BaState* host_st,
                                                         BaTrace* host_trace, double* __restrict__ host_cams, double* __restrict__ host_vb,
-                                                        volatile int* host_done = nullptr)
+                                                        volatile int* host_done = nullptr, int32_t* __restrict__ zero_i32 = nullptr, int zero_n = 0)
 {
     __shared__ int usable, cur;
     __shared__ BaState st_fin;
@@ -475,6 +440,8 @@ static __device__ __forceinline__ void ba_finalize_body(const BaDims& d, const B
     const int tid = blockIdx.x * blockDim.x + threadIdx.x, nth = gridDim.x * blockDim.x;
     const double* Xc = b.Xc + (size_t)cur * d.C * 6;
     const double* Xp = b.Xp + (size_t)cur * d.P * 3;
+    // the grouping's histogram / cursors / span word go back to zero for the next solve's count launch (ba_init_count)
+    for (int i = tid; i < zero_n; i += nth) zero_i32[i] = 0;
     // Everything the HOST waits for is written by workgroup 0 alone and fenced once: the summary and the trace (above), and
     // the cameras as the caller will see them in d_cameras, mirrored into pinned host memory (poses are host-owned objects in
     // the reference — Frame::set_pose, src/Optimization.cpp:363-368 — so the shim needs them there anyway).  Then it raises
@@ -505,9 +472,10 @@ static __device__ __forceinline__ void ba_finalize_body(const BaDims& d, const B
 
 __global__ void ba_finalize(BaDims d, BaBufs b, BaOpt opt, int it, double* __restrict__ cams_out,
                             const uint8_t* __restrict__ cam_free, double* __restrict__ pts_out, BaState* host_st,
-                            BaTrace* host_trace, double* __restrict__ host_cams, double* __restrict__ host_vb, volatile int* host_done)
+                            BaTrace* host_trace, double* __restrict__ host_cams, double* __restrict__ host_vb, volatile int* host_done,
+                            int32_t* __restrict__ zero_i32, int zero_n)
 {
-    ba_finalize_body(d, b, opt, it, cams_out, cam_free, pts_out, host_st, host_trace, host_cams, host_vb, host_done);
+    ba_finalize_body(d, b, opt, it, cams_out, cam_free, pts_out, host_st, host_trace, host_cams, host_vb, host_done, zero_i32, zero_n);
 }
 __global__ void ba_finalize_batch(const BaWin* w, BaOpt opt, int it)
 {
@@ -741,7 +709,7 @@ static int ba_solve_once(rs_context* ctx, int n_cameras, int n_points, int n_obs
     const size_t o_zacc = o_big + big_bytes;
     const size_t ws_bytes = o_zacc + (imu_lds ? align_up(sizeof(double) * ba_imu_lds_total_doubles(Ci, d.n, ns), 256) : 0);
     void* wsv = nullptr;
-    int rc = rs_workspace(ctx, ws_bytes, &wsv);
+    int rc = rs_workspace_quiet(ctx, ws_bytes, &wsv);      // (this solve keeps its own account of what it leaves behind, below)
     if (rc) return rc;
     char* ws = (char*)wsv;
     BaBufs b;
@@ -830,15 +798,30 @@ static int ba_solve_once(rs_context* ctx, int n_cameras, int n_points, int n_obs
         RS_HIP(ctx, hipMemcpyAsync(b.imu.Xv, xv_host.data(), sizeof(double) * 9 * C, hipMemcpyHostToDevice, s));
         RS_HIP(ctx, hipMemcpyAsync(b.imu.Xv + 9 * C, xv_host.data(), sizeof(double) * 9 * C, hipMemcpyHostToDevice, s));
     }
-    {
-        rs_prof_scope ps(ctx, "K0_ba_init");
-        hipLaunchKernelGGL(ba_init, dim3(64), dim3(256), 0, s, d, b, opt, (const double*)d_cameras, (const double*)d_points,
-                           free_mask, from_mask, d_cam_free, zero_ptr, zero_n);
+    // Set-up launches.  Local windows: K0 and the grouping's count in one launch, its scatter (incl. the item masks) in a
+    // second — two instead of four.  The count adds into a histogram that must be zero when the launch starts: the finalize
+    // kernel of the previous solve leaves it so, and the context remembers that (grp_zero_ptr) unless the workspace was
+    // reallocated or another caller asked for workspace bytes reaching into it since (ws_dirty_hi); otherwise one memset.
+    const bool fused_setup = use_mfma && ba_setup_fusable(d, grp);
+    if (fused_setup) {
+        const bool known_zero = ctx->grp_zero_ptr == zero_ptr && ctx->grp_zero_n == zero_n &&
+                                ctx->ws_dirty_hi <= (size_t)((char*)zero_ptr - ws);
+        ctx->grp_zero_ptr = nullptr;                                  // (until this solve's finalize kernel is enqueued)
+        if (!known_zero) RS_HIP(ctx, hipMemsetAsync(zero_ptr, 0, sizeof(int32_t) * (size_t)zero_n, s));
+        ba_launch_setup_fused(ctx, d, b, opt, grp, (const double*)d_cameras, (const double*)d_points, free_mask, from_mask, d_cam_free);
+    } else {
+        ctx->grp_zero_ptr = nullptr;
+        {
+            rs_prof_scope ps(ctx, "K0_ba_init");
+            hipLaunchKernelGGL(ba_init, dim3(64), dim3(256), 0, s, d, b, opt, (const double*)d_cameras, (const double*)d_points,
+                               free_mask, from_mask, d_cam_free, zero_ptr, zero_n);
+        }
+        if (use_mfma) {
+            rc = ba_launch_grouping(ctx, d, b, grp);
+            if (rc) return rc;
+        }
     }
-    if (use_mfma) {
-        rc = ba_launch_grouping(ctx, d, b, grp);
-        if (rc) return rc;
-    }
+    ctx->ws_dirty_hi = 0;
     // Blocked reduced solve: is S block-banded?  The grouping has just computed the largest camera span of a landmark; one
     // word travels to the host (the solve is milliseconds: the wait costs a few per cent of one round) and decides between
     // the one-launch banded factorisation and the general blocked one.  Sharded solves keep the general form: every rank
@@ -970,8 +953,9 @@ static int ba_solve_once(rs_context* ctx, int n_cameras, int n_points, int n_obs
         b.prog = nullptr;
         h_prog->pad = 0;
         hipLaunchKernelGGL(ba_finalize, dim3(32), dim3(256), 0, s, d, b, opt, itf, d_cameras, (const uint8_t*)d_cam_free, d_points, h_st, h_trace,
-                           (double*)((char*)pin + pin_cams), h_vb, &h_prog->pad);
+                           (double*)((char*)pin + pin_cams), h_vb, &h_prog->pad, fused_setup ? zero_ptr : nullptr, fused_setup ? zero_n : 0);
         RS_HIP(ctx, hipGetLastError());
+        if (fused_setup) { ctx->grp_zero_ptr = zero_ptr; ctx->grp_zero_n = zero_n; }      // stream-ordered in front of the next solve
         // wait for the completion flag the last workgroup of ba_finalize raises in pinned memory (summary, trace, camera
         // mirror are then all there); fall back to the stream if it drains without the flag (a failed launch)
         long spins = 0;

@@ -557,6 +557,9 @@ size_t ba_group_bytes(int P, int Cf, int M);
 void ba_group_carve(char* base, int P, int Cf, int M, BaGroup* g);
 void ba_group_zero_range(const BaGroup& g, int32_t** ptr, int* count);
 int ba_launch_grouping(rs_context* ctx, const BaDims& d, const BaBufs& b, const BaGroup& g);
+bool ba_setup_fusable(const BaDims& d, const BaGroup& g);
+void ba_launch_setup_fused(rs_context* ctx, const BaDims& d, const BaBufs& b, const BaOpt& opt, const BaGroup& g, const double* cams_in,
+                           const double* pts_in, unsigned long long free_mask, int from_mask, uint8_t* cam_free);
 size_t ba_schur_lds_bytes(int C, int Cf, int it_l = 64);
 int ba_prepare_schur(int C, int Cf);
 void ba_launch_schur(hipStream_t s, const BaDims& d, const BaBufs& b, const BaOpt& opt, const BaGroup& g, int it);

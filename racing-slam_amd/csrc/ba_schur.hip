@@ -24,6 +24,7 @@
 // stay inside the same 30 KB LDS tile); larger unions fall back to per-landmark
 // f64 atomics (correct for any covisibility, slow).
 #include "ba_common.h"
+#include "ba_init_body.h"
 #include "ba_schur_body.h"
 
 // ------------------------------------------------------------ setup kernels
@@ -40,7 +41,10 @@
 // slot with three xor-shuffles.  The histogram replica of a landmark is the one the scatter kernel will draw its position
 // from: (landmark / 256) mod GRP_REP.
 #define GRP_COUNT_LM 128
-static __device__ __forceinline__ void ba_group_count_body(const BaDims& d, const BaBufs& b, const BaGroup& g)
+// from_mask: the reduced-system slot of a camera comes from the free-camera mask (windows of at most 64 cameras) instead of
+// b.slot — in ba_init_count the table is being written by the same launch.
+static __device__ __forceinline__ void ba_group_count_body(const BaDims& d, const BaBufs& b, const BaGroup& g,
+                                                           const unsigned long long free_mask = 0ull, const int from_mask = 0)
 {
     __shared__ int lh[GRP_LDS_BINS];
     __shared__ int s_span;                 // the workgroup's largest span: ONE atomic on the window's word per workgroup (atomic
@@ -59,7 +63,7 @@ static __device__ __forceinline__ void ba_group_count_body(const BaDims& d, cons
             const int o1 = b.obs_ptr[p + 1];
             for (int o = b.obs_ptr[p] + sub; o < o1; o += 8) {
                 const int c = b.obs_cam[o];
-                const int s = b.slot[c];
+                const int s = from_mask ? ((free_mask >> c & 1ull) ? __popcll(free_mask & ((1ull << c) - 1ull)) : -1) : b.slot[c];
                 g.obs_cs[o] = c | ((s + 1) << 16);
                 if (s < 0) continue;
                 if (s < 64) m0 |= 1ull << s; else m1 |= 1ull << (s - 64);
@@ -134,6 +138,17 @@ static __device__ __forceinline__ void ba_group_scan_body(const BaGroup& g)
 }
 
 
+// the camera mask of landmark p, OR-ed into the mask of the item its sorted position falls into (g.item_mask zeroed before):
+// ~it_l atomic instructions per item word, all items side by side — instead of a launch of its own (ba_group_items)
+static __device__ __forceinline__ void ba_group_or_item(const BaGroup& g, int p, int pos)
+{
+    const unsigned long long m0 = g.mask[2 * (size_t)p], m1 = g.mask[2 * (size_t)p + 1];
+    unsigned long long* im = (unsigned long long*)g.item_mask + 2 * (size_t)(pos / g.it_l);
+    if (m0) atomicOr(im, m0);
+    if (m1) atomicOr(im + 1, m1);
+}
+
+template <bool OR_ITEMS>
 static __device__ __forceinline__ void ba_group_scatter_body(const BaDims& d, const BaBufs& b, const BaGroup& g)
 {
     const int p = blockIdx.x * blockDim.x + threadIdx.x;
@@ -143,6 +158,7 @@ static __device__ __forceinline__ void ba_group_scatter_body(const BaDims& d, co
     g.sorted[pos] = p;
     const int o0 = b.obs_ptr[p];
     g.lm[pos] = make_int4(p, o0, b.obs_ptr[p + 1] - o0, 0);
+    if (OR_ITEMS) ba_group_or_item(g, p, pos);
 }
 
 // one wave per item: lanes = the item's 64 landmarks, 128-bit OR across the wave
@@ -185,14 +201,26 @@ __global__ __launch_bounds__(64 * SCH_WAVES) void ba_schur_mfma_big(BaDims d, Ba
 // single-window and batched (blockIdx.z = window, arguments from the device array) entry points of the grouping kernels
 __global__ __launch_bounds__(1024) void ba_group_count(BaDims d, BaBufs b, BaGroup g) { ba_group_count_body(d, b, g); }
 __global__ __launch_bounds__(1024) void ba_group_scan(BaGroup g) { ba_group_scan_body(g); }
-__global__ __launch_bounds__(256) void ba_group_scatter(BaDims d, BaBufs b, BaGroup g) { ba_group_scatter_body(d, b, g); }
+__global__ __launch_bounds__(256) void ba_group_scatter(BaDims d, BaBufs b, BaGroup g) { ba_group_scatter_body<false>(d, b, g); }
+__global__ __launch_bounds__(256) void ba_group_scatter_items(BaDims d, BaBufs b, BaGroup g) { ba_group_scatter_body<true>(d, b, g); }
+// K0 + the grouping's count in ONE launch (single solves): the init work is spread over the count's workgroups; the
+// histogram they add into was left at zero by the previous solve's finalize kernel (or by a memset: ba.hip), the item masks
+// are zeroed here for the scatter launch that follows
+__global__ __launch_bounds__(1024) void ba_init_count(BaDims d, BaBufs b, BaOpt opt, BaGroup g, const double* __restrict__ cams_in,
+                                                      const double* __restrict__ pts_in, unsigned long long free_mask, int from_mask,
+                                                      uint8_t* __restrict__ cam_free)
+{
+    ba_init_body(d, b, opt, cams_in, pts_in, free_mask, from_mask, cam_free, (int32_t*)g.item_mask, 4 * g.n_items);
+    if ((int)(blockIdx.x * GRP_COUNT_LM) < d.P) ba_group_count_body(d, b, g, free_mask, from_mask);
+}
 
 // Scatter with the scan inside (local windows: at most GRP_SCAN_LDS histogram entries): every workgroup scans the
 // (bucket-major, replica-minor) histogram for itself in LDS — 2.6 k entries for 18 free cameras, one chunk per thread and
 // one workgroup scan — and takes positions as base + atomicAdd on a cursor array that ba_init left at zero.  Replaces the
 // one-workgroup scan launch between count and scatter (a launch gap + 4.8 us for 10 KB of work).
 #define GRP_SCAN_LDS 4096
-__global__ __launch_bounds__(256) void ba_group_scatter_scan(BaDims d, BaBufs b, BaGroup g)
+template <bool OR_ITEMS>
+static __device__ __forceinline__ void ba_group_scatter_scan_body(const BaDims& d, const BaBufs& b, const BaGroup& g)
 {
     __shared__ int base[GRP_SCAN_LDS];
     const int nb = g.n_buckets + 1, total = nb * GRP_REP;
@@ -222,7 +250,10 @@ __global__ __launch_bounds__(256) void ba_group_scatter_scan(BaDims d, BaBufs b,
     g.sorted[pos] = p;
     const int o0 = b.obs_ptr[p];
     g.lm[pos] = make_int4(p, o0, b.obs_ptr[p + 1] - o0, 0);
+    if (OR_ITEMS) ba_group_or_item(g, p, pos);
 }
+__global__ __launch_bounds__(256) void ba_group_scatter_scan(BaDims d, BaBufs b, BaGroup g) { ba_group_scatter_scan_body<false>(d, b, g); }
+__global__ __launch_bounds__(256) void ba_group_scatter_scan_items(BaDims d, BaBufs b, BaGroup g) { ba_group_scatter_scan_body<true>(d, b, g); }
 __global__ __launch_bounds__(256) void ba_group_items(BaDims d, BaGroup g) { ba_group_items_body(d, g); }
 // The round's decision as a launch of its own (one wave per window), for K5 launches whose workgroups do not all run at
 // once: there every item re-deriving it (slot lines, twelve wave reductions, the trust-region logic: 2.7 us) is serial work
@@ -242,7 +273,7 @@ __global__ __launch_bounds__(64) void ba_decide_round_batch(const BaWin* w, BaOp
 }
 __global__ __launch_bounds__(1024) void ba_group_count_batch(const BaWin* w) { const BaWin& x = w[blockIdx.z]; if ((int)(blockIdx.x * GRP_COUNT_LM) < x.d.P) ba_group_count_body(x.d, x.b, x.g); }
 __global__ __launch_bounds__(1024) void ba_group_scan_batch(const BaWin* w) { ba_group_scan_body(w[blockIdx.z].g); }
-__global__ __launch_bounds__(256) void ba_group_scatter_batch(const BaWin* w) { const BaWin& x = w[blockIdx.z]; ba_group_scatter_body(x.d, x.b, x.g); }
+__global__ __launch_bounds__(256) void ba_group_scatter_batch(const BaWin* w) { const BaWin& x = w[blockIdx.z]; ba_group_scatter_body<false>(x.d, x.b, x.g); }
 __global__ __launch_bounds__(256) void ba_group_items_batch(const BaWin* w) { const BaWin& x = w[blockIdx.z]; ba_group_items_body(x.d, x.g); }
 __global__ __launch_bounds__(64 * SCH_WAVES) void ba_schur_mfma_batch(const BaWin* w, BaOpt opt, int it)
 {
@@ -389,6 +420,31 @@ int ba_launch_grouping(rs_context* ctx, const BaDims& d, const BaBufs& b, const 
     }
     hipLaunchKernelGGL(ba_group_items, dim3((g.n_items + 3) / 4), dim3(256), 0, s, d, g);
     return RS_OK;
+}
+
+// K0 + grouping as two launches (ba_init_count; scatter with the item masks) instead of four: windows the one-workgroup
+// grouping does not cover.  The caller guarantees that the histogram / cursor / span words (ba_group_zero_range) are zero.
+bool ba_setup_fusable(const BaDims& d, const BaGroup& g)
+{
+    return !(d.P <= GRP_SMALL_P && g.n_buckets + 1 <= GRP_LDS_BINS) && d.P > 0;
+}
+void ba_launch_setup_fused(rs_context* ctx, const BaDims& d, const BaBufs& b, const BaOpt& opt, const BaGroup& g, const double* cams_in,
+                           const double* pts_in, unsigned long long free_mask, int from_mask, uint8_t* cam_free)
+{
+    hipStream_t s = ctx->stream;
+    {
+        rs_prof_scope ps(ctx, "K0_ba_init_count");
+        const int cb = (d.P + GRP_COUNT_LM - 1) / GRP_COUNT_LM;
+        hipLaunchKernelGGL(ba_init_count, dim3(cb < 16 ? 16 : cb), dim3(1024), 0, s, d, b, opt, g, cams_in, pts_in, free_mask, from_mask, cam_free);
+    }
+    rs_prof_scope ps(ctx, "K5s_group_landmarks");
+    const int pb = (d.P + 255) / 256;
+    if ((g.n_buckets + 1) * GRP_REP <= GRP_SCAN_LDS) {
+        hipLaunchKernelGGL(ba_group_scatter_scan_items, dim3(pb), dim3(256), 0, s, d, b, g);
+    } else {
+        hipLaunchKernelGGL(ba_group_scan, dim3(1), dim3(1024), 0, s, g);
+        hipLaunchKernelGGL(ba_group_scatter_items, dim3(pb), dim3(256), 0, s, d, b, g);
+    }
 }
 
 size_t ba_schur_lds_bytes(int C, int Cf, int it_l)

@@ -35,6 +35,11 @@ struct rs_context {
     // grow-only device workspace (never freed inside an enqueue path)
     void* ws = nullptr;
     size_t ws_bytes = 0;
+    // "known zero" region of the workspace (the landmark grouping's histogram / cursors of the last bundle adjustment, left
+    // at zero by its finalize kernel) and the highest workspace byte any OTHER caller may have written since (rs_workspace)
+    int32_t* grp_zero_ptr = nullptr;
+    int grp_zero_n = 0;
+    size_t ws_dirty_hi = 0;
     // pinned host scratch for small result read-back
     void* pinned = nullptr;
     size_t pinned_bytes = 0;
@@ -97,6 +102,7 @@ int rs_fail(rs_context* ctx, int code, const char* fmt, ...);
 
 // workspace: returns a device pointer with at least `bytes` bytes, 256-B aligned.
 int rs_workspace(rs_context* ctx, size_t bytes, void** out);
+int rs_workspace_quiet(rs_context* ctx, size_t bytes, void** out);   // does not mark the bytes as possibly written (ba.hip keeps its own account)
 int rs_pinned(rs_context* ctx, size_t bytes, void** out);
 // hipFuncSetAttribute(fn, MaxDynamicSharedMemorySize, bytes), but only when `bytes` exceeds what was already set for
 // `fn` in this process: the attribute is sticky and the driver call costs microseconds of host time per launch.

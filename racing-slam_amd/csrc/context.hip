@@ -185,11 +185,18 @@ extern "C" const char* rs_last_error(const rs_context* ctx) { return ctx ? ctx->
 
 int rs_workspace(rs_context* ctx, size_t bytes, void** out)
 {
+    if (bytes > ctx->ws_dirty_hi) ctx->ws_dirty_hi = bytes;      // the caller may write [0, bytes)
+    return rs_workspace_quiet(ctx, bytes, out);
+}
+
+int rs_workspace_quiet(rs_context* ctx, size_t bytes, void** out)
+{
     if (bytes > ctx->ws_bytes) {
         // growing is a synchronising event (first call / larger problem only)
         RS_HIP(ctx, hipStreamSynchronize(ctx->stream));
         if (ctx->ws) RS_HIP(ctx, hipFree(ctx->ws));
         ctx->ws = nullptr;
+        ctx->grp_zero_ptr = nullptr;
         ctx->ws_bytes = 0;
         size_t want = (bytes + (1u << 20)) & ~((size_t)(1u << 20) - 1);
         if (hipMalloc(&ctx->ws, want) != hipSuccess) return rs_fail(ctx, RS_ERR_NOMEM, "workspace of %zu bytes", want);
