@@ -1116,6 +1116,31 @@ def bench_ba(e, args, cfg):
         "in_process_shards": shards})
 
 
+def visible_gpu_count():
+    """GPUs this process would see, WITHOUT a HIP call (a process that has touched the GPU must not fork + exec a launcher on
+    the box; torch.cuda.device_count() stays clear of HIP only while amdsmi imports).  KFD topology nodes with SIMDs are the
+    GPUs; HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES / CUDA_VISIBLE_DEVICES narrow the count."""
+    n = 0
+    base = "/sys/class/kfd/kfd/topology/nodes"
+    try:
+        for node in sorted(os.listdir(base)):
+            try:
+                with open(os.path.join(base, node, "properties")) as f:
+                    props = dict(line.split()[:2] for line in f if len(line.split()) >= 2)
+                if int(props.get("simd_count", "0")) > 0:
+                    n += 1
+            except (OSError, ValueError):
+                pass
+    except OSError:
+        n = 0
+    for var in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        v = os.environ.get(var)
+        if v is not None:
+            ids = [x for x in v.split(",") if x.strip() != ""]
+            n = min(n, len(ids)) if n else len(ids)
+    return n
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -1136,8 +1161,7 @@ def main():
     # 127.0.0.1) BEFORE this process touches a GPU, relay the ranks' output and exit with their status.  On a box with
     # fewer GPUs than ranks the landmark shards run in ONE process on one GPU instead (rs_comm_init_local).
     if args.gpus > 1 and int(os.environ.get("WORLD_SIZE", "1")) == 1:
-        import torch
-        ndev = torch.cuda.device_count()        # does not initialise the GPU
+        ndev = visible_gpu_count()              # from sysfs / the environment: no HIP call in this process
         if ndev >= args.gpus:
             import socket
             import subprocess

@@ -521,6 +521,9 @@ int rs_map_bundle_adjust(rs_context* ctx, rs_map* map, const int32_t* h_kfs, con
  *   lanes                otherwise (or "ba_batch_mode" = 1): up to `RS_BA_BATCH_LANES` child contexts (own stream, own
  *                        workspace), one host thread each, ordinary solves side by side.
  * Results per window are those of rs_bundle_adjust: the same schedule, values to summation-order noise.
+ * Ordering: in both modes the windows' d_cameras / d_points are complete for anything ordered behind the call on THIS
+ * context's stream (the lanes' streams are joined into it before the call returns), and rs_context_synchronize(ctx)
+ * covers them.
  * h_problems[i] is the argument list of rs_bundle_adjust.  rs_ba_get_trace / _cameras refer to single solves only. */
 #define RS_BA_BATCH_LANES 8
 typedef struct rs_ba_problem {

@@ -484,6 +484,21 @@ __global__ void ba_finalize_batch(const BaWin* w, BaOpt opt, int it)
     ba_finalize_body(x.d, b, opt, it, x.cams_out, x.cam_free, x.pts_out, x.h_st, x.h_trace, x.h_cams, nullptr);
 }
 
+// Landmark-sharded solves: two facts every rank must agree on travel as MIN all-reduces of one 64-bit key each (the
+// collective the sharded matcher already uses): the largest camera span of a landmark (decides between the banded and
+// the general reduced solve: every rank must run the same factorisation on the all-reduced system) and "some rank lost a
+// hand-off of its fused K7 + K8 launch" (every rank re-runs the solve, or none: their collectives must stay paired).
+#define BA_KEY_SPAN 58
+#define BA_KEY_LOST 59
+__global__ void ba_span_key(const int32_t* __restrict__ maxspan, unsigned long long* __restrict__ key)
+{
+    *key = ~(unsigned long long)(unsigned)max(*maxspan, 0);            // min of ~span = ~(max span)
+}
+__global__ void ba_lost_key(const BaState* __restrict__ st, unsigned long long* __restrict__ key)
+{
+    *key = st->hand_lost ? 0ull : 1ull;                                // min = 0 as soon as one rank lost a hand-off
+}
+
 // ------------------------------------------------------------------ host side
 extern "C" void rs_ba_default_options(rs_ba_options* o)
 {
@@ -827,16 +842,30 @@ static int ba_solve_once(rs_context* ctx, int n_cameras, int n_points, int n_obs
     // the one-launch banded factorisation and the general blocked one.  Sharded solves keep the general form: every rank
     // must run the same arithmetic on the all-reduced system.
     int band = 0;                     // 1: one workgroup, 2: two-sided (ba_solve_big.hip)
-    if (solve_big && use_mfma && !in && !rs_comm_active(ctx) && ctx->ba_band_mode != 1) {
-        volatile int32_t* h_span = (volatile int32_t*)((char*)pin + pin_prog + 32);
-        *h_span = -1;
-        RS_HIP(ctx, hipMemcpyAsync((void*)h_span, grp.maxspan, sizeof(int32_t), hipMemcpyDeviceToHost, s));
-        long spins = 0;
-        while (*h_span < 0) {
-            if ((++spins & 0x3FFFF) == 0 && hipStreamQuery(s) != hipErrorNotReady) break;
+    if (solve_big && use_mfma && !in && ctx->ba_band_mode != 1) {
+        if (rs_comm_active(ctx)) {
+            // landmark shards: the span of the WHOLE window is the largest of the ranks' spans (round 4; every rank then runs
+            // the same banded factorisation on the same all-reduced system, as it runs the same general one)
+            volatile unsigned long long* h_key = (volatile unsigned long long*)((char*)pin + pin_prog + 32);
+            *h_key = 0ull;
+            hipLaunchKernelGGL(ba_span_key, dim3(1), dim3(1), 0, s, (const int32_t*)grp.maxspan, b.dbg + BA_KEY_SPAN);
+            rc = rs_allreduce_min_u64(ctx, b.dbg + BA_KEY_SPAN, 1);
+            if (rc) return rc;
+            RS_HIP(ctx, hipMemcpyAsync((void*)h_key, b.dbg + BA_KEY_SPAN, sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
+            RS_HIP(ctx, hipStreamSynchronize(s));
+            const unsigned long long span = ~*h_key;
+            if (span <= (unsigned long long)ba_band_max_span()) band = ctx->ba_band_mode == 2 ? 1 : 2;
+        } else {
+            volatile int32_t* h_span = (volatile int32_t*)((char*)pin + pin_prog + 32);
+            *h_span = -1;
+            RS_HIP(ctx, hipMemcpyAsync((void*)h_span, grp.maxspan, sizeof(int32_t), hipMemcpyDeviceToHost, s));
+            long spins = 0;
+            while (*h_span < 0) {
+                if ((++spins & 0x3FFFF) == 0 && hipStreamQuery(s) != hipErrorNotReady) break;
+            }
+            if (*h_span < 0) RS_HIP(ctx, hipStreamSynchronize(s));
+            if (*h_span >= 0 && *h_span <= ba_band_max_span()) band = ctx->ba_band_mode == 2 ? 1 : 2;
         }
-        if (*h_span < 0) RS_HIP(ctx, hipStreamSynchronize(s));
-        if (*h_span >= 0 && *h_span <= ba_band_max_span()) band = ctx->ba_band_mode == 2 ? 1 : 2;
     }
     // One ROUND = K5 + K7 + K8 and evaluates the next `ns` LM iterations of the sequential loop (all of them only if
     // the first ns - 1 are rejected).  At least ceil(max_iter / ns) rounds are needed and at most max_iter; beyond the
@@ -849,13 +878,17 @@ static int ba_solve_once(rs_context* ctx, int n_cameras, int n_points, int n_obs
     b.hand_timeout = 100ull * (unsigned long long)ctx->ba_handoff_timeout_us;
     // The whole round as ONE launch (ba_round.hip: K5's item workgroups become K8's after they have counted themselves for
     // K7): the same conditions plus the MFMA K5 with its camera blocks in LDS, and again every workgroup resident at once.
-    const bool plain_window = allow_fuse && solve_lds && k8_lds && !in && !rs_comm_active(ctx);
+    // (a landmark shard may fuse K7 + K8 too: the launch sits between the two exchange steps of the round, C1 in front of
+    // it and C2 behind; whether a rank fuses is its own business — shard sizes differ — but a lost hand-off is agreed on by
+    // all ranks below, so that every rank re-runs the solve or none does)
+    const bool plain_window = allow_fuse && solve_lds && k8_lds && !in;
     // Measured (tools/round_stamps.py): 86 us per round against 43 + 45 as two launches — the round is a strict
     // chain (linearise -> solve -> back-substitute), so keeping the workgroups resident buys the boundary and little else.
     // It is therefore opt-in ("ba_fuse_mode" 3); the default stays K5, then K7 + K8 in one launch.
-    const bool fuse_round = plain_window && use_mfma && ctx->ba_fuse_mode == 3 &&
+    const bool fuse_round = plain_window && !rs_comm_active(ctx) && use_mfma && ctx->ba_fuse_mode == 3 &&
                             ba_round_eligible(d) && ba_round_workgroups(d, b, grp) <= ctx->n_cu;
-    const bool fuse78 = !fuse_round && plain_window && (ctx->ba_fuse_mode >= 2 || (ctx->ba_fuse_mode == 0 && in_flight.others == 0)) &&
+    const bool fuse78 = !fuse_round && plain_window && d.P > 0 /* an empty landmark shard has no K8 workgroup to clear the accumulators */ &&
+                        (ctx->ba_fuse_mode >= 2 || (ctx->ba_fuse_mode == 0 && in_flight.others == 0)) &&
                         ba_solve_backsub_workgroups(d, b) <= ctx->n_cu;
     if (fuse_round && ba_prepare_round(d) != 0) return rs_fail(ctx, RS_ERR_HIP, "LDS attribute (round)");
     auto enqueue_round = [&](int it) -> int {
@@ -977,6 +1010,16 @@ static int ba_solve_once(rs_context* ctx, int n_cameras, int n_points, int n_obs
     ctx->ba_stats[0] = h_st->n_rounds; ctx->ba_stats[1] = h_st->n_fresh; ctx->ba_stats[2] = h_st->n_sets;
     ctx->ba_stats[3] = rounds;
     *hand_lost = h_st->hand_lost != 0;
+    if (rs_comm_active(ctx) && allow_fuse && solve_lds && k8_lds && !in) {
+        // every rank gets here (the conditions above are the same on all of them: cameras are replicated), fused or not
+        volatile unsigned long long* h_key = (volatile unsigned long long*)((char*)pin + pin_prog + 32);
+        hipLaunchKernelGGL(ba_lost_key, dim3(1), dim3(1), 0, s, (const BaState*)b.st, b.dbg + BA_KEY_LOST);
+        rc = rs_allreduce_min_u64(ctx, b.dbg + BA_KEY_LOST, 1);
+        if (rc) return rc;
+        RS_HIP(ctx, hipMemcpyAsync((void*)h_key, b.dbg + BA_KEY_LOST, sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
+        RS_HIP(ctx, hipStreamSynchronize(s));
+        *hand_lost = *h_key == 0ull;
+    }
     ctx->ba_cams = (const double*)((char*)pin + pin_cams);
     ctx->ba_cams_n = n_cameras;
     if (in && h_st->usable)                                  // unpack_inertial for the optimised frames, src/Optimization.cpp:363-368
@@ -1226,9 +1269,13 @@ extern "C" int rs_bundle_adjust_batch(rs_context* ctx, int n_problems, const rs_
     for (int l = 1; l < lanes; l++) threads.emplace_back(work, l);
     work(0);
     for (auto& t : threads) t.join();
+    // The lanes' finalize kernels raise their host flags while the device-side copies into d_cameras / d_points may still be
+    // running on the LANE streams: the parent's stream (what the caller reads the results on, and what
+    // rs_context_synchronize(ctx) covers) waits for every lane stream here, whatever the windows' status.
+    const int wrc = rs_context_wait_for(ctx, ctx->batch_lanes.data(), lanes);
     for (int l = 0; l < lanes; l++)
         if (status[(size_t)l]) return rs_fail(ctx, status[(size_t)l], "window on lane %d failed: %s", l, rs_last_error(ctx->batch_lanes[(size_t)l]));
-    return RS_OK;
+    return wrc;
 }
 
 static_assert(sizeof(BaTrace) == sizeof(rs_ba_iteration), "BaTrace mirrors rs_ba_iteration");

@@ -138,6 +138,53 @@ def huber(s, a):
     return rho, rho1
 
 
+def reduced_system_condition(w, cams, pts, radius):
+    """Condition of the Jacobi-scaled reduced camera system (point blocks eliminated) of a window at the state (cams, pts):
+    {"undamped": (cond, smallest, largest eigenvalue), "final radius": ...} — what bounds how far two correct f64 solves of
+    the window may differ (tools/tol_check.py, tests/test_gpu_round3.py::test_bundle_adjust_banded_reduced_solve)."""
+    obs_pt = np.repeat(np.arange(len(pts)), np.diff(w["obs_ptr"]))
+    obs_cam = np.asarray(w["obs_cam"], np.int64)
+    r = residuals(cams, pts, obs_cam, obs_pt, np.asarray(w["obs_uv"], np.float32), w["K"])
+    jc, jp = jacobian_blocks(cams, pts, obs_cam, obs_pt, np.asarray(w["obs_uv"], np.float32), w["K"])
+    _, rho1 = huber(np.sum(r * r, axis=1), np.sqrt(5.991))
+    free = np.asarray(w["cam_free"], bool)
+    slot = np.where(free, np.cumsum(free) - 1, -1)
+    n = 6 * int(free.sum())
+    U = np.zeros((n, n))
+    P = len(pts)
+    V = np.zeros((P, 3, 3))
+    Wl = [[] for _ in range(P)]
+    for o in range(len(obs_cam)):
+        wgt = rho1[o]
+        p = obs_pt[o]
+        V[p] += wgt * jp[o].T @ jp[o]
+        s = slot[obs_cam[o]]
+        if s >= 0:
+            U[6 * s:6 * s + 6, 6 * s:6 * s + 6] += wgt * jc[o].T @ jc[o]
+            Wl[p].append((s, wgt * jc[o].T @ jp[o]))
+    out = {}
+    for name, rad in (("undamped", None), ("final radius", radius)):
+        # Jacobi scaling 1 / (1 + sqrt(diag)) and Ceres' damping diag / radius
+        sc = 1.0 / (1.0 + np.sqrt(np.diag(U)))
+        S = U.copy()
+        if rad is not None:
+            S += np.diag(np.clip(np.diag(U) * sc * sc, 1e-6, 1e32) / (rad * sc * sc))
+        for p in range(P):
+            Vp = V[p].copy()
+            if rad is not None:
+                sp = 1.0 / (1.0 + np.sqrt(np.diag(V[p])))
+                Vp += np.diag(np.clip(np.diag(V[p]) * sp * sp, 1e-6, 1e32) / (rad * sp * sp))
+            Vi = np.linalg.inv(Vp)
+            for (s1, W1) in Wl[p]:
+                for (s2, W2) in Wl[p]:
+                    S[6 * s1:6 * s1 + 6, 6 * s2:6 * s2 + 6] -= W1 @ Vi @ W2.T
+        Ss = S * sc[:, None] * sc[None, :]
+        ev = np.linalg.eigvalsh(0.5 * (Ss + Ss.T))
+        out[name] = (ev[-1] / max(ev[0], 1e-300), ev[0], ev[-1])
+    return out
+
+
+
 class Problem:
     def __init__(self, cams, cam_free, pts, obs_ptr, obs_cam, obs_uv, K, huber_a=np.sqrt(5.991), imu=None,
                  points_constant=False, prior=None, delta=None):

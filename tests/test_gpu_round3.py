@@ -403,14 +403,21 @@ def test_bundle_adjust_banded_reduced_solve(ctx, oracle, synth, kw, banded):
         assert [t["outcome"] for t in tr] == [t["outcome"] for t in otr], mode
         assert np.allclose([t["cost"] for t in tr], [t["cost"] for t in otr], rtol=1e-7), mode      # (two f64 trajectories from a far-off start: 2e-9 by the fifth step)
         assert np.isclose(s["final_cost"], os_["final_cost"], rtol=1e-7), mode
-        # (the long-track window is weakly constrained along its gauge directions: 5e-8 on rotation components there)
-        tol = (1e-6, 1e-8, 1e-7) if banded else (1e-5, 1e-6, 1e-5)
-        assert np.allclose(c, rc, rtol=tol[0], atol=tol[1]) and np.allclose(p, rp, rtol=tol[0], atol=tol[2]), mode
+        if banded:
+            assert np.allclose(c, rc, rtol=1e-6, atol=1e-8) and np.allclose(p, rp, rtol=1e-6, atol=1e-7), mode
+        else:
+            # The long-track window is ILL-CONDITIONED, and its tolerance is an absolute one derived from
+            # measurement (tools/tol_check.py, round 4): the Jacobi-scaled reduced camera system at the solution is singular
+            # to working precision undamped (smallest eigenvalue -6e-8 against 2.2: the 40-frame chain of long tracks is
+            # almost free along its gauge directions) and has condition 7.3e6 at the final radius (3.3e6).  Four GPU runs of
+            # the SAME kernels differ by up to 3.3e-7 on a camera entry and 1.7e-5 on a point coordinate (the order of the
+            # f64 atomics, amplified over ten LM steps); GPU against oracle: 4.4e-7 / 9.0e-6.  Asserted at ~10x those figures.
+            assert np.abs(c - rc).max() < 5e-6 and np.abs(p - rp).max() < 1e-4, (mode, np.abs(c - rc).max(), np.abs(p - rp).max())
     if banded:
         assert np.allclose(runs[0][2], runs[1][2], rtol=1e-8, atol=1e-10)
         assert np.allclose(runs[0][2], runs[2][2], rtol=1e-8, atol=1e-10)      # two-sided against the one-workgroup form
-    else:       # (the same kernels both times; two runs of this weakly constrained window differ by 3e-9 through the atomics' order)
-        assert np.allclose(runs[0][2], runs[1][2], rtol=1e-5, atol=1e-6)
+    else:       # the same kernels both times: run-to-run noise of the ill-conditioned window (measured 1.1e-7 .. 3.3e-7)
+        assert np.abs(runs[0][2] - runs[1][2]).max() < 5e-6
 
 
 @pytest.mark.parametrize("bounds", [(0, 1000, 2000, 3000), (0, 1700, 1700, 3000), (0, 5, 2990, 3000)])
