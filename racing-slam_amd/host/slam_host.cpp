@@ -8,6 +8,7 @@
 #include <cstdio>
 #include <cstring>
 #include <stdexcept>
+#include <cstdint>
 #include <unordered_map>
 
 namespace slam {
@@ -73,6 +74,77 @@ bool rs_ok(int rc, const char* what)
 }
 
 rs_ba_summary g_summary{};
+
+// Pointer -> dense index, for flattening the reference's pointer graph (MapPoint has no id: src/MapPoint.h:12-39).  Open
+// addressing over a power-of-two table of {key, value, generation} entries (one cache line per probe), multiplicative hash
+// of the address; the table is kept between calls and "cleared" by bumping the generation — std::unordered_map (a node per
+// entry, cleared and rebuilt per call) spent 50 - 100 ns per operation and build_local_window + bundle_adjust make ~10^5 of
+// them per key frame; allocating and zeroing a fresh 0.8 MB table per call cost another 0.2 ms.
+class PtrIndex {
+  public:
+    // a table for about `expected` distinct keys (it grows by itself beyond that)
+    explicit PtrIndex(std::vector<char>& storage, size_t expected) : m_store(storage)
+    {
+        size_t cap = 64;
+        while (cap < 2 * expected + 2) cap <<= 1;
+        Header* h = header();
+        if (!h || h->cap < cap) {
+            m_store.assign(sizeof(Header) + cap * sizeof(Entry), 0);
+            h = header();
+            h->cap = cap; h->gen = 0;
+        }
+        if (++h->gen == 0) {                                   // generation wrapped: really clear
+            std::memset(entries(), 0, h->cap * sizeof(Entry));
+            h->gen = 1;
+        }
+        m_gen = h->gen; m_mask = h->cap - 1; m_e = entries(); m_used = 0;
+    }
+    // index of p, inserting it with value `fresh` if absent; *inserted says which
+    int find_or_insert(const void* p, int fresh, bool* inserted)
+    {
+        size_t h = slot(p);
+        while (m_e[h].gen == m_gen && m_e[h].key != p) h = (h + 1) & m_mask;
+        if (m_e[h].gen == m_gen) { *inserted = false; return m_e[h].val; }
+        m_e[h].key = p; m_e[h].val = fresh; m_e[h].gen = m_gen; *inserted = true;
+        if (2 * ++m_used > m_mask) grow();
+        return fresh;
+    }
+    int find(const void* p) const
+    {
+        size_t h = slot(p);
+        while (m_e[h].gen == m_gen && m_e[h].key != p) h = (h + 1) & m_mask;
+        return m_e[h].gen == m_gen ? m_e[h].val : -1;
+    }
+
+  private:
+    struct Entry { const void* key; int val; unsigned gen; };
+    struct Header { size_t cap; unsigned gen; unsigned pad; };
+    Header* header() { return m_store.size() >= sizeof(Header) ? reinterpret_cast<Header*>(m_store.data()) : nullptr; }
+    Entry* entries() { return reinterpret_cast<Entry*>(m_store.data() + sizeof(Header)); }
+    size_t slot(const void* p) const { return (size_t)(((uintptr_t)p >> 4) * 0x9E3779B97F4A7C15ull >> 20) & m_mask; }
+    void grow()
+    {
+        std::vector<Entry> live;
+        for (size_t i = 0; i <= m_mask; i++)
+            if (m_e[i].gen == m_gen) live.push_back(m_e[i]);
+        const size_t cap = 2 * (m_mask + 1);
+        m_store.assign(sizeof(Header) + cap * sizeof(Entry), 0);
+        Header* h = header();
+        h->cap = cap; h->gen = 1;
+        m_gen = 1; m_mask = cap - 1; m_e = entries();
+        for (const Entry& e : live) {
+            size_t q = slot(e.key);
+            while (m_e[q].gen == m_gen) q = (q + 1) & m_mask;
+            m_e[q] = Entry{e.key, e.val, m_gen};
+        }
+    }
+    std::vector<char>& m_store;
+    Entry* m_e = nullptr;
+    size_t m_mask = 0, m_used = 0;
+    unsigned m_gen = 0;
+};
+// storage of the tables, kept between calls (the callers are single-threaded: SURVEY.md 8b)
+std::vector<char> g_pid_store, g_fid_store;
 
 }  // namespace
 
@@ -475,16 +547,17 @@ bool bundle_adjust(const std::vector<FrameConfig>& frames, const Camera& camera,
     for (size_t c = 0; c < C; c++) { rs_pack_pose(frames[c].frame->pose().data(), &cams[6 * c]); cam_free[c] = frames[c].optimize ? 1 : 0; }
     // free points: matched by an optimised frame, >= 2 observations (:287-302), in first-seen order
     std::vector<MapPoint*> free_pts;
-    std::unordered_map<const MapPoint*, int> pid;
     std::vector<std::vector<MapPointMatch>> matches(C);          // (map_matches() builds a list: once per frame)
     size_t n_matches = 0;
     for (size_t c = 0; c < C; c++) { matches[c] = frames[c].frame->map_matches(); n_matches += matches[c].size(); }
-    pid.reserve(n_matches);
+    PtrIndex pid(g_pid_store, n_matches / 2 + 16);
     for (size_t c = 0; c < C; c++) {
         if (!frames[c].optimize) continue;
         for (const auto& m : matches[c]) {
             if (m.point.observations().size() < 2) continue;
-            if (pid.emplace(&m.point, (int)free_pts.size()).second) free_pts.push_back(&m.point);
+            bool fresh = false;
+            pid.find_or_insert(&m.point, (int)free_pts.size(), &fresh);
+            if (fresh) free_pts.push_back(&m.point);
         }
     }
     const size_t P = free_pts.size();
@@ -496,10 +569,10 @@ bool bundle_adjust(const std::vector<FrameConfig>& frames, const Camera& camera,
     std::vector<int32_t> obs_ptr(P + 1, 0);
     for (size_t c = 0; c < C; c++)
         for (const auto& m : matches[c]) {
-            auto it = pid.find(&m.point);
-            if (it == pid.end()) continue;
-            hits.push_back(Hit{it->second, (int)c, frames[c].frame->keypoint(m.keypoint_index).pt});
-            obs_ptr[(size_t)it->second + 1]++;
+            const int id = pid.find(&m.point);
+            if (id < 0) continue;
+            hits.push_back(Hit{id, (int)c, frames[c].frame->keypoint(m.keypoint_index).pt});
+            obs_ptr[(size_t)id + 1]++;
         }
     for (size_t p = 0; p < P; p++) obs_ptr[p + 1] += obs_ptr[p];
     std::vector<int32_t> obs_cam(hits.size()), fill(obs_ptr.begin(), obs_ptr.end() - 1);
@@ -539,26 +612,40 @@ std::vector<FrameConfig> build_local_window(const std::vector<std::shared_ptr<Ke
 {
     const int n = (int)key_frames.size();
     int new_index = -1;
-    std::unordered_map<const Frame*, int> fid;
-    for (int i = 0; i < n; i++) { fid[key_frames[(size_t)i].get()] = i; if (key_frames[(size_t)i].get() == &new_frame) new_index = i; }
-    std::unordered_map<const MapPoint*, int> pid;
+    PtrIndex fid(g_fid_store, (size_t)n);
+    size_t n_matches = 0;
+    for (int i = 0; i < n; i++) {
+        bool fresh;
+        fid.find_or_insert(static_cast<const Frame*>(key_frames[(size_t)i].get()), i, &fresh);
+        if (key_frames[(size_t)i].get() == &new_frame) new_index = i;
+        n_matches += key_frames[(size_t)i]->num_map_matches();
+    }
+    PtrIndex pid(g_pid_store, (n_matches + new_frame.num_map_matches()) / 2 + 16);
     std::vector<const MapPoint*> pts;
     std::vector<int32_t> frame_ptr((size_t)n + 2, 0), frame_pt;
+    frame_pt.reserve(n_matches + new_frame.num_map_matches());
     auto add_frame = [&](const Frame& f, int slot) {
-        for (const auto& m : f.map_matches()) {
-            auto it = pid.find(&m.point);
-            if (it == pid.end()) { it = pid.emplace(&m.point, (int)pts.size()).first; pts.push_back(&m.point); }
-            frame_pt.push_back(it->second);
+        const std::vector<MapPoint*>& tab = f.match_table();   // ascending keypoint index, as map_matches()
+        for (size_t k = 0; k < tab.size(); k++) {
+            const MapPoint* mp = tab[k];
+            if (!mp) continue;
+            bool fresh = false;
+            const int id = pid.find_or_insert(mp, (int)pts.size(), &fresh);
+            if (fresh) pts.push_back(mp);
+            frame_pt.push_back(id);
         }
         frame_ptr[(size_t)slot + 1] = (int32_t)frame_pt.size();
     };
     for (int i = 0; i < n; i++) add_frame(*key_frames[(size_t)i], i);
     if (new_index < 0) add_frame(new_frame, n); else frame_ptr[(size_t)n + 1] = frame_ptr[(size_t)n];
     std::vector<int32_t> pt_ptr(pts.size() + 1, 0), pt_obs;
+    pt_obs.reserve(frame_pt.size());
     for (size_t p = 0; p < pts.size(); p++) {
+        if (p + 8 < pts.size()) __builtin_prefetch(pts[p + 8]);                   // (the points are scattered heap objects)
+        if (p + 4 < pts.size()) __builtin_prefetch(pts[p + 4]->observations().data());
         for (const auto& o : pts[p]->observations()) {
-            auto it = fid.find(o.first);
-            if (it != fid.end()) pt_obs.push_back(it->second);
+            const int f = fid.find(static_cast<const Frame*>(o.first));
+            if (f >= 0) pt_obs.push_back(f);
         }
         pt_ptr[p + 1] = (int32_t)pt_obs.size();
     }

@@ -76,6 +76,8 @@ class Frame {
     bool is_matched(const MapPoint& p) const;
     size_t num_map_matches() const { return m_num; }
     std::vector<MapPointMatch> map_matches() const;            // ascending keypoint index, src/Frame.cpp:154-174
+    const std::vector<MapPoint*>& match_table() const { return m_map_matches; }   // keypoint -> point or null (what the reference's
+                                                               // MapPointIterator walks, src/Frame.h:20-33: no list is built)
     const std::vector<int32_t>& kd_node_kp() const { return m_kd_node_kp; }
     const std::vector<int32_t>& kd_left() const { return m_kd_left; }
     const std::vector<int32_t>& kd_right() const { return m_kd_right; }

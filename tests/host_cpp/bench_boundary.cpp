@@ -134,6 +134,19 @@ int main(int argc, char** argv)
         for (size_t i = 0; i < kp_landmark[k].size(); i++)
             if (point_of[kp_landmark[k][i]] >= 0) { map.associate(*kfs[k], map[(size_t)point_of[kp_landmark[k][i]]], i); n_obs++; }
 
+    if (argc > 2 && std::string(argv[2]) == "window") {
+        // host-only leg (no GPU needed): build_local_window alone, for profiling the flattening on any machine
+        std::vector<double> t;
+        size_t n_frames = 0;
+        for (int r = 0; r < std::max(reps, 20); r++) {
+            const auto t0 = clk::now();
+            n_frames = optimization::build_local_window(kfs, *kfs[NKF - 1], 20, false).size();
+            t.push_back(std::chrono::duration<double, std::micro>(clk::now() - t0).count());
+        }
+        std::sort(t.begin(), t.end());
+        std::printf("{\"build_local_window_us\": %.1f, \"frames\": %zu, \"map_points\": %zu, \"observations\": %zu}\n", t[t.size() / 2], n_frames, map.size(), n_obs);
+        return 0;
+    }
     MapMatcher matcher(camera, 64.f, NORM_HAMMING);
     std::string js = "{";
     auto add = [&](const char* name, const Stat& s, const std::string& extra) {
@@ -267,6 +280,46 @@ int main(int argc, char** argv)
     std::snprintf(ex, sizeof ex, "\"n\": %zu, \"kept\": %zu", p1.size(), kept);
     add("triangulate_points_frame_pair", s_tn, ex);
 
+    // ---- the track stage of a key frame (Mapper::triangulate_tracks, src/Mapper.cpp:246-305), both ways a drop-in can run it:
+    //   (a) the UNCHANGED Mapper loop: one triangulate_points call with ONE correspondence per track (:253) — timed here as
+    //       the loop itself over the tracks (first sighting against the key frame), host objects in / out per call;
+    //   (b) the body handed over in one piece (integration/reference_shim/Mapper_triangulate_tracks.inc ->
+    //       tracks::select_track_points -> rs_triangulate_tracks): one call per key frame.
+    {
+        const int kfi = NKF - 1;
+        std::vector<tracks::Track> trk;
+        std::vector<Mat4f> traj(poses.begin(), poses.begin() + NKF);
+        // key frame with NO map matches of its own (a fresh key frame's tracks are its unmatched keypoints)
+        ExtractedFeatures f2 = kfs[(size_t)kfi]->features();
+        KeyFrame kf_tracks(Frame(kfi, std::move(f2)));
+        kf_tracks.set_pose(poses[(size_t)kfi]);
+        for (size_t i = 0; i < kp_landmark[(size_t)kfi].size() && trk.size() < 2000; i++) {
+            const int lm = kp_landmark[(size_t)kfi][i];
+            tracks::Track t;
+            t.keypoint_index = i;
+            for (int k = std::max(0, kfi - 12); k < kfi; k++)
+                for (size_t j = 0; j < kp_landmark[(size_t)k].size(); j++)
+                    if (kp_landmark[(size_t)k][j] == lm) { t.sightings.push_back(tracks::TrackSighting{(size_t)k, kfs[(size_t)k]->keypoint(j).pt}); break; }
+            if (!t.sightings.empty()) trk.push_back(std::move(t));
+        }
+        size_t n_sight = 0;
+        for (const auto& t : trk) n_sight += t.sightings.size();
+        size_t made = 0;
+        const Stat s_loop = measure(std::max(reps / 6, 3), [&] {
+            made = 0;
+            for (const auto& t : trk) {
+                const std::vector<Vec2f> a{t.sightings.front().pixel}, b{kf_tracks.keypoint(t.keypoint_index).pt};
+                made += triangulation::triangulate_points(a, b, traj[t.sightings.front().frame_index], kf_tracks.pose(), camera, 1.0f, 4.0f).size();
+            }
+        });
+        std::snprintf(ex, sizeof ex, "\"tracks\": %zu, \"triangulated\": %zu, \"note\": \"the unchanged Mapper loop: one N = 1 triangulate_points call per track\"", trk.size(), made);
+        add("triangulate_tracks_unchanged_mapper_loop", s_loop, ex);
+        size_t n_acc = 0;
+        const Stat s_inc = measure(reps, [&] { n_acc = tracks::select_track_points(kf_tracks, trk, traj, camera).accepted.size(); });
+        std::snprintf(ex, sizeof ex, "\"tracks\": %zu, \"sightings\": %zu, \"accepted\": %zu, \"note\": \"Mapper_triangulate_tracks.inc: one call per key frame\"", trk.size(), n_sight, n_acc);
+        add("triangulate_tracks_inc", s_inc, ex);
+    }
+
     // refine_pose of the new frame (matches taken from match_map)
     for (auto& m : matcher.match_map(new_frame, map)) new_frame.add_map_match(m);
     const Mat4f pose0 = new_frame.pose();
@@ -281,18 +334,24 @@ int main(int argc, char** argv)
     for (size_t i = 0; i < map.size(); i++) pos0.push_back(map[i].position());
     std::vector<Mat4f> perturbed = kf_pose0;
     for (int k = 2; k < NKF; k++) perturbed[(size_t)k] = make_pose(0.026 * k + 0.004 * gauss(rng), 0.02 * k + 0.01 * gauss(rng), 0.01 * gauss(rng), 0.5 * k + 0.01 * gauss(rng));
-    double t_window = 0;
-    const Stat s_ba = measure(std::max(reps / 3, 5), [&] {
+    // (untimed: the perturbed poses and the positions are put back — a reset of this benchmark's state, not part of the call)
+    std::vector<double> t_windows;
+    const Stat s_ba = measure_with_setup(std::max(reps / 3, 5), [&] {
         for (int k = 0; k < NKF; k++) kfs[(size_t)k]->set_pose(perturbed[(size_t)k]);
         for (size_t i = 0; i < map.size(); i++) map[i].set_position(pos0[i]);
+    }, [&] {
         const auto t0 = clk::now();
         auto window = optimization::build_local_window(kfs, *kfs[NKF - 1], 20, false);
-        t_window = std::chrono::duration<double, std::micro>(clk::now() - t0).count();
+        t_windows.push_back(std::chrono::duration<double, std::micro>(clk::now() - t0).count());
         optimization::bundle_adjust(window, camera, map);
     });
+    std::sort(t_windows.begin(), t_windows.end());
     const rs_ba_summary& su = optimization::last_summary();
-    std::snprintf(ex, sizeof ex, "\"key_frames\": %d, \"iterations\": %d, \"usable\": %d, \"build_local_window_us\": %.1f, "
-                  "\"note\": \"includes restoring 20 poses and the map positions on the host\"", NKF, su.iterations, su.usable, t_window);
+    int fstats[8] = {0};
+    rs_ba_get_stats(Session::get().ctx(), fstats);
+    std::snprintf(ex, sizeof ex, "\"key_frames\": %d, \"iterations\": %d, \"usable\": %d, \"build_local_window_us\": %.1f, \"ba_rounds\": %d, "
+                  "\"note\": \"build_local_window + bundle_adjust: flatten, upload, solve, read-back, write-back into the host objects\"", NKF,
+                  su.iterations, su.usable, t_windows[t_windows.size() / 2], fstats[0]);
     add("bundle_adjust", s_ba, ex);
     js += "}";
     std::printf("%s\n", js.c_str());
