@@ -420,7 +420,7 @@ int rs_point_errors(rs_context* ctx, int n_points, const float* d_positions /*[P
  * free frame that observes them:  X' = R_after^T ((R_before X + t_before) - t_after), in f32.
  * Entry i moves point d_point_idx[i] (NULL = point i) of d_positions [.][3] with frame d_frame_idx[i];
  * d_poses_before / d_poses_after [n_frames][16] are Frame::pose() before and after rs_bundle_adjust.  A point must
- * be listed at most once (it has one observation). */
+ * be listed at most once (it has one observation); an entry whose frame index is outside [0, n_frames) is skipped. */
 int rs_reanchor_points(rs_context* ctx, int n, const int32_t* d_point_idx, const int32_t* d_frame_idx,
                        const float* d_poses_before, const float* d_poses_after, int n_frames,
                        float* d_positions);
@@ -507,7 +507,9 @@ int rs_bundle_adjust(rs_context* ctx,
  * a usable solve the map — device image and mirror — takes the result.  The caller gets the same for its own objects:
  * h_out_poses [n_kfs][16] (unchanged rows for fixed key frames / unusable solves) and the free points, in ascending
  * slot order, with their new positions (h_out_points / h_out_xyz, `capacity` entries; *h_n_points = how many there
- * were).  Free points: alive, >= 2 observations, matched by an optimised frame of the list (:287-302). */
+ * were).  Free points: alive, >= 2 observations, matched by an optimised frame of the list (:287-302).  The flattened
+ * path (host mirror / shim -> rs_bundle_adjust) lists the same set in first-seen order (the reference's, :287-302): the
+ * f64 summation order inside the solve differs, so the two agree to the solver's noise (1e-9 relative), not bit for bit. */
 int rs_map_bundle_adjust(rs_context* ctx, rs_map* map, const int32_t* h_kfs, const uint8_t* h_free, int n_kfs,
                          const float h_intrinsics[4], const rs_ba_options* options, rs_ba_summary* h_summary,
                          float* h_out_poses, int32_t* h_out_points, float* h_out_xyz, int capacity, int* h_n_points);
@@ -714,7 +716,10 @@ int rs_comm_destroy(rs_context* ctx);
  * stream, on one device or on peer-accessible devices): context i becomes rank i of an in-process group whose
  * all-reduce is a deterministic on-device sum in rank order.  Every member must then make the same sequence of
  * rs_bundle_adjust calls, each from its own thread.  Used to run landmark shards side by side on one GPU and to
- * test the N > 1 path on a one-GPU box.  rs_comm_destroy on every member releases the group. */
+ * test the N > 1 path on a one-GPU box.  rs_comm_destroy on every member releases the group.
+ * A group in which an exchange step failed (a member's HIP error, or a member that did not arrive within 30 s) stays
+ * failed: every later exchange step of every member returns RS_ERR_HIP at once ("... failed in an earlier exchange
+ * step"); destroy the group on every member and create it again. */
 int rs_comm_init_local(rs_context** ctxs, int n);
 /* Evidence of what the exchange step runs over: *h_ranks = number of ranks of the attached communicator as RCCL
  * itself reports it (ncclCommCount) or the size of the in-process group; *h_kind = 0 none, 1 RCCL, 2 in-process. */

@@ -520,6 +520,14 @@ static int local_allreduce(rs_context* ctx, double* d_buf, size_t count, bool mi
     // second barrier.
     rs_local_group* g = ctx->local;
     const int r = ctx->rank;
+    {
+        // a group that has failed once (a member's error, or a barrier that timed out) stays failed: its barrier generations
+        // may be mixed up by a straggler.  Later exchange steps return at once instead of waiting 2 x 30 s again; the group
+        // must be destroyed (rs_comm_destroy on every member) and created anew.
+        std::lock_guard<std::mutex> lk(g->m);
+        if (g->failed)
+            return rs_fail(ctx, RS_ERR_HIP, "the in-process group failed in an earlier exchange step: destroy it (rs_comm_destroy on every member) and create it again");
+    }
     bool bad = false;
     auto chk = [&](hipError_t e, const char* what) {
         if (e != hipSuccess && !bad) { bad = true; rs_fail(ctx, RS_ERR_HIP, "%s failed in the in-process exchange step: %s", what, hipGetErrorString(e)); }

@@ -279,13 +279,14 @@ extern "C" int rs_point_errors(rs_context* ctx, int n_points, const float* d_pos
 // One lane per listed point.  f32 operation order as everywhere in this library: a 3-term dot product is
 // (a0 b0 + a1 b1) + a2 b2 (Eigen's own order is unspecified upstream).
 __global__ __launch_bounds__(256) void k13_reanchor(int n, const int32_t* __restrict__ point_idx,
-                                                    const int32_t* __restrict__ frame_idx,
+                                                    const int32_t* __restrict__ frame_idx, int n_frames,
                                                     const float* __restrict__ before, const float* __restrict__ after,
                                                     float* __restrict__ pos)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const int p = point_idx ? point_idx[i] : i;
+    if ((unsigned)frame_idx[i] >= (unsigned)n_frames) return;      // no such frame: the point stays where it is (both K13 forms)
     float B[16], A[16];
     load_pose(before, frame_idx[i], B);
     load_pose(after, frame_idx[i], A);
@@ -313,7 +314,7 @@ extern "C" int rs_reanchor_points(rs_context* ctx, int n, const int32_t* d_point
     RS_HIP(ctx, hipSetDevice(ctx->device));
     {
         rs_prof_scope ps(ctx, "K13_reanchor");
-        hipLaunchKernelGGL(k13_reanchor, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, n, d_point_idx, d_frame_idx,
+        hipLaunchKernelGGL(k13_reanchor, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, n, d_point_idx, d_frame_idx, n_frames,
                            d_poses_before, d_poses_after, d_positions);
     }
     RS_HIP(ctx, hipGetLastError());
@@ -324,13 +325,14 @@ extern "C" int rs_reanchor_points(rs_context* ctx, int n, const int32_t* d_point
 #define K13_ARG_FRAMES 32
 struct K13Poses { float before[K13_ARG_FRAMES][12]; float after[K13_ARG_FRAMES][12]; };
 __global__ __launch_bounds__(256) void k13_reanchor_args(int n, const int32_t* __restrict__ point_idx,
-                                                         const int32_t* __restrict__ frame_idx, K13Poses poses,
+                                                         const int32_t* __restrict__ frame_idx, int n_frames, K13Poses poses,
                                                          float* __restrict__ pos)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const int p = point_idx ? point_idx[i] : i;
     const int f = frame_idx[i];
+    if ((unsigned)f >= (unsigned)n_frames) return;                 // (an index beyond the argument block would read past it)
     const float* B = poses.before[f];
     const float* A = poses.after[f];
     const float X[3] = {pos[3 * (size_t)p], pos[3 * (size_t)p + 1], pos[3 * (size_t)p + 2]};
@@ -362,7 +364,7 @@ extern "C" int rs_reanchor_points_host_poses(rs_context* ctx, int n, const int32
         }
         for (int f = n_frames; f < K13_ARG_FRAMES; f++) { memset(P.before[f], 0, sizeof P.before[f]); memset(P.after[f], 0, sizeof P.after[f]); }
         rs_prof_scope ps(ctx, "K13_reanchor");
-        hipLaunchKernelGGL(k13_reanchor_args, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, n, d_point_idx, d_frame_idx, P, d_positions);
+        hipLaunchKernelGGL(k13_reanchor_args, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, n, d_point_idx, d_frame_idx, n_frames, P, d_positions);
     } else {
         // larger sets of frames: both pose arrays through the context's workspace (copied before this call returns)
         void* ws = nullptr;
@@ -375,7 +377,7 @@ extern "C" int rs_reanchor_points_host_poses(rs_context* ctx, int n, const int32
         RS_HIP(ctx, hipMemcpyAsync(d_after, h_poses_after, bytes, hipMemcpyHostToDevice, ctx->stream));
         RS_HIP(ctx, hipStreamSynchronize(ctx->stream));          // pageable sources: the copies have read them
         rs_prof_scope ps(ctx, "K13_reanchor");
-        hipLaunchKernelGGL(k13_reanchor, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, n, d_point_idx, d_frame_idx,
+        hipLaunchKernelGGL(k13_reanchor, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, n, d_point_idx, d_frame_idx, n_frames,
                            d_before, d_after, d_positions);
     }
     RS_HIP(ctx, hipGetLastError());
