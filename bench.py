@@ -54,7 +54,7 @@ PMC_NAMES = {"K5_ba_schur_mfma": "ba_schur_mfma", "K7_ba_reduced_solve": "ba_red
              "K1b_merge_filter": "k1_merge_filter", "K2_reproj_match": "k2_reproj_match_grouped",
              "K4_triangulate_dlt": "k4_triangulate", "K7_ba_reduced_solve_blocked": "ba_big_update",
              "K6_tracks": "k6_tracks", "K12_point_errors": "k12_point_errors", "K11_refine_pose": "ba_refine_pose"}
-PMC_ROUNDS = ("round3", "round2")      # newest committed counter file first
+PMC_ROUNDS = ("round4", "round3", "round2")      # newest committed counter file first
 
 
 def kernel_source_hash():

@@ -468,6 +468,50 @@ static __device__ __forceinline__ void ba_schur_body(const BaDims& d, const BaBu
     // three tile columns of a landmark are recombined by a 3x3 upper-triangular matrix M^T, M = L_s^-1 L_{s-1}; the
     // rhs row (g^T L^-T) transforms the same way.  One pass over the tile in LDS instead of zeroing it and evaluating
     // every observation again (compact 4x4-tile items only: the 8x8 class reuses the tile for two half batches).
+    // The workgroup's scalar sums (cost, gradient maximum, failure counts) and its U / gc block sums go to global memory by a
+    // handful of atomics.  They are final once pass 1 and the Cholesky factors are done, so the all-sets path issues them
+    // BEFORE its SYRK + scatter: behind the scatter's ~24 atomic instructions per wave they queued for ~3 us at the end of the
+    // kernel (a wave stalls at 16 - 32 outstanding atomics); the other paths run them at the end as before.
+    __shared__ double redw[SCH_WAVES][2 + BA_MAXSETS];
+    bool epilogue_done = false;
+    auto epilogue = [&]() {
+        epilogue_done = true;
+        cost = wave_sum(cost);
+#pragma unroll
+        for (int k = 0; k < BA_MAXSETS; k++) fail[k] = wave_sum(fail[k]);
+        gmax = wave_max_nonneg(gmax);
+        const int nwaves = (int)(blockDim.x >> 6);
+        if (lane == 0) {
+            redw[wave][0] = cost; redw[wave][1] = gmax;
+#pragma unroll
+            for (int k = 0; k < BA_MAXSETS; k++) redw[wave][2 + k] = fail[k];
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) {      // one atomic per workgroup, spread over BA_NSLOT lines
+            double c = 0.0, gm = 0.0, f[BA_MAXSETS];
+#pragma unroll
+            for (int k = 0; k < BA_MAXSETS; k++) f[k] = 0.0;
+            for (int w = 0; w < nwaves; w++) {
+                c += redw[w][0]; gm = fmax(gm, redw[w][1]);
+#pragma unroll
+                for (int k = 0; k < BA_MAXSETS; k++) f[k] += redw[w][2 + k];
+            }
+            const size_t slot = (size_t)(item & (BA_NSLOT - 1)) * BA_SLOT_STRIDE;
+            if (c != 0.0) atomicAdd(&b.scal[slot], c);
+#pragma unroll
+            for (int k = 0; k < BA_MAXSETS; k++)
+                if (f[k] > 0.0) atomicAdd(&b.scal[slot + 1 + k], f[k]);      // slot field 1 + set
+            if (gm > 0.0) atomic_max_nonneg(&b.gmax[slot], gm);
+        }
+        for (int i = threadIdx.x; i < min(ns, SCH_UCAP) * 42; i += blockDim.x) {
+            const int s = gslot[i / 42], k = i % 42;          // rank in the union -> free-camera slot
+            const double v = ulds[i];
+            if (v != 0.0) {
+                if (k < 36) atomicAdd(&b.U[rep_off + s * 36 + k], v);
+                else atomicAdd(&b.gc[rep_off + 6 * s + (k - 36)], v);
+            }
+        }
+    };
     double Lprev[6] = {0, 0, 0, 0, 0, 0};
     bool prev_all_ok = false;
     double* Mt = (double*)(gslot + 32);                       // [it_l][6] behind the slot table ([2][it_l][6] as Gt)
@@ -576,6 +620,7 @@ static __device__ __forceinline__ void ba_schur_body(const BaDims& d, const BaBu
             }
             __syncthreads();
             BA_STAMP(b, 4);
+            epilogue();                                        // (its atomics leave in front of the scatter's)
             {
                 const int nw = (int)(blockDim.x >> 6);
                 double* const S0 = b.S + (size_t)((unsigned)item % (unsigned)b.srep) * b.s_rep_stride;
@@ -745,42 +790,7 @@ static __device__ __forceinline__ void ba_schur_body(const BaDims& d, const BaBu
     for (int k = 0; k < 6; k++) Lprev[k] = Lc[k];
     }   // sets
     BA_STAMP(b, 5);
-    cost = wave_sum(cost);
-#pragma unroll
-    for (int k = 0; k < BA_MAXSETS; k++) fail[k] = wave_sum(fail[k]);
-    gmax = wave_max_nonneg(gmax);
-    __shared__ double redw[SCH_WAVES][2 + BA_MAXSETS];
-    const int nwaves = (int)(blockDim.x >> 6);
-    if (lane == 0) {
-        redw[wave][0] = cost; redw[wave][1] = gmax;
-#pragma unroll
-        for (int k = 0; k < BA_MAXSETS; k++) redw[wave][2 + k] = fail[k];
-    }
-    __syncthreads();
-    if (threadIdx.x == 0) {      // one atomic per workgroup, spread over BA_NSLOT lines
-        double c = 0.0, gm = 0.0, f[BA_MAXSETS];
-#pragma unroll
-        for (int k = 0; k < BA_MAXSETS; k++) f[k] = 0.0;
-        for (int w = 0; w < nwaves; w++) {
-            c += redw[w][0]; gm = fmax(gm, redw[w][1]);
-#pragma unroll
-            for (int k = 0; k < BA_MAXSETS; k++) f[k] += redw[w][2 + k];
-        }
-        const size_t slot = (size_t)(item & (BA_NSLOT - 1)) * BA_SLOT_STRIDE;
-        if (c != 0.0) atomicAdd(&b.scal[slot], c);
-#pragma unroll
-        for (int k = 0; k < BA_MAXSETS; k++)
-            if (f[k] > 0.0) atomicAdd(&b.scal[slot + 1 + k], f[k]);      // slot field 1 + set
-        if (gm > 0.0) atomic_max_nonneg(&b.gmax[slot], gm);
-    }
-    for (int i = threadIdx.x; i < min(ns, SCH_UCAP) * 42; i += blockDim.x) {
-        const int s = gslot[i / 42], k = i % 42;          // rank in the union -> free-camera slot
-        const double v = ulds[i];
-        if (v != 0.0) {
-            if (k < 36) atomicAdd(&b.U[rep_off + s * 36 + k], v);
-            else atomicAdd(&b.gc[rep_off + 6 * s + (k - 36)], v);
-        }
-    }
+    if (!epilogue_done) epilogue();
     BA_STAMP(b, 6);
     BA_STAMP_FLUSH(b, 8);
     if (ROUND) {

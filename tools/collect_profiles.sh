@@ -1,11 +1,11 @@
 #!/bin/bash
 # Runs on the GPU box (gpurun): rocprofv3 kernel stats + FETCH / WRITE / MFMA counter passes of bench.py per configuration,
 # and the plain bench lines.  Counters are collected in runs of their own with --kernel-trace only (no --stats, no other
-# trace domain).  Output: gpurun_out/prof_r3/{<cfg>_kernel_stats.csv, pmc_<cfg>.csv, pmc_mfma_pass.csv, bench_<cfg>.json};
-# copy into profiles/ (round3_*) to commit.
+# trace domain).  Output: gpurun_out/prof_r4/{<cfg>_kernel_stats.csv, pmc_<cfg>.csv, pmc_mfma_pass.csv, bench_<cfg>.json};
+# copy into profiles/ (round4_*) to commit.
 set -e
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
-OUT=gpurun_out/prof_r3
+OUT=gpurun_out/prof_r4
 mkdir -p $OUT
 for cfg in ${BENCH_CFGS:-pass cfg2 cfg3 cfg4 cfg5}; do
   steps=50; [ $cfg = cfg5 ] && steps=10

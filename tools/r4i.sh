@@ -1,0 +1,12 @@
+set -e
+mkdir -p gpurun_out/r4i
+python -m pytest tests -m gpu -x -q -k "bundle_adjust or ba_ or smoke or inertial or round4" > gpurun_out/r4i/tests.log 2>&1 || { tail -40 gpurun_out/r4i/tests.log; exit 1; }
+tail -2 gpurun_out/r4i/tests.log
+python tools/ab_time.py
+python tools/ab_time.py
+python bench.py --config pass --steps 50 --no-cpu-baseline --no-boundary > gpurun_out/r4i/bench_pass.json 2> gpurun_out/r4i/bench_pass.err
+python - <<PY
+import json
+d=json.load(open("gpurun_out/r4i/bench_pass.json"))
+print("pass", round(d["value"],1), "ms", round(d["ms_per_step"],4), d.get("per_kernel_us"))
+PY
