@@ -595,7 +595,7 @@ static BaLayout ba_layout(const BaDims& d, int ns, int max_iter, size_t n_ranks,
     L.st = carve(sizeof(BaState) * 2);
     L.set = carve(sizeof(BaSetOut) * 2 * BA_MAXSETS);
     L.trace = carve(sizeof(BaTrace) * (size_t)(max_iter + 1));
-    L.dbg = carve(sizeof(unsigned long long) * 64);
+    L.dbg = carve(sizeof(unsigned long long) * BA_DBG_WORDS);
     L.fre = carve(C);
     L.grp = carve(grp_bytes);
     L.bytes = off;
@@ -708,8 +708,10 @@ static int ba_solve_once(rs_context* ctx, int n_cameras, int n_points, int n_obs
         for (int f = 0; f < in->n_factors && imu_lds; f++) imu_lds = inert[in->factors[f].cam_j] == inert[in->factors[f].cam_i] + 1;
     int ns = 1;
     if (use_mfma && k8_lds && solve_lds && (!in || imu_lds)) {
-        ns = ctx->ba_sets > 0 ? ctx->ba_sets : BA_DEFAULT_SETS;
+        // (inertial solves keep three: their per-radius elimination kernels were sized and tested for that)
+        ns = ctx->ba_sets > 0 ? ctx->ba_sets : (in ? BA_CALIBRATED_SETS : BA_DEFAULT_SETS);
         if (ns > BA_MAXSETS) ns = BA_MAXSETS;
+        if (in && ns > BA_CALIBRATED_SETS) ns = BA_CALIBRATED_SETS;
         if (ns > opt.max_iter) ns = opt.max_iter > 0 ? opt.max_iter : 1;
     }
     const size_t C = (size_t)d.C;
@@ -735,7 +737,7 @@ static int ba_solve_once(rs_context* ctx, int n_cameras, int n_points, int n_obs
     double* const pts_base = b.pt_scal;
     BaSetOut* const set_base = b.set_out;
 #if RS_STAMPS
-    RS_HIP(ctx, hipMemsetAsync(b.dbg, 0, sizeof(unsigned long long) * 64, ctx->stream));
+    RS_HIP(ctx, hipMemsetAsync(b.dbg, 0, sizeof(unsigned long long) * BA_DBG_WORDS, ctx->stream));
 #endif
     ctx->ba_cache = b.dbg;
 
@@ -885,7 +887,7 @@ static int ba_solve_once(rs_context* ctx, int n_cameras, int n_points, int n_obs
     // Measured (tools/round_stamps.py): 86 us per round against 43 + 45 as two launches — the round is a strict
     // chain (linearise -> solve -> back-substitute), so keeping the workgroups resident buys the boundary and little else.
     // It is therefore opt-in ("ba_fuse_mode" 3); the default stays K5, then K7 + K8 in one launch.
-    const bool fuse_round = plain_window && !rs_comm_active(ctx) && use_mfma && ctx->ba_fuse_mode == 3 &&
+    const bool fuse_round = plain_window && !rs_comm_active(ctx) && use_mfma && ctx->ba_fuse_mode == 3 && ns <= BA_CALIBRATED_SETS &&
                             ba_round_eligible(d) && ba_round_workgroups(d, b, grp) <= ctx->n_cu;
     const bool fuse78 = !fuse_round && plain_window && d.P > 0 /* an empty landmark shard has no K8 workgroup to clear the accumulators */ &&
                         (ctx->ba_fuse_mode >= 2 || (ctx->ba_fuse_mode == 0 && in_flight.others == 0)) &&
@@ -1100,8 +1102,8 @@ static int ba_solve_batch_grid(rs_context* ctx, int B, const rs_ba_problem* Q, c
     opt.dmax = options->max_lm_diagonal; opt.ftol = options->function_tolerance;
     opt.gtol = options->gradient_tolerance; opt.ptol = options->parameter_tolerance;
     if (opt.max_iter < 1 || opt.max_iter > 1000) return 1;
-    int ns = ctx->ba_sets > 0 ? ctx->ba_sets : BA_DEFAULT_SETS;
-    if (ns > BA_MAXSETS) ns = BA_MAXSETS;
+    int ns = ctx->ba_sets > 0 ? ctx->ba_sets : BA_CALIBRATED_SETS;      // (throughput mode: extra radii are CU time other windows want)
+    if (ns > BA_CALIBRATED_SETS) ns = BA_CALIBRATED_SETS;
     if (ns > opt.max_iter) ns = opt.max_iter;
     std::vector<BaWin> wins((size_t)B);
     std::vector<size_t> ws_off((size_t)B), pin_off((size_t)B);

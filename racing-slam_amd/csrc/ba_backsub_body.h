@@ -13,9 +13,9 @@
 //                               the solve (code 2: nothing left to do)
 //   b.dbg[BA_HAND + set]        delta_c is complete in memory (code 0), or the solver has failed (code 1)
 // b.dbg[BA_HAND_ERR] counts consumers that gave up waiting (ba_finalize turns that into RS_BA_FAILURE).
-#define BA_HAND 48
-#define BA_HAND_TAKEN 52
-#define BA_HAND_ERR 56
+#define BA_HAND 64              // [BA_MAXSETS] (8 reserved)
+#define BA_HAND_TAKEN 72        // [BA_MAXSETS]
+#define BA_HAND_ERR 80
 // One launch per LM round (ba_round, ba_solve.hip): the item workgroups count themselves here when their part of the
 // linearisation — S, rhs, U, gc, cost and failure slots, all accumulated by memory-side atomics — is complete; the K7
 // workgroups wait for n_rounds * n_items.  A line of its own (the stamps use 0 - 15 and 32 - 43).

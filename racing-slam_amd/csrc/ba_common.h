@@ -17,10 +17,14 @@
 #define BA_SLOT_STRIDE 8      // doubles per slot line
 #define BA_UREP 8             // replicas of the camera-side accumulators (U, gc, rhs): workgroup w adds
                               // into replica w % 8, K7 folds them; cuts same-line atomic traffic 8x
+#define BA_DBG_WORDS 96
 #define BA_MAX_LDS_N 126      // largest reduced system kept in LDS by K7
 #define BA_DEFAULT_SREP 1      // replicas of S on the local-window path (BaBufs::srep)
-#define BA_DEFAULT_SETS 3      // default number of speculative radii per round on the local-window path
-#define BA_MAXSETS 3          // speculative trust-region radii evaluated per round (see "Speculative radii" below)
+#define BA_DEFAULT_SETS (BA_MAXSETS < 5 ? BA_MAXSETS : 5)      // default number of speculative radii a round MAY evaluate on the local-window path (ba_round_sets below)
+#define BA_CALIBRATED_SETS 3   // ... once the trust-region radius is calibrated
+#ifndef BA_MAXSETS
+#define BA_MAXSETS 5          // speculative trust-region radii evaluated per round (see "Speculative radii" below)
+#endif
 
 struct BaState {
     double radius, decrease_factor, x_cost, initial_cost;
@@ -32,6 +36,9 @@ struct BaState {
     int nact;                 // sets evaluated by THIS round (1 .. ns)
     int n_rounds, n_fresh, n_sets;        // accounting: rounds that did work, of those relinearised, sets evaluated
     int hand_lost;                        // set by ba_finalize: a consumer of the fused K7 + K8 launch gave up waiting (the host re-runs the solve)
+    int calibrated;                       // 0: no step rejected yet, 1: inside an unresolved rejection streak, 2: an accepted step has
+                                          // followed a rejected one (the radius has found the problem's scale) — ba_decide
+    int pad_[3];
 };
 
 // Speculative radii.  After a REJECTED step Ceres does not relinearise: x stays, the radius becomes
@@ -129,7 +136,7 @@ struct BaBufs {
     BaSetOut* set_out;            // [ns] K7 results of sets >= 1, THIS round
     const BaSetOut* set_prev;     // the previous round's
     BaProgress* prog;             // pinned host memory (null when the caller does not poll)
-    unsigned long long* dbg;   // [64] in-kernel phase cycle counters (diagnostic; rs_prof_counters)
+    unsigned long long* dbg;   // [BA_DBG_WORDS]: in-kernel phase counters in [0, 64) (diagnostic; rs_prof_counters), hand-off words behind them
     unsigned long long hand_timeout;   // fused K7 + K8 launch: ticks of the 100 MHz wall clock a consumer waits for a hand-off word
     BaTrace* trace;          // [max_iter] per-iteration record (rs_ba_get_trace)
     BaState* st;             // state of THIS iteration (st[it & 1])
@@ -401,39 +408,71 @@ __device__ __forceinline__ double slot_max_bits(const double* base)
 __device__ __forceinline__ void ba_decide(const BaBufs& b, const BaOpt& opt, int it, BaTrace* trace, BaState* out,
                                           bool count_round = true)
 {
+    // K8's partial sums of the previous round, one slot line per lane: ALL loads go out first (clamped addresses, no
+    // branches), then the wave reductions.  The sums were made by memory-side atomics, so every load is a ~1 us trip; issued
+    // set by set behind `if (k < ns)` they were three (now five) round trips in a row and most of the round's decision.
     double ps[BA_MAXSETS][4];
+    {
+        const int lane = threadIdx.x & 63;
+        double raw[BA_MAXSETS][4];
 #pragma unroll
-    for (int k = 0; k < BA_MAXSETS; k++) {
+        for (int k = 0; k < BA_MAXSETS; k++) {
+            const double* base = b.pt_prev + ((size_t)min(k, b.ns - 1) * BA_NSLOT + lane) * BA_SLOT_STRIDE;
 #pragma unroll
-        for (int f = 0; f < 4; f++) ps[k][f] = 0.0;
-        if (it > 0 && k < b.ns) {
-            const double* base = b.pt_prev + (size_t)k * BA_NSLOT * BA_SLOT_STRIDE;
+            for (int f = 0; f < 4; f++) raw[k][f] = it > 0 ? base[f] : 0.0;
+        }
 #pragma unroll
-            for (int f = 0; f < 4; f++) ps[k][f] = slot_sum(base, f);
+        for (int k = 0; k < BA_MAXSETS; k++) {
+#pragma unroll
+            for (int f = 0; f < 4; f++) ps[k][f] = 0.0;
+            if (it > 0 && k < b.ns) {
+#pragma unroll
+                for (int f = 0; f < 4; f++) ps[k][f] = wave_sum(raw[k][f]);
+            }
         }
     }
+    // the walk over the sets is a ROLLED loop (one copy of the decision's code — divisions, square roots — instead of one per
+    // set: the kernels that start with it load that code cold): lane 0 parks the sums in LDS and indexes them by set
+    __shared__ double ps_sh[BA_MAXSETS][4];
     if (threadIdx.x == 0) {
+#pragma unroll
+        for (int k = 0; k < BA_MAXSETS; k++)
+#pragma unroll
+            for (int f = 0; f < 4; f++) ps_sh[k][f] = ps[k][f];
         BaState s = *b.st_prev;
         if (it > 0) {
             const int nb = b.ns + 1;
             const int nact_prev = s.nact;
-#pragma unroll
-            for (int k = 0; k < BA_MAXSETS; k++) {
-                if (k >= nact_prev || s.done) break;
+            bool accepted = false;
+#pragma unroll 1
+            for (int k = 0; k < nact_prev && !s.done; k++) {
                 if (k > 0) {
                     const BaSetOut so = b.set_prev[k];
 #pragma unroll
                     for (int q = 0; q < 4; q++) s.cam_scal[q] = so.cam_scal[q];
                     s.solver_failed = so.solver_failed;
                 }
-                ba_apply_decision(s, ps[k][0], ps[k][1], ps[k][2], ps[k][3], opt, trace);
-                if (s.fresh) { s.cur = (s.cur + 1 + k) % nb; break; }
+                const volatile double* pk = ps_sh[k];
+                ba_apply_decision(s, pk[0], pk[1], pk[2], pk[3], opt, trace);
+                if (s.fresh) {
+                    if (s.calibrated == 1) s.calibrated = 2;       // an accepted step has resolved a rejection streak
+                    s.cur = (s.cur + 1 + k) % nb;
+                    accepted = true;
+                    break;
+                }
+                if (s.calibrated == 0) s.calibrated = 1;           // first rejected / invalid step of the solve
             }
+            // a round whose every set was rejected: the streak is longer than the round was deep
+            if (!accepted && !s.done && s.calibrated == 2) s.calibrated = 1;
         }
-        // How many radii this round speculates on: the first step (initial radius 1e4: practically Gauss-Newton)
-        // and a step after two successful ones in a row are most likely accepted — extra sets would be wasted
-        // work in K5 — so those rounds evaluate one radius only.
-        s.nact = (it == 0 || s.consec_accepts >= 2) ? 1 : b.ns;
+        // How many radii this round speculates on.  The first step (initial radius 1e4: practically Gauss-Newton) and a
+        // step after two successful ones in a row are most likely accepted — extra sets would be wasted work in K5 — so
+        // those rounds evaluate one radius only.  Otherwise: while the radius is UNCALIBRATED (s.calibrated < 2) — it still is
+        // Ceres' arbitrary initial 1e4 times the growth of the first accepted steps, no rejection streak has been resolved by
+        // an accepted step yet, or the last round was rejected to its last set — a streak can be long (the radius shrinks by
+        // 2, 8, 64, 1024 ...), and the round evaluates every set it has (5 by default); once calibrated, streaks are short
+        // and three sets cover them (the benchmark window's A RRRR A RR A A: rounds of 1, 5, 3, 3 sets instead of 1, 3, 3, 3, 3).
+        s.nact = (it == 0 || s.consec_accepts >= 2) ? 1 : (s.calibrated == 2 ? min(b.ns, BA_CALIBRATED_SETS) : b.ns);
         if (!s.done && count_round) { s.n_rounds++; s.n_fresh += s.fresh; s.n_sets += s.nact; }
         *out = s;
     }

@@ -36,7 +36,7 @@ static __device__ __forceinline__ void ba_init_body(const BaDims& d, const BaBuf
         s.iter = 0; s.successful = 0; s.invalid_steps = 0; s.done = 0;
         s.termination = 0; s.cur = 0; s.have_scale = 0; s.solver_failed = 0;
         s.fresh = 1; s.usable = 0; s.consec_accepts = 0; s.nact = 1;
-        s.n_rounds = 0; s.n_fresh = 0; s.n_sets = 0; s.hand_lost = 0;
+        s.n_rounds = 0; s.n_fresh = 0; s.n_sets = 0; s.hand_lost = 0; s.calibrated = 0; s.pad_[0] = s.pad_[1] = s.pad_[2] = 0;
         b.st[1] = s;      // the state iteration 0 starts from (st[(0 + 1) & 1])
     }
 }

@@ -451,7 +451,7 @@ size_t ba_schur_lds_bytes(int C, int Cf, int it_l)
 {
     (void)Cf;
     const size_t prep = C <= SCH_MAXC_LDS ? (size_t)C * BA_PREP_LDS : 0;
-    return sizeof(double) * ((size_t)sch_tile_doubles(it_l) + (size_t)SCH_UCAP * 42 + prep + 12 * IT_L) + sizeof(int) * 32;   // + Mt / Gt
+    return sizeof(double) * ((size_t)sch_tile_doubles(it_l) + (size_t)SCH_UCAP * 42 + prep + 6 * (BA_MAXSETS - 1) * IT_L) + sizeof(int) * 32;   // + Mt / Gt
 }
 
 int ba_prepare_schur(int C, int Cf)

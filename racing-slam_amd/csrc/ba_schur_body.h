@@ -168,10 +168,13 @@ __device__ __forceinline__ void syrk_scatter(const double* yt, int nchunks, int 
 // landmark: the A operand of every set is Y_0 as it stands, the B operand of set s is Y_0 G_s, formed on the fly from the
 // landmark's three tile columns.  One K loop feeds NS accumulator sets: the tile is read once, no transform pass, no
 // barrier between the sets, and the scatter's index arithmetic is shared.  Gt[s - 1][landmark][6] (xx xy xz yy yz zz).
-template <int NM, int NS, int STRIDE>
+// PLAIN: accumulator slot 0 is set 0 (B operand = Y_0 itself) and slots 1 .. NS - 1 go through Gt[0 .. NS - 2]; otherwise all NS
+// slots go through Gt[0 .. NS - 1] (the second pass of a round with more than three radii).
+template <int NM, int NS, bool PLAIN, int STRIDE>
 __device__ __forceinline__ void syrk_tiles_sets(const double* yt, const double* Gt, int it_l, int nchunks, const int* tr, const int* tc,
                                                 d4 (*acc)[3], int lr, int lk)
 {
+    constexpr int NG = PLAIN ? NS - 1 : NS;
     // column 4 kc + lk = 3 p + kk of the tile
     auto load = [&](int kc, double* a, double* bp, double (*yb)[3], double (*g)[3]) {
         const int col = 4 * kc + lk;
@@ -181,13 +184,13 @@ __device__ __forceinline__ void syrk_tiles_sets(const double* yt, const double* 
 #pragma unroll
         for (int t = 0; t < NM; t++) {
             a[t] = ca[16 * tr[t]];
-            bp[t] = ca[16 * tc[t]];                        // set 0's B operand (one more LDS read instead of a per-lane select)
+            if (PLAIN) bp[t] = ca[16 * tc[t]];             // set 0's B operand (one more LDS read instead of a per-lane select)
             yb[t][0] = c0[16 * tc[t]]; yb[t][1] = c0[STRIDE + 16 * tc[t]]; yb[t][2] = c0[2 * STRIDE + 16 * tc[t]];
         }
         // row kk of the symmetric G: (kk, 0) (kk, 1) (kk, 2) in xx xy xz yy yz zz order
         const int i0 = kk, i1 = kk == 0 ? 1 : (kk == 1 ? 3 : 4), i2 = kk == 0 ? 2 : (kk == 1 ? 4 : 5);
 #pragma unroll
-        for (int s = 0; s < NS - 1; s++) {
+        for (int s = 0; s < NG; s++) {
             const double* gp = Gt + ((size_t)s * it_l + p) * 6;
             g[s][0] = gp[i0]; g[s][1] = gp[i1]; g[s][2] = gp[i2];
         }
@@ -195,15 +198,15 @@ __device__ __forceinline__ void syrk_tiles_sets(const double* yt, const double* 
     auto mma = [&](const double* a, const double* bp, const double (*yb)[3], const double (*g)[3]) {
 #pragma unroll
         for (int t = 0; t < NM; t++) {
-            acc[t][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[t], bp[t], acc[t][0], 0, 0, 0);
+            if (PLAIN) acc[t][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[t], bp[t], acc[t][0], 0, 0, 0);
 #pragma unroll
-            for (int s = 0; s < NS - 1; s++) {
+            for (int s = 0; s < NG; s++) {
                 const double bs = fma(yb[t][2], g[s][2], fma(yb[t][1], g[s][1], yb[t][0] * g[s][0]));
-                acc[t][s + 1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[t], bs, acc[t][s + 1], 0, 0, 0);
+                acc[t][s + (PLAIN ? 1 : 0)] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[t], bs, acc[t][s + (PLAIN ? 1 : 0)], 0, 0, 0);
             }
         }
     };
-    double a0[NM], b0[NM], yb0[NM][3], g0[2][3], a1[NM], b1[NM], yb1[NM][3], g1[2][3];
+    double a0[NM], b0[NM], yb0[NM][3], g0[3][3], a1[NM], b1[NM], yb1[NM][3], g1[3][3];
     load(0, a0, b0, yb0, g0);
     for (int kc = 0; kc < nchunks; kc += 2) {
         load(min(kc + 1, nchunks - 1), a1, b1, yb1, g1);
@@ -213,7 +216,7 @@ __device__ __forceinline__ void syrk_tiles_sets(const double* yt, const double* 
     }
 }
 
-template <int NS, int STRIDE>
+template <int NS, bool PLAIN, int STRIDE>
 __device__ __forceinline__ void syrk_scatter_sets(const double* yt, const double* Gt, int it_l, int nchunks, int ns, const int* gslot, int n,
                                                   int wave, int nw, double* __restrict__ S0, double* __restrict__ rhs0)
 {
@@ -236,9 +239,9 @@ __device__ __forceinline__ void syrk_scatter_sets(const double* yt, const double
         if (tile < ntiles) { tile_rc(tile, nt_used, tr[t], tc[t]); nmine = t + 1; }
     }
     switch (nmine) {                          // wave-uniform
-    case 1: syrk_tiles_sets<1, NS, STRIDE>(yt, Gt, it_l, nchunks, tr, tc, acc, lr, lk); break;
-    case 2: syrk_tiles_sets<2, NS, STRIDE>(yt, Gt, it_l, nchunks, tr, tc, acc, lr, lk); break;
-    case 3: syrk_tiles_sets<3, NS, STRIDE>(yt, Gt, it_l, nchunks, tr, tc, acc, lr, lk); break;
+    case 1: syrk_tiles_sets<1, NS, PLAIN, STRIDE>(yt, Gt, it_l, nchunks, tr, tc, acc, lr, lk); break;
+    case 2: syrk_tiles_sets<2, NS, PLAIN, STRIDE>(yt, Gt, it_l, nchunks, tr, tc, acc, lr, lk); break;
+    case 3: syrk_tiles_sets<3, NS, PLAIN, STRIDE>(yt, Gt, it_l, nchunks, tr, tc, acc, lr, lk); break;
     default: break;
     }
     // C/D layout of v_mfma_f64_16x16x4_f64: col = lane & 15, row = (lane >> 4) + 4 * reg; one index computation per entry
@@ -518,59 +521,53 @@ static __device__ __forceinline__ void ba_schur_body(const BaDims& d, const BaBu
     int set_first = 0;
     // ---- several radii, compact 4x4-tile item: every set in ONE pass over the tile (syrk_tiles_sets above)
     if (K5_ALLSETS && st.nact > 1 && ns > 0 && ns <= 10) {
-        double Li0[6] = {0, 0, 0, 0, 0, 0}, L0[6] = {0, 0, 0, 0, 0, 0}, Iall[BA_MAXSETS][6], lamall[BA_MAXSETS][3];
-        bool okall[BA_MAXSETS];
-#pragma unroll
-        for (int set = 0; set < BA_MAXSETS; set++) {
-            okall[set] = false;
-#pragma unroll
-            for (int k = 0; k < 6; k++) Iall[set][k] = 0.0;
-#pragma unroll
-            for (int k = 0; k < 3; k++) lamall[set][k] = 0.0;
-            if (set >= st.nact || p < 0) continue;
+        double Li0[6] = {0, 0, 0, 0, 0, 0}, L0[6] = {0, 0, 0, 0, 0, 0};
+        // damped block of one set: damping, Cholesky, inverse; false when the block is not positive definite
+        auto damped = [&](int set, double lam[3], double Li[6], double I[6], double Lc[6]) -> bool {
             const double radius = ba_set_radius(st, set);
 #pragma unroll
             for (int k = 0; k < 3; k++) {
                 const double s2 = sp[k] * sp[k];
-                lamall[set][k] = clampd(s2 * Vd[k], opt.dmin, opt.dmax) / (radius * s2);
+                lam[k] = clampd(s2 * Vd[k], opt.dmin, opt.dmax) / (radius * s2);
             }
-            const double Vdm[6] = {V[0] + lamall[set][0], V[1], V[2], V[3] + lamall[set][1], V[4], V[5] + lamall[set][2]};
-            double Li[6], Lc[6];
-            okall[set] = chol3_inv(Vdm, Li, Iall[set], Lc);
-            if (!okall[set]) {
+            const double Vdm[6] = {V[0] + lam[0], V[1], V[2], V[3] + lam[1], V[4], V[5] + lam[2]};
+            const bool ok = chol3_inv(Vdm, Li, I, Lc);
+            if (!ok) {
 #pragma unroll
-                for (int k = 0; k < 6; k++) Iall[set][k] = 0.0;
+                for (int k = 0; k < 6; k++) { I[k] = 0.0; Li[k] = 0.0; Lc[k] = 0.0; }
             }
-            if (set == 0) {
-#pragma unroll
-                for (int k = 0; k < 6; k++) { Li0[k] = okall[0] ? Li[k] : 0.0; L0[k] = okall[0] ? Lc[k] : 0.0; }
-            }
-        }
+            return ok;
+        };
+        double lam0[3] = {0, 0, 0}, I0[6] = {0, 0, 0, 0, 0, 0};
+        bool ok0 = false;
+        if (p >= 0) ok0 = damped(0, lam0, Li0, I0, L0);
         // a landmark whose block is not positive definite at the FIRST radius has no Y_0 to derive the later sets from:
         // such an item (not seen on real windows) takes the set-by-set path below
-        if (__syncthreads_or((p >= 0 && !okall[0]) ? 1 : 0) == 0) {
-            if (p >= 0 && sub == 0) {
+        if (__syncthreads_or((p >= 0 && !ok0) ? 1 : 0) == 0) {
 #pragma unroll
-                for (int set = 0; set < BA_MAXSETS; set++) {
-                    if (set >= st.nact) continue;
-                    if (!okall[set]) {
+            for (int set = 0; set < BA_MAXSETS; set++) {
+                if (set >= st.nact) continue;
+                double lam[3] = {lam0[0], lam0[1], lam0[2]}, Li[6], I[6] = {I0[0], I0[1], I0[2], I0[3], I0[4], I0[5]}, Lc[6];
+                bool ok = ok0;
+                if (set > 0 && p >= 0) ok = damped(set, lam, Li, I, Lc);
+                if (set > 0 && p < 0) {
+#pragma unroll
+                    for (int k = 0; k < 6; k++) I[k] = 0.0;
+                }
+                if (p >= 0 && sub == 0) {
+                    if (!ok) {
 #pragma unroll
                         for (int k = 0; k < BA_MAXSETS; k++) fail[k] = (k == set) ? 1.0 : fail[k];
                     }
                     double* lamp_set = b.lamp + ((size_t)set * d.P + p) * 3;
                     double* vinv_set = b.Vinv + ((size_t)set * d.P + p) * 6;
 #pragma unroll
-                    for (int k = 0; k < 3; k++) lamp_set[k] = lamall[set][k];
+                    for (int k = 0; k < 3; k++) lamp_set[k] = lam[k];
 #pragma unroll
-                    for (int k = 0; k < 6; k++) vinv_set[k] = Iall[set][k];
+                    for (int k = 0; k < 6; k++) vinv_set[k] = I[k];
                 }
-            }
-            if (sub == 0 && wl < g.it_l) {
-                // G_s = L_0^T I_s L_0 (symmetric; L_0 lower: 00 10 11 20 21 22; I_s: xx xy xz yy yz zz); zero for an empty slot
-#pragma unroll
-                for (int set = 1; set < BA_MAXSETS; set++) {
-                    if (set >= st.nact) continue;
-                    const double I[6] = {Iall[set][0], Iall[set][1], Iall[set][2], Iall[set][3], Iall[set][4], Iall[set][5]};
+                if (set > 0 && sub == 0 && wl < g.it_l) {
+                    // G_s = L_0^T I_s L_0 (symmetric; L_0 lower: 00 10 11 20 21 22; I_s: xx xy xz yy yz zz); zero for an empty slot
                     // T = I L_0 (3x3): T[r][c] = sum_k I[r][k] L0[k][c]
                     const double T00 = I[0] * L0[0] + I[1] * L0[1] + I[2] * L0[3], T01 = I[1] * L0[2] + I[2] * L0[4], T02 = I[2] * L0[5];
                     const double T10 = I[1] * L0[0] + I[3] * L0[1] + I[4] * L0[3], T11 = I[3] * L0[2] + I[4] * L0[4], T12 = I[4] * L0[5];
@@ -585,10 +582,11 @@ static __device__ __forceinline__ void ba_schur_body(const BaDims& d, const BaBu
                     gt[5] = L0[5] * T22;
                 }
             }
+            const bool okall0 = ok0;
             // Y_0 into the tile (the first tile was zeroed at kernel start)
             const double t0 = Li0[0] * gv[0], t1 = Li0[1] * gv[0] + Li0[2] * gv[1], t2 = Li0[3] * gv[0] + Li0[4] * gv[1] + Li0[5] * gv[2];
             BA_STAMP(b, 2);
-            if (p >= 0 && okall[0] && wl < g.it_l) {
+            if (p >= 0 && okall0 && wl < g.it_l) {
                 for (int j = sub; j < nobs; j += SCH_SUBS) {
                     int cs = cs0;
                     float2 uvv = uv0;                          // round 0 is still in registers
@@ -624,8 +622,17 @@ static __device__ __forceinline__ void ba_schur_body(const BaDims& d, const BaBu
             {
                 const int nw = (int)(blockDim.x >> 6);
                 double* const S0 = b.S + (size_t)((unsigned)item % (unsigned)b.srep) * b.s_rep_stride;
-                if (st.nact == 2) syrk_scatter_sets<2, YT_STRIDE4>(yt, Mt, g.it_l, 3 * g.it_l / 4, ns, gslot, d.n, wave, nw, S0, rhs_rep);
-                else syrk_scatter_sets<3, YT_STRIDE4>(yt, Mt, g.it_l, 3 * g.it_l / 4, ns, gslot, d.n, wave, nw, S0, rhs_rep);
+                const int nch = 3 * g.it_l / 4;
+                // sets 0 .. 2 in one pass over the tile, sets 3 .. 4 (rounds that speculate deeper) in a second one
+                if (st.nact == 2) syrk_scatter_sets<2, true, YT_STRIDE4>(yt, Mt, g.it_l, nch, ns, gslot, d.n, wave, nw, S0, rhs_rep);
+                else syrk_scatter_sets<3, true, YT_STRIDE4>(yt, Mt, g.it_l, nch, ns, gslot, d.n, wave, nw, S0, rhs_rep);
+                if (st.nact > 3) {
+                    const double* Gt2 = Mt + (size_t)2 * g.it_l * 6;                     // G of sets 3, 4
+                    double* const S3 = S0 + (size_t)3 * d.n * d.n;
+                    double* const rhs3 = rhs_rep + (size_t)3 * d.n;
+                    if (st.nact == 4) syrk_scatter_sets<1, false, YT_STRIDE4>(yt, Gt2, g.it_l, nch, ns, gslot, d.n, wave, nw, S3, rhs3);
+                    else syrk_scatter_sets<2, false, YT_STRIDE4>(yt, Gt2, g.it_l, nch, ns, gslot, d.n, wave, nw, S3, rhs3);
+                }
             }
             set_first = st.nact;                               // nothing left for the set-by-set loop
         }

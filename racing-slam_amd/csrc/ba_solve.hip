@@ -60,10 +60,15 @@ size_t ba_reduced_solve_lds_bytes(int n)
     return sizeof(double) * ((size_t)(n + 1) * LD + 2 * (size_t)n + 6 * (size_t)n + 6 * (size_t)n + 3 * (size_t)n + 8 + 2 * 8 * 128);
 }
 
+// workgroups of the fused launch that must be resident AT ONCE: the K7 workgroups of every set (producers: dispatched first,
+// they never wait) and the K8 workgroups of the sets a calibrated round evaluates (<= 3).  A deeper round (up to 5 sets, once or
+// twice per solve) runs its last sets' K8 workgroups in a second shift behind the hand-off, which is published by then; the
+// workgroups of sets the round does not evaluate return as soon as the accumulators are cleared.
 int ba_solve_backsub_workgroups(const BaDims& d, const BaBufs& b)
 {
     const int per = K7_THREADS / 4;
-    return b.ns * (1 + (d.P + per - 1) / per);
+    const int resident_sets = b.ns < BA_CALIBRATED_SETS ? b.ns : BA_CALIBRATED_SETS;
+    return b.ns + resident_sets * ((d.P + per - 1) / per);
 }
 
 void ba_launch_solve_backsub(hipStream_t s, const BaDims& d, const BaBufs& b, const BaOpt& opt)

@@ -118,11 +118,12 @@ extern "C" int rs_context_fork(rs_context* ctx, rs_context* const* others, int n
     return RS_OK;
 }
 
+#define BA_MAXSETS_KNOB 5        /* = BA_MAXSETS (ba_common.h) */
 extern "C" int rs_context_set_int(rs_context* ctx, const char* name, int value)
 {
     if (!ctx || !name) return RS_ERR_INVALID;
     if (strcmp(name, "ba_speculative_sets") == 0) {
-        if (value < 0 || value > 3) return rs_fail(ctx, RS_ERR_INVALID, "ba_speculative_sets must be 0 (default) .. 3");
+        if (value < 0 || value > BA_MAXSETS_KNOB) return rs_fail(ctx, RS_ERR_INVALID, "ba_speculative_sets must be 0 (default) .. 5");
         ctx->ba_sets = value;
         return RS_OK;
     }

@@ -610,24 +610,28 @@ def test_bundle_adjust_cfg3_trace(ctx, oracle, synth):
                                 dict(n_kf=5, n_points=100, run_max=5, config_id=48, outlier_frac=0.15, rot_noise_deg=1.0),
                                 dict(n_kf=12, n_points=3000, run_max=8, config_id=19, outlier_frac=0.06)])
 def test_bundle_adjust_speculative_radii_do_not_change_the_schedule(ctx, rs, oracle, synth, kw):
-    """Speculative radii (1, 2 or 3 trust-region radii evaluated per round) only change how many
-    launches a solve takes: per-iteration outcomes, radii, costs and the result are those of the sequential loop
-    (ns = 1) and of the oracle, whatever the accept / reject pattern (cfg 3: A R R R R A R R A A)."""
+    """Speculative radii (1 .. 5 trust-region radii evaluated per round; 0 = the default: up to 5 while the radius
+    is uncalibrated, 3 afterwards) only change how many launches a solve takes: per-iteration outcomes, radii, costs and the
+    result are those of the sequential loop (ns = 1) and of the oracle, whatever the accept / reject pattern
+    (cfg 3: A R R R R A R R A A)."""
     w = synth.make_ba_window(**kw)
     args = (w["cam_free"],)
     runs = {}
     try:
-        for ns in (1, 2, 3):
+        for ns in (1, 2, 3, 4, 5, 0):
             ctx.set_int("ba_speculative_sets", ns)
             dc, dp = ctx.dev(w["cams"]), ctx.dev(w["points"])
             s = ctx.bundle_adjust(dc, w["cam_free"], dp, ctx.dev(w["obs_ptr"]), ctx.dev(w["obs_cam"]), ctx.dev(w["obs_uv"]), w["K"])
-            runs[ns] = (s, ctx.ba_trace(), to_np(dc), to_np(dp))
+            runs[ns] = (s, ctx.ba_trace(), to_np(dc), to_np(dp), ctx.ba_stats())
     finally:
         ctx.set_int("ba_speculative_sets", 0)
     _, _, os_, otr = oracle.bundle_adjust_trace(w["cams"], w["cam_free"], w["points"], w["obs_ptr"], w["obs_cam"], w["obs_uv"], w["K"])
-    s1, t1, c1, p1 = runs[1]
-    for ns in (1, 2, 3):
-        s, tr, c, p = runs[ns]
+    s1, t1, c1, p1, _ = runs[1]
+    if not kw:      # the benchmark window: rounds of 1, 5, 3, 3 radii by default (five while the radius is uncalibrated)
+        assert (runs[0][4]["rounds"], runs[0][4]["set_evaluations"]) == (4, 12), runs[0][4]
+        assert (runs[3][4]["rounds"], runs[3][4]["set_evaluations"]) == (5, 13), runs[3][4]
+    for ns in (1, 2, 3, 4, 5, 0):
+        s, tr, c, p, _ = runs[ns]
         assert (s["iterations"], s["successful_steps"], s["termination"], s["usable"]) == \
                (os_["iterations"], os_["successful_steps"], os_["termination"], os_["usable"]), ns
         assert [t["outcome"] for t in tr] == [t["outcome"] for t in otr], ns

@@ -196,6 +196,7 @@ def test_bundle_adjust_round_in_one_launch(ctx, oracle, synth, kw):
     runs = []
     retries_before = ctx.ba_stats()["handoff_retries"]
     try:
+        ctx.set_int("ba_speculative_sets", 3)       # (the one-launch round is built for up to three radii per round)
         for mode in (1,) + (3,) * 12:
             ctx.set_int("ba_fuse_mode", mode)
             dc, dp = ctx.dev(w["cams"]), ctx.dev(w["points"])
@@ -205,6 +206,7 @@ def test_bundle_adjust_round_in_one_launch(ctx, oracle, synth, kw):
             runs.append((s, ctx.ba_trace(), to_np(dc), to_np(dp), prof))
     finally:
         ctx.set_int("ba_fuse_mode", 0)
+        ctx.set_int("ba_speculative_sets", 0)
     assert "K578_ba_round" in runs[1][4] and "K5_ba_schur_mfma" not in runs[1][4]
     assert "K578_ba_round" not in runs[0][4]
     s1, t1, c1, p1, _ = runs[0]
