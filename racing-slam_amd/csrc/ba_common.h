@@ -473,6 +473,8 @@ __device__ __forceinline__ void ba_decide(const BaBufs& b, const BaOpt& opt, int
         // 2, 8, 64, 1024 ...), and the round evaluates every set it has (5 by default); once calibrated, streaks are short
         // and three sets cover them (the benchmark window's A RRRR A RR A A: rounds of 1, 5, 3, 3 sets instead of 1, 3, 3, 3, 3).
         s.nact = (it == 0 || s.consec_accepts >= 2) ? 1 : (s.calibrated == 2 ? min(b.ns, BA_CALIBRATED_SETS) : b.ns);
+        // never more sets than iterations the solve has left (its last round has often one: the benchmark window's fourth)
+        s.nact = max(1, min(s.nact, opt.max_iter - s.iter));
         if (!s.done && count_round) { s.n_rounds++; s.n_fresh += s.fresh; s.n_sets += s.nact; }
         *out = s;
     }
