@@ -1160,7 +1160,7 @@ static int ba_solve_batch_grid(rs_context* ctx, int B, const rs_ba_problem* Q, c
         ba_group_set_items(&w.g, d.P, true, ctx->ba_batch_item);
         b.obs_cs = w.g.obs_cs;
         max_items = std::max(max_items, w.g.n_items);
-        k5_lds = std::max(k5_lds, ba_schur_lds_bytes(d.C, d.Cf, w.g.it_l));
+        k5_lds = std::max(k5_lds, ba_schur_lds_bytes(d.C, d.Cf, w.g.it_l, ns));
         w.st_base = b.st; w.pts_base = b.pt_scal; w.set_base = b.set_out; w.pts_block = L.pts_block;
         char* hp = pin + pin_off[(size_t)i];
         w.h_st = (BaState*)hp;

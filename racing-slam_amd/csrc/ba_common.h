@@ -601,7 +601,7 @@ int ba_launch_grouping(rs_context* ctx, const BaDims& d, const BaBufs& b, const 
 bool ba_setup_fusable(const BaDims& d, const BaGroup& g);
 void ba_launch_setup_fused(rs_context* ctx, const BaDims& d, const BaBufs& b, const BaOpt& opt, const BaGroup& g, const double* cams_in,
                            const double* pts_in, unsigned long long free_mask, int from_mask, uint8_t* cam_free);
-size_t ba_schur_lds_bytes(int C, int Cf, int it_l = 64);
+size_t ba_schur_lds_bytes(int C, int Cf, int it_l = 64, int ns = BA_MAXSETS);   // ns: speculative sets of the solve (sizes the G tables)
 int ba_prepare_schur(int C, int Cf);
 void ba_launch_schur(hipStream_t s, const BaDims& d, const BaBufs& b, const BaOpt& opt, const BaGroup& g, int it);
 // ---- blocked reduced solve for n > BA_MAX_LDS_N (ba_solve_big.hip)

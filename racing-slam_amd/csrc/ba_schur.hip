@@ -447,11 +447,15 @@ void ba_launch_setup_fused(rs_context* ctx, const BaDims& d, const BaBufs& b, co
     }
 }
 
-size_t ba_schur_lds_bytes(int C, int Cf, int it_l)
+size_t ba_schur_lds_bytes(int C, int Cf, int it_l, int ns)
 {
     (void)Cf;
     const size_t prep = C <= SCH_MAXC_LDS ? (size_t)C * BA_PREP_LDS : 0;
-    return sizeof(double) * ((size_t)sch_tile_doubles(it_l) + (size_t)SCH_UCAP * 42 + prep + 6 * (BA_MAXSETS - 1) * IT_L) + sizeof(int) * 32;   // + Mt / Gt
+    // behind the slot table: Mt [it_l][6] (set-by-set path) or Gt [ns - 1][it_l][6] (all sets in one pass) — sized by the
+    // item and the solve, not by their maxima: throughput mode runs TWO workgroups of 32-landmark items per compute unit
+    // and has 160 KB for both
+    const size_t gt = 6 * (size_t)(ns > 2 ? ns - 1 : 1) * (size_t)it_l;
+    return sizeof(double) * ((size_t)sch_tile_doubles(it_l) + (size_t)SCH_UCAP * 42 + prep + gt) + sizeof(int) * 32;
 }
 
 int ba_prepare_schur(int C, int Cf)
@@ -463,9 +467,9 @@ int ba_prepare_schur(int C, int Cf)
 void ba_launch_schur(hipStream_t s, const BaDims& d, const BaBufs& b, const BaOpt& opt, const BaGroup& g, int it)
 {
     if (d.C <= SCH_MAXC_LDS)
-        hipLaunchKernelGGL(ba_schur_mfma, dim3(g.n_items), dim3(8 * g.it_l), ba_schur_lds_bytes(d.C, d.Cf, g.it_l), s, d, b, opt, g, it);
+        hipLaunchKernelGGL(ba_schur_mfma, dim3(g.n_items), dim3(8 * g.it_l), ba_schur_lds_bytes(d.C, d.Cf, g.it_l, b.ns), s, d, b, opt, g, it);
     else
-        hipLaunchKernelGGL(ba_schur_mfma_big, dim3(g.n_items), dim3(8 * g.it_l), ba_schur_lds_bytes(d.C, d.Cf, g.it_l), s, d, b, opt, g, it);
+        hipLaunchKernelGGL(ba_schur_mfma_big, dim3(g.n_items), dim3(8 * g.it_l), ba_schur_lds_bytes(d.C, d.Cf, g.it_l, b.ns), s, d, b, opt, g, it);
 }
 
 void ba_launch_decide(hipStream_t s, const BaBufs& b, const BaOpt& opt, int it)
