@@ -76,9 +76,12 @@ int rs_context_wait_for(rs_context* ctx, rs_context* const* others, int n);
 /* The other direction with ONE event: everything enqueued on each of `others` after this call waits for everything
  * enqueued so far on `ctx` (the fork in front of side-by-side chains). */
 int rs_context_fork(rs_context* ctx, rs_context* const* others, int n);
-/* Tuning knobs (integers by name).  "ba_speculative_sets": 1 .. 3 trust-region radii evaluated per round of
- * rs_bundle_adjust on the local-window path (0 = library default); the LM schedule, iteration count and
- * results do not depend on it (tests/test_gpu_parity.py), only the number of launches does.
+/* Tuning knobs (integers by name).  "ba_speculative_sets": at most 1 .. 5 trust-region radii evaluated per round of
+ * rs_bundle_adjust on the local-window path (0 = library default: 5; inertial solves and batches of windows: 3).  A round
+ * evaluates one radius where a step is most likely accepted (first round, after two accepted steps in a row), all of them
+ * while the trust region is uncalibrated (no rejection streak resolved by an accepted step yet, or the last round rejected
+ * to its last set), three once it is, and never more than the iterations left.  The LM schedule, iteration count and results
+ * do not depend on any of this (tests/test_gpu_parity.py), only the number of launches does.  "ba_fuse_mode" 3 needs <= 3.
  * "ba_imu_mode": rs_bundle_adjust_inertial — 0 (default) the velocity / bias blocks are eliminated around the
  * local-window reduced solve where the window allows it, 1 always the blocked solve of the full camera-side system.
  * "ba_fuse_mode": rs_bundle_adjust on a single local window (vision only, one rank) — the reduced solve and the
