@@ -23,7 +23,8 @@
 // issues a vector instruction every ~6 cycles whether or not it depends on the one before (f64 fma 6.0 dependent, 5.5
 // independent; v_rcp_f64 26; a double through v_readlane 48; dependent ds_read 60), and two waves on one SIMD each keep that
 // rate — the chain is bound by the instruction COUNT per wave, so the step's row work is split over two waves and nothing
-// is computed or moved twice.  K7_V2 0 (default) is round 1's two-barrier form.
+// is computed or moved twice.  K7_V2 2: the same without ANY workgroup barrier inside the loop — progress words in LDS between
+// the chain waves and the tile waves (every spin bounded).  K7_V2 0 (default) is round 1's two-barrier form.
 #ifndef K7_V2
 #define K7_V2 0
 #endif
@@ -315,10 +316,26 @@ static __device__ __forceinline__ void ba_reduced_solve_lds_body(const BaDims& d
     //   tile waves: rank-6 trailing update of step J - 1 with operands read from the factor panel A (columns of step J - 1,
     //               written one interval earlier) and dd[(J - 1) & 1], then publish block column J + 1 raw
     // Nothing is read in the interval in which it is written except by the wave that wrote it.
-    double* const Dg = Pd;                 // [6][6] final diagonal block of this step (rows written by the lanes that own them)
-    double* const Pds = Pd + 64;           // [6][6] Pds[e * 6 + k] = F[r0 + k][e] d_e of the step before
-    double* const ddv = Pd + 128;          // [2][8] pivots of step J in ddv[(J & 1) * 8 + e]; entries 6, 7 stay zero
-    volatile int* const dflag = (volatile int*)(Pd + 160);   // [2] dflag[w] = J + 1: chain wave w has written its rows of block J
+#if K7_V2 == 2
+    // barrier-free form: the two chain waves may be a step apart, so the scratch blocks are three deep (step J uses J % 3)
+#define K7_RING(J_) ((J_) % 3)
+#else
+#define K7_RING(J_) 0
+#endif
+    double* const Dg0 = Pd;                // [3][36] final diagonal block of a step (rows written by the lanes that own them)
+    double* const Pds0 = Pd + 108;         // [3][36] Pds[e * 6 + k] = F[r0 + k][e] d_e of a step, read by the fix-up of the next
+    double* const ddv = Pd + 216;          // [2][8] pivots of step J in ddv[(J & 1) * 8 + e]; entries 6, 7 stay zero
+    volatile int* const dflag = (volatile int*)(Pd + 232);   // [2] dflag[w] = J + 1: chain wave w has written its rows of block J
+    volatile int* const cflag = dflag + 2;                   // [2] cflag[w] = J + 1: chain wave w has finished step J (panel in A, pivots)
+    volatile int* const tflag = dflag + 4;                   // [6] tflag[t] = J + 1: tile wave t has published block column J + 1
+    // bounded spin on a word in LDS (the barrier-free form): a wave that gives up marks the solve failed and goes on
+    auto wait_for = [&](volatile int* word, int want) {
+        int spins = 0;
+        while (*word < want) {
+            if (++spins > (1 << 20)) { s_fail = 1; break; }
+            __builtin_amdgcn_s_sleep(1);                   // (back-to-back polls of eight waves starve the LDS pipe the chain needs)
+        }
+    };
     if (chain) {
         BA_STAMP(b, 1);
         const int sl = wave >> 2;                          // this wave's rows: 64 sl + lane
@@ -342,16 +359,37 @@ static __device__ __forceinline__ void ba_reduced_solve_lds_body(const BaDims& d
 #endif
         for (int J = 0; J < NB; J++) {
             const int c0 = 6 * J, r0 = c0 + 6;
+            double* const Dg = Dg0 + 36 * K7_RING(J);
+            double* const Pds = Pds0 + 36 * K7_RING(J);
+            const double* const Pdp = Pds0 + 36 * K7_RING(J + 2);           // the step before (J - 1 = J + 2 mod 3)
             if (64 * sl + 63 < c0 || 64 * sl > n) {        // none of this wave's rows is left (or it never had any)
+#if K7_V2 == 2
+                if (lane == 0) cflag[sl] = NB + 1;         // nobody waits for this wave any more
+                break;
+#else
                 __syncthreads();
                 continue;
+#endif
             }
+#if K7_V2 == 2
+            {
+                // block column J is published (every tile wave has finished its step J - 1); the other chain wave is at most
+                // one step behind (the scratch rings are three deep) and, where it owns rows of block J, has finished step J - 1
+                // (its part of Pds)
+                const int other = sl ^ 1;
+#pragma unroll
+                for (int t = 0; t < K7_NTW; t++) wait_for(tflag + t, J);
+                const bool other_owns = (c0 >> 6) == other || ((c0 + 5) >> 6) == other;
+                wait_for(cflag + other, other_owns ? J : J - 1);
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            }
+#endif
             double x[6];
 #pragma unroll
             for (int k = 0; k < 6; k++) x[k] = A[ic * LD + c0 + k];
             if (J > 0) {
                 // step J - 1's update of block column J: A[i][c0 + k] -= sum_e F_i[e] d_e F[c0 + k][e]
-                const double2* g2 = reinterpret_cast<const double2*>(Pds);
+                const double2* g2 = reinterpret_cast<const double2*>(Pdp);
 #pragma unroll
                 for (int e = 0; e < 6; e++) {
                     const double2 g01 = g2[3 * e], g23 = g2[3 * e + 1], g45 = g2[3 * e + 2];
@@ -445,9 +483,18 @@ static __device__ __forceinline__ void ba_reduced_solve_lds_body(const BaDims& d
             for (int e = 0; e < 6; e++) Fp[e] = F[e];
             if (lane == 0 && fbad) s_fail = 1;
             K7_CSTAMP(4);
+#if K7_V2 == 2
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_s_waitcnt(0xc07f);                            // lgkmcnt(0): panel, Pds and pivots are in LDS
+            if (lane == 0) cflag[sl] = J + 1;
+#else
             __syncthreads();                                               // barrier J
+#endif
             K7_CSTAMP(5);
         }
+#if K7_V2 == 2
+        if (lane == 0 && cflag[sl] < NB) cflag[sl] = NB + 1;               // (left the loop after the last step)
+#endif
 #if RS_STAMPS >= 2
         if (tid == 0 && blockIdx.x == 0) { for (int q = 0; q < 6; q++) b.dbg[16 + q] += cs_[q]; }
 #endif
@@ -517,6 +564,11 @@ static __device__ __forceinline__ void ba_reduced_solve_lds_body(const BaDims& d
         for (int J = 0; J < NB; J++) {
             const int c0 = 6 * J, r0 = c0 + 6;
             if (J > 0) {
+#if K7_V2 == 2
+                wait_for(cflag + 0, J);                                    // both chain waves have finished step J - 1
+                wait_for(cflag + 1, J);
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#endif
                 // trailing update of step J - 1; live region: columns >= c0.  No row masks: rows that are already factored
                 // only put garbage into accumulator entries that are never read again.
                 const int cm = c0 - 6;
@@ -543,7 +595,13 @@ static __device__ __forceinline__ void ba_reduced_solve_lds_body(const BaDims& d
                         if (pmask[s] >> q & 1) A[paddr[s] + q * LD4] = acc[s][q];
                 }
             }
+#if K7_V2 == 2
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_s_waitcnt(0xc07f);                            // lgkmcnt(0): the column is in LDS
+            if (lane == 0) tflag[tw] = J + 1;
+#else
             __syncthreads();                                               // barrier J
+#endif
         }
     }
 #else
