@@ -49,3 +49,13 @@ def test_default_options_match_oracle(rs, oracle):
     a, b = rs.default_options(), oracle.default_options()
     for name, _ in a._fields_:
         assert getattr(a, name) == getattr(b, name), name
+
+
+def test_bench_metric_is_baseline_json_s_string():
+    """The line bench.py prints must carry BASELINE.json's metric character for character (the driver matches on it)."""
+    import json
+    import bench
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with open(os.path.join(root, "BASELINE.json"), encoding="utf-8") as f:
+        assert bench.METRIC == json.load(f)["metric"]
+    assert bench.visible_gpu_count() >= 0        # sysfs / environment only: no HIP call
