@@ -179,3 +179,34 @@ def test_sharded_bundle_adjust_keeps_the_fused_solve_launch(rs, synth, bounds):
         assert ("K78_ba_solve_backsub" in out[r][4]) == (hi > lo), (r, sorted(out[r][4]))
         assert out[r][5]["handoff_retries"] == out[0][5]["handoff_retries"]      # a lost hand-off is re-run by EVERY rank or by none
     _check_shards(ref, out, shards, 1e-9)
+
+
+@pytest.mark.parametrize("kw", [dict(n_kf=10, n_points=1500, run_max=7, config_id=201, outlier_frac=0.15, rot_noise_deg=3.0),
+                                dict(n_kf=14, n_points=2500, run_max=9, config_id=202, outlier_frac=0.02, rot_noise_deg=0.2, pixel_noise=0.3),
+                                dict(n_kf=7, n_points=600, run_max=5, config_id=203, outlier_frac=0.25, rot_noise_deg=4.0),
+                                dict(n_kf=20, n_points=6000, config_id=204, outlier_frac=0.08, rot_noise_deg=1.5),
+                                dict(n_kf=9, n_points=1200, run_max=6, config_id=205, outlier_frac=0.0, rot_noise_deg=0.1, pixel_noise=0.2),
+                                dict(n_kf=16, n_points=4000, run_max=10, config_id=206, outlier_frac=0.12, rot_noise_deg=2.5)])
+def test_speculation_depth_policy_keeps_the_schedule(ctx, oracle, synth, kw):
+    """Round 4's depth policy (one radius where a step is most likely accepted, five while the trust region is uncalibrated,
+    three afterwards, never more than the iterations left; csrc/ba_common.h, ba_decide) on windows with different accept /
+    reject patterns — long rejection streaks, clean convergence, early termination: the per-iteration record must be the
+    oracle's, and the rounds must be fewer than the iterations wherever a step was rejected."""
+    w = synth.make_ba_window(**kw)
+    _, _, os_, otr = oracle.bundle_adjust_trace(w["cams"], w["cam_free"], w["points"], w["obs_ptr"], w["obs_cam"], w["obs_uv"], w["K"])
+    rc, rp, _ = oracle.bundle_adjust(w["cams"], w["cam_free"], w["points"], w["obs_ptr"], w["obs_cam"], w["obs_uv"], w["K"])
+    dc, dp = ctx.dev(w["cams"]), ctx.dev(w["points"])
+    s = ctx.bundle_adjust(dc, w["cam_free"], dp, ctx.dev(w["obs_ptr"]), ctx.dev(w["obs_cam"]), ctx.dev(w["obs_uv"]), w["K"])
+    tr, st = ctx.ba_trace(), ctx.ba_stats()
+    assert (s["iterations"], s["successful_steps"], s["termination"], s["usable"]) == \
+           (os_["iterations"], os_["successful_steps"], os_["termination"], os_["usable"])
+    assert [t["outcome"] for t in tr] == [t["outcome"] for t in otr]
+    assert np.allclose([t["radius"] for t in tr], [t["radius"] for t in otr], rtol=1e-7)
+    assert np.allclose([t["cost"] for t in tr], [t["cost"] for t in otr], rtol=1e-8)
+    assert np.allclose(to_np(dc), rc, rtol=1e-6, atol=1e-8)
+    out = [t["outcome"] for t in otr]
+    # a rejected step FOLLOWED by another iteration shares its round with it (a rejection in the very last iteration has a
+    # round of its own: the cap "never more radii than iterations left")
+    shared = any(o in (0, -1) for o in out[:-1])
+    assert st["rounds"] <= s["iterations"] and (not shared or st["rounds"] < s["iterations"]), (st, out)
+    assert st["set_evaluations"] >= s["iterations"] - (1 if s["termination"] != 0 else 0)
