@@ -403,6 +403,9 @@ __global__ __launch_bounds__(BA_THREADS) void ba_backsub_cost(BaDims d, BaBufs b
 }
 
 // -------------------------------------------------------------------- finalize
+#ifndef BA_FINALIZE_WGS
+#define BA_FINALIZE_WGS 32
+#endif
 static __device__ __forceinline__ void ba_finalize_body(const BaDims& d, const BaBufs& b, const BaOpt& opt, int it, double* __restrict__ cams_out,
                                                         const uint8_t* __restrict__ cam_free, double* __restrict__ pts_out, BaState* host_st,
                                                         BaTrace* host_trace, double* __restrict__ host_cams, double* __restrict__ host_vb,
@@ -427,7 +430,7 @@ static __device__ __forceinline__ void ba_finalize_body(const BaDims& d, const B
         if (blockIdx.x == 0) {
             *b.st = st;
             *host_st = st;            // the summary goes straight into pinned host memory: no copy launch after the solve
-            __threadfence_system();
+            if (!host_done) __threadfence_system();      // (with a completion flag, the ONE fence in front of the flag covers it)
         }
     }
     __syncthreads();
@@ -987,7 +990,7 @@ static int ba_solve_once(rs_context* ctx, int n_cameras, int n_points, int n_obs
         b.set_prev = set_base + (size_t)((itf + 1) & 1) * BA_MAXSETS;
         b.prog = nullptr;
         h_prog->pad = 0;
-        hipLaunchKernelGGL(ba_finalize, dim3(32), dim3(256), 0, s, d, b, opt, itf, d_cameras, (const uint8_t*)d_cam_free, d_points, h_st, h_trace,
+        hipLaunchKernelGGL(ba_finalize, dim3(BA_FINALIZE_WGS), dim3(256), 0, s, d, b, opt, itf, d_cameras, (const uint8_t*)d_cam_free, d_points, h_st, h_trace,
                            (double*)((char*)pin + pin_cams), h_vb, &h_prog->pad, fused_setup ? zero_ptr : nullptr, fused_setup ? zero_n : 0);
         RS_HIP(ctx, hipGetLastError());
         if (fused_setup) { ctx->grp_zero_ptr = zero_ptr; ctx->grp_zero_n = zero_n; }      // stream-ordered in front of the next solve
