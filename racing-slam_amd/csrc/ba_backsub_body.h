@@ -46,29 +46,36 @@ __device__ __forceinline__ unsigned ba_hand_wait(const unsigned long long* hand,
 }
 
 #if RS_STAMPS
-#define K78_STAMP(b, i) do { if (threadIdx.x == 0 && (FUSED) && vb == 0 && set == 0) (b).dbg[32 + (i)] = wall_clock64(); } while (0)
+#define K78_STAMP(b, i) do { if (threadIdx.x == 0 && (FUSED) && vb == 0 && set0 == 0 && pass == 0) (b).dbg[32 + (i)] = wall_clock64(); } while (0)
 #else
 #define K78_STAMP(b, i) do { } while (0)
 #endif
 
 // FUSED = false: the K8 launch (blockIdx.x = landmark block of 64, blockIdx.y = set; K7 has finished).
-// FUSED = true: a consumer workgroup of ba_solve_backsub: landmark block `vb` of blockDim.x / 4 landmarks, set `set`.
+// FUSED = true: a consumer workgroup of ba_solve_backsub: landmark block `vb` of blockDim.x / 4 landmarks, sets `set0`,
+// `set0 + set_stride`, ... of the round's active ones (set_stride = 0: `set0` only).  The fused grid holds the workgroups of
+// BA_CALIBRATED_SETS sets, which are resident together; in a deeper round a workgroup evaluates its second radius with the
+// landmark records, the observations and the current cameras' blocks it already holds, instead of a second shift of
+// workgroups that would start from their own loads behind the hand-off.
 // All loads that do not depend on K7 are issued first; the accumulators are cleared once every active set's K7 has
 // taken them (BA_HAND_TAKEN); delta_c is read behind the set's BA_HAND word with L1-bypassing loads, and the candidate
 // cameras' blocks are formed here (K7 forms the same for the next round after it has published).
 template <bool FUSED>
 // st_in: the round's state where the caller holds it already (ba_round: the state block is being written by another
 // workgroup of the same launch); nullptr = read the state block.
-static __device__ __forceinline__ void ba_backsub_cost4_body(const BaDims& d, const BaBufs& b, const int vb, const int set,
+static __device__ __forceinline__ void ba_backsub_cost4_body(const BaDims& d, const BaBufs& b, const int vb, const int set0, const int set_stride,
                                                             const size_t wg_index, const size_t wg_count, const BaState* st_in = nullptr)
 {
+    static_assert(BA_MAXSETS <= 2 * BA_CALIBRATED_SETS, "a consumer workgroup holds V^-1 and the damping of at most two sets");
     extern __shared__ __attribute__((aligned(16))) double lds[];
     // ---- loads that depend on nothing but the landmark index go out first, together with the state block
     const int lane = threadIdx.x & 63, l = lane & 15, sub = lane >> 4;
     const int p = vb * (int)(blockDim.x >> 2) + (threadIdx.x >> 6) * 16 + l;
-    const bool valid = p < d.P;             // `set`: speculative radius evaluated by this workgroup (ba_common.h)
+    const bool valid = p < d.P;
+    int pass = 0;
+    const int set1 = set_stride > 0 && set0 + set_stride < b.ns ? set0 + set_stride : -1;     // second radius of a deep round
     int o0 = 0, nobs = 0;
-    double g[3] = {0, 0, 0}, I[6] = {0, 0, 0, 0, 0, 0}, lamp[3] = {0, 0, 0}, Xq[BA_MAXSETS + 1][3];
+    double g[3] = {0, 0, 0}, I[6] = {0, 0, 0, 0, 0, 0}, lamp[3] = {0, 0, 0}, I1[6] = {0, 0, 0, 0, 0, 0}, lamp1[3] = {0, 0, 0}, Xq[BA_MAXSETS + 1][3];
 #pragma unroll
     for (int q = 0; q <= BA_MAXSETS; q++) Xq[q][0] = Xq[q][1] = Xq[q][2] = 0.0;
     if (valid) {
@@ -77,7 +84,8 @@ static __device__ __forceinline__ void ba_backsub_cost4_body(const BaDims& d, co
 #pragma unroll
         for (int k = 0; k < 3; k++) {
             g[k] = b.gp[3 * (size_t)p + k];
-            lamp[k] = b.lamp[((size_t)set * d.P + p) * 3 + k];
+            lamp[k] = b.lamp[((size_t)set0 * d.P + p) * 3 + k];
+            if (set1 >= 0) lamp1[k] = b.lamp[((size_t)set1 * d.P + p) * 3 + k];
         }
         // x may live in any of the ns + 1 state buffers: all of them are fetched before the state block is known
 #pragma unroll
@@ -87,7 +95,10 @@ static __device__ __forceinline__ void ba_backsub_cost4_body(const BaDims& d, co
                 for (int k = 0; k < 3; k++) Xq[q][k] = b.Xp[((size_t)q * d.P + p) * 3 + k];
             }
 #pragma unroll
-        for (int k = 0; k < 6; k++) I[k] = b.Vinv[((size_t)set * d.P + p) * 6 + k];
+        for (int k = 0; k < 6; k++) {
+            I[k] = b.Vinv[((size_t)set0 * d.P + p) * 6 + k];
+            if (set1 >= 0) I1[k] = b.Vinv[((size_t)set1 * d.P + p) * 6 + k];
+        }
     }
     K78_STAMP(b, 0);
     const BaState st = st_in ? *st_in : *b.st;
@@ -102,9 +113,9 @@ static __device__ __forceinline__ void ba_backsub_cost4_body(const BaDims& d, co
     };
     __shared__ unsigned hand_code[BA_MAXSETS];
     if (!FUSED) {
-        const int set_failed = set == 0 ? st.solver_failed : b.set_out[set].solver_failed;
+        const int set_failed = set0 == 0 ? st.solver_failed : b.set_out[set0].solver_failed;
         clear_accumulators();
-        if (set_failed || set >= st.nact) return;
+        if (set_failed || set0 >= st.nact) return;
     } else {
         // every active set's K7 has taken the accumulators: clear them now, under the factorisation
         if ((int)threadIdx.x < st.nact) hand_code[threadIdx.x] = ba_hand_wait(b.dbg + BA_HAND_TAKEN, (int)threadIdx.x, (unsigned)st.n_rounds, b.hand_timeout);
@@ -114,17 +125,17 @@ static __device__ __forceinline__ void ba_backsub_cost4_body(const BaDims& d, co
         if (lost) { if (threadIdx.x == 0) atomicAdd(b.dbg + BA_HAND_ERR, 1ull); return; }
         if (conv) return;                           // converged in K7's gradient test: the solve is over (st.done there)
         clear_accumulators();
-        if (set >= st.nact) return;
+        if (set0 >= st.nact) return;
         __syncthreads();                            // hand_code is reused below
     }
     double* cprep = lds;                                    // [C][BA_PREP_LDS] current
     double* cprepn = lds + (size_t)d.C * BA_PREP_LDS;       // [C][BA_PREP_LDS] candidate
     double* dcl = cprepn + (size_t)d.C * BA_PREP_LDS;       // [n] delta_c
+    double* xcl = dcl + d.n;                                // [C][6] current cameras    (fused only)
+    int* sll = (int*)(xcl + (size_t)d.C * 6);               // [C] slot map              (fused only)
     const double* gprep = b.prep + (size_t)st.cur * d.C * BA_PREP;
-    const int cand = (st.cur + 1 + set) % (b.ns + 1);        // this set's candidate buffer (written by K7)
-    double* gprepn = b.prep + (size_t)cand * d.C * BA_PREP;
-    // second round trip: K7's candidate camera blocks (prep[cur^1]) and the current ones -> LDS, and the
-    // first K8_PRE observations of every lane (12 per landmark; later rounds load on demand, inside the loops)
+    // second round trip: the current cameras' blocks -> LDS, and the first K8_PRE observations of every lane (12 per
+    // landmark; later rounds load on demand, inside the loops)
     int cs_pre[K8_PRE];
     float2 uv_pre[K8_PRE];
 #pragma unroll
@@ -138,43 +149,13 @@ static __device__ __forceinline__ void ba_backsub_cost4_body(const BaDims& d, co
             uv_pre[r] = b.obs_uv[oi];
         }
     }
-    if (!FUSED) {
-        for (int i = threadIdx.x; i < d.C * BA_PREP; i += blockDim.x) {
-            const int li = (i / BA_PREP) * BA_PREP_LDS + i % BA_PREP;
-            cprep[li] = gprep[i]; cprepn[li] = gprepn[i];
-        }
-        for (int i = threadIdx.x; i < d.n; i += blockDim.x) dcl[i] = b.dc[(size_t)set * BA_DC_STRIDE(d.n) + i];
-    } else {
+    for (int i = threadIdx.x; i < d.C * BA_PREP; i += blockDim.x) cprep[(i / BA_PREP) * BA_PREP_LDS + i % BA_PREP] = gprep[i];
+    if (FUSED) {
         // everything above is in flight while this set's K7 (workgroup `set` of the same launch) is still solving
-        double* xcl = dcl + d.n;                    // [C][6] current cameras
-        int* sll = (int*)(xcl + (size_t)d.C * 6);   // [C] slot map
-        for (int i = threadIdx.x; i < d.C * BA_PREP; i += blockDim.x) cprep[(i / BA_PREP) * BA_PREP_LDS + i % BA_PREP] = gprep[i];
         for (int i = threadIdx.x; i < d.C * 6; i += blockDim.x) xcl[i] = b.Xc[(size_t)st.cur * d.C * 6 + i];
         for (int i = threadIdx.x; i < d.C; i += blockDim.x) sll[i] = b.slot[i];
-        K78_STAMP(b, 1);
-        if (threadIdx.x == 0) hand_code[set] = ba_hand_wait(b.dbg + BA_HAND, set, (unsigned)st.n_rounds, b.hand_timeout);
-        K78_STAMP(b, 2);
-        __syncthreads();
-        const unsigned code = hand_code[set];
-        if (code == 4u) { if (threadIdx.x == 0) atomicAdd(b.dbg + BA_HAND_ERR, 1ull); return; }
-        if (code & 1u) return;                      // this set's solver failed
-        for (int i = threadIdx.x; i < d.n; i += blockDim.x) dcl[i] = ba_load_sc1(b.dc + (size_t)set * BA_DC_STRIDE(d.n) + i);
-        __syncthreads();
-        // the candidate's cameras and their blocks, exactly as K7's epilogue forms them for the next linearisation
-        for (int c = threadIdx.x; c < d.C; c += blockDim.x) {
-            const int s = sll[c];
-            double xn[6];
-#pragma unroll
-            for (int k = 0; k < 6; k++) xn[k] = s >= 0 ? xcl[6 * c + k] + dcl[6 * s + k] : xcl[6 * c + k];
-            cam_prepare(xn, cprepn + (size_t)c * BA_PREP_LDS);
-        }
     }
-    __syncthreads();
-    K78_STAMP(b, 3);
-    const double* prep = cprep;
-
-    double* Xn = b.Xp + (size_t)cand * d.P * 3;
-    double cost = 0.0, mcc = 0.0, ssq = 0.0, xsq = 0.0;
+    K78_STAMP(b, 1);
     double X[3];
 #pragma unroll
     for (int k = 0; k < 3; k++) {
@@ -183,63 +164,106 @@ static __device__ __forceinline__ void ba_backsub_cost4_body(const BaDims& d, co
         for (int q = 1; q <= BA_MAXSETS; q++) v = (st.cur == q) ? Xq[q][k] : v;
         X[k] = v;
     }
-    double t[3] = {0, 0, 0};
-    ObsLin o;
-    for (int j = sub, r = 0; j < nobs; j += 4, r++) {
-        int cs;
-        float2 uvv;
-        if (r < K8_PRE) { cs = r == 0 ? cs_pre[0] : r == 1 ? cs_pre[1] : cs_pre[2]; uvv = r == 0 ? uv_pre[0] : r == 1 ? uv_pre[1] : uv_pre[2]; }
-        else {
-            const int oi = o0 + j;
-            if (b.obs_cs) cs = b.obs_cs[oi];
-            else { const int c = b.obs_cam[oi]; cs = c | ((b.slot[c] + 1) << 16); }
-            uvv = b.obs_uv[oi];
+    const double* prep = cprep;
+    __shared__ double redw[K8_MAX_THREADS / 64][4];
+
+#pragma unroll 1
+    for (; pass < 2; pass++) {
+        const int set = pass ? set1 : set0;                     // the radius evaluated in this pass (ba_common.h)
+        if (set < 0 || set >= st.nact) break;
+        if (pass) {
+#pragma unroll
+            for (int k = 0; k < 6; k++) I[k] = I1[k];
+#pragma unroll
+            for (int k = 0; k < 3; k++) lamp[k] = lamp1[k];
+            __syncthreads();                                    // dcl, cprepn, hand_code and redw are reused
         }
-        const int c = cs & 0xFFFF, s = (cs >> 16) - 1;
-        if (s < 0) continue;
-        obs_eval<true>(prep + (size_t)c * BA_PREP_LDS, X, uvv, d, o);
-        double m0 = 0.0, m1 = 0.0;
+        const int cand = (st.cur + 1 + set) % (b.ns + 1);        // this set's candidate buffer (written by K7)
+        const double* gprepn = b.prep + (size_t)cand * d.C * BA_PREP;
+        if (!FUSED) {
+            // K7's candidate camera blocks and its delta_c
+            for (int i = threadIdx.x; i < d.C * BA_PREP; i += blockDim.x) cprepn[(i / BA_PREP) * BA_PREP_LDS + i % BA_PREP] = gprepn[i];
+            for (int i = threadIdx.x; i < d.n; i += blockDim.x) dcl[i] = b.dc[(size_t)set * BA_DC_STRIDE(d.n) + i];
+        } else {
+            if (threadIdx.x == 0) hand_code[set] = ba_hand_wait(b.dbg + BA_HAND, set, (unsigned)st.n_rounds, b.hand_timeout);
+            K78_STAMP(b, 2);
+            __syncthreads();
+            const unsigned code = hand_code[set];
+            if (code == 4u) { if (threadIdx.x == 0) atomicAdd(b.dbg + BA_HAND_ERR, 1ull); return; }
+            if (code & 1u) continue;                    // this set's solver failed
+            for (int i = threadIdx.x; i < d.n; i += blockDim.x) dcl[i] = ba_load_sc1(b.dc + (size_t)set * BA_DC_STRIDE(d.n) + i);
+            __syncthreads();
+            // the candidate's cameras and their blocks, exactly as K7's epilogue forms them for the next linearisation
+            for (int c = threadIdx.x; c < d.C; c += blockDim.x) {
+                const int s = sll[c];
+                double xn[6];
 #pragma unroll
-        for (int a = 0; a < 6; a++) { const double dc = dcl[6 * s + a]; m0 += o.jc[a] * dc; m1 += o.jc[6 + a] * dc; }
-#pragma unroll
-        for (int k = 0; k < 3; k++) t[k] += o.w * (o.jp[k] * m0 + o.jp[3 + k] * m1);   // W_i^T delta_c
-    }
-#pragma unroll
-    for (int k = 0; k < 3; k++) { t[k] += __shfl_xor(t[k], 16, 64); t[k] += __shfl_xor(t[k], 32, 64); }
-    double Xc[3] = {0, 0, 0};
-    if (valid) {
-        const double I0 = I[0], I1 = I[1], I2 = I[2], I3 = I[3], I4 = I[4], I5 = I[5];
-        const double tt[3] = {t[0] + g[0], t[1] + g[1], t[2] + g[2]};
-        const double dp[3] = {-(I0 * tt[0] + I1 * tt[1] + I2 * tt[2]), -(I1 * tt[0] + I3 * tt[1] + I4 * tt[2]),
-                              -(I2 * tt[0] + I4 * tt[1] + I5 * tt[2])};
-#pragma unroll
-        for (int k = 0; k < 3; k++) {
-            Xc[k] = X[k] + dp[k];
-            if (sub == 0) {
-                Xn[3 * (size_t)p + k] = Xc[k];
-                mcc += 0.5 * (dp[k] * dp[k] * lamp[k] - dp[k] * g[k]);
-                ssq += (X[k] - Xc[k]) * (X[k] - Xc[k]);
-                xsq += X[k] * X[k];
+                for (int k = 0; k < 6; k++) xn[k] = s >= 0 ? xcl[6 * c + k] + dcl[6 * s + k] : xcl[6 * c + k];
+                cam_prepare(xn, cprepn + (size_t)c * BA_PREP_LDS);
             }
         }
+        __syncthreads();
+        K78_STAMP(b, 3);
+
+        double* Xn = b.Xp + (size_t)cand * d.P * 3;
+        double cost = 0.0, mcc = 0.0, ssq = 0.0, xsq = 0.0;
+        double t[3] = {0, 0, 0};
+        ObsLin o;
+        for (int j = sub, r = 0; j < nobs; j += 4, r++) {
+            int cs;
+            float2 uvv;
+            if (r < K8_PRE) { cs = r == 0 ? cs_pre[0] : r == 1 ? cs_pre[1] : cs_pre[2]; uvv = r == 0 ? uv_pre[0] : r == 1 ? uv_pre[1] : uv_pre[2]; }
+            else {
+                const int oi = o0 + j;
+                if (b.obs_cs) cs = b.obs_cs[oi];
+                else { const int c = b.obs_cam[oi]; cs = c | ((b.slot[c] + 1) << 16); }
+                uvv = b.obs_uv[oi];
+            }
+            const int c = cs & 0xFFFF, s = (cs >> 16) - 1;
+            if (s < 0) continue;
+            obs_eval<true>(prep + (size_t)c * BA_PREP_LDS, X, uvv, d, o);
+            double m0 = 0.0, m1 = 0.0;
+#pragma unroll
+            for (int a = 0; a < 6; a++) { const double dc = dcl[6 * s + a]; m0 += o.jc[a] * dc; m1 += o.jc[6 + a] * dc; }
+#pragma unroll
+            for (int k = 0; k < 3; k++) t[k] += o.w * (o.jp[k] * m0 + o.jp[3 + k] * m1);   // W_i^T delta_c
+        }
+#pragma unroll
+        for (int k = 0; k < 3; k++) { t[k] += __shfl_xor(t[k], 16, 64); t[k] += __shfl_xor(t[k], 32, 64); }
+        double Xc[3] = {0, 0, 0};
+        if (valid) {
+            const double I0 = I[0], I1_ = I[1], I2 = I[2], I3 = I[3], I4 = I[4], I5 = I[5];
+            const double tt[3] = {t[0] + g[0], t[1] + g[1], t[2] + g[2]};
+            const double dp[3] = {-(I0 * tt[0] + I1_ * tt[1] + I2 * tt[2]), -(I1_ * tt[0] + I3 * tt[1] + I4 * tt[2]),
+                                  -(I2 * tt[0] + I4 * tt[1] + I5 * tt[2])};
+#pragma unroll
+            for (int k = 0; k < 3; k++) {
+                Xc[k] = X[k] + dp[k];
+                if (sub == 0) {
+                    Xn[3 * (size_t)p + k] = Xc[k];
+                    mcc += 0.5 * (dp[k] * dp[k] * lamp[k] - dp[k] * g[k]);
+                    ssq += (X[k] - Xc[k]) * (X[k] - Xc[k]);
+                    xsq += X[k] * X[k];
+                }
+            }
+        }
+        for (int j = sub, r = 0; j < nobs; j += 4, r++) {
+            int c;
+            float2 uvv;
+            if (r < K8_PRE) { c = (r == 0 ? cs_pre[0] : r == 1 ? cs_pre[1] : cs_pre[2]) & 0xFFFF; uvv = r == 0 ? uv_pre[0] : r == 1 ? uv_pre[1] : uv_pre[2]; }
+            else { c = b.obs_cam[o0 + j]; uvv = b.obs_uv[o0 + j]; }
+            obs_eval<false>(cprepn + (size_t)c * BA_PREP_LDS, Xc, uvv, d, o);
+            cost += 0.5 * o.rho;
+        }
+        cost = wave_sum(cost); mcc = wave_sum(mcc); ssq = wave_sum(ssq); xsq = wave_sum(xsq);
+        if (lane == 0) { redw[threadIdx.x >> 6][0] = cost; redw[threadIdx.x >> 6][1] = mcc; redw[threadIdx.x >> 6][2] = ssq; redw[threadIdx.x >> 6][3] = xsq; }
+        __syncthreads();
+        if (threadIdx.x < 4) {       // one atomic per workgroup and scalar, spread over BA_NSLOT lines
+            double v = 0.0;
+            for (int w = 0; w < (int)(blockDim.x >> 6); w++) v += redw[w][threadIdx.x];
+            atomicAdd(&b.pt_scal[((size_t)set * BA_NSLOT + ((size_t)vb & (BA_NSLOT - 1))) * BA_SLOT_STRIDE + threadIdx.x], v);
+        }
+        K78_STAMP(b, 4);
     }
-    for (int j = sub, r = 0; j < nobs; j += 4, r++) {
-        int c;
-        float2 uvv;
-        if (r < K8_PRE) { c = (r == 0 ? cs_pre[0] : r == 1 ? cs_pre[1] : cs_pre[2]) & 0xFFFF; uvv = r == 0 ? uv_pre[0] : r == 1 ? uv_pre[1] : uv_pre[2]; }
-        else { c = b.obs_cam[o0 + j]; uvv = b.obs_uv[o0 + j]; }
-        obs_eval<false>(cprepn + (size_t)c * BA_PREP_LDS, Xc, uvv, d, o);
-        cost += 0.5 * o.rho;
-    }
-    cost = wave_sum(cost); mcc = wave_sum(mcc); ssq = wave_sum(ssq); xsq = wave_sum(xsq);
-    __shared__ double redw[K8_MAX_THREADS / 64][4];
-    if (lane == 0) { redw[threadIdx.x >> 6][0] = cost; redw[threadIdx.x >> 6][1] = mcc; redw[threadIdx.x >> 6][2] = ssq; redw[threadIdx.x >> 6][3] = xsq; }
-    __syncthreads();
-    if (threadIdx.x < 4) {       // one atomic per workgroup and scalar, spread over BA_NSLOT lines
-        double v = 0.0;
-        for (int w = 0; w < (int)(blockDim.x >> 6); w++) v += redw[w][threadIdx.x];
-        atomicAdd(&b.pt_scal[((size_t)set * BA_NSLOT + ((size_t)vb & (BA_NSLOT - 1))) * BA_SLOT_STRIDE + threadIdx.x], v);
-    }
-    K78_STAMP(b, 4);
 }
 

@@ -31,8 +31,8 @@
 __global__ __launch_bounds__(K7_THREADS) void ba_reduced_solve_lds(BaDims d, BaBufs b, BaOpt opt) { ba_reduced_solve_lds_body<false>(d, b, opt); }
 
 // K7 + K8 in ONE launch (single local window, vision only, one rank): workgroups [0, ns) are K7, one per speculative
-// set; the others are K8's, `nblk` landmark blocks of K7_THREADS / 4 landmarks per set, and wait for their set's
-// hand-off word.  A K8 launch behind K7 costs the launch gap plus K8's own prologue (state, landmark records, Jacobi
+// set; the others are K8's, `nblk` landmark blocks of K7_THREADS / 4 landmarks for each of `rs` = min(ns, BA_CALIBRATED_SETS)
+// sets, and wait for their set's hand-off word; in a round deeper than `rs` a K8 workgroup evaluates set s + rs after set s.  A K8 launch behind K7 costs the launch gap plus K8's own prologue (state, landmark records, Jacobi
 // scale, V^-1, the first observations: two dependent round trips) AFTER the solve; here all of that is in flight
 // while K7 is solving, and what remains behind the hand-off is one round trip for delta_c / the candidate's camera
 // blocks and the arithmetic.  Producers never wait for consumers and are dispatched first, and a consumer's wait
@@ -42,8 +42,8 @@ __global__ __launch_bounds__(K7_THREADS) void ba_solve_backsub(BaDims d, BaBufs 
     if ((int)blockIdx.x < b.ns) {
         ba_reduced_solve_lds_body<true>(d, b, opt);
     } else {
-        const int v = (int)blockIdx.x - b.ns;
-        ba_backsub_cost4_body<true>(d, b, v % nblk, v / nblk, (size_t)v, (size_t)gridDim.x - b.ns);
+        const int v = (int)blockIdx.x - b.ns, rs = ((int)gridDim.x - b.ns) / nblk;
+        ba_backsub_cost4_body<true>(d, b, v % nblk, v / nblk, rs, (size_t)v, (size_t)gridDim.x - b.ns);
     }
 }
 // batched: blockIdx.x = speculative set, blockIdx.z = window
@@ -60,15 +60,14 @@ size_t ba_reduced_solve_lds_bytes(int n)
     return sizeof(double) * ((size_t)(n + 1) * LD + 2 * (size_t)n + 6 * (size_t)n + 6 * (size_t)n + 3 * (size_t)n + 8 + 2 * 8 * 128);
 }
 
-// workgroups of the fused launch that must be resident AT ONCE: the K7 workgroups of every set (producers: dispatched first,
-// they never wait) and the K8 workgroups of the sets a calibrated round evaluates (<= 3).  A deeper round (up to 5 sets, once or
-// twice per solve) runs its last sets' K8 workgroups in a second shift behind the hand-off, which is published by then; the
-// workgroups of sets the round does not evaluate return as soon as the accumulators are cleared.
+// workgroups of the fused launch, all resident at once: the K7 workgroups of every set (producers: dispatched first, they
+// never wait) and the K8 workgroups of the sets a calibrated round evaluates (<= 3).  In a deeper round (up to 5 sets, once
+// or twice per solve) the K8 workgroups of sets 0 and 1 go on to sets 3 and 4, whose hand-off is published by then.
+static inline int ba_backsub_resident_sets(const BaBufs& b) { return b.ns < BA_CALIBRATED_SETS ? b.ns : BA_CALIBRATED_SETS; }
 int ba_solve_backsub_workgroups(const BaDims& d, const BaBufs& b)
 {
     const int per = K7_THREADS / 4;
-    const int resident_sets = b.ns < BA_CALIBRATED_SETS ? b.ns : BA_CALIBRATED_SETS;
-    return b.ns + resident_sets * ((d.P + per - 1) / per);
+    return b.ns + ba_backsub_resident_sets(b) * ((d.P + per - 1) / per);
 }
 
 void ba_launch_solve_backsub(hipStream_t s, const BaDims& d, const BaBufs& b, const BaOpt& opt)
@@ -76,7 +75,7 @@ void ba_launch_solve_backsub(hipStream_t s, const BaDims& d, const BaBufs& b, co
     const size_t lds = max(ba_reduced_solve_lds_bytes(d.n), ba_backsub_lds_bytes(d.C, d.n));
     (void)rs_lds_attr((const void*)ba_solve_backsub, lds);
     const int per = K7_THREADS / 4, nblk = (d.P + per - 1) / per;
-    hipLaunchKernelGGL(ba_solve_backsub, dim3(b.ns + nblk * b.ns), dim3(K7_THREADS), lds, s, d, b, opt, nblk);
+    hipLaunchKernelGGL(ba_solve_backsub, dim3(b.ns + nblk * ba_backsub_resident_sets(b)), dim3(K7_THREADS), lds, s, d, b, opt, nblk);
 }
 
 void ba_launch_reduced_solve_lds(hipStream_t s, const BaDims& d, const BaBufs& b, const BaOpt& opt)

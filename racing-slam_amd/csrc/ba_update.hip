@@ -13,14 +13,14 @@
 
 __global__ __launch_bounds__(K8_THREADS) void ba_backsub_cost4(BaDims d, BaBufs b)
 {
-    ba_backsub_cost4_body<false>(d, b, (int)blockIdx.x, (int)blockIdx.y, (size_t)blockIdx.y * gridDim.x + blockIdx.x, (size_t)gridDim.x * gridDim.y);
+    ba_backsub_cost4_body<false>(d, b, (int)blockIdx.x, (int)blockIdx.y, 0, (size_t)blockIdx.y * gridDim.x + blockIdx.x, (size_t)gridDim.x * gridDim.y);
 }
 // batched: blockIdx.x = landmark block, blockIdx.y = speculative set, blockIdx.z = window
 __global__ __launch_bounds__(K8_THREADS) void ba_backsub_cost4_batch(const BaWin* w, int it)
 {
     const BaWin& x = w[blockIdx.z];
     const BaBufs b = ba_win_round(x, it, false);
-    ba_backsub_cost4_body<false>(x.d, b, (int)blockIdx.x, (int)blockIdx.y, (size_t)blockIdx.y * gridDim.x + blockIdx.x, (size_t)gridDim.x * gridDim.y);
+    ba_backsub_cost4_body<false>(x.d, b, (int)blockIdx.x, (int)blockIdx.y, 0, (size_t)blockIdx.y * gridDim.x + blockIdx.x, (size_t)gridDim.x * gridDim.y);
 }
 
 size_t ba_backsub_lds_bytes(int C, int n)
