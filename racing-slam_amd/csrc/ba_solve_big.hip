@@ -30,6 +30,7 @@ struct BigBufs {
     double* yf;      // [n] D^-1 L^-1 g
     int* fail;       // [1]
     double* sep;     // [2][WB * WB + WB] two-sided banded factorisation: each side's Schur update of the separator block + right-hand side
+    double* Ad;      // [n][6] banded factorisation: the damped matrix's entries inside the cameras' own 6 x 6 blocks, (hi, lo) at [hi][lo % 6]
 };
 
 __device__ __forceinline__ double rl64(double v, int lane)
@@ -40,7 +41,7 @@ __device__ __forceinline__ double rl64(double v, int lane)
 }
 
 // ------------------------------------------------------------------ prologue
-__global__ __launch_bounds__(1024) void ba_big_prologue(BaDims d, BaBufs b, BaOpt opt, BigBufs g)
+__global__ __launch_bounds__(1024) void ba_big_prologue(BaDims d, BaBufs b, BaOpt opt, BigBufs g, int band)
 {
     const int n = d.n, tid = threadIdx.x, nt = blockDim.x;
     __shared__ BaState st;
@@ -103,6 +104,15 @@ __global__ __launch_bounds__(1024) void ba_big_prologue(BaDims d, BaBufs b, BaOp
         b.dc[i] = yy;                           // y
     }
     __syncthreads();
+    // the damped matrix inside the cameras' own blocks (S + U + damping), for the banded factorisation's single-load fetch
+    if (band)
+        for (int idx = tid; idx < 6 * n; idx += nt) {
+            const int hi = idx / 6, lo = (hi / 6) * 6 + idx % 6;
+            if (lo > hi) continue;
+            double v = b.S[(size_t)lo * n + hi] + b.U[(hi / 6) * 36 + (lo % 6) * 6 + (hi % 6)];
+            if (hi == lo) v += b.rhs[hi];
+            g.Ad[idx] = v;
+        }
 }
 
 // The lower triangle (incl. the diagonal) of the damped reduced matrix, in place: S is accumulated in its upper
@@ -659,6 +669,237 @@ static __device__ __attribute__((noinline)) void band_fetch(const double* __rest
     if (t < WB) yP[t] = (!tz && J + 1 < NB && inside(r1 + t)) ? vy : 0.0;
 }
 
+#ifndef BAND_V2
+#define BAND_V2 1
+#endif
+#ifndef BAND_DIAG
+#define BAND_DIAG 0           // timing diagnostics (wrong results): 1 no factor stores, 2 no fetch, 4 no tile updates
+#endif
+#if BAND_V2
+// ---- the panel of one block column, 8 columns per step, with the chain kept off the matrix cores (the form of ba_solve.hip's
+// K7 on a window in LDS).  The first 8 waves of the workgroup have ROLES (512 threads: 256 registers per lane, where 1024
+// threads leave 128 and the chain's 36-entry triangle + row state spills; waves w, w + 4 share a SIMD; f64 MFMA and f64 VALU
+// share one datapath per SIMD, so the chain's SIMD carries no tile wave):
+//   chain waves `dw` and `dw ^ 4`   lane = panel row (the 64 rows of D / of P); the row's entries in the step's 8 columns live in
+//                     registers.  Per step: the 8 x 8 diagonal sub-block goes through a 64-double scratch, EVERY lane factors
+//                     it (L D L^T in registers, no cross-lane traffic), solves its own row t = a L^-T, l = t D^-1, writes l in
+//                     place and t for the tile waves, then applies the step's rank-8 update to its entries in the NEXT 8
+//                     columns itself — the chain never waits for the trailing update
+//   wave 5            the right-hand side row: the same factorisation, y's row solve, and its whole rank-8 update (two columns
+//                     per lane) every step
+//   tile waves        (5, on the other three SIMDs) the rank-8 update of the panel's remaining columns on the matrix cores,
+//                     two MFMAs per 16 x 16 tile, finished before the chain reads the step after next's raw columns; then
+//                     whatever the caller hands them (after_step: the factor's columns to memory, the next blocks' fetch)
+// two workgroup barriers per step.  Rows above the step's sub-block are finished and idle; identity padding needs no masks.
+#define BAND_TS 10
+#define BAND_RHS_WAVE 5         // (SIMD 1: its factorisation runs while the tile waves of that SIMD wait for the step's multipliers)
+#define BAND_NT 5               // tile waves: 1, 2, 3, 6, 7 (waves beyond the first eight of a larger workgroup only keep the barriers)
+#define band_is_tile(wave) ((wave) < 8 && ((wave) & 3) != 0 && (wave) != BAND_RHS_WAVE)
+#define band_tile_index(wave) ((wave) < 4 ? (wave) - 1 : (wave) - 3)         // 0 .. 4
+// live tiles of a step by lo = (c + 8) / 16: tile rows lo .. 7 x tile columns lo .. min(row, 3), the triangle of the D rows first, then
+// the P rows' rectangle; entry = 4 * tile row + tile column
+__device__ static const unsigned char BAND_TILES[4][26] = {
+    {0, 4, 5, 8, 9, 10, 12, 13, 14, 15, 16, 17, 18, 19, 20, 21, 22, 23, 24, 25, 26, 27, 28, 29, 30, 31},
+    {5, 9, 10, 13, 14, 15, 17, 18, 19, 21, 22, 23, 25, 26, 27, 29, 30, 31, 0, 0, 0, 0, 0, 0, 0, 0},
+    {10, 14, 15, 18, 19, 22, 23, 26, 27, 30, 31, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0},
+    {15, 19, 23, 27, 31, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}};
+struct BandWin {
+    double* Dm;    // [WB][WBS] D = A[J][J], factored in place (strictly lower: multipliers)
+    double* Pp;    // [WB][WBS] P = A[J+1][J], becomes the multipliers L_{J+1,J}      (unused without P rows)
+    double* y;     // [2 WB] the right-hand side's entries of blocks J and J+1; block J's become D^-1 L^-1 g
+    double* Tt;    // [2 WB][BAND_TS] t = l D of the current step, by panel row
+    double* scr;   // [8][8] the step's diagonal sub-block as the chain publishes it
+    double* L2;    // [8][8] multipliers of the NEXT sub-block's rows (16-byte aligned: read as double2)
+    double* dvl;   // [WB] pivots
+};
+template <typename Step>
+static __device__ __forceinline__ void band_block8(const BandWin& W, const int s_first, const int dw, const bool has_p, bool& bad, Step&& after_step,
+                                                   unsigned long long* stamps = nullptr)
+{
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+#if RS_STAMPS
+    // thread 0 (a chain wave): [0] wait for the sub-block, [1] factor + row solve, [2] wait for the step's multipliers, [3] fix-up;
+    // thread 64 (a tile wave): [4] the two waits (and the caller's work between them), [5] update
+    unsigned long long tq_ = wall_clock64();
+#define BLOCK_STAMP(i) do { if (stamps && (tid & ~64) == 0) { const unsigned long long t_ = wall_clock64(); if ((i) < 4 ? tid == 0 : tid == 64) atomicAdd(stamps + (i), t_ - tq_); tq_ = t_; } } while (0)
+#else
+#define BLOCK_STAMP(i) do { } while (0)
+#endif
+    const int lr = lane & 15, lk = lane >> 4;
+    const bool chain_d = wave == dw, chain_p = has_p && wave == (dw ^ 4), rhs = wave == BAND_RHS_WAVE;
+    const bool chain = chain_d || chain_p, tile = band_is_tile(wave);
+    const int tw = band_tile_index(wave);
+    double* const rp = chain_p ? W.Pp + lane * WBS : W.Dm + lane * WBS;     // chain: this lane's panel row
+    const int irow = chain_p ? WB + lane : lane;
+    double cur[8], t[8];
+#pragma unroll
+    for (int k = 0; k < 8; k++) { cur[k] = 0.0; t[k] = 0.0; }
+    if (chain) {
+#pragma unroll
+        for (int k = 0; k < 8; k++) cur[k] = rp[8 * s_first + k];
+    } else if (rhs) {
+#pragma unroll
+        for (int k = 0; k < 8; k++) cur[k] = W.y[8 * s_first + k];
+    }
+    for (int s = s_first; s < WB / 8; s++) {
+        const int c = 8 * s;
+        if (chain_d && (unsigned)(lane - c) < 8u) {
+#pragma unroll
+            for (int k = 0; k < 8; k++) W.scr[(lane - c) * 8 + k] = cur[k];
+        }
+        lds_barrier();                                                       // the diagonal sub-block is published
+        BLOCK_STAMP(0);
+        if (chain || rhs) {
+            // L D L^T of the sub-block, right-looking, interleaved with the lane's own row solve t = a L^-T (forward substitution
+            // with the unit-lower block; row q of L is final when column q is eliminated, and dead afterwards), l = t D^-1
+            const int m = irow - c;                  // < 0: finished row, 0 .. 7: a row of the sub-block itself, >= 8: below it
+            double L[8][8], F[8], pv[8];
+#pragma unroll
+            for (int a = 0; a < 8; a++)
+#pragma unroll
+                for (int e = 0; e <= a; e++) L[a][e] = W.scr[a * 8 + e];
+#pragma unroll
+            for (int q = 0; q < 8; q++) {
+                double sacc = cur[q];
+#pragma unroll
+                for (int e = 0; e < q; e++) sacc -= t[e] * L[q][e];
+                t[q] = (chain && q > m) ? 0.0 : sacc;                        // (row m of the sub-block: L is lower triangular)
+                const double piv = L[q][q];
+                bad = bad || !(piv > 0.0) || !isfinite(piv);
+                const double rd = rcp_nr(piv);
+                pv[q] = piv;
+                F[q] = t[q] * rd;
+                double lc[8];
+#pragma unroll
+                for (int a = q + 1; a < 8; a++) lc[a] = L[a][q] * rd;
+#pragma unroll
+                for (int a = q + 1; a < 8; a++)
+#pragma unroll
+                    for (int e = q + 1; e <= a; e++) L[a][e] -= lc[a] * L[e][q];
+#pragma unroll
+                for (int a = q + 1; a < 8; a++) L[a][q] = lc[a];
+            }
+            // raw entries of the next 8 columns: the tile waves have finished the previous step's update
+            double nxt[8];
+#pragma unroll
+            for (int k = 0; k < 8; k++) nxt[k] = 0.0;
+            if (chain && s + 1 < WB / 8) {
+#pragma unroll
+                for (int k = 0; k < 8; k++) nxt[k] = rp[c + 8 + k];
+            }
+            if (chain) {
+                if (m >= 0) {
+                    // (a row of the sub-block writes zeros above its diagonal: the upper triangle is never read)
+                    double2* tt2 = reinterpret_cast<double2*>(W.Tt + irow * BAND_TS);
+#pragma unroll
+                    for (int k = 0; k < 8; k++) rp[c + k] = F[k];
+#pragma unroll
+                    for (int k = 0; k < 4; k++) tt2[k] = make_double2(t[2 * k], t[2 * k + 1]);
+                    if ((unsigned)(m - 8) < 8u) {
+                        double2* l2w = reinterpret_cast<double2*>(W.L2 + (m - 8) * 8);
+#pragma unroll
+                        for (int k = 0; k < 4; k++) l2w[k] = make_double2(F[2 * k], F[2 * k + 1]);
+                    }
+                    if (m == 0) {
+#pragma unroll
+                        for (int k = 0; k < 8; k++) W.dvl[c + k] = pv[k];
+                    }
+                }
+#pragma unroll
+                for (int k = 0; k < 8; k++) cur[k] = nxt[k];
+            } else if (lane == 0) {
+#pragma unroll
+                for (int k = 0; k < 8; k++) W.y[c + k] = F[k];
+            }
+        } else if (s > s_first) {
+            // the tile waves would wait for the step's multipliers: the caller's work on the PREVIOUS step's finished columns (its
+            // factor columns to memory, the next blocks' fetch) runs here, off the chain's critical path
+            after_step(s - 1, c - 8);
+        }
+        BLOCK_STAMP(1);
+        lds_barrier();                                                       // multipliers and t of the step are in LDS
+        BLOCK_STAMP(tid == 0 ? 2 : 4);
+        if (chain) {
+            if (s + 1 < WB / 8) {
+                // this step's update of the next 8 columns of the lane's row: a[c+8+j] -= sum_k t_k l_{c+8+j, k}
+                const double2* l2 = reinterpret_cast<const double2*>(W.L2);
+#pragma unroll
+                for (int j = 0; j < 8; j++) {
+                    const double2 a01 = l2[4 * j], a23 = l2[4 * j + 1], a45 = l2[4 * j + 2], a67 = l2[4 * j + 3];
+                    cur[j] -= (t[0] * a01.x + t[1] * a01.y) + (t[2] * a23.x + t[3] * a23.y) + ((t[4] * a45.x + t[5] * a45.y) + (t[6] * a67.x + t[7] * a67.y));
+                }
+            }
+        } else if (rhs) {
+            // the right-hand side's columns lane (block J) and WB + lane (block J+1)
+            if (lane >= c + 8) {
+                const double* l = W.Dm + lane * WBS + c;
+                double acc = 0.0;
+#pragma unroll
+                for (int k = 0; k < 8; k++) acc += t[k] * l[k];
+                W.y[lane] -= acc;
+            }
+            if (has_p) {
+                const double* l = W.Pp + lane * WBS + c;
+                double acc = 0.0;
+#pragma unroll
+                for (int k = 0; k < 8; k++) acc += t[k] * l[k];
+                W.y[WB + lane] -= acc;
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                 // (one wave: its LDS accesses are in order)
+            if (s + 1 < WB / 8) {
+#pragma unroll
+                for (int k = 0; k < 8; k++) cur[k] = W.y[c + 8 + k];
+            }
+        } else if (tile && !(BAND_DIAG & 4)) {
+            // tile q of the step's list (BAND_TILES; without P rows only its triangle) -> wave q % BAND_NT
+            const int pdiff = has_p ? (int)(W.Pp - W.Dm) : 0;                   // (P rows: the same LDS allocation as D)
+            const int lo = (c + 8) >> 4, nlo = 4 - lo, tri = (nlo * (nlo + 1)) >> 1, ntile = tri + (has_p ? 4 * nlo : 0);
+            // two tiles per round: the operands and old values of both travel together (one LDS round trip), their MFMAs interleave;
+            // entries outside the live lower triangle are rewritten as they are: nobody writes them in this phase
+#pragma unroll 1
+            for (int q = tw; q < ntile; q += 2 * BAND_NT) {
+                const bool two = q + BAND_NT < ntile;                            // (wave-uniform; else the second tile repeats the first, unwritten)
+                int tr[2], tc[2], pr0[2], qq[2];
+                double x0[2], x1[2], z0[2], z1[2], old[2][4];
+                double* e0[2];
+#pragma unroll
+                for (int u = 0; u < 2; u++) {
+                    const int code = BAND_TILES[lo][(u && two) ? q + BAND_NT : q];
+                    tr[u] = code >> 2; tc[u] = code & 3;
+                    const double* X = W.Tt + (16 * tr[u] + lr) * BAND_TS + lk;
+                    const double* Z = W.Dm + (16 * tc[u] + lr) * WBS + c + lk;
+                    x0[u] = X[0]; x1[u] = X[4]; z0[u] = Z[0]; z1[u] = Z[4];
+                    pr0[u] = 16 * tr[u] + lk; qq[u] = 16 * tc[u] + lr;
+                    e0[u] = W.Dm + (tr[u] < 4 ? pr0[u] * WBS : pdiff + (pr0[u] - WB) * WBS) + qq[u];
+#pragma unroll
+                    for (int reg = 0; reg < 4; reg++) old[u][reg] = e0[u][4 * reg * WBS];
+                }
+                d4 acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0};
+                acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(x0[0], z0[0], acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(x0[1], z0[1], acc1, 0, 0, 0);
+                acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(x1[0], z1[0], acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(x1[1], z1[1], acc1, 0, 0, 0);
+#pragma unroll
+                for (int reg = 0; reg < 4; reg++) {
+                    const int pr = pr0[0] + 4 * reg;
+                    e0[0][4 * reg * WBS] = (pr >= c + 8 && qq[0] >= c + 8 && qq[0] <= pr) ? old[0][reg] - acc0[reg] : old[0][reg];
+                }
+                if (two) {
+#pragma unroll
+                    for (int reg = 0; reg < 4; reg++) {
+                        const int pr = pr0[1] + 4 * reg;
+                        e0[1][4 * reg * WBS] = (pr >= c + 8 && qq[1] >= c + 8 && qq[1] <= pr) ? old[1][reg] - acc1[reg] : old[1][reg];
+                    }
+                }
+            }
+        }
+        BLOCK_STAMP(tid == 0 ? 3 : 5);
+    }
+    if (!(chain || rhs)) after_step(WB / 8 - 1, WB - 8);
+#undef BLOCK_STAMP
+}
+#endif
+
 // Two-sided form (`split`): the band is cut at a SEPARATOR block column Js = (NB - 1) / 2.  Workgroup 0 eliminates the block
 // columns above it in order, workgroup 1 the ones below it in REVERSE order (the same algorithm on the matrix with rows and
 // columns reversed, v -> 64 NB - 1 - v: a band stays a band; the identity padding of the last real block becomes the head of
@@ -667,6 +908,177 @@ static __device__ __attribute__((noinline)) void band_fetch(const double* __rest
 // g.sep; ba_big_finish adds them, factors the separator and substitutes backwards on both sides in lock step.  The chain of
 // dependent 16-column sub-blocks is 17 + 4 instead of 37 at n = 588.  Factor blocks are stored at the REAL positions of their
 // (virtual) rows and columns, so side 1's land in the upper triangle of g.Ls.
+#if BAND_V2
+// doubles of LDS: four block buffers, the side's right-hand side (np + WB), the t panel, scratch, next multipliers, pivots
+static inline size_t band_factor_lds_doubles(int n) { const size_t np = (size_t)((n + WB - 1) / WB) * WB; return (size_t)4 * WB * WBS + np + WB + 2 * WB * BAND_TS + 64 + 64 + WB; }
+#define BAND_THREADS 512
+__global__ __launch_bounds__(BAND_THREADS) void ba_band_factor(BaDims d, BaBufs b, BigBufs g, int split)
+{
+    if (b.st->done) return;
+    extern __shared__ __attribute__((aligned(16))) double wl[];
+    const int n = d.n, tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lr = lane & 15, lk = lane >> 4;
+    const int NB = (n + WB - 1) / WB, np = NB * WB;
+    // the window: D = A[J][J] and T = A[J+1][J+1] alternate between two buffers (T becomes the next D by a pointer swap), P =
+    // A[J+1][J] and the NEXT block's P likewise
+    double* Dm = wl;                               // [WB][WBS]
+    double* Tm = Dm + WB * WBS;                    // [WB][WBS]
+    double* Pp = Tm + WB * WBS;                    // [WB][WBS]
+    double* Pn = Pp + WB * WBS;                    // [WB][WBS] A[J+2][J+1], fetched during block J
+    double* yv = Pn + WB * WBS;                    // [np + WB] the right-hand side in this side's order; becomes D^-1 L^-1 g
+    double* Tt = yv + np + WB;                     // [2 WB][BAND_TS]
+    double* scr = Tt + 2 * WB * BAND_TS;           // [8][8]
+    double* L2 = scr + 64;                         // [8][8]
+    double* dvl = L2 + 64;                         // [WB]
+    const int rev = split ? (int)blockIdx.x : 0;
+    const int Js = (NB - 1) / 2;
+    const int ND = split ? (rev ? NB - 1 - Js : Js) : NB;     // block columns this workgroup eliminates
+    const int pad = np - n;                                     // identity padding: the tail of the real order = the head of the reversed one
+    // virtual index -> real index; entries outside the matrix are identity
+    auto phi = [&](int v) { return rev ? np - 1 - v : v; };
+    auto inside = [&](int v) { return (unsigned)phi(v) < (unsigned)n; };
+    // A'(r, k), clamped to the matrix (masked by the caller): ONE load — S's upper triangle, or the prologue's sum S + U + damping
+    // inside a camera's own block
+    auto entry = [&](int r, int k) {
+        const int i = min(max(phi(r), 0), n - 1), j = min(max(phi(k), 0), n - 1), hi = max(i, j), lo = min(i, j);
+        const double* p = hi / 6 == lo / 6 ? g.Ad + hi * 6 + lo % 6 : b.S + (size_t)lo * n + hi;
+        return *p;
+    };
+#if RS_STAMPS
+    unsigned long long tq = wall_clock64(), acc_t[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#define BAND_STAMP(i) do { if (tid == 0) { const unsigned long long t_ = wall_clock64(); acc_t[i] += t_ - tq; tq = t_; } } while (0)
+#else
+#define BAND_STAMP(i) do { } while (0)
+#endif
+    if (tid < WB) dvl[tid] = 1.0;
+    // block 0: D and P from memory (identity / zero outside the matrix); the right-hand side of every block.  Side 1 starts
+    // the separator's entries from zero: it contributes updates only.
+    for (int idx = tid; idx < WB * WB; idx += BAND_THREADS) {
+        const int r = idx / WB, k = idx % WB;
+        Dm[r * WBS + k] = (inside(r) && inside(k)) ? entry(r, k) : (r == k ? 1.0 : 0.0);
+        Pp[r * WBS + k] = (1 < NB && inside(WB + r) && inside(k)) ? entry(WB + r, k) : 0.0;
+    }
+    for (int v = tid; v < np + WB; v += BAND_THREADS)
+        yv[v] = (v < np && inside(v) && !(split && rev && v >= WB * ND)) ? b.dc[phi(v)] : 0.0;
+    const bool tile = band_is_tile(wave);
+    constexpr int NTT = 64 * BAND_NT;                                        // threads of the tile waves
+    const int tt = band_tile_index(wave) * 64 + lane;                        // 0 .. NTT - 1
+    int dw = 0;
+    lds_barrier();
+    BAND_STAMP(0);
+    bool bad = false;
+    for (int J = 0; J < ND; J++) {
+        const int c0 = WB * J, r1 = c0 + WB, r2 = r1 + WB;
+        const bool has_p = J + 1 < NB;
+        const int hp = has_p ? (rev ? WB : min(WB, n - r1)) : 0;            // rows of block J+1
+        const bool tz = split && rev && J + 1 == ND;                        // T is the separator's block seen from side 1
+        // the tile waves fetch this step's T = A[J+1][J+1] (needed by the trailing update at the end of the block; its buffer
+        // was the previous block's D) and the NEXT block's P = A[J+2][J+1] — original entries of S: nothing outside the band
+        // ever updates them — requested behind the first step's update, placed behind the third's
+        // in chunks of two values per lane, each requested behind one step's update and placed behind the next one's
+        constexpr int CH = 4;                                                  // values of a chunk
+        double fv[CH] = {0.0, 0.0, 0.0, 0.0};
+        int chunk = 0;
+        bool pending = false;
+        auto request = [&](int ch) {                                         // (clamped addresses; masks when the values are placed)
+#pragma unroll
+            for (int u = 0; u < CH; u++) {
+                const int idx = min(tt + NTT * (CH * ch + u), 2 * WB * WB - 1);
+                fv[u] = entry(((idx >> 12) ? r2 : r1) + ((idx >> 6) & 63), r1 + (idx & 63));
+            }
+        };
+        auto place = [&](int ch) {
+#pragma unroll
+            for (int u = 0; u < CH; u++) {
+                const int idx = tt + NTT * (CH * ch + u), which = idx >> 12, r = (idx >> 6) & 63, k = idx & 63;
+                if (idx >= 2 * WB * WB) continue;
+                const bool vk = has_p && inside(r1 + k);
+                if (which) Pn[r * WBS + k] = (J + 2 < NB && inside(r2 + r) && vk) ? fv[u] : 0.0;
+                else Tm[r * WBS + k] = tz ? 0.0 : ((has_p && inside(r1 + r) && vk) ? fv[u] : (r == k ? 1.0 : 0.0));
+            }
+        };
+        constexpr int NCHUNK = (2 * WB * WB + CH * NTT - 1) / (CH * NTT);       // 7: requested behind steps 0 .. 6
+        // the factor's columns c .. c+7 -> memory (the backward substitution reads them): unit-lower L_JJ and L_{J+1,J}; element
+        // e = row * 8 + column of the step's 128 x 8 values, two per tile thread (row and base address are the block's)
+        constexpr int NST = (2 * WB * 8 + NTT - 1) / NTT;                    // 4
+        int st_src[NST], st_row[NST];                                        // (offsets: D rows into Dm, P rows into Pp)
+        long long st_dst[NST];
+#pragma unroll
+        for (int u = 0; u < NST; u++) {
+            const int e = tt + NTT * u, i = e >> 3, kk = e & 7;
+            const bool isd = i < WB, ok = e < 2 * WB * 8 && (isd ? inside(c0 + i) : (i - WB < hp && inside(r1 + i - WB)));
+            st_row[u] = ok ? (isd ? i : WB) : -1;                             // D row i: columns <= i; P rows: every column
+            st_src[u] = (isd ? i : i - WB) * WBS + kk;
+            st_dst[u] = (long long)phi(isd ? c0 + i : r1 + i - WB) * n + phi(c0 + kk);
+        }
+        auto store_cols = [&](int c) {
+#pragma unroll
+            for (int u = 0; u < NST; u++) {
+                const int col = c + ((tt + NTT * u) & 7);
+                if (st_row[u] < 0 || col > st_row[u] || !inside(c0 + col)) continue;
+                const double v = st_row[u] == WB ? Pp[st_src[u] + c] : Dm[st_src[u] + c];
+                g.Ls[st_dst[u] + (rev ? -c : c)] = col < st_row[u] ? v : 1.0;
+            }
+        };
+        const int s_first = (rev && J == 0) ? (pad >> 3) : 0;               // whole sub-blocks of side 1's padding are identity already
+        const BandWin W = {Dm, Pp, yv + c0, Tt, scr, L2, dvl};
+        band_block8(W, s_first, dw, has_p, bad, [&](int, int c) {
+            if (!tile) return;
+            // (the fetched values first: waiting for them behind this step's stores would wait for the stores as well)
+#if !(BAND_DIAG & 2)
+            if (pending) place(chunk - 1);
+#endif
+#if !(BAND_DIAG & 1)
+            store_cols(c);
+#endif
+#if !(BAND_DIAG & 2)
+            pending = chunk < NCHUNK;
+            if (pending) request(chunk++);
+#endif
+        }, RS_STAMPS ? (unsigned long long*)b.dbg + (blockIdx.x == 0 ? 0 : 8) : nullptr);
+        if (tile) {                                                             // (a short first block of side 1: the rest, waiting)
+            if (pending) place(chunk - 1);
+            for (; chunk < NCHUNK; chunk++) { request(chunk); place(chunk); }
+        }
+        BAND_STAMP(1);
+        // D^-1 L^-1 g and D of the block
+        if (wave == BAND_RHS_WAVE && inside(c0 + lane)) { g.yf[phi(c0 + lane)] = yv[c0 + lane]; g.dv[phi(c0 + lane)] = dvl[lane]; }
+        if (!has_p) break;                                                       // last block
+        // ---- trailing update on the matrix cores: T -= (L_P D) L_P^T (lower tiles); the right-hand side is up to date
+        lds_barrier();                                                           // (T's last values have just been placed)
+        for (int q = wave; q < 10; q += BAND_THREADS / 64) {                     // ten lower tiles of the 4 x 4
+            const int tr = q < 1 ? 0 : q < 3 ? 1 : q < 6 ? 2 : 3, tc = q - (tr * (tr + 1)) / 2;
+            d4 acc = {0.0, 0.0, 0.0, 0.0};
+            const double* X = Pp + (16 * tr + lr) * WBS + lk;
+            const double* Z = Pp + (16 * tc + lr) * WBS + lk;
+#pragma unroll 4
+            for (int kc = 0; kc < WB / 4; kc++)
+                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(X[4 * kc] * dvl[4 * kc + lk], Z[4 * kc], acc, 0, 0, 0);
+#pragma unroll
+            for (int reg = 0; reg < 4; reg++) Tm[(16 * tr + lk + 4 * reg) * WBS + 16 * tc + lr] -= acc[reg];
+        }
+        lds_barrier();
+        BAND_STAMP(2);
+        if (split && J == ND - 1) {
+            // the separator's block as this side leaves it (lower triangle, this side's order) and its right-hand side
+            double* sp = g.sep + (size_t)rev * (WB * WB + WB);
+            for (int idx = tid; idx < WB * WB; idx += BAND_THREADS) {
+                const int r = idx / WB, k = idx % WB;
+                if (k <= r) sp[idx] = Tm[r * WBS + k];
+            }
+            if (tid < WB) sp[WB * WB + tid] = yv[r1 + tid];
+            break;
+        }
+        // ---- shift the window by swapping buffers: T becomes D, the fetched P the panel's; the chain waves swap their rows
+        { double* t_ = Dm; Dm = Tm; Tm = t_; t_ = Pp; Pp = Pn; Pn = t_; }
+        dw ^= 4;
+    }
+    if (__any(bad) && lane == 0) *g.fail = 1;
+#if RS_STAMPS
+    if (tid == 0) for (int q = 0; q < 8; q++) b.dbg[(blockIdx.x == 0 ? 16 : 40) + q] += acc_t[q];     // side 0: 16.., side 1: 40..
+#endif
+}
+#else
 __global__ __launch_bounds__(1024) void ba_band_factor(BaDims d, BaBufs b, BigBufs g, int split)
 {
     if (b.st->done) return;
@@ -708,7 +1120,7 @@ __global__ __launch_bounds__(1024) void ba_band_factor(BaDims d, BaBufs b, BigBu
 #endif
     if (tid < WB) dvl[tid] = 1.0;
     // block 0: D, P and the right-hand side from memory (identity / zero outside the matrix)
-    for (int idx = tid; idx < WB * WB; idx += 1024) {
+    for (int idx = tid; idx < WB * WB; idx += BAND_THREADS) {
         const int r = idx / WB, k = idx % WB;
         Dm[r * WBS + k] = (inside(r) && inside(k)) ? entry(r, k) : (r == k ? 1.0 : 0.0);
         Pp[r * WBS + k] = (inside(WB + r) && inside(k)) ? entry(WB + r, k) : 0.0;
@@ -771,7 +1183,7 @@ __global__ __launch_bounds__(1024) void ba_band_factor(BaDims d, BaBufs b, BigBu
         if (split && J == ND - 1) {
             // the separator's block as this side leaves it (lower triangle, this side's order) and its right-hand side
             double* sp = g.sep + (size_t)rev * (WB * WB + WB);
-            for (int idx = tid; idx < WB * WB; idx += 1024) {
+            for (int idx = tid; idx < WB * WB; idx += BAND_THREADS) {
                 const int r = idx / WB, k = idx % WB;
                 if (k <= r) sp[idx] = Tm[r * WBS + k];
             }
@@ -789,6 +1201,46 @@ __global__ __launch_bounds__(1024) void ba_band_factor(BaDims d, BaBufs b, BigBu
     if (tid == 0) for (int q = 0; q < 8; q++) b.dbg[(blockIdx.x == 0 ? 16 : 40) + q] += acc_t[q];     // side 0: 16.., side 1: 40..
 #endif
 }
+
+#endif
+
+#if BAND_V2
+// Two-sided form, between the two sides' launch and ba_big_finish: ONE workgroup of BAND_THREADS adds the two sides' Schur
+// updates of the separator block, factors it with the same 8-column chain (band_block8 without P rows: in ba_big_finish, whose
+// 1024 threads leave 128 registers per lane, the chain spills) and leaves L_s (row-major [WB][WB], lower) and D^-1 L^-1 y_s in
+// g.sep where side 0's contribution was.
+static inline size_t band_sep_lds_doubles() { return (size_t)WB * WBS + 2 * WB + WB * BAND_TS + 64 + 64 + WB; }
+__global__ __launch_bounds__(BAND_THREADS) void ba_band_sep(BaDims d, BaBufs b, BigBufs g)
+{
+    if (b.st->done || *g.fail) return;
+    extern __shared__ __attribute__((aligned(16))) double wl[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    double* Pm = wl;                                               // [WB][WBS] the separator's block
+    double* ys = Pm + WB * WBS;                                    // [2 WB] its right-hand side (second half unused)
+    double* Tt = ys + 2 * WB;                                      // [WB][BAND_TS]
+    double* scr = Tt + WB * BAND_TS;
+    double* L2 = scr + 64;
+    double* dvl = L2 + 64;
+    // lower triangle = side 0's block + side 1's update (transposed back from its reversed order)
+    for (int idx = tid; idx < WB * WB; idx += BAND_THREADS) {
+        const int r = idx / WB, k = idx % WB;
+        const int lo = min(r, k), hi = max(r, k);                  // symmetric image; only hi >= lo is stored by the sides
+        Pm[r * WBS + k] = g.sep[hi * WB + lo] + g.sep[WB * WB + WB + (WB - 1 - lo) * WB + (WB - 1 - hi)];
+    }
+    if (tid < WB) {
+        ys[tid] = g.sep[WB * WB + tid] + g.sep[WB * WB + WB + WB * WB + (WB - 1 - tid)];
+        dvl[tid] = 1.0;
+    }
+    lds_barrier();
+    bool bad = false;
+    const BandWin Ws = {Pm, nullptr, ys, Tt, scr, L2, dvl};
+    band_block8(Ws, 0, 0, false, bad, [](int, int) {});
+    if (__any(bad) && lane == 0) *g.fail = 1;
+    lds_barrier();
+    for (int idx = tid; idx < WB * WB; idx += BAND_THREADS) g.sep[idx] = Pm[(idx / WB) * WBS + idx % WB];
+    if (tid < WB) g.sep[WB * WB + tid] = ys[tid];
+}
+#endif
 
 // the band's backward substitution L^T x = D^-1 L^-1 g: per 64-column block, from the last,
 //   v = yf_J - L_{J+1,J}^T x_{J+1}  (64 x 64, all threads),   L_JJ^T x_J = v  (one wave, the block's columns in registers)
@@ -850,11 +1302,20 @@ static __device__ __forceinline__ void band_sep_backsub(const BigBufs& g, int n,
     const int NB = (n + WB - 1) / WB, np = NB * WB, Js = (NB - 1) / 2;
     double* Pm = W;                                                // [WB][WBS] the separator's block, then its right-hand side row
     double* ys = Pm + WB * WBS;
+#if !BAND_V2
     double* Tt = Pm + WROWS * WBS;
     double* Mi = Tt + 16 * WTILES * 17;
     double* rdl = Mi + 16 * 17;
     double* dvl = rdl + 16;
+#endif
     const int s0 = WB * Js;                                        // first real index of the separator
+#if BAND_V2
+    // the separator's factor and D^-1 L^-1 y_s, as ba_band_sep left them
+    for (int idx = tid; idx < WB * WB; idx += nt) Pm[(idx / WB) * WBS + idx % WB] = g.sep[idx];
+    if (tid < WB) ys[tid] = g.sep[WB * WB + tid];
+    for (int i = tid; i < n; i += nt) y[i] = g.yf[i];
+    lds_barrier();
+#else
     // separator: lower triangle = side 0's block + side 1's update (transposed back from its reversed order)
     for (int idx = tid; idx < WB * WB; idx += nt) {
         const int r = idx / WB, k = idx % WB;
@@ -871,6 +1332,7 @@ static __device__ __forceinline__ void band_sep_backsub(const BigBufs& g, int n,
     unsigned long long tq = 0, acc_t[8] = {0, 0, 0, 0, 0, 0, 0, 0};      // (phase stamps of RS_STAMPS builds: unused here)
     band_panel(Pm, nullptr, ys, Tt, Mi, rdl, dvl, WB, 0, 0, bad, acc_t, tq, []() {});
     if (__any(bad) && lane == 0) *s_fail = 1;
+#endif
     // x_s = L_s^-T (D^-1 L^-1 y_s): one wave, the block's columns in registers
     if (tid < 64) {
         double v = ys[tid];
@@ -1124,12 +1586,13 @@ static void big_carve(char* ws, size_t n, BigBufs* g)
     g->dv = (double*)(ws + off); off += al(sizeof(double) * n);
     g->yf = (double*)(ws + off); off += al(sizeof(double) * n);
     g->fail = (int*)(ws + off); off += 256;
-    g->sep = (double*)(ws + off);
+    g->sep = (double*)(ws + off); off += al(sizeof(double) * 2 * (64 * 64 + 64));
+    g->Ad = (double*)(ws + off);
 }
 
 size_t ba_big_bytes(int n)
 {
-    return sizeof(double) * ((size_t)n * n + BB * BB + 2 * (size_t)n + 2 * (64 * 64 + 64)) + 256 * 6;
+    return sizeof(double) * ((size_t)n * n + BB * BB + 2 * (size_t)n + 2 * (64 * 64 + 64) + 6 * (size_t)n) + 256 * 8;
 }
 
 // largest camera span (slots) whose block band fits the one-launch factorisation: 6 span + 5 <= WB columns
@@ -1142,6 +1605,9 @@ int ba_launch_reduced_solve_big(rs_context* ctx, const BaDims& d, const BaBufs& 
     big_carve(ws, n, &g);
     hipStream_t s = ctx->stream;
     if (band == 2 && (d.n + WB - 1) / WB < 3) band = 1;                  // no room for a separator between two sides
+#if BAND_V2
+    if (band && sizeof(double) * band_factor_lds_doubles(d.n) > 160 * 1024) band = 0;       // (n > 2300: the general blocked form)
+#endif
     // y, diagonal block, backsub partial sums; two-sided band: y + the panel window of the separator's factorisation
     // (two-sided band: the panel window of the separator's factorisation, then two diagonal blocks + two multiplier blocks + partial sums)
     const size_t lds_fin = sizeof(double) * (n + (band == 2 ? (size_t)4 * WB * WBS + 1024 : (size_t)WB * WBS + 1024));
@@ -1149,13 +1615,25 @@ int ba_launch_reduced_solve_big(rs_context* ctx, const BaDims& d, const BaBufs& 
         RS_HIP(ctx, rs_lds_attr((const void*)ba_big_finish, lds_fin));
     const size_t lds_upd = sizeof(double) * (6 * BB * BBS + 2 * BB * 17 + BB);
     RS_HIP(ctx, rs_lds_attr((const void*)ba_big_update, lds_upd));
-    hipLaunchKernelGGL(ba_big_prologue, dim3(1), dim3(1024), 0, s, d, b, opt, g);
+    hipLaunchKernelGGL(ba_big_prologue, dim3(1), dim3(1024), 0, s, d, b, opt, g, band);
     if (!band) hipLaunchKernelGGL(ba_big_assemble, dim3(256), dim3(256), 0, s, d, b);
     if (band) {
+#if BAND_V2
+        const size_t lds_band = sizeof(double) * band_factor_lds_doubles(d.n);
+#else
         const size_t lds_band = sizeof(double) * ((size_t)4 * WB * WBS + 2 * WB + (size_t)16 * WTILES * 17 + 16 * 17 + 16 + WB);
+#endif
         RS_HIP(ctx, rs_lds_attr((const void*)ba_band_factor, lds_band));
-        rs_prof_scope ps(ctx, "K7b_band_factor");
-        hipLaunchKernelGGL(ba_band_factor, dim3(band == 2 ? 2 : 1), dim3(1024), lds_band, s, d, b, g, band == 2 ? 1 : 0);
+        {
+            rs_prof_scope ps(ctx, "K7b_band_factor");
+            hipLaunchKernelGGL(ba_band_factor, dim3(band == 2 ? 2 : 1), dim3(BAND_V2 ? 512 : 1024), lds_band, s, d, b, g, band == 2 ? 1 : 0);
+        }
+#if BAND_V2
+        if (band == 2) {
+            rs_prof_scope ps(ctx, "K7c_band_separator");
+            hipLaunchKernelGGL(ba_band_sep, dim3(1), dim3(BAND_THREADS), sizeof(double) * band_sep_lds_doubles(), s, d, b, g);
+        }
+#endif
     } else {
         big_launch_factor(s, d, b, g, lds_upd);
     }

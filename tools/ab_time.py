@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""A/B timing of one cfg-3 solve (and of the benchmark pass, --pass) for the library named by RS_LIB (build.py, RS_VARIANT):
+"""A/B timing of one cfg-3 solve (cfg5: the 100-KF / 80k-landmark window) for the library named by RS_LIB (build.py, RS_VARIANT):
 run once per variant in the same gpurun call.  Prints the per-kernel HIP-event times of the solve."""
 import importlib
 import os
@@ -15,7 +15,8 @@ import torch  # noqa: E402
 ctx = rs.Context(0)
 for k, v in (a.split("=") for a in sys.argv[1:] if "=" in a):
     ctx.set_int(k, int(v))
-w = synth.make_ba_window()
+big = "cfg5" in sys.argv[1:]
+w = synth.make_ba_window(n_kf=100, n_points=80000, config_id=5) if big else synth.make_ba_window()
 c0, p0 = ctx.dev(w["cams"]), ctx.dev(w["points"])
 dev = [ctx.dev(w[k]) for k in ("obs_ptr", "obs_cam", "obs_uv")]
 dc, dp = c0.clone(), p0.clone()
@@ -26,7 +27,7 @@ torch.cuda.synchronize()
 best = 1e9
 for rep in range(5):
     t0 = time.perf_counter()
-    n = 40
+    n = 10 if big else 40
     for _ in range(n):
         dc.copy_(c0); dp.copy_(p0)
         s = ctx.bundle_adjust(dc, w["cam_free"], dp, *dev, w["K"])
