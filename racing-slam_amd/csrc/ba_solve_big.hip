@@ -469,213 +469,24 @@ __global__ __launch_bounds__(256) void ba_big_update(BaDims d, BaBufs b, BigBufs
 // block column on a window in LDS —
 //     D = A[J][J] (64 x 64),  P = A[J+1][J],  the right-hand side's entries of block J      (the 129-row panel)
 //     T = A[J+1][J+1],  the right-hand side's entries of block J+1,  and the NEXT step's P
-// — per block: the panel is factored as four 16-column sub-blocks (band_panel: wave 0 the 16 x 16 diagonal sub-block in
-// registers and its inverse; the rows below and the rank-16 update of the remaining columns on the matrix cores), which leaves
-// L_JJ, D_J, the multipliers L_{J+1,J} and D^-1 L^-1 g in place; then T -= L_P D L_P^T on the matrix cores, the factor's
-// blocks go to memory for the backward substitution, T becomes the next D by a pointer swap.  The blocks of the next step
-// (original entries of S: nothing outside the band ever updates them) are fetched by the waves that would wait while wave 0
-// factors the first diagonal sub-block.  ba_band_factor runs as ONE workgroup over all block columns, or as TWO that
-// eliminate from both ends of the band towards a separator block (see there).
+// — per block: the 129-row panel [D; P; right-hand side] is factored in place in eight 8-column steps (band_block8, below), which
+// leaves L_JJ, D_J, the multipliers L_{J+1,J} and D^-1 L^-1 g; then T -= L_P D L_P^T on the matrix cores, T becomes the next D by
+// a pointer swap.  The factor's columns go to memory step by step (the backward substitution reads them); the blocks of the next
+// step (original entries of S: nothing outside the band ever updates them) are fetched by the tile waves, a few values per step.
+// ba_band_factor runs as ONE workgroup over all block columns, or as TWO that eliminate from both ends of the band towards a
+// separator block (see there), which ba_band_sep factors.  Round 4 (8-column chain with roles per wave, 512 threads): 158 -> 124 us
+// per LM step at n = 588 against round 3's four 16-column sub-blocks per block with ONE wave factoring the 16 x 16 diagonal
+// sub-block and its inverse by v_readlane broadcasts (6 us of the 8.7 us per sub-block).
 #define WB 64
 #define WBS 65
 #define WROWS (2 * WB + 1)
-#define WTILES ((WROWS + 15) / 16)          // row tiles of the panel (9)
 // barrier for LDS traffic only: __syncthreads() also waits for every global access in flight (vmcnt), which would serialise
 // the stores of the factor with the factorisation
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
-// The 129-row panel [D; P; rhs] of one block column in LDS (three buffers: Dm [WB][WBS], Pp [WB][WBS], yrow [WB]), factored
-// in place as four 16-column sub-blocks (all 16 waves of the workgroup call this together): afterwards D holds L_JJ below
-// its diagonal and d on it, P the multipliers L_{J+1,J}, the right-hand side row D^-1 L^-1 g, dvl the pivots.  w: columns of
-// the block, hp: rows of P, c_first: first sub-block that is not identity padding.  idle(): what waves 1..15 do while wave 0
-// factors the FIRST diagonal sub-block (they would wait at the barrier: the banded kernel has them fetch the next blocks —
-// in a branch of their own, so the fetched values do not add to the register pressure of wave 0's chain).
-template <typename Idle>
-static __device__ __forceinline__ void band_panel(double* Dm, double* Pp, double* yrow, double* Tt, double* Mi, double* rdl, double* dvl,
-                                                  int w, int hp, int c_first, bool& bad, unsigned long long* acc_t, unsigned long long& tq,
-                                                  Idle&& idle)
-{
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int lr = lane & 15, lk = lane >> 4;
-#if RS_STAMPS
-#define PANEL_STAMP(i) do { if (tid == 0) { const unsigned long long t_ = wall_clock64(); acc_t[i] += t_ - tq; tq = t_; } } while (0)
-#else
-#define PANEL_STAMP(i) do { } while (0)
-#endif
-    for (int c = c_first; c < w; c += 16) {
-        if (wave == 0) {
-            // A: the 16 x 16 diagonal sub-block in registers (lane = row; pivots and column entries by v_readlane)
-            int r = lr;
-            double a[16];
-#pragma unroll
-            for (int k = 0; k < 16; k++) a[k] = Dm[(c + r) * WBS + c + k];
-            double my_rd = 1.0, my_piv = 1.0;
-            // software-pipelined: column cc + 1 is updated first and its pivot's reciprocal (a chain of ten dependent
-            // instructions) is in flight under the updates of columns cc + 2 .. 15 — the same operations in another order
-            double piv = rl64(a[0], 0);
-            double rd = rcp_nr(piv);
-            double lc = a[0] * rd;
-#pragma unroll
-            for (int cc = 0; cc < 16; cc++) {
-                asm volatile("" : "+v"(r));
-                double piv_n = 1.0, rd_n = 1.0, lc_n = 0.0;
-                if (cc + 1 < 16) {
-                    a[cc + 1] -= lc * rl64(a[cc], cc + 1);
-                    piv_n = rl64(a[cc + 1], cc + 1);
-                    rd_n = rcp_nr(piv_n);
-                    lc_n = a[cc + 1] * rd_n;
-                }
-#pragma unroll
-                for (int k = cc + 2; k < 16; k++) a[k] -= lc * rl64(a[cc], k);
-                bad = bad || !(piv > 0.0) || !isfinite(piv);
-                a[cc] = r > cc ? lc : a[cc];
-                my_rd = r == cc ? rd : my_rd;
-                my_piv = r == cc ? piv : my_piv;
-                piv = piv_n; rd = rd_n; lc = lc_n;
-                __builtin_amdgcn_sched_barrier(0);
-            }
-            if (lane < 16) {
-#pragma unroll
-                for (int k = 0; k < 16; k++) Dm[(c + r) * WBS + c + k] = a[k];      // multipliers below the diagonal, d on it
-                rdl[r] = my_rd;
-                dvl[c + r] = my_piv;
-            }
-            // A': row r of M = L^-1 (unit lower) by lane r: m_rj = -sum_{k > j} m_rk l_kj for j < r.  L is read back from the
-            // panel image just written — the same address in every lane, i.e. LDS broadcasts — with two partial sums per
-            // entry (as v_readlane broadcasts from the lanes' registers the 120 column entries cost 2.5 us per sub-block).
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            if (lane < 16) {
-                double m[16];
-#pragma unroll
-                for (int k = 0; k < 16; k++) m[k] = (k == r) ? 1.0 : 0.0;
-#pragma unroll
-                for (int jj = 14; jj >= 0; jj--) {
-                    asm volatile("" : "+v"(r));
-                    double s0 = 0.0, s1 = 0.0;
-#pragma unroll
-                    for (int k = jj + 1; k < 16; k += 2) {
-                        s0 -= m[k] * Dm[(c + k) * WBS + c + jj];             // m[k] = 0 beyond the row's diagonal
-                        if (k + 1 < 16) s1 -= m[k + 1] * Dm[(c + k + 1) * WBS + c + jj];
-                    }
-                    m[jj] = jj < r ? s0 + s1 : m[jj];
-                }
-#pragma unroll
-                for (int k = 0; k < 16; k++) Mi[r * 17 + k] = m[k];
-            }
-        } else if (c == c_first) {
-            idle();
-        }
-        lds_barrier();
-        PANEL_STAMP(1);
-        const int wpad = (w + 15) & ~15;                                    // (rows w .. wpad-1 are identity padding: whole tiles)
-        const int below = max(0, wpad - c - 16);                            // D rows under the sub-block
-        const int nrows = below + hp + 1;                                   // + P rows + the right-hand side row
-        auto rowp = [&](int pr) -> double* { return pr < below ? Dm + (c + 16 + pr) * WBS : (pr < below + hp ? Pp + (pr - below) * WBS : yrow); };
-        const int ntile = (nrows + 15) / 16;
-        // B: T = R M^T on the matrix cores, one 16-row tile of the rows below per wave; multipliers = T D^-1
-        if (wave < ntile) {
-            const int prA = min(16 * wave + lr, nrows - 1);                  // operand row of this lane (clamped: masked at the store)
-            const double* R = rowp(prA) + c + lk;
-            const double* Mr = Mi + lr * 17 + lk;
-            double ra[4], mb[4];
-#pragma unroll
-            for (int kc = 0; kc < 4; kc++) { ra[kc] = R[4 * kc]; mb[kc] = Mr[4 * kc]; }
-            d4 acc = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-            for (int kc = 0; kc < 4; kc++) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(ra[kc], mb[kc], acc, 0, 0, 0);
-            const double rdj = rdl[lr];
-#pragma unroll
-            for (int reg = 0; reg < 4; reg++) {
-                const int pr = 16 * wave + lk + 4 * reg;
-                Tt[pr * 17 + lr] = acc[reg];
-                if (pr < nrows) rowp(pr)[c + lr] = acc[reg] * rdj;
-            }
-        }
-        lds_barrier();
-        PANEL_STAMP(2);
-        // C: rank-16 update of the panel's remaining columns on the matrix cores: rows below x D rows below
-        {
-            const int ctile = below / 16;                                    // w - c - 16 is a multiple of 16 (identity padding)
-            for (int t = wave; t < ntile * ctile; t += 16) {
-                const int tr = t / ctile, tc = t % ctile;
-                const double* X = Tt + (16 * tr + lr) * 17 + lk;
-                const double* Z = Dm + (c + 16 + 16 * tc + lr) * WBS + c + lk;
-                double xa[4], zb[4];
-#pragma unroll
-                for (int kc = 0; kc < 4; kc++) { xa[kc] = X[4 * kc]; zb[kc] = Z[4 * kc]; }
-                d4 acc = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-                for (int kc = 0; kc < 4; kc++) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(xa[kc], zb[kc], acc, 0, 0, 0);
-#pragma unroll
-                for (int reg = 0; reg < 4; reg++) {
-                    const int pr = 16 * tr + lk + 4 * reg, qq = 16 * tc + lr;
-                    if (pr < nrows && (pr >= below || qq <= pr)) rowp(pr)[c + 16 + qq] -= acc[reg];
-                }
-            }
-        }
-        lds_barrier();
-        PANEL_STAMP(3);
-    }
-#undef PANEL_STAMP
-}
-
-// What the 15 idle waves of ba_band_factor do during the first diagonal sub-block of block column J: T = A'[J+1][J+1] and the
-// right-hand side of block J+1, Pn = A'[J+2][J+1], from the lower triangle of S through the side's index map (v -> np - 1 - v
-// for the reversed side), identity / zero outside the matrix, zeros for T when it is the separator's block seen from side 1.
-// A function of its own: inlined, the compiler computes its 20 addresses in front of the branch, in wave 0's path as well,
-// and spills them.
-// entry (hi, lo), hi >= lo, of the damped reduced matrix from the accumulators as K5 / the prologue leave them — S in its UPPER
-// triangle, the cameras' own blocks in U, the damping in lam — summed in ba_big_assemble's order (the banded path has no
-// assemble launch: nothing outside the band is ever needed)
-struct BandSrc { const double* S; const double* U; const double* lam; const double* dc; int n; };
-static __device__ __forceinline__ double band_entry(const BandSrc& a, int hi, int lo)
-{
-    double v = a.S[(size_t)lo * a.n + hi];
-    const double u = a.U[(hi / 6) * 36 + (lo % 6) * 6 + (hi % 6)], l = a.lam[hi];
-    if (hi / 6 == lo / 6) v += u;
-    if (hi == lo) v += l;
-    return v;
-}
-static __device__ __attribute__((noinline)) void band_fetch(const double* __restrict__ S, const double* __restrict__ U, const double* __restrict__ lam,
-                                                            const double* __restrict__ dc, int n, int np, int rev,
-                                                            int J, int NB, bool tz, double* Tm, double* Pn, double* yP)
-{
-    const BandSrc src = {S, U, lam, dc, n};
-    const int t = (int)threadIdx.x - 64;                                     // 0 .. 959
-    const int r1 = WB * (J + 1), r2 = r1 + WB;
-    auto phi = [&](int v) { return rev ? np - 1 - v : v; };
-    auto inside = [&](int v) { return (unsigned)phi(v) < (unsigned)n; };
-    auto entry = [&](int r, int k) {
-        const int i = min(max(phi(r), 0), n - 1), j = min(max(phi(k), 0), n - 1);
-        return band_entry(src, max(i, j), min(i, j));
-    };
-    double vT[5], vP[5];
-#pragma unroll
-    for (int u = 0; u < 5; u++) {                                            // (clamped addresses; masks when the values are placed)
-        const int idx = min(t + 960 * u, WB * WB - 1), r = idx / WB, k = idx % WB;
-        vT[u] = entry(r1 + r, r1 + k);
-        vP[u] = entry(r2 + r, r1 + k);
-    }
-    const double vy = dc[min(max(phi(r1 + (t & (WB - 1))), 0), n - 1)];
-#pragma unroll
-    for (int u = 0; u < 5; u++) {
-        const int idx = t + 960 * u, r = idx / WB, k = idx % WB;
-        if (idx < WB * WB) {
-            const bool vr1 = J + 1 < NB && inside(r1 + r), vr2 = J + 2 < NB && inside(r2 + r), vk = J + 1 < NB && inside(r1 + k);
-            Tm[r * WBS + k] = tz ? 0.0 : ((vr1 && vk) ? vT[u] : (r == k ? 1.0 : 0.0));
-            Pn[r * WBS + k] = (vr2 && vk) ? vP[u] : 0.0;
-        }
-    }
-    if (t < WB) yP[t] = (!tz && J + 1 < NB && inside(r1 + t)) ? vy : 0.0;
-}
-
-#ifndef BAND_V2
-#define BAND_V2 1
-#endif
 #ifndef BAND_DIAG
-#define BAND_DIAG 0           // timing diagnostics (wrong results): 1 no factor stores, 2 no fetch, 4 no tile updates
+#define BAND_DIAG 0           // timing diagnostics (wrong results): 1 no factor stores, 2 the whole fetch at the end of the block, 4 no tile updates
 #endif
-#if BAND_V2
 // ---- the panel of one block column, 8 columns per step, with the chain kept off the matrix cores (the form of ba_solve.hip's
 // K7 on a window in LDS).  The first 8 waves of the workgroup have ROLES (512 threads: 256 registers per lane, where 1024
 // threads leave 128 and the chain's 36-entry triangle + row state spills; waves w, w + 4 share a SIMD; f64 MFMA and f64 VALU
@@ -692,10 +503,19 @@ static __device__ __attribute__((noinline)) void band_fetch(const double* __rest
 //                     whatever the caller hands them (after_step: the factor's columns to memory, the next blocks' fetch)
 // two workgroup barriers per step.  Rows above the step's sub-block are finished and idle; identity padding needs no masks.
 #define BAND_TS 10
+#ifndef BAND_CHAIN_X
+#define BAND_CHAIN_X 4          // the chain waves are dw and dw ^ BAND_CHAIN_X: 1 = on two SIMDs (each has the FP64 pipe to itself in the
+#endif                          // factorisation), 4 = on one SIMD (no tile wave's MFMAs next to the chain)
+#define BAND_NT 5               // tile waves (waves beyond the first eight of a larger workgroup only keep the barriers)
+#if BAND_CHAIN_X == 1
+#define BAND_RHS_WAVE 2
+#define band_is_tile(wave) ((wave) >= 3 && (wave) < 8)
+#define band_tile_index(wave) ((wave) - 3)                                   // 0 .. 4
+#else
 #define BAND_RHS_WAVE 5         // (SIMD 1: its factorisation runs while the tile waves of that SIMD wait for the step's multipliers)
-#define BAND_NT 5               // tile waves: 1, 2, 3, 6, 7 (waves beyond the first eight of a larger workgroup only keep the barriers)
 #define band_is_tile(wave) ((wave) < 8 && ((wave) & 3) != 0 && (wave) != BAND_RHS_WAVE)
 #define band_tile_index(wave) ((wave) < 4 ? (wave) - 1 : (wave) - 3)         // 0 .. 4
+#endif
 // live tiles of a step by lo = (c + 8) / 16: tile rows lo .. 7 x tile columns lo .. min(row, 3), the triangle of the D rows first, then
 // the P rows' rectangle; entry = 4 * tile row + tile column
 __device__ static const unsigned char BAND_TILES[4][26] = {
@@ -726,7 +546,7 @@ static __device__ __forceinline__ void band_block8(const BandWin& W, const int s
 #define BLOCK_STAMP(i) do { } while (0)
 #endif
     const int lr = lane & 15, lk = lane >> 4;
-    const bool chain_d = wave == dw, chain_p = has_p && wave == (dw ^ 4), rhs = wave == BAND_RHS_WAVE;
+    const bool chain_d = wave == dw, chain_p = has_p && wave == (dw ^ BAND_CHAIN_X), rhs = wave == BAND_RHS_WAVE;
     const bool chain = chain_d || chain_p, tile = band_is_tile(wave);
     const int tw = band_tile_index(wave);
     double* const rp = chain_p ? W.Pp + lane * WBS : W.Dm + lane * WBS;     // chain: this lane's panel row
@@ -850,21 +670,23 @@ static __device__ __forceinline__ void band_block8(const BandWin& W, const int s
 #pragma unroll
                 for (int k = 0; k < 8; k++) cur[k] = W.y[c + 8 + k];
             }
-        } else if (tile && !(BAND_DIAG & 4)) {
-            // tile q of the step's list (BAND_TILES; without P rows only its triangle) -> wave q % BAND_NT
+        }
+        if ((tile || rhs) && !(BAND_DIAG & 4)) {                                 // (the right-hand side's wave joins as sixth tile wave)
+            // tile q of the step's list (BAND_TILES; without P rows only its triangle) -> tile wave q % 6
             const int pdiff = has_p ? (int)(W.Pp - W.Dm) : 0;                   // (P rows: the same LDS allocation as D)
             const int lo = (c + 8) >> 4, nlo = 4 - lo, tri = (nlo * (nlo + 1)) >> 1, ntile = tri + (has_p ? 4 * nlo : 0);
             // two tiles per round: the operands and old values of both travel together (one LDS round trip), their MFMAs interleave;
             // entries outside the live lower triangle are rewritten as they are: nobody writes them in this phase
+            constexpr int NT6 = BAND_NT + 1;
 #pragma unroll 1
-            for (int q = tw; q < ntile; q += 2 * BAND_NT) {
-                const bool two = q + BAND_NT < ntile;                            // (wave-uniform; else the second tile repeats the first, unwritten)
+            for (int q = rhs ? BAND_NT : tw; q < ntile; q += 2 * NT6) {
+                const bool two = q + NT6 < ntile;                                // (wave-uniform; else the second tile repeats the first, unwritten)
                 int tr[2], tc[2], pr0[2], qq[2];
                 double x0[2], x1[2], z0[2], z1[2], old[2][4];
                 double* e0[2];
 #pragma unroll
                 for (int u = 0; u < 2; u++) {
-                    const int code = BAND_TILES[lo][(u && two) ? q + BAND_NT : q];
+                    const int code = BAND_TILES[lo][(u && two) ? q + NT6 : q];
                     tr[u] = code >> 2; tc[u] = code & 3;
                     const double* X = W.Tt + (16 * tr[u] + lr) * BAND_TS + lk;
                     const double* Z = W.Dm + (16 * tc[u] + lr) * WBS + c + lk;
@@ -879,16 +701,26 @@ static __device__ __forceinline__ void band_block8(const BandWin& W, const int s
                 acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(x0[1], z0[1], acc1, 0, 0, 0);
                 acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(x1[0], z1[0], acc0, 0, 0, 0);
                 acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(x1[1], z1[1], acc1, 0, 0, 0);
+                // a tile below the diagonal and wholly behind column c + 8 needs no masks (most are)
+                if (tr[0] > tc[0] && 16 * tc[0] >= c + 8 && tr[1] > tc[1] && 16 * tc[1] >= c + 8) {
 #pragma unroll
-                for (int reg = 0; reg < 4; reg++) {
-                    const int pr = pr0[0] + 4 * reg;
-                    e0[0][4 * reg * WBS] = (pr >= c + 8 && qq[0] >= c + 8 && qq[0] <= pr) ? old[0][reg] - acc0[reg] : old[0][reg];
-                }
-                if (two) {
+                    for (int reg = 0; reg < 4; reg++) e0[0][4 * reg * WBS] = old[0][reg] - acc0[reg];
+                    if (two) {
+#pragma unroll
+                        for (int reg = 0; reg < 4; reg++) e0[1][4 * reg * WBS] = old[1][reg] - acc1[reg];
+                    }
+                } else {
 #pragma unroll
                     for (int reg = 0; reg < 4; reg++) {
-                        const int pr = pr0[1] + 4 * reg;
-                        e0[1][4 * reg * WBS] = (pr >= c + 8 && qq[1] >= c + 8 && qq[1] <= pr) ? old[1][reg] - acc1[reg] : old[1][reg];
+                        const int pr = pr0[0] + 4 * reg;
+                        e0[0][4 * reg * WBS] = (pr >= c + 8 && qq[0] >= c + 8 && qq[0] <= pr) ? old[0][reg] - acc0[reg] : old[0][reg];
+                    }
+                    if (two) {
+#pragma unroll
+                        for (int reg = 0; reg < 4; reg++) {
+                            const int pr = pr0[1] + 4 * reg;
+                            e0[1][4 * reg * WBS] = (pr >= c + 8 && qq[1] >= c + 8 && qq[1] <= pr) ? old[1][reg] - acc1[reg] : old[1][reg];
+                        }
                     }
                 }
             }
@@ -898,7 +730,6 @@ static __device__ __forceinline__ void band_block8(const BandWin& W, const int s
     if (!(chain || rhs)) after_step(WB / 8 - 1, WB - 8);
 #undef BLOCK_STAMP
 }
-#endif
 
 // Two-sided form (`split`): the band is cut at a SEPARATOR block column Js = (NB - 1) / 2.  Workgroup 0 eliminates the block
 // columns above it in order, workgroup 1 the ones below it in REVERSE order (the same algorithm on the matrix with rows and
@@ -908,7 +739,6 @@ static __device__ __forceinline__ void band_block8(const BandWin& W, const int s
 // g.sep; ba_big_finish adds them, factors the separator and substitutes backwards on both sides in lock step.  The chain of
 // dependent 16-column sub-blocks is 17 + 4 instead of 37 at n = 588.  Factor blocks are stored at the REAL positions of their
 // (virtual) rows and columns, so side 1's land in the upper triangle of g.Ls.
-#if BAND_V2
 // doubles of LDS: four block buffers, the side's right-hand side (np + WB), the t panel, scratch, next multipliers, pivots
 static inline size_t band_factor_lds_doubles(int n) { const size_t np = (size_t)((n + WB - 1) / WB) * WB; return (size_t)4 * WB * WBS + np + WB + 2 * WB * BAND_TS + 64 + 64 + WB; }
 #define BAND_THREADS 512
@@ -1071,130 +901,7 @@ __global__ __launch_bounds__(BAND_THREADS) void ba_band_factor(BaDims d, BaBufs 
         }
         // ---- shift the window by swapping buffers: T becomes D, the fetched P the panel's; the chain waves swap their rows
         { double* t_ = Dm; Dm = Tm; Tm = t_; t_ = Pp; Pp = Pn; Pn = t_; }
-        dw ^= 4;
-    }
-    if (__any(bad) && lane == 0) *g.fail = 1;
-#if RS_STAMPS
-    if (tid == 0) for (int q = 0; q < 8; q++) b.dbg[(blockIdx.x == 0 ? 16 : 40) + q] += acc_t[q];     // side 0: 16.., side 1: 40..
-#endif
-}
-#else
-__global__ __launch_bounds__(1024) void ba_band_factor(BaDims d, BaBufs b, BigBufs g, int split)
-{
-    if (b.st->done) return;
-    extern __shared__ __attribute__((aligned(16))) double wl[];
-    // the window: D = A[J][J] and T = A[J+1][J+1] alternate between two buffers (T becomes the next D by a pointer swap), P =
-    // A[J+1][J] and the NEXT block's P likewise, and so do the right-hand sides of blocks J and J+1
-    double* Dm = wl;                               // [WB][WBS]
-    double* Tm = Dm + WB * WBS;                    // [WB][WBS]
-    double* Pp = Tm + WB * WBS;                    // [WB][WBS]
-    double* Pn = Pp + WB * WBS;                    // [WB][WBS] A[J+2][J+1], fetched during block J
-    double* yrow = Pn + WB * WBS;                  // [WB] right-hand side, block J
-    double* yP = yrow + WB;                        // [WB] right-hand side, block J+1
-    double* Tt = yP + WB;                          // [16 WTILES][17] T = R L^-T of the current sub-block, by row below
-    double* Mi = Tt + 16 * WTILES * 17;            // [16][17] inverse of the sub-block's unit-lower L
-    double* rdl = Mi + 16 * 17;                    // [16] 1 / d of the current sub-block
-    double* dvl = rdl + 16;                        // [WB] d of the block
-    const int n = d.n, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int lr = lane & 15, lk = lane >> 4;
-    const int NB = (n + WB - 1) / WB, np = NB * WB;
-    const int rev = split ? (int)blockIdx.x : 0;
-    const int Js = (NB - 1) / 2;
-    const int ND = split ? (rev ? NB - 1 - Js : Js) : NB;     // block columns this workgroup eliminates
-    const int pad = np - n;                                     // identity padding: the tail of the real order = the head of the reversed one
-    // virtual index -> real index; entries outside the matrix are identity
-    auto phi = [&](int v) { return rev ? np - 1 - v : v; };
-    auto inside = [&](int v) { return (unsigned)phi(v) < (unsigned)n; };
-    const BandSrc src = {b.S, b.U, b.rhs, b.dc, n};             // (the prologue left the damping in b.rhs)
-    auto entry = [&](int r, int k) {                            // A'(r, k), clamped to the matrix (masked by the caller)
-        const int i = min(max(phi(r), 0), n - 1), j = min(max(phi(k), 0), n - 1);
-        return band_entry(src, max(i, j), min(i, j));
-    };
-    auto rhs_at = [&](int v) { return min(max(phi(v), 0), n - 1); };
-#if RS_STAMPS
-    unsigned long long tq = wall_clock64(), acc_t[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-#define BAND_STAMP(i) do { if (tid == 0) { const unsigned long long t_ = wall_clock64(); acc_t[i] += t_ - tq; tq = t_; } } while (0)
-#else
-    unsigned long long tq = 0, *acc_t = nullptr;
-#define BAND_STAMP(i) do { } while (0)
-#endif
-    if (tid < WB) dvl[tid] = 1.0;
-    // block 0: D, P and the right-hand side from memory (identity / zero outside the matrix)
-    for (int idx = tid; idx < WB * WB; idx += BAND_THREADS) {
-        const int r = idx / WB, k = idx % WB;
-        Dm[r * WBS + k] = (inside(r) && inside(k)) ? entry(r, k) : (r == k ? 1.0 : 0.0);
-        Pp[r * WBS + k] = (inside(WB + r) && inside(k)) ? entry(WB + r, k) : 0.0;
-    }
-    if (tid < WB) yrow[tid] = inside(tid) ? b.dc[rhs_at(tid)] : 0.0;
-    lds_barrier();
-    bool bad = false;
-    for (int J = 0; J < ND; J++) {
-        const int c0 = WB * J, w = rev ? WB : min(WB, n - c0);
-        const int r1 = c0 + WB, hp = J + 1 < NB ? (rev ? WB : min(WB, n - r1)) : 0;      // rows of block J+1
-        // While wave 0 factors the first diagonal sub-block the other 15 waves fetch this step's T = A[J+1][J+1] and the
-        // right-hand side of block J+1 (needed by the trailing update at the end of the step; their buffers were the previous
-        // step's D and right-hand side row) and the NEXT step's P = A[J+2][J+1] — original entries of S: nothing outside the
-        // band ever updates them.  Side 1 starts the separator's block from zero: it contributes updates only.
-        auto fetch = [&]() { band_fetch(b.S, b.U, b.rhs, b.dc, n, np, rev, J, NB, split && rev && J + 1 == ND, Tm, Pn, yP); };
-        // ---- factor the panel: four 16-column sub-blocks (whole sub-blocks of side 1's padding are identity already)
-        const int c_first = (rev && J == 0) ? (pad & ~15) : 0;
-        band_panel(Dm, Pp, yrow, Tt, Mi, rdl, dvl, w, hp, c_first, bad, acc_t, tq, fetch);
-        // ---- the factor's blocks -> memory (the backward substitution reads them), D^-1 L^-1 g, D
-#pragma unroll
-        for (int u = 0; u < 4; u++) {
-            const int idx = tid + 1024 * u, r = idx / WB, k = idx % WB;
-            if (inside(c0 + r) && inside(c0 + k))
-                g.Ls[(size_t)phi(c0 + r) * n + phi(c0 + k)] = k < r ? Dm[r * WBS + k] : (k == r ? 1.0 : 0.0);
-            if (r < hp && inside(r1 + r) && inside(c0 + k))
-                g.Ls[(size_t)phi(r1 + r) * n + phi(c0 + k)] = Pp[r * WBS + k];
-        }
-        if (tid < WB && inside(c0 + tid)) { g.yf[phi(c0 + tid)] = yrow[tid]; g.dv[phi(c0 + tid)] = dvl[tid]; }
-        BAND_STAMP(4);
-        if (hp == 0) break;                                                      // last block
-        // ---- trailing update on the matrix cores: T -= (L_P D) L_P^T (lower tiles), yP -= L_P D yf
-        {
-            const int tr = wave >> 2, tc = wave & 3;                             // 16 waves = 4 x 4 tiles
-            if (tr >= tc) {
-                d4 acc = {0.0, 0.0, 0.0, 0.0};
-                const double* X = Pp + (16 * tr + lr) * WBS + lk;
-                const double* Z = Pp + (16 * tc + lr) * WBS + lk;
-#pragma unroll 4
-                for (int kc = 0; kc < WB / 4; kc++)
-                    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(X[4 * kc] * dvl[4 * kc + lk], Z[4 * kc], acc, 0, 0, 0);
-#pragma unroll
-                for (int reg = 0; reg < 4; reg++) Tm[(16 * tr + lk + 4 * reg) * WBS + 16 * tc + lr] -= acc[reg];
-            }
-            if (tr == 0 && tc >= 1) {
-                // the right-hand side on three of the idle waves: column tile tc - 1 (and 3 by wave 1 as well) of the one-row
-                // product  yP -= (yf D) L_P^T: operand row 0 = yf D, rows 1..15 zero
-                for (int ct = tc - 1; ct < 4; ct += 3) {
-                    d4 acc = {0.0, 0.0, 0.0, 0.0};
-                    const double* Y = yrow + lk;
-                    const double* Z = Pp + (16 * ct + lr) * WBS + lk;
-#pragma unroll 4
-                    for (int kc = 0; kc < WB / 4; kc++)
-                        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(lr == 0 ? Y[4 * kc] * dvl[4 * kc + lk] : 0.0, Z[4 * kc], acc, 0, 0, 0);
-                    if (lk == 0) yP[16 * ct + lr] -= acc[0];                      // output row 0 = lanes with lk == 0, register 0
-                }
-            }
-        }
-        lds_barrier();
-        BAND_STAMP(5);
-        if (split && J == ND - 1) {
-            // the separator's block as this side leaves it (lower triangle, this side's order) and its right-hand side
-            double* sp = g.sep + (size_t)rev * (WB * WB + WB);
-            for (int idx = tid; idx < WB * WB; idx += BAND_THREADS) {
-                const int r = idx / WB, k = idx % WB;
-                if (k <= r) sp[idx] = Tm[r * WBS + k];
-            }
-            if (tid < WB) sp[WB * WB + tid] = yP[tid];
-            break;
-        }
-        // ---- shift the window by swapping buffers: T becomes D, yP the right-hand side row, the fetched P the panel's (every
-        // reader of the old D, P and right-hand side row is behind the barrier above)
-        { double* t_ = Dm; Dm = Tm; Tm = t_; t_ = yrow; yrow = yP; yP = t_; t_ = Pp; Pp = Pn; Pn = t_; }
-        if (tid < WB) dvl[tid] = 1.0;                                            // (wave 0, which is also the next writer)
-        BAND_STAMP(6);
+        dw ^= BAND_CHAIN_X;
     }
     if (__any(bad) && lane == 0) *g.fail = 1;
 #if RS_STAMPS
@@ -1202,9 +909,6 @@ __global__ __launch_bounds__(1024) void ba_band_factor(BaDims d, BaBufs b, BigBu
 #endif
 }
 
-#endif
-
-#if BAND_V2
 // Two-sided form, between the two sides' launch and ba_big_finish: ONE workgroup of BAND_THREADS adds the two sides' Schur
 // updates of the separator block, factors it with the same 8-column chain (band_block8 without P rows: in ba_big_finish, whose
 // 1024 threads leave 128 registers per lane, the chain spills) and leaves L_s (row-major [WB][WB], lower) and D^-1 L^-1 y_s in
@@ -1240,7 +944,6 @@ __global__ __launch_bounds__(BAND_THREADS) void ba_band_sep(BaDims d, BaBufs b, 
     for (int idx = tid; idx < WB * WB; idx += BAND_THREADS) g.sep[idx] = Pm[(idx / WB) * WBS + idx % WB];
     if (tid < WB) g.sep[WB * WB + tid] = ys[tid];
 }
-#endif
 
 // the band's backward substitution L^T x = D^-1 L^-1 g: per 64-column block, from the last,
 //   v = yf_J - L_{J+1,J}^T x_{J+1}  (64 x 64, all threads),   L_JJ^T x_J = v  (one wave, the block's columns in registers)
@@ -1294,7 +997,7 @@ static __device__ __forceinline__ void band_backsub(const BigBufs& g, int n, dou
 
 // Two-sided form: the separator's block (both sides' updates added) is factored here, then x_s, then both sides substitute
 // backwards away from the separator in lock step — side 0 in the real order, side 1 in its reversed order (roles: below).
-//   W: LDS window of band_panel (the separator's block and right-hand side row, Tt, Mi, rdl, dvl); afterwards the same memory
+//   W: LDS window (the separator's factor and D^-1 L^-1 y_s from ba_band_sep); afterwards the same memory
 //   serves as two diagonal blocks + two multiplier blocks [2][2][WB][WBS] + partial sums [2][7][WB].
 static __device__ __forceinline__ void band_sep_backsub(const BigBufs& g, int n, double* y, double* W, int* s_fail)
 {
@@ -1302,37 +1005,12 @@ static __device__ __forceinline__ void band_sep_backsub(const BigBufs& g, int n,
     const int NB = (n + WB - 1) / WB, np = NB * WB, Js = (NB - 1) / 2;
     double* Pm = W;                                                // [WB][WBS] the separator's block, then its right-hand side row
     double* ys = Pm + WB * WBS;
-#if !BAND_V2
-    double* Tt = Pm + WROWS * WBS;
-    double* Mi = Tt + 16 * WTILES * 17;
-    double* rdl = Mi + 16 * 17;
-    double* dvl = rdl + 16;
-#endif
     const int s0 = WB * Js;                                        // first real index of the separator
-#if BAND_V2
     // the separator's factor and D^-1 L^-1 y_s, as ba_band_sep left them
     for (int idx = tid; idx < WB * WB; idx += nt) Pm[(idx / WB) * WBS + idx % WB] = g.sep[idx];
     if (tid < WB) ys[tid] = g.sep[WB * WB + tid];
     for (int i = tid; i < n; i += nt) y[i] = g.yf[i];
     lds_barrier();
-#else
-    // separator: lower triangle = side 0's block + side 1's update (transposed back from its reversed order)
-    for (int idx = tid; idx < WB * WB; idx += nt) {
-        const int r = idx / WB, k = idx % WB;
-        const int lo = min(r, k), hi = max(r, k);                  // symmetric image; only hi >= lo is stored by the sides
-        Pm[r * WBS + k] = g.sep[hi * WB + lo] + g.sep[WB * WB + WB + (WB - 1 - lo) * WB + (WB - 1 - hi)];
-    }
-    if (tid < WB) {
-        ys[tid] = g.sep[WB * WB + tid] + g.sep[WB * WB + WB + WB * WB + (WB - 1 - tid)];
-        dvl[tid] = 1.0;
-    }
-    for (int i = tid; i < n; i += nt) y[i] = g.yf[i];
-    lds_barrier();
-    bool bad = false;
-    unsigned long long tq = 0, acc_t[8] = {0, 0, 0, 0, 0, 0, 0, 0};      // (phase stamps of RS_STAMPS builds: unused here)
-    band_panel(Pm, nullptr, ys, Tt, Mi, rdl, dvl, WB, 0, 0, bad, acc_t, tq, []() {});
-    if (__any(bad) && lane == 0) *s_fail = 1;
-#endif
     // x_s = L_s^-T (D^-1 L^-1 y_s): one wave, the block's columns in registers
     if (tid < 64) {
         double v = ys[tid];
@@ -1605,9 +1283,7 @@ int ba_launch_reduced_solve_big(rs_context* ctx, const BaDims& d, const BaBufs& 
     big_carve(ws, n, &g);
     hipStream_t s = ctx->stream;
     if (band == 2 && (d.n + WB - 1) / WB < 3) band = 1;                  // no room for a separator between two sides
-#if BAND_V2
     if (band && sizeof(double) * band_factor_lds_doubles(d.n) > 160 * 1024) band = 0;       // (n > 2300: the general blocked form)
-#endif
     // y, diagonal block, backsub partial sums; two-sided band: y + the panel window of the separator's factorisation
     // (two-sided band: the panel window of the separator's factorisation, then two diagonal blocks + two multiplier blocks + partial sums)
     const size_t lds_fin = sizeof(double) * (n + (band == 2 ? (size_t)4 * WB * WBS + 1024 : (size_t)WB * WBS + 1024));
@@ -1618,22 +1294,16 @@ int ba_launch_reduced_solve_big(rs_context* ctx, const BaDims& d, const BaBufs& 
     hipLaunchKernelGGL(ba_big_prologue, dim3(1), dim3(1024), 0, s, d, b, opt, g, band);
     if (!band) hipLaunchKernelGGL(ba_big_assemble, dim3(256), dim3(256), 0, s, d, b);
     if (band) {
-#if BAND_V2
         const size_t lds_band = sizeof(double) * band_factor_lds_doubles(d.n);
-#else
-        const size_t lds_band = sizeof(double) * ((size_t)4 * WB * WBS + 2 * WB + (size_t)16 * WTILES * 17 + 16 * 17 + 16 + WB);
-#endif
         RS_HIP(ctx, rs_lds_attr((const void*)ba_band_factor, lds_band));
         {
             rs_prof_scope ps(ctx, "K7b_band_factor");
-            hipLaunchKernelGGL(ba_band_factor, dim3(band == 2 ? 2 : 1), dim3(BAND_V2 ? 512 : 1024), lds_band, s, d, b, g, band == 2 ? 1 : 0);
+            hipLaunchKernelGGL(ba_band_factor, dim3(band == 2 ? 2 : 1), dim3(BAND_THREADS), lds_band, s, d, b, g, band == 2 ? 1 : 0);
         }
-#if BAND_V2
         if (band == 2) {
             rs_prof_scope ps(ctx, "K7c_band_separator");
             hipLaunchKernelGGL(ba_band_sep, dim3(1), dim3(BAND_THREADS), sizeof(double) * band_sep_lds_doubles(), s, d, b, g);
         }
-#endif
     } else {
         big_launch_factor(s, d, b, g, lds_upd);
     }
