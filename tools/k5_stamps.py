@@ -11,9 +11,10 @@ rs, synth = pkg.rsgpu, pkg.synth
 
 ctx = rs.Context(0)
 ctx.set_int("ba_fuse_mode", 1)      # K7's stamps belong to the two-launch form (the fused launch: tools/k78_stamps.py)
-w = synth.make_ba_window()
+big = "cfg5" in sys.argv[1:]
+w = synth.make_ba_window(n_kf=100, n_points=80000, config_id=5) if big else synth.make_ba_window()
 dev = [ctx.dev(w[k]) for k in ("obs_ptr", "obs_cam", "obs_uv")]
-for ns in (1, 3):
+for ns in ((1,) if big else (1, 3)):
     ctx.set_int("ba_speculative_sets", ns)
     dc, dp = ctx.dev(w["cams"]), ctx.dev(w["points"])
     s = ctx.bundle_adjust(dc, w["cam_free"], dp, *dev, w["K"])
@@ -21,5 +22,6 @@ for ns in (1, 3):
     c = ctx.prof_counters(16)
     st = ctx.ba_stats()
     print("ns", ns, "rounds", st, "K7 phases (cycles):", c[:8])
-    print("   K5 phases (us per launch @100MHz?):", [round(v / max(st["rounds"], 1) / 100.0, 2) for v in c[8:16]], "raw", c[8:16])
+    names = ("union+loads", "linearise(pass 1)", "block inverse", "tile zero/Y", "Y -> tile + barrier", "SYRK + scatter", "epilogue", "-")
+    print("   K5 phases of the middle workgroup, cycles per launch:", {n: int(v / max(st["rounds"], 1)) for n, v in zip(names, c[8:16])})
 ctx.close()
