@@ -398,6 +398,8 @@ def test_bundle_adjust_banded_reduced_solve(ctx, oracle, synth, kw, banded):
         ctx.set_int("ba_band_mode", 0)
     assert ("K7b_band_factor" in runs[0][4]) == banded and "K7b_band_factor" not in runs[1][4]
     assert ("K7b_band_factor" in runs[2][4]) == banded
+    # (round 4) the two-sided form factors its separator block in a launch of its own; the one-workgroup form has none
+    assert ("K7c_band_separator" in runs[0][4]) == banded and "K7c_band_separator" not in runs[2][4]
     for mode in (0, 2, 1):
         s, tr, c, p, _ = runs[mode]
         assert (s["iterations"], s["successful_steps"], s["termination"], s["usable"]) == \
