@@ -374,6 +374,8 @@ def test_triangulate_host_fast_path(ctx, oracle, synth, n):
                                        (dict(n_kf=60, n_points=2500, run_min=2, run_max=10, config_id=141), True),      # n = 348: 5 full blocks + 28 columns
                                        (dict(n_kf=33, n_points=900, run_min=2, run_max=10, config_id=142), True),       # n = 186
                                        (dict(n_kf=34, n_points=900, run_min=2, run_max=10, config_id=144), True),       # n = 192: whole blocks, no padding
+                                       (dict(n_kf=35, n_points=900, run_min=2, run_max=10, config_id=145), True),       # n = 198: 58 padded columns (side 1 starts in its last 8-column step)
+                                       (dict(n_kf=43, n_points=1200, run_min=2, run_max=10, config_id=146), True),      # n = 246: 10 padded columns
                                        (dict(n_kf=40, n_points=4000, run_min=3, run_max=24, config_id=143), False)])    # spans up to 23: not banded
 def test_bundle_adjust_banded_reduced_solve(ctx, oracle, synth, kw, banded):
     """VERDICT r2 #5 (cfg 5's reduced solve was 13 + 12 dependent launches per LM step): when every landmark is seen by key
