@@ -894,7 +894,7 @@ static int ba_solve_once(rs_context* ctx, int n_cameras, int n_points, int n_obs
                             ba_round_eligible(d) && ba_round_workgroups(d, b, grp) <= ctx->n_cu;
     const bool fuse78 = !fuse_round && plain_window && d.P > 0 /* an empty landmark shard has no K8 workgroup to clear the accumulators */ &&
                         (ctx->ba_fuse_mode >= 2 || (ctx->ba_fuse_mode == 0 && in_flight.others == 0)) &&
-                        ba_solve_backsub_workgroups(d, b) <= ctx->n_cu;
+                        ba_solve_backsub_workgroups(d, b, ctx->n_cu) <= ctx->n_cu;
     if (fuse_round && ba_prepare_round(d) != 0) return rs_fail(ctx, RS_ERR_HIP, "LDS attribute (round)");
     auto enqueue_round = [&](int it) -> int {
         // double-buffered state / step-scalar blocks: round `it` works on [it & 1] and reads [(it + 1) & 1]
@@ -934,7 +934,7 @@ static int ba_solve_once(rs_context* ctx, int n_cameras, int n_points, int n_obs
             if (rc2) return rc2;
         } else if (solve_lds && fuse78) {
             rs_prof_scope ps(ctx, "K78_ba_solve_backsub");
-            ba_launch_solve_backsub(s, d, b, opt);
+            ba_launch_solve_backsub(s, d, b, opt, ctx->n_cu);
         } else if (solve_lds) {
             rs_prof_scope ps(ctx, "K7_ba_reduced_solve");
             ba_launch_reduced_solve_lds(s, d, b, opt);

@@ -54,9 +54,9 @@ __device__ __forceinline__ unsigned ba_hand_wait(const unsigned long long* hand,
 // FUSED = false: the K8 launch (blockIdx.x = landmark block of 64, blockIdx.y = set; K7 has finished).
 // FUSED = true: a consumer workgroup of ba_solve_backsub: landmark block `vb` of blockDim.x / 4 landmarks, sets `set0`,
 // `set0 + set_stride`, ... of the round's active ones (set_stride = 0: `set0` only).  The fused grid holds the workgroups of
-// BA_CALIBRATED_SETS sets, which are resident together; in a deeper round a workgroup evaluates its second radius with the
-// landmark records, the observations and the current cameras' blocks it already holds, instead of a second shift of
-// workgroups that would start from their own loads behind the hand-off.
+// as many sets as are resident together (<= BA_CALIBRATED_SETS; fewer for windows of more than 10.7 k landmarks); in a deeper
+// round a workgroup evaluates its next radius with the landmark records, the observations and the current cameras' blocks it
+// already holds, instead of a second shift of workgroups that would start from their own loads behind the hand-off.
 // All loads that do not depend on K7 are issued first; the accumulators are cleared once every active set's K7 has
 // taken them (BA_HAND_TAKEN); delta_c is read behind the set's BA_HAND word with L1-bypassing loads, and the candidate
 // cameras' blocks are formed here (K7 forms the same for the next round after it has published).
@@ -66,14 +66,14 @@ template <bool FUSED>
 static __device__ __forceinline__ void ba_backsub_cost4_body(const BaDims& d, const BaBufs& b, const int vb, const int set0, const int set_stride,
                                                             const size_t wg_index, const size_t wg_count, const BaState* st_in = nullptr)
 {
-    static_assert(BA_MAXSETS <= 2 * BA_CALIBRATED_SETS, "a consumer workgroup holds V^-1 and the damping of at most two sets");
+
     extern __shared__ __attribute__((aligned(16))) double lds[];
     // ---- loads that depend on nothing but the landmark index go out first, together with the state block
     const int lane = threadIdx.x & 63, l = lane & 15, sub = lane >> 4;
     const int p = vb * (int)(blockDim.x >> 2) + (threadIdx.x >> 6) * 16 + l;
     const bool valid = p < d.P;
     int pass = 0;
-    const int set1 = set_stride > 0 && set0 + set_stride < b.ns ? set0 + set_stride : -1;     // second radius of a deep round
+    const int set1 = set_stride > 0 && set0 + set_stride < b.ns ? set0 + set_stride : -1;     // second radius (its V^-1 and damping travel with the first's)
     int o0 = 0, nobs = 0;
     double g[3] = {0, 0, 0}, I[6] = {0, 0, 0, 0, 0, 0}, lamp[3] = {0, 0, 0}, I1[6] = {0, 0, 0, 0, 0, 0}, lamp1[3] = {0, 0, 0}, Xq[BA_MAXSETS + 1][3];
 #pragma unroll
@@ -168,16 +168,22 @@ static __device__ __forceinline__ void ba_backsub_cost4_body(const BaDims& d, co
     __shared__ double redw[K8_MAX_THREADS / 64][4];
 
 #pragma unroll 1
-    for (; pass < 2; pass++) {
-        const int set = pass ? set1 : set0;                     // the radius evaluated in this pass (ba_common.h)
-        if (set < 0 || set >= st.nact) break;
-        if (pass) {
+    for (;; pass++) {
+        const int set = set0 + pass * set_stride;               // the radius evaluated in this pass (ba_common.h)
+        if (pass && (set_stride <= 0 || set >= b.ns)) break;
+        if (set >= st.nact) break;
+        if (pass == 1) {
 #pragma unroll
             for (int k = 0; k < 6; k++) I[k] = I1[k];
 #pragma unroll
             for (int k = 0; k < 3; k++) lamp[k] = lamp1[k];
-            __syncthreads();                                    // dcl, cprepn, hand_code and redw are reused
+        } else if (pass > 1 && valid) {                         // (fewer than three sets resident: a third pass loads its own)
+#pragma unroll
+            for (int k = 0; k < 6; k++) I[k] = b.Vinv[((size_t)set * d.P + p) * 6 + k];
+#pragma unroll
+            for (int k = 0; k < 3; k++) lamp[k] = b.lamp[((size_t)set * d.P + p) * 3 + k];
         }
+        if (pass) __syncthreads();                              // dcl, cprepn, hand_code and redw are reused
         const int cand = (st.cur + 1 + set) % (b.ns + 1);        // this set's candidate buffer (written by K7)
         const double* gprepn = b.prep + (size_t)cand * d.C * BA_PREP;
         if (!FUSED) {

@@ -623,8 +623,8 @@ size_t ba_imu_lds_total_doubles(int Ci, int n, int ns);
 size_t ba_reduced_solve_lds_bytes(int n);
 int ba_prepare_reduced_solve_lds(int n);
 void ba_launch_reduced_solve_lds(hipStream_t s, const BaDims& d, const BaBufs& b, const BaOpt& opt);
-int ba_solve_backsub_workgroups(const BaDims& d, const BaBufs& b);
-void ba_launch_solve_backsub(hipStream_t s, const BaDims& d, const BaBufs& b, const BaOpt& opt);   // K7 + K8 in one launch (ba_solve.hip)
+int ba_solve_backsub_workgroups(const BaDims& d, const BaBufs& b, int n_cu);
+void ba_launch_solve_backsub(hipStream_t s, const BaDims& d, const BaBufs& b, const BaOpt& opt, int n_cu);   // K7 + K8 in one launch (ba_solve.hip)
 // ---- K5 + K7 + K8 of a round in one launch (ba_round.hip)
 bool ba_round_eligible(const BaDims& d);
 int ba_round_workgroups(const BaDims& d, const BaBufs& b, const BaGroup& g);

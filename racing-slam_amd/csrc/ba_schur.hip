@@ -380,12 +380,20 @@ void ba_group_zero_range(const BaGroup& g, int32_t** ptr, int* count)
 }
 
 static size_t al256(size_t v) { return (v + 255) & ~(size_t)255; }
+// landmarks per item of a single solve: the smallest of 40, 48, 56, 64 that keeps the items within ONE shift of 256 workgroups
+// (an item's time grows with its landmarks; a second shift costs a whole item's time), 64 beyond that
+static int ba_default_item(int P)
+{
+    for (int it = IT_L_SMALL; it < IT_L; it += 8)
+        if (P <= 256 * it) return it;
+    return IT_L;
+}
 
 void ba_group_carve(char* base, int P, int Cf, int M, BaGroup* g)
 {
     const size_t nb = ((size_t)Cf * Cf + 2) * GRP_REP;
     const size_t ni_max = ((size_t)P + 31) / 32 + 1;
-    g->it_l = P <= 256 * IT_L_SMALL ? IT_L_SMALL : IT_L;
+    g->it_l = ba_default_item(P);
     const size_t ni = P > 0 ? ((size_t)P + g->it_l - 1) / g->it_l : 1;     // an empty landmark shard keeps one (empty) item:
     size_t off = 0;                                                            // its workgroup runs the round's decision
     g->sorted = (int32_t*)(base + off); off += al256(sizeof(int32_t) * P);
@@ -505,7 +513,7 @@ void ba_group_set_items(BaGroup* g, int P, bool throughput, int batch_item)
 {
     // throughput mode (windows batched in one grid): 32 landmarks per item by default — a 75 KB LDS image, so that TWO
     // workgroups share a compute unit and one's barriers / LDS round trips are covered by the other's arithmetic
-    const int tp = (batch_item == 32 || batch_item == 40 || batch_item == 64) ? batch_item : 32;
-    g->it_l = throughput ? tp : (P <= 256 * IT_L_SMALL ? IT_L_SMALL : IT_L);
+    const int tp = (batch_item >= 32 && batch_item <= 64 && batch_item % 8 == 0) ? batch_item : 32;
+    g->it_l = throughput ? tp : ba_default_item(P);
     g->n_items = P > 0 ? (P + g->it_l - 1) / g->it_l : 1;
 }

@@ -61,21 +61,28 @@ size_t ba_reduced_solve_lds_bytes(int n)
 }
 
 // workgroups of the fused launch, all resident at once: the K7 workgroups of every set (producers: dispatched first, they
-// never wait) and the K8 workgroups of the sets a calibrated round evaluates (<= 3).  In a deeper round (up to 5 sets, once
-// or twice per solve) the K8 workgroups of sets 0 and 1 go on to sets 3 and 4, whose hand-off is published by then.
-static inline int ba_backsub_resident_sets(const BaBufs& b) { return b.ns < BA_CALIBRATED_SETS ? b.ns : BA_CALIBRATED_SETS; }
-int ba_solve_backsub_workgroups(const BaDims& d, const BaBufs& b)
+// never wait) and the K8 workgroups of `rs` sets: as many of the sets a calibrated round evaluates (<= 3) as the chip holds
+// beside them (3 up to 10.7 k landmarks, 2 up to 16 k, 1 up to 32 k).  In a deeper round the K8 workgroups of set s go on to
+// sets s + rs, s + 2 rs, ..., whose hand-off is published by then.
+static inline int ba_backsub_resident_sets(const BaDims& d, const BaBufs& b, int n_cu)
+{
+    const int per = K7_THREADS / 4, nblk = (d.P + per - 1) / per;
+    int rs = b.ns < BA_CALIBRATED_SETS ? b.ns : BA_CALIBRATED_SETS;
+    while (rs > 1 && b.ns + rs * nblk > n_cu) rs--;
+    return rs;
+}
+int ba_solve_backsub_workgroups(const BaDims& d, const BaBufs& b, int n_cu)
 {
     const int per = K7_THREADS / 4;
-    return b.ns + ba_backsub_resident_sets(b) * ((d.P + per - 1) / per);
+    return b.ns + ba_backsub_resident_sets(d, b, n_cu) * ((d.P + per - 1) / per);
 }
 
-void ba_launch_solve_backsub(hipStream_t s, const BaDims& d, const BaBufs& b, const BaOpt& opt)
+void ba_launch_solve_backsub(hipStream_t s, const BaDims& d, const BaBufs& b, const BaOpt& opt, int n_cu)
 {
     const size_t lds = max(ba_reduced_solve_lds_bytes(d.n), ba_backsub_lds_bytes(d.C, d.n));
     (void)rs_lds_attr((const void*)ba_solve_backsub, lds);
     const int per = K7_THREADS / 4, nblk = (d.P + per - 1) / per;
-    hipLaunchKernelGGL(ba_solve_backsub, dim3(b.ns + nblk * ba_backsub_resident_sets(b)), dim3(K7_THREADS), lds, s, d, b, opt, nblk);
+    hipLaunchKernelGGL(ba_solve_backsub, dim3(b.ns + nblk * ba_backsub_resident_sets(d, b, n_cu)), dim3(K7_THREADS), lds, s, d, b, opt, nblk);
 }
 
 void ba_launch_reduced_solve_lds(hipStream_t s, const BaDims& d, const BaBufs& b, const BaOpt& opt)

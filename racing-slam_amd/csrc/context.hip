@@ -138,12 +138,12 @@ extern "C" int rs_context_set_int(rs_context* ctx, const char* name, int value)
         return RS_OK;
     }
     if (strcmp(name, "ba_item_landmarks") == 0) {
-        if (value != 0 && value != 32 && value != 40 && value != 64) return rs_fail(ctx, RS_ERR_INVALID, "ba_item_landmarks must be 0 (default), 32, 40 or 64");
+        if (value != 0 && (value < 32 || value > 64 || value % 8)) return rs_fail(ctx, RS_ERR_INVALID, "ba_item_landmarks must be 0 (default) or 32, 40, 48, 56, 64");
         ctx->ba_item = value;
         return RS_OK;
     }
     if (strcmp(name, "ba_batch_item_landmarks") == 0) {
-        if (value != 0 && value != 32 && value != 40 && value != 64) return rs_fail(ctx, RS_ERR_INVALID, "ba_batch_item_landmarks must be 0 (default), 32, 40 or 64");
+        if (value != 0 && (value < 32 || value > 64 || value % 8)) return rs_fail(ctx, RS_ERR_INVALID, "ba_batch_item_landmarks must be 0 (default) or 32, 40, 48, 56, 64");
         ctx->ba_batch_item = value;
         return RS_OK;
     }

@@ -542,7 +542,7 @@ def test_context_fork_and_wait_for_order_streams(rs, oracle, synth):
 
 
 def test_bundle_adjust_item_size_and_decision_launch(ctx, oracle, synth):
-    """"ba_item_landmarks" (32 / 40 / 64 landmarks per workgroup of K5) and the round's decision as a launch of its own in front
+    """"ba_item_landmarks" (32 ... 64 landmarks per workgroup of K5, in steps of 8) and the round's decision as a launch of its own in front
     of K5 (taken when a solve has more items than compute units: 9000 landmarks in items of 32 = 282 items): the LM schedule
     and the results do not depend on either (atomic order only)."""
     w = synth.make_ba_window(n_kf=12, n_points=9000, config_id=151)
@@ -550,7 +550,7 @@ def test_bundle_adjust_item_size_and_decision_launch(ctx, oracle, synth):
     rc, rp, _ = oracle.bundle_adjust(w["cams"], w["cam_free"], w["points"], w["obs_ptr"], w["obs_cam"], w["obs_uv"], w["K"])
     runs = {}
     try:
-        for item in (0, 32, 40, 64):
+        for item in (0, 32, 40, 48, 56, 64):
             ctx.set_int("ba_item_landmarks", item)
             dc, dp = ctx.dev(w["cams"]), ctx.dev(w["points"])
             s = ctx.bundle_adjust(dc, w["cam_free"], dp, ctx.dev(w["obs_ptr"]), ctx.dev(w["obs_cam"]), ctx.dev(w["obs_uv"]), w["K"])
@@ -563,4 +563,4 @@ def test_bundle_adjust_item_size_and_decision_launch(ctx, oracle, synth):
         assert np.allclose([t["cost"] for t in tr], [t["cost"] for t in otr], rtol=1e-8), item
         assert np.allclose(c, rc, rtol=1e-7, atol=1e-9) and np.allclose(p, rp, rtol=1e-7, atol=1e-8), item
     with pytest.raises(Exception):
-        ctx.set_int("ba_item_landmarks", 48)
+        ctx.set_int("ba_item_landmarks", 44)

@@ -13,10 +13,11 @@ rs, synth = pkg.rsgpu, pkg.synth
 import torch  # noqa: E402
 
 ctx = rs.Context(0)
-for k, v in (a.split("=") for a in sys.argv[1:] if "=" in a):
+for k, v in (a.split("=") for a in sys.argv[1:] if "=" in a and not a.startswith("points=")):
     ctx.set_int(k, int(v))
 big = "cfg5" in sys.argv[1:]
-w = synth.make_ba_window(n_kf=100, n_points=80000, config_id=5) if big else synth.make_ba_window()
+npts = [int(a.split("=")[1]) for a in sys.argv[1:] if a.startswith("points=")]
+w = synth.make_ba_window(n_kf=100, n_points=80000, config_id=5) if big else (synth.make_ba_window(n_points=npts[0]) if npts else synth.make_ba_window())
 c0, p0 = ctx.dev(w["cams"]), ctx.dev(w["points"])
 dev = [ctx.dev(w[k]) for k in ("obs_ptr", "obs_cam", "obs_uv")]
 dc, dp = c0.clone(), p0.clone()
