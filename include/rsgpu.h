@@ -96,9 +96,8 @@ int rs_context_fork(rs_context* ctx, rs_context* const* others, int n);
  * both ends of the band towards a separator block, which a launch of its own factors; 1 always the general
  * blocked factorisation (two launches per 48 columns); 2 the banded factorisation by one workgroup from one end; same
  * results to rounding.
- * "ba_item_landmarks": landmarks per workgroup of the linearisation / Schur kernel of a single solve — 0 (default) the
- * smallest of 40 / 48 / 56 / 64 that keeps one workgroup per compute unit (40 up to 10240 landmarks, ... 64 beyond
- * 14336); or 32 / 40 / 48 / 56 / 64.
+ * "ba_item_landmarks": landmarks per workgroup of the linearisation / Schur kernel of a single solve — 0 (default) 40
+ * for windows of at most 10240 landmarks (one workgroup per compute unit), 64 beyond; or 32 / 40 / 48 / 56 / 64.
  * "ba_handoff_timeout_us": how long (1 .. 1000000, default 4000) a workgroup of that fused launch waits for a hand-off
  * word before it gives up; a solve in which that happened is re-run once as separate launches from its untouched
  * inputs (rs_ba_get_stats [4] counts them) — the caller sees the same result either way.

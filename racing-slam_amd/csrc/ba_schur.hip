@@ -380,14 +380,10 @@ void ba_group_zero_range(const BaGroup& g, int32_t** ptr, int* count)
 }
 
 static size_t al256(size_t v) { return (v + 255) & ~(size_t)255; }
-// landmarks per item of a single solve: the smallest of 40, 48, 56, 64 that keeps the items within ONE shift of 256 workgroups
-// (an item's time grows with its landmarks; a second shift costs a whole item's time), 64 beyond that
-static int ba_default_item(int P)
-{
-    for (int it = IT_L_SMALL; it < IT_L; it += 8)
-        if (P <= 256 * it) return it;
-    return IT_L;
-}
+// landmarks per item of a single solve: 40 while that keeps the items within ONE shift of 256 workgroups, 64 beyond.  (48 / 56
+// are there as "ba_item_landmarks": 3 us per launch faster at 11 - 14 k landmarks when the items' camera unions are small, 10 us
+// slower when they are not — the 8 x 8-tile class deals its 36 tiles to the workgroup's waves, and 6 waves carry 6 each.)
+static int ba_default_item(int P) { return P <= 256 * IT_L_SMALL ? IT_L_SMALL : IT_L; }
 
 void ba_group_carve(char* base, int P, int Cf, int M, BaGroup* g)
 {
