@@ -210,3 +210,35 @@ def test_speculation_depth_policy_keeps_the_schedule(ctx, oracle, synth, kw):
     shared = any(o in (0, -1) for o in out[:-1])
     assert st["rounds"] <= s["iterations"] and (not shared or st["rounds"] < s["iterations"]), (st, out)
     assert st["set_evaluations"] >= s["iterations"] - (1 if s["termination"] != 0 else 0)
+
+
+@pytest.mark.parametrize("n_points,config_id,resident", [(11400, 3, 2), (17000, 35, 1), (17000, 36, 1)])
+def test_fused_solve_launch_with_fewer_resident_radii(ctx, oracle, synth, n_points, config_id, resident):
+    """The fused K7 + K8 launch holds the K8 workgroups of 3 speculative radii up to 10.7 k landmarks, of 2 up to 16 k, of 1 up to
+    32 k (csrc/ba_solve.hip, ba_backsub_resident_sets): a K8 workgroup then evaluates radius s + rs, s + 2 rs, ... after radius s.
+    Windows whose schedules have rejection streaks (so that the later passes' results are the ones taken): the launch is the
+    fused one, the schedule is the oracle's step for step, the result the oracle's."""
+    w = synth.make_ba_window(n_points=n_points, config_id=config_id)
+    _, _, os_, otr = oracle.bundle_adjust_trace(w["cams"], w["cam_free"], w["points"], w["obs_ptr"], w["obs_cam"], w["obs_uv"], w["K"])
+    rc, rp, _ = oracle.bundle_adjust(w["cams"], w["cam_free"], w["points"], w["obs_ptr"], w["obs_cam"], w["obs_uv"], w["K"])
+    assert [t["outcome"] for t in otr].count(0) >= 3                  # (the window was chosen for its rejected steps)
+    ctx.set_int("ba_fuse_mode", 2)
+    try:
+        dc, dp = ctx.dev(w["cams"]), ctx.dev(w["points"])
+        ctx.prof_begin()
+        s = ctx.bundle_adjust(dc, w["cam_free"], dp, ctx.dev(w["obs_ptr"]), ctx.dev(w["obs_cam"]), ctx.dev(w["obs_uv"]), w["K"])
+        prof = ctx.prof_end()
+        tr = ctx.ba_trace()
+    finally:
+        ctx.set_int("ba_fuse_mode", 0)
+    assert "K78_ba_solve_backsub" in prof and "K8_ba_backsub_cost" not in prof
+    per = 128                                                           # landmarks per K8 workgroup of the fused launch
+    assert 5 + (resident + 1) * ((n_points + per - 1) // per) > 256 >= 5 + resident * ((n_points + per - 1) // per)
+    assert [t["outcome"] for t in tr] == [t["outcome"] for t in otr]
+    assert (s["iterations"], s["successful_steps"], s["termination"]) == (os_["iterations"], os_["successful_steps"], os_["termination"])
+    assert np.allclose([t["cost"] for t in tr], [t["cost"] for t in otr], rtol=1e-9)
+    assert np.isclose(s["final_cost"], os_["final_cost"], rtol=1e-10)
+    assert np.allclose(to_np(dc), rc, rtol=1e-7, atol=1e-9)
+    # (a few landmarks of such a window are seen along nearly parallel rays: their V has condition 1e10 and they move by 1e-4
+    # for camera differences of 1e-14; tools/fuse_soak.py counts them)
+    assert np.mean(np.abs(to_np(dp) - rp).max(axis=1) < 1e-6) > 0.995
