@@ -497,11 +497,15 @@ __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(
 //                     place and t for the tile waves, then applies the step's rank-8 update to its entries in the NEXT 8
 //                     columns itself — the chain never waits for the trailing update
 //   wave 5            the right-hand side row: the same factorisation, y's row solve, and its whole rank-8 update (two columns
-//                     per lane) every step
+//                     per lane) every step; then it takes tiles as a sixth tile wave
 //   tile waves        (5, on the other three SIMDs) the rank-8 update of the panel's remaining columns on the matrix cores,
-//                     two MFMAs per 16 x 16 tile, finished before the chain reads the step after next's raw columns; then
-//                     whatever the caller hands them (after_step: the factor's columns to memory, the next blocks' fetch)
-// two workgroup barriers per step.  Rows above the step's sub-block are finished and idle; identity padding needs no masks.
+//                     two 16 x 16 tiles per LDS round trip (operands and old values together, two MFMAs per tile), finished
+//                     before the chain reads the step after next's raw columns; and, in the window where they would wait for
+//                     the chain's factorisation, whatever the caller hands them for the PREVIOUS step's finished columns
+//                     (after_step: the factor's columns to memory, the next blocks' fetch)
+// two workgroup barriers per step.  Measured and dropped: tiles resident in registers as in K7, a pivot wave
+// that factors the next sub-block one step ahead (a single wave's 8 x 8 factorisation takes as long as the chain's whole step),
+// the chain waves on two SIMDs.  Rows above the step's sub-block are finished and idle; identity padding needs no masks.
 #define BAND_TS 10
 #ifndef BAND_CHAIN_X
 #define BAND_CHAIN_X 4          // the chain waves are dw and dw ^ BAND_CHAIN_X: 1 = on two SIMDs (each has the FP64 pipe to itself in the
@@ -736,8 +740,8 @@ static __device__ __forceinline__ void band_block8(const BandWin& W, const int s
 // columns reversed, v -> 64 NB - 1 - v: a band stays a band; the identity padding of the last real block becomes the head of
 // its first block and whole padded sub-blocks are skipped); the bandwidth (<= 64) keeps the two sides uncoupled.  Each side
 // leaves its Schur update of the separator block — side 0: A_ss - update, side 1: - update (in its reversed order) — in
-// g.sep; ba_big_finish adds them, factors the separator and substitutes backwards on both sides in lock step.  The chain of
-// dependent 16-column sub-blocks is 17 + 4 instead of 37 at n = 588.  Factor blocks are stored at the REAL positions of their
+// g.sep; ba_band_sep adds them and factors the separator, ba_big_finish substitutes backwards on both sides in lock step.  The
+// chain of dependent 8-column steps is 34 + 8 instead of 74 at n = 588.  Factor blocks are stored at the REAL positions of their
 // (virtual) rows and columns, so side 1's land in the upper triangle of g.Ls.
 // doubles of LDS: four block buffers, the side's right-hand side (np + WB), the t panel, scratch, next multipliers, pivots
 static inline size_t band_factor_lds_doubles(int n) { const size_t np = (size_t)((n + WB - 1) / WB) * WB; return (size_t)4 * WB * WBS + np + WB + 2 * WB * BAND_TS + 64 + 64 + WB; }
